@@ -1,0 +1,94 @@
+"""numpy MODEL of the incremental exact decode the HIP path implements (test infrastructure).
+
+The reference re-runs the whole Text2Mel graph at every step (synthesize.py:47-54).
+The HIP decode instead keeps
+  * TextEnc K,V (computed once: pure function of L),
+  * per-layer AudioEnc activation histories indexed by absolute time (Q[t] for t<=j depends only
+    on Y[<t], which is final -> exactly incremental),
+  * and at every step re-evaluates the 3-key windowed attention and the AudioDec dependency cone
+    (85/83/45/15/5/3/1 rows) with the CURRENT window, because the reference tiles step j's mask
+    over all time rows (networks.py:145).
+All buffers carry PAD zero rows in front of t=0: post-LN activations are never written there, so
+reading them reproduces the per-layer causal zero padding (modules.py:121-125,173-177).
+
+This file states that algorithm in numpy so that the cone tables in dc_tts_amd/layers.py and the
+buffer scheme can be checked against the oracle's full-recompute loop on CPU, before any GPU run.
+"""
+import numpy as np
+
+from dc_tts_amd.layers import audioenc_layers, audiodec_layers, audiodec_cone
+from oracle import dctts_ref as O
+
+PAD = 64
+
+
+def _layer_rows(l, P, inbuf, t_rows, dtype):
+    """Evaluate one causal layer for absolute-time rows ``t_rows`` (all >= 0) by tap gather from
+    ``inbuf`` (B, PAD+T, Cin).  Returns (B, len(t_rows), Cout)."""
+    t = np.asarray(t_rows)
+    if l.kind == "C":
+        Wk = P[l.scope + "/conv1d/kernel"]
+        y = inbuf[:, PAD + t, :] @ Wk[0] + P[l.scope + "/conv1d/bias"]
+        y = O.normalize(y, P[l.scope + "/normalize/gamma"], P[l.scope + "/normalize/beta"])
+        return O.relu(y) if l.act == "relu" else y
+    Wk = P[l.scope + "/conv1d/kernel"]
+    k = Wk.shape[0]
+    y = 0
+    for j in range(k):                      # causal: tap j sees x[t - (k-1-j)*rate]
+        y = y + inbuf[:, PAD + t - (k - 1 - j) * l.rate, :] @ Wk[j]
+    y = y + P[l.scope + "/conv1d/bias"]
+    C = l.cout
+    H1 = O.sigmoid(O.normalize(y[..., :C], P[l.scope + "/H1/gamma"], P[l.scope + "/H1/beta"]))
+    H2 = O.normalize(y[..., C:], P[l.scope + "/H2/gamma"], P[l.scope + "/H2/beta"])
+    return H1 * H2 + (1.0 - H1) * inbuf[:, PAD + t, :]
+
+
+def incremental_decode(L, W, hp, dtype=np.float32, frozen_R=False):
+    """Returns (Y (B,T,80), max_att trajectory (B,T) int64).  ``frozen_R=True`` is the 'obvious'
+    cache (R[t] frozen at step t, single AudioDec row) that does NOT match the reference."""
+    B, T = L.shape[0], hp.max_T
+    K, V = O.TextEnc(L, W, hp, dtype)
+    ae, ad = audioenc_layers(hp), audiodec_layers(hp)
+    cone = audiodec_cone(hp)
+    Pe = O._Scoped(W, "Text2Mel/AudioEnc", dtype)
+    Pd = O._Scoped(W, "Text2Mel/AudioDec", dtype)
+    Ypad = np.zeros((B, PAD + T + 1, hp.n_mels), dtype)          # Ypad[PAD + t] = S[t] = Y[t-1]
+    AE = [np.zeros((B, PAD + T, l.cout), dtype) for l in ae]
+    Rbuf = np.zeros((B, PAD + T, 2 * hp.d), dtype)
+    AD = [np.zeros((B, PAD + T, l.cout), dtype) for l in ad]
+    Y = np.zeros((B, T, hp.n_mels), dtype)
+    traj = np.zeros((B, T), np.int64)
+    p = np.zeros((B,), np.int64)
+    scale = dtype(1.0 / np.sqrt(dtype(hp.d)))
+    for j in range(T):
+        # --- AudioEnc: one new row per utterance
+        src = Ypad
+        for li, l in enumerate(ae):
+            AE[li][:, PAD + j, :] = _layer_rows(l, Pe, src, [j], dtype)[:, 0, :]
+            src = AE[li]
+        Qh = AE[-1]
+        # --- windowed attention for the rows AudioDec C_1 must emit
+        offs = cone[0] if not frozen_R else [0]
+        rows = [j + o for o in offs if j + o >= 0]
+        for b in range(B):
+            n0 = int(p[b]); n1 = min(n0 + hp.attention_win_size, hp.max_N)
+            q = Qh[b, PAD + np.asarray(rows), :]                 # (R, d)
+            lg = (q @ K[b, n0:n1, :].T) * scale                  # (R, <=3)
+            lg = lg - lg.max(-1, keepdims=True)
+            a = np.exp(lg); a = a / a.sum(-1, keepdims=True)
+            Rbuf[b, PAD + np.asarray(rows), :hp.d] = a @ V[b, n0:n1, :]
+            Rbuf[b, PAD + np.asarray(rows), hp.d:] = q
+            if True:
+                jj = rows.index(j)
+                traj[b, j] = n0 + int(np.argmax(a[jj]))
+        # --- AudioDec dependency cone
+        src = Rbuf
+        for li, l in enumerate(ad):
+            offs_l = cone[li] if not frozen_R else [0]
+            rows_l = [j + o for o in offs_l if j + o >= 0]
+            AD[li][:, PAD + np.asarray(rows_l), :] = _layer_rows(l, Pd, src, rows_l, dtype)
+            src = AD[li]
+        Y[:, j, :] = O.sigmoid(AD[-1][:, PAD + j, :])
+        Ypad[:, PAD + j + 1, :] = Y[:, j, :]
+        p = traj[:, j].copy()
+    return Y, traj
