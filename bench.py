@@ -1,0 +1,170 @@
+"""bench.py -- mel frames/s + RTF of the DC-TTS synthesis path on MI355X (BASELINE.json metric).
+
+One "step" = one full synthesis of a batch of B=32 utterances on each GPU: TextEnc once, the 210-step
+autoregressive Text2Mel decode (exact-parity incremental algorithm), one SSRN pass -> (32, 840, 1025)
+linear spectrogram; inputs (character ids) and weights are resident in HBM before the timed region.
+Multi-GPU: utterances shard embarrassingly, 32 per GPU, no collective on the data path ("weak").
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+DOMINANT_KERNEL_ID = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
+
+
+def cpu_baseline(hp, W, seconds_budget=25.0):
+    """The oracle (a port: numpy restatement of the reference, TF being uninstallable here) timed on the host
+    cores, on a bounded sample: a few steps of the reference's full-recompute loop (synthesize.py:47-54, TextEnc
+    recomputed every step as the reference does) for a small batch, plus one SSRN pass, prorated per mel frame."""
+    from dc_tts_amd.weights import synthetic_text
+    from oracle import dctts_ref as O
+    Bs, steps = 2, 3
+    L = synthetic_text(hp, B=Bs, seed=99)
+    Y = np.zeros((Bs, hp.max_T, hp.n_mels), np.float32)
+    prev = np.zeros((Bs,), np.int32)
+    O.text2mel_graph(L, Y, prev, W, hp)                       # warm BLAS threads
+    t0 = time.perf_counter()
+    for j in range(steps):
+        g = O.text2mel_graph(L, Y, prev, W, hp)               # full graph incl. TextEnc, like the reference
+        Y[:, j, :] = g["Y"][:, j, :]
+        prev = g["max_attentions"][:, j].astype(np.int32)
+    t_step = (time.perf_counter() - t0) / steps               # seconds per loop step for Bs utterances
+    t0 = time.perf_counter()
+    O.SSRN(Y[:1], W, hp)
+    t_ssrn = time.perf_counter() - t0                         # seconds per utterance
+    per_frame = t_step / Bs + t_ssrn / hp.max_T               # one loop step yields one mel frame per utterance
+    return {"value": 1.0 / per_frame, "unit": "mel frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{steps} steps of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, "
+                      f"B={Bs}, N={hp.max_N}, T={hp.max_T}) + 1 SSRN pass (B=1), numpy fp32 on all host cores, "
+                      f"prorated per mel frame",
+            "rtf": per_frame / hp.seconds_per_mel_frame}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
+    ap.add_argument("--max-T", type=int, default=210)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from dc_tts_amd.engine import Engine
+    from dc_tts_amd.hyperparams import hp as hp0
+    from dc_tts_amd.layers import ssrn_layers
+    from dc_tts_amd.weights import synthetic_text, synthetic_weights
+
+    hp = hp0.replace(max_T=args.max_T)
+    B, T = args.batch, hp.max_T
+    W = synthetic_weights(hp, seed=1234, perturb=True)
+    eng = Engine(W, hp, device=local, decode_graph=not args.no_graph)
+    L = torch.from_numpy(synthetic_text(hp, B=B, seed=1234 + rank)).cuda()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.synthesize(L)
+    barrier()
+    eng.prof_enable(DOMINANT_KERNEL_ID)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        Y, Z, mx = eng.synthesize(L)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    elapsed = t1 - t0
+    eng.prof_enable(-1)
+    n_launch, dom_ms = eng.prof_collect()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- untimed: per-phase breakdown (torch events on the launch stream)
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    phases = None
+    if rank == 0:
+        ms_te = timed(lambda: eng.text_enc(L))
+        ms_t2m = timed(lambda: eng.text2mel(L))
+        ms_ssrn = timed(lambda: eng.ssrn(Y, want_logits=False))
+        phases = {"textenc_ms": round(ms_te, 3), "text2mel_total_ms": round(ms_t2m, 3),
+                  "decode_us_per_step": round((ms_t2m - ms_te) * 1e3 / T, 2), "ssrn_ms": round(ms_ssrn, 3)}
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        value = frames / elapsed
+        rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
+        # roofline of the dominant kernel: algorithmic FLOPs of one launch = 2 * rows * K * N of the layer
+        C = 2 * hp.c                                             # SSRN HC_11 / HC_12: 1024 -> 2048, k = 3
+        flops_per_launch = 2.0 * (B * 4 * T) * (3 * C) * (2 * C)
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                "traffic": None, "kernel": "hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11/HC_12, 1024ch k=3, fused LN+gate)",
+                "launches": n_launch, "avg_launch_ms": None, "flop_per_launch": flops_per_launch}
+        if n_launch > 0:
+            avg_ms = dom_ms / n_launch
+            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_ms=round(avg_ms, 4))
+        # whole-pipeline algorithmic FLOPs per mel frame: TextEnc/T + AudioEnc + AudioDec cone + attention + SSRN
+        flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6
+        out = {
+            "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
+            "rtf": rtf, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded character ids, seeded random-init weights)",
+            "config": {"workload": f"full Text2Mel autoregressive decode + SSRN, batch={B}/GPU, max_N={hp.max_N}, "
+                                   f"max_T={T} mel frames -> ({B},{4 * T},{hp.n_linear}) per GPU; exact-parity incremental decode",
+                       "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_graph": not args.no_graph,
+                       "sharding": f"{world} x {B} utterances, no collective"},
+            "pipeline_tflops": round(value * flop_frame / 1e12, 2),
+            "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "phases": phases, "roofline": roof, "device_bytes": eng.device_bytes(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(hp, W)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""ctypes binding of libdctts_hip.so (include/dctts_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``dc_tts_amd/build.py``.  There is NO
+fallback: if the shared object is missing or fails to load, importing the product path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdctts_hip.so")
+
+c_int = ctypes.c_int
+c_void_p = ctypes.c_void_p
+c_size_t = ctypes.c_size_t
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("vocab_size", c_int), ("e", c_int), ("d", c_int), ("c", c_int), ("n_mels", c_int),
+                ("n_linear", c_int), ("max_N", c_int), ("attention_win_size", c_int)]
+
+
+# name -> (restype, argtypes); every symbol include/dctts_hip.h declares
+SYMBOLS = {
+    "dctts_create": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(Config)]),
+    "dctts_destroy": (c_int, [c_void_p]),
+    "dctts_last_error": (ctypes.c_char_p, []),
+    "dctts_weights_set": (c_int, [c_void_p, ctypes.c_char_p, c_void_p, ctypes.POINTER(ctypes.c_int64), c_int]),
+    "dctts_weights_finalize": (c_int, [c_void_p]),
+    "dctts_textenc_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dctts_audioenc_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dctts_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dctts_audiodec_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dctts_ssrn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dctts_text2mel_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dctts_synthesize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dctts_set_decode_graph": (c_int, [c_void_p, c_int]),
+    "dctts_device_bytes": (c_size_t, [c_void_p]),
+    "dctts_debug_layer": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dctts_prof_enable": (c_int, [c_void_p, c_int]),
+    "dctts_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once).  Raises RuntimeError if it is not built -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  dc_tts_amd has no CPU or PyTorch fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().dctts_last_error().decode("utf-8", "replace")

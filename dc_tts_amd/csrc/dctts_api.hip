@@ -1,0 +1,710 @@
+// dctts_api.hip -- host side of libdctts_hip.so: context, weight packing, network drivers, decode loop.
+// Implements include/dctts_hip.h.  Reference call sites: networks.py:14-292, train.py:48-77,
+// synthesize.py:45-57.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dctts_hip.h"
+#include "attn_kernels.h"
+#include "hconv_kernel.h"
+
+using namespace dctts;
+
+namespace dctts {
+
+#define HCONV_CASE(E, NT_, NW_)                                                        \
+  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                      \
+    hipLaunchKernelGGL((hconv_kernel<E, NT_, NW_>), grid, dim3(NW_ * 64), 0, stream, p); \
+    return hipGetLastError();                                                          \
+  }
+
+hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream) {
+  const dim3 grid((p.M + 31) / 32);
+  if (p.M <= 0) return hipSuccess;
+  HCONV_CASE(EPI_HC, 2, 8)
+  HCONV_CASE(EPI_HC, 4, 8)
+  HCONV_CASE(EPI_HC, 8, 8)
+  HCONV_CASE(EPI_C, 1, 4)
+  HCONV_CASE(EPI_C, 1, 8)
+  HCONV_CASE(EPI_C, 2, 8)
+  HCONV_CASE(EPI_C, 4, 8)
+  HCONV_CASE(EPI_C, 3, 11)
+  return hipErrorInvalidConfiguration;
+}
+
+}  // namespace dctts
+
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e__ = (x);                                                                           \
+    if (e__ != hipSuccess)                                                                          \
+      return fail(DCTTS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e__) + " @" + std::to_string(__LINE__)); \
+  } while (0)
+#define CHK(x) do { int r__ = (x); if (r__ != 0) return r__; } while (0)
+
+static const int PAD = 64;   // zero rows in front of / behind every tap-read activation buffer (>= 2*27)
+
+struct HostTensor { std::vector<float> v; std::vector<int64_t> shape; };
+
+struct DevLayer {
+  ConvShape shape{0, 0, 0};
+  int ntaps = 1, cin = 0, cin_p = 0, tap_off[3] = {0, 0, 0}, cout = 0, act = ACT_NONE;
+  float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+  bool deconv_phase = false; int phase = 0;
+};
+
+struct View {            // a (B, rows, stride) activation buffer; row0 = index of t = 0 inside a batch item
+  float* p; long bstride; long row0; int stride;
+};
+
+struct Buf { void* p = nullptr; size_t bytes = 0; };
+
+struct dctts_ctx {
+  dctts_config cfg;
+  int device = 0;
+  std::map<std::string, HostTensor> hw;
+  bool finalized = false;
+  std::vector<void*> wallocs;
+  size_t wbytes = 0;
+  std::vector<DevLayer> textenc, audioenc, audiodec, ssrn;
+  float* embed = nullptr;
+  std::vector<int*> cone_dev; std::vector<int> cone_len;
+  std::map<std::string, Buf> ws;       // named workspaces; key includes the geometry
+  std::string ws_geom_textenc, ws_geom_t2m, ws_geom_dec, ws_geom_ssrn;
+  int use_graph = 0;
+  hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;
+  // profiling
+  int prof_id = -1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+};
+
+static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------ weights
+static int get_w(dctts_ctx* c, const std::string& name, const std::vector<int64_t>& shape, const HostTensor** out) {
+  auto it = c->hw.find(name);
+  if (it == c->hw.end()) return fail(DCTTS_ERR_WEIGHTS, "missing variable " + name);
+  if (it->second.shape != shape) return fail(DCTTS_ERR_WEIGHTS, "bad shape for " + name);
+  *out = &it->second;
+  return 0;
+}
+
+static int upload(dctts_ctx* c, const std::vector<float>& h, float** d) {
+  void* p = nullptr;
+  HIPCHK(hipMalloc(&p, h.size() * sizeof(float)));
+  HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->wallocs.push_back(p); c->wbytes += h.size() * sizeof(float);
+  *d = (float*)p;
+  return 0;
+}
+
+// Pack W(tap, c, col) into MFMA fragment order: [tile][kgroup][lane][4],
+// lane l, element i  <-  k = 8*kg + 4*(l>>5) + i,  column of tile / (l&31)   (hconv_kernel.h).
+static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p,
+                                 const ConvShape& s, int cout, bool hc) {
+  const int tiles = s.nt * s.nw, KG = ntaps * cin_p / 8;
+  std::vector<float> out((size_t)tiles * KG * 256, 0.f);
+  for (int gt = 0; gt < tiles; ++gt)
+    for (int kg = 0; kg < KG; ++kg)
+      for (int l = 0; l < 64; ++l) {
+        int col;
+        if (hc) { const int ch = (gt / 2) * 32 + (l & 31); col = ch < cout ? (gt & 1) * cout + ch : -1; }
+        else    { const int ch = gt * 32 + (l & 31);       col = ch < cout ? ch : -1; }
+        if (col < 0) continue;
+        for (int i = 0; i < 4; ++i) {
+          const int k = kg * 8 + 4 * (l >> 5) + i, tap = k / cin_p, cc = k % cin_p;
+          if (cc < cin_real) out[(((size_t)gt * KG + kg) * 64 + l) * 4 + i] = W(tap, cc, col);
+        }
+      }
+  return out;
+}
+
+static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L) {
+  const HostTensor *k, *b, *be, *ga;
+  CHK(get_w(c, scope + "/conv1d/kernel", {1, cin_real, cout}, &k));
+  CHK(get_w(c, scope + "/conv1d/bias", {cout}, &b));
+  CHK(get_w(c, scope + "/normalize/beta", {cout}, &be));
+  CHK(get_w(c, scope + "/normalize/gamma", {cout}, &ga));
+  L->shape = pick_shape(EPI_C, cout);
+  L->ntaps = 1; L->cin = cin_read; L->cin_p = round_up(cin_real, 32); L->cout = cout; L->act = act;
+  L->tap_off[0] = L->tap_off[1] = L->tap_off[2] = 0;
+  const float* kv = k->v.data();
+  auto W = [=](int, int cc, int col) { return kv[(size_t)cc * cout + col]; };
+  CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
+  CHK(upload(c, b->v, &L->bias)); CHK(upload(c, ga->v, &L->g1)); CHK(upload(c, be->v, &L->b1));
+  return 0;
+}
+
+static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rate, bool causal, DevLayer* L) {
+  const HostTensor *kw, *b, *b1, *g1, *b2, *g2;
+  CHK(get_w(c, scope + "/conv1d/kernel", {k, C, 2 * C}, &kw));
+  CHK(get_w(c, scope + "/conv1d/bias", {2 * C}, &b));
+  CHK(get_w(c, scope + "/H1/beta", {C}, &b1)); CHK(get_w(c, scope + "/H1/gamma", {C}, &g1));
+  CHK(get_w(c, scope + "/H2/beta", {C}, &b2)); CHK(get_w(c, scope + "/H2/gamma", {C}, &g2));
+  L->shape = pick_shape(EPI_HC, C);
+  L->ntaps = k; L->cin = C; L->cin_p = round_up(C, 32); L->cout = C; L->act = ACT_NONE;
+  for (int j = 0; j < 3; ++j) L->tap_off[j] = 0;
+  if (k == 3) {
+    // tf.layers.conv1d tap j reads x[t + j*rate - pad_left]: CAUSAL pad_left = 2*rate, SAME pad_left = rate
+    const int pl = causal ? 2 * rate : rate;
+    for (int j = 0; j < 3; ++j) L->tap_off[j] = j * rate - pl;
+  }
+  const float* kv = kw->v.data();
+  auto W = [=](int tap, int cc, int col) { return kv[((size_t)tap * C + cc) * (2 * C) + col]; };
+  CHK(upload(c, pack_b(W, k, C, L->cin_p, L->shape, C, true), &L->wp));
+  CHK(upload(c, b->v, &L->bias));
+  CHK(upload(c, g1->v, &L->g1)); CHK(upload(c, b1->v, &L->b1));
+  CHK(upload(c, g2->v, &L->g2)); CHK(upload(c, b2->v, &L->b2));
+  return 0;
+}
+
+// conv2d_transpose (1,3,Cout,Cin), stride 2, 'same' (modules.py:232-239):
+//   out[2t]   = b + x[t] W0 + x[t-1] W2      (phase 0: taps {0,-1})
+//   out[2t+1] = b + x[t] W1                  (phase 1: tap  {0})
+static int make_D(dctts_ctx* c, const std::string& scope, int C, DevLayer* even, DevLayer* odd) {
+  const HostTensor *kw, *b, *be, *ga;
+  CHK(get_w(c, scope + "/conv2d_transpose/kernel", {1, 3, C, C}, &kw));
+  CHK(get_w(c, scope + "/conv2d_transpose/bias", {C}, &b));
+  CHK(get_w(c, scope + "/normalize/beta", {C}, &be));
+  CHK(get_w(c, scope + "/normalize/gamma", {C}, &ga));
+  const float* kv = kw->v.data();
+  float *bias, *g, *bb;
+  CHK(upload(c, b->v, &bias)); CHK(upload(c, ga->v, &g)); CHK(upload(c, be->v, &bb));
+  for (int ph = 0; ph < 2; ++ph) {
+    DevLayer* L = ph ? odd : even;
+    L->shape = pick_shape(EPI_C, C);
+    L->ntaps = ph ? 1 : 2; L->cin = C; L->cin_p = round_up(C, 32); L->cout = C; L->act = ACT_NONE;
+    L->tap_off[0] = 0; L->tap_off[1] = -1; L->tap_off[2] = 0;
+    L->deconv_phase = true; L->phase = ph;
+    auto W = [=](int tap, int cc, int col) {
+      const int j = ph ? 1 : (tap == 0 ? 0 : 2);
+      return kv[((size_t)j * C + col) * C + cc];          // kernel[0][j][out][in]
+    };
+    CHK(upload(c, pack_b(W, L->ntaps, C, L->cin_p, L->shape, C, false), &L->wp));
+    L->bias = bias; L->g1 = g; L->b1 = bb;
+  }
+  return 0;
+}
+
+static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& ad) {
+  // output-row offsets (relative to the newest frame) each AudioDec layer must emit
+  std::vector<std::vector<int>> out(ad.size());
+  std::vector<int> need{0};
+  for (int i = (int)ad.size() - 1; i >= 0; --i) {
+    out[i] = need;
+    if (ad[i].ntaps > 1) {
+      std::vector<char> mark(4096, 0);
+      for (int o : need) for (int j = 0; j < ad[i].ntaps; ++j) mark[-(o + ad[i].tap_off[j])] = 1;
+      need.clear();
+      for (int o = 0; o < 4096; ++o) if (mark[o]) need.push_back(-o);
+    }
+  }
+  return out;
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI: lifetime
+extern "C" const char* dctts_last_error(void) { return g_err.c_str(); }
+
+extern "C" int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg) {
+  if (!out || !cfg) return fail(DCTTS_ERR_ARG, "null argument");
+  if (cfg->d != 256) return fail(DCTTS_ERR_ARG, "attention kernels are specialised for d == 256");
+  HIPCHK(hipSetDevice(device));
+  dctts_ctx* c = new dctts_ctx();
+  c->cfg = *cfg; c->device = device;
+  *out = c;
+  return 0;
+}
+
+static void free_ws(dctts_ctx* c) {
+  for (auto& kv : c->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  c->ws.clear();
+}
+
+extern "C" int dctts_destroy(dctts_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+  if (c->graph) (void)hipGraphDestroy(c->graph);
+  free_ws(c);
+  for (void* p : c->wallocs) (void)hipFree(p);
+  for (int* p : c->cone_dev) (void)hipFree(p);
+  for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  delete c;
+  return 0;
+}
+
+extern "C" int dctts_weights_set(dctts_ctx* c, const char* name, const float* data, const int64_t* shape, int ndim) {
+  if (!c || !name || !data || !shape || ndim < 1 || ndim > 4) return fail(DCTTS_ERR_ARG, "bad argument");
+  if (c->finalized) return fail(DCTTS_ERR_STATE, "weights already finalized");
+  HostTensor t; size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.v.assign(data, data + n);
+  c->hw[name] = std::move(t);
+  return 0;
+}
+
+extern "C" int dctts_weights_finalize(dctts_ctx* c) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  if (c->finalized) return 0;
+  HIPCHK(hipSetDevice(c->device));
+  const dctts_config& g = c->cfg;
+  const int d = g.d, cc = g.c, F = g.n_linear, Fp = round_up(F, 32);
+  char nm[64];
+  // ---- TextEnc (networks.py:14-71)
+  {
+    const std::string s = "Text2Mel/TextEnc/";
+    const HostTensor* tab;
+    CHK(get_w(c, s + "embed_1/lookup_table", {g.vocab_size, g.e}, &tab));
+    std::vector<float> t = tab->v;
+    for (int i = 0; i < g.e; ++i) t[i] = 0.f;                     // modules.py:36-38: row 0 := zeros
+    CHK(upload(c, t, &c->embed));
+    int i = 2; DevLayer L;
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.e, g.e, 2 * d, ACT_RELU, &L)); c->textenc.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * d, 2 * d, 2 * d, ACT_NONE, &L)); c->textenc.push_back(L);
+    for (int rep = 0; rep < 2; ++rep) for (int j = 0, r = 1; j < 4; ++j, r *= 3) {
+      snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, r, false, &L)); c->textenc.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, 1, false, &L)); c->textenc.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 1, 1, false, &L)); c->textenc.push_back(L); }
+  }
+  // ---- AudioEnc (networks.py:73-124), causal
+  {
+    const std::string s = "Text2Mel/AudioEnc/";
+    int i = 1; DevLayer L;
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.n_mels, g.n_mels, d, ACT_RELU, &L)); c->audioenc.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_RELU, &L)); c->audioenc.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_NONE, &L)); c->audioenc.push_back(L);
+    for (int rep = 0; rep < 2; ++rep) for (int j = 0, r = 1; j < 4; ++j, r *= 3) {
+      snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, r, true, &L)); c->audioenc.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, 3, true, &L)); c->audioenc.push_back(L); }
+  }
+  // ---- AudioDec (networks.py:157-212), causal
+  {
+    const std::string s = "Text2Mel/AudioDec/";
+    int i = 1; DevLayer L;
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * d, 2 * d, d, ACT_NONE, &L)); c->audiodec.push_back(L);
+    for (int j = 0, r = 1; j < 4; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, r, true, &L)); c->audiodec.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, 1, true, &L)); c->audiodec.push_back(L); }
+    for (int rep = 0; rep < 3; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_RELU, &L)); c->audiodec.push_back(L); }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, g.n_mels, ACT_SIGMOID, &L)); c->audiodec.push_back(L);
+    auto cone = audiodec_cone(c->audiodec);
+    for (auto& v : cone) {
+      int* dp = nullptr;
+      HIPCHK(hipMalloc((void**)&dp, v.size() * sizeof(int)));
+      HIPCHK(hipMemcpy(dp, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+      c->cone_dev.push_back(dp); c->cone_len.push_back((int)v.size());
+    }
+  }
+  // ---- SSRN (networks.py:214-292), SAME
+  {
+    const std::string s = "SSRN/";
+    int i = 1; DevLayer L, L2;
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.n_mels, g.n_mels, cc, ACT_NONE, &L)); c->ssrn.push_back(L);
+    for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L)); c->ssrn.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) {
+      snprintf(nm, 64, "D_%d", i++); L = DevLayer(); L2 = DevLayer(); CHK(make_D(c, s + nm, cc, &L, &L2)); c->ssrn.push_back(L); c->ssrn.push_back(L2);
+      for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L)); c->ssrn.push_back(L); }
+    }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, cc, cc, 2 * cc, ACT_NONE, &L)); c->ssrn.push_back(L);
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * cc, 3, 1, false, &L)); c->ssrn.push_back(L); }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * cc, 2 * cc, F, ACT_NONE, &L)); c->ssrn.push_back(L);
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_RELU, &L)); c->ssrn.push_back(L); }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_SIGMOID, &L)); c->ssrn.push_back(L);
+  }
+  HIPCHK(hipDeviceSynchronize());
+  c->hw.clear();
+  c->finalized = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ workspaces
+static int ws_get(dctts_ctx* c, const std::string& name, size_t bytes, void** out) {
+  Buf& b = c->ws[name];
+  if (b.bytes != bytes) {
+    if (b.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    HIPCHK(hipMalloc(&b.p, bytes));
+    HIPCHK(hipMemset(b.p, 0, bytes));      // pad rows/columns stay zero: kernels never write them
+    HIPCHK(hipDeviceSynchronize());
+    b.bytes = bytes;
+  }
+  *out = b.p;
+  return 0;
+}
+
+static int ws_view(dctts_ctx* c, const std::string& name, int B, long rows, long row0, int stride, View* v) {
+  void* p;
+  CHK(ws_get(c, name, (size_t)B * rows * stride * sizeof(float), &p));
+  *v = View{(float*)p, rows, row0, stride};
+  return 0;
+}
+
+extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
+  size_t n = c->wbytes;
+  for (auto& kv : c->ws) n += kv.second.bytes;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ one conv launch
+struct RowMap { int B; int R; const int* offs; const int* step; };
+
+static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* gather, const View& out,
+                    const RowMap& rm, hipStream_t st, int out_zero_to = 0, const View* out2 = nullptr,
+                    int out_tmul = 1, int out_tadd = 0) {
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.in = in.p; p.gather = gather; p.in_bstride = in.bstride; p.in_row0 = in.row0; p.in_stride = in.stride;
+  p.cin = L.cin; p.cin_p = L.cin_p; p.ntaps = L.ntaps;
+  for (int j = 0; j < 3; ++j) p.tap_off[j] = L.tap_off[j];
+  p.M = rm.B * rm.R; p.R = rm.R; p.offs = rm.offs; p.step = rm.step;
+  p.wp = L.wp; p.bias = L.bias; p.g1 = L.g1; p.b1 = L.b1; p.g2 = L.g2; p.b2 = L.b2; p.cout = L.cout;
+  p.out = out.p; p.out_bstride = out.bstride; p.out_row0 = out.row0; p.out_stride = out.stride;
+  p.out_tmul = out_tmul; p.out_tadd = out_tadd; p.out_zero_to = out_zero_to;
+  if (out2) { p.out2 = out2->p; p.out2_bstride = out2->bstride; p.out2_row0 = out2->row0; p.out2_stride = out2->stride; }
+  p.act = L.act;
+  const int kid = L.shape.epi * 10000 + L.shape.nt * 100 + L.shape.nw;
+  const bool prof = (c->prof_id == kid);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+  HIPCHK(launch_hconv(L.shape, p, st));
+  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); }
+  return 0;
+}
+
+static int check_ready(dctts_ctx* c) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  if (!c->finalized) return fail(DCTTS_ERR_WEIGHTS, "weights not finalized");
+  if (hipSetDevice(c->device) != hipSuccess) return fail(DCTTS_ERR_HIP, "hipSetDevice");
+  return 0;
+}
+
+static std::string geom(const char* tag, int a, int b, int cdim = 0) {
+  char s[96]; snprintf(s, 96, "%s:%d:%d:%d", tag, a, b, cdim); return s;
+}
+
+static void drop_ws_prefix(dctts_ctx* c, const std::string& prefix) {
+  for (auto it = c->ws.begin(); it != c->ws.end();) {
+    if (it->first.compare(0, prefix.size(), prefix) == 0) { if (it->second.p) (void)hipFree(it->second.p); it = c->ws.erase(it); }
+    else ++it;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ TextEnc
+static int textenc_into(dctts_ctx* c, const int32_t* L, int B, int N, View* kv_out, hipStream_t st) {
+  const int D2 = 2 * c->cfg.d;
+  const std::string g = geom("te", B, N);
+  if (g != c->ws_geom_textenc) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "te."); c->ws_geom_textenc = g; }
+  View a, b, kv;
+  CHK(ws_view(c, "te.a", B, PAD + N + PAD, PAD, D2, &a));
+  CHK(ws_view(c, "te.b", B, PAD + N + PAD, PAD, D2, &b));
+  CHK(ws_view(c, "te.kv", B, N, 0, D2, &kv));
+  const RowMap rm{B, N, nullptr, nullptr};
+  const View tab{c->embed, 0, 0, c->cfg.e};
+  const size_t nl = c->textenc.size();
+  CHK(run_conv(c, c->textenc[0], tab, (const int*)L, a, rm, st));          // embed + C_2
+  View cur = a, nxt = b;
+  for (size_t i = 1; i < nl; ++i) {
+    const View& o = (i + 1 == nl) ? kv : nxt;
+    CHK(run_conv(c, c->textenc[i], cur, nullptr, o, rm, st));
+    View t = cur; cur = nxt; nxt = t;
+  }
+  *kv_out = kv;
+  return 0;
+}
+
+extern "C" int dctts_textenc_fwd(dctts_ctx* c, const int32_t* L, int B, int N, float* K, float* V, void* stream) {
+  CHK(check_ready(c));
+  if (!L || !K || !V || B <= 0 || N <= 0) return fail(DCTTS_ERR_ARG, "textenc: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  View kv;
+  CHK(textenc_into(c, L, B, N, &kv, st));
+  const int d = c->cfg.d;
+  HIPCHK(hipMemcpy2DAsync(K, d * sizeof(float), kv.p, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpy2DAsync(V, d * sizeof(float), kv.p + d, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ AudioEnc / AudioDec (full sequence)
+static int t2m_ws(dctts_ctx* c, int B, int T, View* a, View* b) {
+  const std::string g = geom("t2m", B, T);
+  if (g != c->ws_geom_t2m) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "t2m."); c->ws_geom_t2m = g; }
+  CHK(ws_view(c, "t2m.a", B, PAD + T, PAD, c->cfg.d, a));
+  CHK(ws_view(c, "t2m.b", B, PAD + T, PAD, c->cfg.d, b));
+  return 0;
+}
+
+extern "C" int dctts_audioenc_fwd(dctts_ctx* c, const float* S, int B, int T, float* Q, void* stream) {
+  CHK(check_ready(c));
+  if (!S || !Q || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audioenc: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  View a, b; CHK(t2m_ws(c, B, T, &a, &b));
+  const RowMap rm{B, T, nullptr, nullptr};
+  const View vin{const_cast<float*>(S), T, 0, c->cfg.n_mels}, vout{Q, T, 0, c->cfg.d};
+  const size_t nl = c->audioenc.size();
+  View cur = vin, nxt = a, other = b;
+  for (size_t i = 0; i < nl; ++i) {
+    const View& o = (i + 1 == nl) ? vout : nxt;
+    CHK(run_conv(c, c->audioenc[i], cur, nullptr, o, rm, st));
+    cur = nxt; View t = nxt; nxt = other; other = t;
+  }
+  return 0;
+}
+
+extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, float* logits, float* Y, void* stream) {
+  CHK(check_ready(c));
+  if (!R || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audiodec: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  View a, b; CHK(t2m_ws(c, B, T, &a, &b));
+  const RowMap rm{B, T, nullptr, nullptr};
+  const View vin{const_cast<float*>(R), T, 0, 2 * c->cfg.d}, vout{Y, T, 0, c->cfg.n_mels}, vlog{logits, T, 0, c->cfg.n_mels};
+  const size_t nl = c->audiodec.size();
+  View cur = vin, nxt = a, other = b;
+  for (size_t i = 0; i < nl; ++i) {
+    const bool last = (i + 1 == nl);
+    CHK(run_conv(c, c->audiodec[i], cur, nullptr, last ? vout : nxt, rm, st, 0, (last && logits) ? &vlog : nullptr));
+    cur = nxt; View t = nxt; nxt = other; other = t;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ Attention (full)
+extern "C" int dctts_attention_fwd(dctts_ctx* c, const float* Q, const float* K, const float* V, int B, int T, int N,
+                                   int monotonic, const int32_t* prev_max, float* R, float* alignments,
+                                   int64_t* max_attentions, void* stream) {
+  CHK(check_ready(c));
+  if (!Q || !K || !V || !R || B <= 0 || T <= 0 || N <= 0) return fail(DCTTS_ERR_ARG, "attention: bad argument");
+  if (monotonic && !prev_max) return fail(DCTTS_ERR_ARG, "attention: monotonic mode needs prev_max_attentions");
+  if (monotonic && N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "attention: monotonic mask is built from hp.max_N (networks.py:142); N must equal it");
+  const int d = c->cfg.d;
+  AttnFullParams p;
+  p.Q = Q; p.q_stride = d; p.q_bstride = T; p.K = K; p.k_stride = d; p.k_bstride = N; p.V = V; p.v_stride = d; p.v_bstride = N;
+  p.T = T; p.N = N; p.d = d; p.monotonic = monotonic; p.prev_max = prev_max; p.win = c->cfg.attention_win_size;
+  p.R = R; p.align = alignments; p.maxatt = (long long*)max_attentions;
+  hipLaunchKernelGGL(attention_full_kernel, dim3(T, B), dim3(256), (d + N) * sizeof(float), (hipStream_t)stream, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ SSRN
+extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, void* stream) {
+  CHK(check_ready(c));
+  if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int cc = c->cfg.c, F = c->cfg.n_linear, Fp = round_up(F, 32);
+  const std::string g = geom("ssrn", B, T);
+  if (g != c->ws_geom_ssrn) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "ssrn."); c->ws_geom_ssrn = g; }
+  View s1a, s1b, s2a, s2b, s4a, s4b, w4a, w4b, z4a, z4b;
+  CHK(ws_view(c, "ssrn.s1a", B, PAD + T + PAD, PAD, cc, &s1a)); CHK(ws_view(c, "ssrn.s1b", B, PAD + T + PAD, PAD, cc, &s1b));
+  CHK(ws_view(c, "ssrn.s2a", B, PAD + 2 * T + PAD, PAD, cc, &s2a)); CHK(ws_view(c, "ssrn.s2b", B, PAD + 2 * T + PAD, PAD, cc, &s2b));
+  CHK(ws_view(c, "ssrn.s4a", B, PAD + 4 * T + PAD, PAD, cc, &s4a)); CHK(ws_view(c, "ssrn.s4b", B, PAD + 4 * T + PAD, PAD, cc, &s4b));
+  CHK(ws_view(c, "ssrn.w4a", B, PAD + 4 * T + PAD, PAD, 2 * cc, &w4a)); CHK(ws_view(c, "ssrn.w4b", B, PAD + 4 * T + PAD, PAD, 2 * cc, &w4b));
+  CHK(ws_view(c, "ssrn.z4a", B, 4 * T, 0, Fp, &z4a)); CHK(ws_view(c, "ssrn.z4b", B, 4 * T, 0, Fp, &z4b));
+  const View vin{const_cast<float*>(Y), T, 0, c->cfg.n_mels}, vz{Z, 4L * T, 0, F}, vlog{logits, 4L * T, 0, F};
+  const RowMap r1{B, T, nullptr, nullptr}, r2{B, 2 * T, nullptr, nullptr}, r4{B, 4 * T, nullptr, nullptr};
+  const std::vector<DevLayer>& S = c->ssrn;
+  size_t i = 0;
+  CHK(run_conv(c, S[i++], vin, nullptr, s1a, r1, st));            // C_1
+  CHK(run_conv(c, S[i++], s1a, nullptr, s1b, r1, st));            // HC_2
+  CHK(run_conv(c, S[i++], s1b, nullptr, s1a, r1, st));            // HC_3
+  CHK(run_conv(c, S[i++], s1a, nullptr, s2a, r1, st, 0, nullptr, 2, 0));   // D_4 even rows
+  CHK(run_conv(c, S[i++], s1a, nullptr, s2a, r1, st, 0, nullptr, 2, 1));   // D_4 odd rows
+  CHK(run_conv(c, S[i++], s2a, nullptr, s2b, r2, st));            // HC_5
+  CHK(run_conv(c, S[i++], s2b, nullptr, s2a, r2, st));            // HC_6
+  CHK(run_conv(c, S[i++], s2a, nullptr, s4a, r2, st, 0, nullptr, 2, 0));   // D_7
+  CHK(run_conv(c, S[i++], s2a, nullptr, s4a, r2, st, 0, nullptr, 2, 1));
+  CHK(run_conv(c, S[i++], s4a, nullptr, s4b, r4, st));            // HC_8
+  CHK(run_conv(c, S[i++], s4b, nullptr, s4a, r4, st));            // HC_9
+  CHK(run_conv(c, S[i++], s4a, nullptr, w4a, r4, st));            // C_10
+  CHK(run_conv(c, S[i++], w4a, nullptr, w4b, r4, st));            // HC_11
+  CHK(run_conv(c, S[i++], w4b, nullptr, w4a, r4, st));            // HC_12
+  CHK(run_conv(c, S[i++], w4a, nullptr, z4a, r4, st, Fp));        // C_13 (pad columns written as 0)
+  CHK(run_conv(c, S[i++], z4a, nullptr, z4b, r4, st, Fp));        // C_14
+  CHK(run_conv(c, S[i++], z4b, nullptr, z4a, r4, st, Fp));        // C_15
+  CHK(run_conv(c, S[i++], z4a, nullptr, vz, r4, st, 0, logits ? &vlog : nullptr));   // C_16 + sigmoid
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)
+struct DecodeWs {
+  View kv, ypad, rbuf, logits; std::vector<View> ae, ad; int* pm_all; int* step;
+};
+
+static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
+  const std::string g = geom("dec", B, T, N);
+  if (g != c->ws_geom_dec) {
+    (void)hipDeviceSynchronize(); drop_ws_prefix(c, "dec."); c->ws_geom_dec = g;
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  }
+  const int d = c->cfg.d, nm = c->cfg.n_mels;
+  // ypad row (PAD + t) holds S[t] = Y[t-1]  (train.py:51); row PAD is the zero frame fed at t = 0
+  CHK(ws_view(c, "dec.ypad", B, PAD + T + 1, PAD, nm, &w->ypad));
+  CHK(ws_view(c, "dec.rbuf", B, PAD + T, PAD, 2 * d, &w->rbuf));
+  CHK(ws_view(c, "dec.logits", B, T, 0, nm, &w->logits));
+  w->ae.resize(c->audioenc.size()); w->ad.resize(c->audiodec.size());
+  for (size_t i = 0; i < w->ae.size(); ++i) CHK(ws_view(c, "dec.ae" + std::to_string(i), B, PAD + T, PAD, d, &w->ae[i]));
+  for (size_t i = 0; i + 1 < w->ad.size(); ++i) CHK(ws_view(c, "dec.ad" + std::to_string(i), B, PAD + T, PAD, d, &w->ad[i]));
+  void* p;
+  CHK(ws_get(c, "dec.pm", (size_t)(T + 1) * B * sizeof(int), &p)); w->pm_all = (int*)p;
+  CHK(ws_get(c, "dec.step", 64, &p)); w->step = (int*)p;
+  return 0;
+}
+
+static int decode_step_launch(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t st) {
+  const int d = c->cfg.d;
+  // AudioEnc: one new row per utterance, taps read the per-layer history
+  const RowMap r1{B, 1, nullptr, w.step};
+  View cur = w.ypad;
+  for (size_t i = 0; i < c->audioenc.size(); ++i) { CHK(run_conv(c, c->audioenc[i], cur, nullptr, w.ae[i], r1, st)); cur = w.ae[i]; }
+  // windowed attention for the rows AudioDec C_1 must emit, with the CURRENT window
+  AttnWinParams a;
+  a.Qh = w.ae.back().p; a.q_bstride = w.ae.back().bstride; a.q_row0 = w.ae.back().row0; a.q_stride = d;
+  a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N;
+  a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
+  a.step = w.step; a.offs = c->cone_dev[0]; a.R = c->cone_len[0];
+  a.pm_all = w.pm_all; a.B = B;
+  a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0;
+  hipLaunchKernelGGL(attention_window_kernel, dim3((a.R + 3) / 4, B), dim3(256), 0, st, a);
+  HIPCHK(hipGetLastError());
+  // AudioDec dependency cone
+  cur = w.rbuf;
+  const size_t nl = c->audiodec.size();
+  for (size_t i = 0; i < nl; ++i) {
+    const RowMap rm{B, c->cone_len[i], c->cone_dev[i], w.step};
+    if (i + 1 == nl) {
+      // sigmoid(logits) of frame j becomes S[j+1]: write at ypad row (PAD + 1 + j); raw logits kept per frame
+      View yo = w.ypad; yo.row0 = w.ypad.row0 + 1;
+      CHK(run_conv(c, c->audiodec[i], cur, nullptr, yo, rm, st, 0, &w.logits));
+    } else {
+      CHK(run_conv(c, c->audiodec[i], cur, nullptr, w.ad[i], rm, st));
+      cur = w.ad[i];
+    }
+  }
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, st, w.step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, hipStream_t st) {
+  if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
+  DecodeWs w;
+  CHK(decode_ws(c, B, N, T, &w));
+  CHK(textenc_into(c, L, B, N, &w.kv, st));
+  HIPCHK(hipMemsetAsync(w.step, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.pm_all, 0, (size_t)B * sizeof(int), st));      // prev_max_attentions = zeros (synthesize.py:46)
+  if (c->use_graph) {
+    const std::string g = geom("graph", B, T, N);
+    if (!c->graph_exec || c->graph_geom != g) {
+      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+      if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+      hipStream_t cs;
+      HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+      const int prof_keep = c->prof_id; c->prof_id = -1;
+      int rc = decode_step_launch(c, w, B, N, cs);
+      c->prof_id = prof_keep;
+      hipError_t e = hipStreamEndCapture(cs, &c->graph);
+      if (rc != 0) { (void)hipStreamDestroy(cs); return rc; }
+      HIPCHK(e);
+      HIPCHK(hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+      HIPCHK(hipStreamDestroy(cs));
+      c->graph_geom = g;
+    }
+    for (int j = 0; j < T; ++j) HIPCHK(hipGraphLaunch(c->graph_exec, st));
+  } else {
+    for (int j = 0; j < T; ++j) CHK(decode_step_launch(c, w, B, N, st));
+  }
+  const int nm = c->cfg.n_mels;
+  HIPCHK(hipMemcpy2DAsync(Y, (size_t)T * nm * sizeof(float), w.ypad.p + (w.ypad.row0 + 1) * nm,
+                          (size_t)w.ypad.bstride * nm * sizeof(float), (size_t)T * nm * sizeof(float), B,
+                          hipMemcpyDeviceToDevice, st));
+  if (maxatt) {
+    hipLaunchKernelGGL(traj_to_i64_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, w.pm_all, (long long*)maxatt, B, T);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, void* stream) {
+  CHK(check_ready(c));
+  if (!L || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "decode: bad argument");
+  return decode_impl(c, L, B, N, T, Y, maxatt, (hipStream_t)stream);
+}
+
+extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, float* Z, int64_t* maxatt, void* stream) {
+  CHK(check_ready(c));
+  if (!L || !Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "synthesize: bad argument");
+  CHK(decode_impl(c, L, B, N, T, Y, maxatt, (hipStream_t)stream));
+  return dctts_ssrn_fwd(c, Y, B, T, nullptr, Z, stream);                  // synthesize.py:57
+}
+
+extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  c->use_graph = enable ? 1 : 0;
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ per-layer test hook
+// Runs ONE device layer of a network on a caller tensor X (B,T,Cin) -> out (B,T',Cout); T' = 2T for a
+// transposed conv (both phases run).  Used by tests/ to compare every kernel shape class with the oracle.
+extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const float* X, int B, int T, float* out, void* stream) {
+  CHK(check_ready(c));
+  if (!net || !X || !out || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "debug_layer: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const std::string n(net);
+  const std::vector<DevLayer>* V = n == "textenc" ? &c->textenc : n == "audioenc" ? &c->audioenc : n == "audiodec" ? &c->audiodec : n == "ssrn" ? &c->ssrn : nullptr;
+  if (!V || index < 0 || index >= (int)V->size()) return fail(DCTTS_ERR_ARG, "debug_layer: unknown net / index");
+  const DevLayer& L = (*V)[index];
+  const RowMap rm{B, T, nullptr, nullptr};
+  if (n == "textenc" && index == 0) {      // embed + C_2: X is really int32 ids (B,T)
+    const View tab{c->embed, 0, 0, c->cfg.e}, vo{out, T, 0, L.cout};
+    return run_conv(c, L, tab, (const int*)X, vo, rm, st);
+  }
+  const int cin_real = (L.cin == round_up(c->cfg.n_linear, 32)) ? c->cfg.n_linear : L.cin;
+  drop_ws_prefix(c, "dbg.");
+  View vi;
+  CHK(ws_view(c, "dbg.in", B, PAD + T + PAD, PAD, L.cin, &vi));
+  for (int b = 0; b < B; ++b)
+    HIPCHK(hipMemcpy2DAsync(vi.p + ((long)b * vi.bstride + PAD) * L.cin, (size_t)L.cin * sizeof(float),
+                            X + (long)b * T * cin_real, (size_t)cin_real * sizeof(float), (size_t)cin_real * sizeof(float), T,
+                            hipMemcpyDeviceToDevice, st));
+  if (L.deconv_phase) {
+    if (L.phase != 0 || index + 1 >= (int)V->size()) return fail(DCTTS_ERR_ARG, "debug_layer: give the even phase of a D layer");
+    const View vo{out, 2L * T, 0, L.cout};
+    CHK(run_conv(c, L, vi, nullptr, vo, rm, st, 0, nullptr, 2, 0));
+    return run_conv(c, (*V)[index + 1], vi, nullptr, vo, rm, st, 0, nullptr, 2, 1);
+  }
+  const View vo{out, T, 0, L.cout};
+  return run_conv(c, L, vi, nullptr, vo, rm, st);
+}
+
+// ------------------------------------------------------------------------------------------------ profiling aid
+extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  c->prof_id = kernel_id;
+  return 0;
+}
+
+extern "C" int dctts_prof_collect(dctts_ctx* c, int* launches, double* total_ms) {
+  if (!c || !launches || !total_ms) return fail(DCTTS_ERR_ARG, "null argument");
+  double tot = 0; int n = 0;
+  for (auto& e : c->prof_ev) {
+    HIPCHK(hipEventSynchronize(e.second));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+    tot += ms; ++n;
+    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+  }
+  c->prof_ev.clear();
+  *launches = n; *total_ms = tot;
+  return 0;
+}

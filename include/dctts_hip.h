@@ -1,0 +1,111 @@
+/* dctts_hip.h -- C ABI of the MI355X-native DC-TTS synthesis path (libdctts_hip.so).
+ *
+ * The reference (Kyubyong/dc_tts) has no FFI / plugin registry; the seam it offers is the Python
+ * function surface of networks.py, called from train.py:55,58,64,68,77 and driven by
+ * synthesize.py:47-57.  Each entry point below replaces one of those call sites and is what a
+ * binding (ctypes / cgo / JNI) would target; the Python host layer dc_tts_amd/networks.py is one
+ * such binding and mirrors the reference's names and argument order.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer on the context's GPU unless it says "host";
+ *   - tensors are channel-last, contiguous: (B, time, C) float32; ids/indices int32 in,
+ *     max_attentions int64 out (tf.argmax default), exactly as the reference graph;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are stream-ordered
+ *     and never synchronise the device, except where noted (weight upload, workspace growth);
+ *   - return value 0 = ok, negative = dctts_status; nothing throws across the ABI;
+ *   - only training=False (inference) semantics exist: dropout (modules.py:139,195,245) is identity.
+ */
+#ifndef DCTTS_HIP_H
+#define DCTTS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dctts_ctx dctts_ctx;
+
+typedef enum {
+  DCTTS_OK = 0,
+  DCTTS_ERR_ARG = -1,       /* bad pointer / shape / mode (the reference would raise from TF) */
+  DCTTS_ERR_HIP = -2,       /* a HIP runtime call failed: see dctts_last_error() */
+  DCTTS_ERR_WEIGHTS = -3,   /* missing / mis-shaped variable, or weights not finalized */
+  DCTTS_ERR_STATE = -4
+} dctts_status;
+
+/* hyperparams.py:19,14,29-32,38-39 -- the constants the kernels are specialised on */
+typedef struct {
+  int vocab_size;   /* len(hp.vocab) = 32 */
+  int e;            /* 128 */
+  int d;            /* 256 */
+  int c;            /* 512 */
+  int n_mels;       /* 80 */
+  int n_linear;     /* 1 + n_fft/2 = 1025 */
+  int max_N;        /* 180 */
+  int attention_win_size; /* 3 */
+} dctts_config;
+
+/* Lifetime.  One context per (process, GPU); re-entrant per context. */
+int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg);
+int dctts_destroy(dctts_ctx* ctx);
+const char* dctts_last_error(void);
+
+/* Weights: replaces the implicit tf.get_variable / tf.layers variables restored by name in
+ * synthesize.py:32-40.  `name` is the TF variable name, e.g.
+ * "Text2Mel/AudioEnc/HC_7/conv1d/kernel"; `data` is a HOST float32 array in TF layout
+ * (conv kernel (k,Cin,Cout); conv2d_transpose kernel (1,k,Cout,Cin)).  finalize packs every
+ * kernel into MFMA fragment order and uploads (synchronises the device). */
+int dctts_weights_set(dctts_ctx* ctx, const char* name, const float* data, const int64_t* shape, int ndim);
+int dctts_weights_finalize(dctts_ctx* ctx);
+
+/* networks.py:14  TextEnc(L) -> (K, V).  L (B,N) int32; K,V (B,N,d). */
+int dctts_textenc_fwd(dctts_ctx* ctx, const int32_t* L, int B, int N, float* K, float* V, void* stream);
+/* networks.py:73  AudioEnc(S) -> Q.  S (B,T,n_mels); Q (B,T,d).  Causal. */
+int dctts_audioenc_fwd(dctts_ctx* ctx, const float* S, int B, int T, float* Q, void* stream);
+/* networks.py:126 Attention(Q,K,V,mononotic_attention,prev_max_attentions) -> (R, alignments, max_attentions).
+ * Q (B,T,d); K,V (B,N,d); prev_max (B,) int32 (required iff monotonic); R (B,T,2d);
+ * alignments (B,N,T) or NULL; max_attentions (B,T) int64 or NULL.  Monotonic mode requires
+ * N == max_N (the mask is built from hp.max_N, networks.py:142-143). */
+int dctts_attention_fwd(dctts_ctx* ctx, const float* Q, const float* K, const float* V, int B, int T, int N,
+                        int monotonic, const int32_t* prev_max, float* R, float* alignments,
+                        int64_t* max_attentions, void* stream);
+/* networks.py:157 AudioDec(R) -> (logits, Y).  R (B,T,2d); logits,Y (B,T,n_mels). */
+int dctts_audiodec_fwd(dctts_ctx* ctx, const float* R, int B, int T, float* logits, float* Y, void* stream);
+/* networks.py:214 SSRN(Y) -> (logits, Z).  Y (B,T,n_mels); logits,Z (B,4T,n_linear); logits may be NULL. */
+int dctts_ssrn_fwd(dctts_ctx* ctx, const float* Y, int B, int T, float* logits, float* Z, void* stream);
+
+/* synthesize.py:45-54: the autoregressive Text2Mel loop for max_T = T steps, as an incremental
+ * decoder that is arithmetically the reference's full-recompute loop (TextEnc once, AudioEnc
+ * incrementally, windowed attention + the 85-row AudioDec dependency cone re-evaluated with the
+ * current window at every step).  L (B,N) int32, N == max_N.  Y (B,T,n_mels) out;
+ * max_attentions (B,T) int64 out or NULL (column j = the value fed back as prev_max at step j+1). */
+int dctts_text2mel_decode(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y,
+                          int64_t* max_attentions, void* stream);
+/* synthesize.py:45-57: decode + one SSRN pass.  Z (B,4T,n_linear). */
+int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y, float* Z,
+                     int64_t* max_attentions, void* stream);
+
+/* Decode launch mode: 0 = one kernel launch per layer per step (eager), 1 = one hipGraph replay per step. */
+int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
+
+/* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
+size_t dctts_device_bytes(const dctts_ctx* ctx);
+
+/* Test hook: run ONE device layer of a network ("textenc" | "audioenc" | "audiodec" | "ssrn") on a caller
+ * tensor X (B,T,Cin) -> out (B,T',Cout) (T' = 2T for a transposed conv, index = its even phase;
+ * "textenc" index 0 = embed + C_2 and takes int32 ids).  Layer order = networks.py source order, with
+ * each D layer occupying two consecutive indices.  Synchronises (allocates a scratch copy of X). */
+int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X, int B, int T, float* out, void* stream);
+
+/* Measurement aid for bench.py's roofline object: HIP events are recorded on the launch stream
+ * around every launch of the conv kernel instantiation `kernel_id` = epi*10000 + NT*100 + NW
+ * (epi 0 = C, 1 = HC) while enabled.  collect() synchronises those events, returns the number of
+ * launches and their summed duration, and clears the list. */
+int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);
+int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTTS_HIP_H */

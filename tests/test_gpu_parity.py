@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Tolerance: BASELINE.json's north_star asks for mel / linear spectrograms within 1e-3 max-abs fp32 of the
+reference; the oracle is the reference restatement.  Integer outputs (attention trajectory) must be exact.
+Run on the GPU box with  python -m pytest tests -m gpu.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dc_tts_amd.hyperparams import hp
+from dc_tts_amd.layers import audiodec_layers, audioenc_layers, ssrn_layers, textenc_layers
+from dc_tts_amd.weights import synthetic_text
+from oracle import dctts_ref as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3          # north_star: max-abs fp32 on the (sigmoid) spectrogram outputs
+TOL_INNER = 2e-3    # un-squashed intermediate activations (|x| up to ~5): same relative class
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+_engines = {}
+
+
+def engine_for(weights, max_T=hp.max_T):
+    from dc_tts_amd.engine import Engine
+    if max_T not in _engines:
+        _engines[max_T] = Engine(weights, hp.replace(max_T=max_T))
+    return _engines[max_T]
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max())
+
+
+def test_native_library_is_loaded(weights):
+    """The product path runs in libdctts_hip.so, not in a torch fallback."""
+    eng = engine_for(weights)
+    assert eng.lib._name.endswith("dc_tts_amd/lib/libdctts_hip.so")
+    with open("/proc/self/maps") as f:
+        assert "libdctts_hip.so" in f.read()
+    assert eng.device_bytes() > 200e6        # 209.5 MB of fp32 weights packed on the device
+
+
+# ---------------------------------------------------------------- every kernel shape class, one layer at a time
+def _dev_index(layers, li, net):
+    """logical layer index -> device layer index (textenc: embed is fused into C_2; ssrn: D = 2 entries)."""
+    if net == "textenc":
+        return li - 1
+    if net == "ssrn":
+        return li + sum(1 for l in layers[:li] if l.kind == "D")
+    return li
+
+
+CASES = []
+for net, fn, scope, causal in (("textenc", textenc_layers, "Text2Mel/TextEnc", False), ("audioenc", audioenc_layers, "Text2Mel/AudioEnc", True),
+                               ("audiodec", audiodec_layers, "Text2Mel/AudioDec", True), ("ssrn", ssrn_layers, "SSRN", False)):
+    seen = set()
+    for li, l in enumerate(fn(hp)):
+        key = (l.kind, l.cin, l.cout, l.size, l.rate, l.act)
+        if l.kind == "E" or key in seen:
+            continue
+        seen.add(key)
+        CASES.append(pytest.param(net, scope, causal, li, id=f"{net}-{l.scope}-{l.kind}{l.cin}to{l.cout}k{l.size}d{l.rate}"))
+
+
+@pytest.mark.parametrize("net,scope,causal,li", CASES)
+def test_layer_vs_oracle(weights, net, scope, causal, li):
+    fn = {"textenc": textenc_layers, "audioenc": audioenc_layers, "audiodec": audiodec_layers, "ssrn": ssrn_layers}[net]
+    layers = fn(hp)
+    l = layers[li]
+    eng = engine_for(weights)
+    rng = np.random.default_rng(100 + li)
+    B, T = 2, 75                                   # 150 rows: 4 full 32-row tiles + a ragged one
+    P = O._Scoped(weights, scope, np.float32)
+    pad = "CAUSAL" if causal else "SAME"
+    di = _dev_index(layers, li, net)
+    if net == "textenc" and li == 1:               # embed + C_2 fused
+        ids = rng.integers(0, len(hp.vocab), (B, T)).astype(np.int32)
+        ref = O.conv1d(O.embed(ids, P["embed_1/lookup_table"]), P, "C_2", act=O.relu)
+        got = eng.debug_layer(net, 0, dev(ids), l.cout).cpu().numpy()
+    else:
+        x = rng.standard_normal((B, T, l.cin)).astype(np.float32)
+        if l.kind == "C":
+            ref = O.conv1d(x, P, l.scope, padding=pad, act=O.relu if l.act == "relu" else None)
+            got = eng.debug_layer(net, di, dev(x), l.cout).cpu().numpy()
+        elif l.kind == "HC":
+            ref = O.hc(x, P, l.scope, rate=l.rate, padding=pad)
+            got = eng.debug_layer(net, di, dev(x), l.cout).cpu().numpy()
+        else:
+            ref = O.conv1d_transpose(x, P, l.scope)
+            got = eng.debug_layer(net, di, dev(x), l.cout, upsample=2).cpu().numpy()
+    # the last layer of AudioDec / SSRN carries the network's sigmoid in its epilogue
+    if (net == "audiodec" and li == len(layers) - 1) or (net == "ssrn" and li == len(layers) - 1):
+        ref = O.sigmoid(ref)
+    assert got.shape == ref.shape
+    err = maxabs(got, ref)
+    assert err < 2e-4, f"{net}/{l.scope}: max-abs {err}"
+
+
+# ---------------------------------------------------------------- network functions (the drop-in boundary)
+def test_textenc(weights):
+    eng = engine_for(weights)
+    L = synthetic_text(hp, B=3, seed=5)
+    K, V = eng.text_enc(dev(L))
+    Kr, Vr = O.TextEnc(L, weights, hp)
+    assert maxabs(K.cpu().numpy(), Kr) < TOL_INNER and maxabs(V.cpu().numpy(), Vr) < TOL_INNER
+
+
+def test_audioenc_and_causality(weights):
+    eng = engine_for(weights)
+    rng = np.random.default_rng(6)
+    S = rng.random((2, 70, hp.n_mels), dtype=np.float32)
+    Q = eng.audio_enc(dev(S)).cpu().numpy()
+    assert maxabs(Q, O.AudioEnc(S, weights, hp)) < TOL_INNER
+    S2 = S.copy(); S2[:, 40:] = rng.random((2, 30, hp.n_mels), dtype=np.float32)
+    Q2 = eng.audio_enc(dev(S2)).cpu().numpy()
+    np.testing.assert_array_equal(Q[:, :40], Q2[:, :40])          # bit-identical prefix: causal
+
+
+@pytest.mark.parametrize("mono", [True, False])
+def test_attention(weights, mono):
+    T = 40
+    eng = engine_for(weights, max_T=T)
+    h = hp.replace(max_T=T)
+    rng = np.random.default_rng(7)
+    Q = rng.standard_normal((3, T, h.d)).astype(np.float32)
+    K = rng.standard_normal((3, h.max_N, h.d)).astype(np.float32)
+    V = rng.standard_normal((3, h.max_N, h.d)).astype(np.float32)
+    pm = np.array([0, 57, 178], np.int32)
+    R, al, mx = eng.attention(dev(Q), dev(K), dev(V), mono, dev(pm) if mono else None)
+    Rr, alr, mxr = O.Attention(Q, K, V, h, mono, pm if mono else None)
+    assert mx.dtype == torch.int64 and tuple(al.shape) == (3, h.max_N, T)
+    np.testing.assert_array_equal(mx.cpu().numpy(), mxr)
+    assert maxabs(R.cpu().numpy(), Rr) < 1e-4 and maxabs(al.cpu().numpy(), alr) < 1e-5
+    if mono:
+        a = al.cpu().numpy()
+        assert np.all(a[1, :57] == 0) and np.all(a[1, 60:] == 0)   # exact zeros outside the window
+
+
+def test_attention_errors(weights):
+    eng = engine_for(weights, max_T=40)
+    Q = torch.zeros(1, 40, hp.d, device="cuda"); K = torch.zeros(1, 100, hp.d, device="cuda")
+    with pytest.raises(ValueError):            # monotonic mask is built from hp.max_N (networks.py:142)
+        eng.attention(Q, K, K, True, torch.zeros(1, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.attention(Q, K, K, True, None)
+    from dc_tts_amd import networks
+    networks.bind(eng)
+    with pytest.raises(NotImplementedError):
+        networks.AudioEnc(torch.zeros(1, 4, hp.n_mels, device="cuda"))          # training=True default
+
+
+def test_audiodec(weights):
+    eng = engine_for(weights)
+    rng = np.random.default_rng(8)
+    R = rng.standard_normal((2, 100, 2 * hp.d)).astype(np.float32)
+    lg, Y = eng.audio_dec(dev(R))
+    lgr, Yr = O.AudioDec(R, weights, hp)
+    assert maxabs(Y.cpu().numpy(), Yr) < TOL and maxabs(lg.cpu().numpy(), lgr) < TOL_INNER
+
+
+def test_ssrn(weights):
+    eng = engine_for(weights)
+    rng = np.random.default_rng(9)
+    Y = rng.random((2, 37, hp.n_mels), dtype=np.float32)          # odd length: ragged tiles at T, 2T and 4T
+    lg, Z = eng.ssrn(dev(Y))
+    lgr, Zr = O.SSRN(Y, weights, hp)
+    assert tuple(Z.shape) == (2, 148, hp.n_linear)
+    assert maxabs(Z.cpu().numpy(), Zr) < TOL and maxabs(lg.cpu().numpy(), lgr) < 5e-3
+
+
+def test_networks_surface_and_golden(weights):
+    """The reference-named functions on the committed golden inputs (tests/golden/networks_seed1234.npz)."""
+    from dc_tts_amd import networks
+    g = np.load(os.path.join(GOLD, "networks_seed1234.npz"))
+    T = g["S"].shape[1]
+    networks.bind(engine_for(weights, max_T=T))
+    K, V = networks.TextEnc(dev(g["L"]), training=False)
+    Q = networks.AudioEnc(dev(g["S"]), training=False)
+    R, al, mx = networks.Attention(Q, K, V, mononotic_attention=True, prev_max_attentions=dev(g["prev_max"]))
+    lg, Y = networks.AudioDec(R, training=False)
+    zl, Z = networks.SSRN(Y[:, :8].contiguous(), training=False)
+    assert maxabs(K.cpu().numpy()[:, ::9, ::8], g["K_sub"]) < TOL_INNER
+    assert maxabs(Q.cpu().numpy()[:, ::3, ::4], g["Q_sub"]) < TOL_INNER
+    np.testing.assert_array_equal(mx.cpu().numpy(), g["max_att"])
+    assert maxabs(Y.cpu().numpy(), g["Y"]) < TOL
+    assert maxabs(Z.cpu().numpy()[:, :, ::16], g["Z_sub"]) < TOL
+
+
+# ---------------------------------------------------------------- the autoregressive loop
+@pytest.mark.parametrize("graph", [False, True])
+def test_decode_vs_oracle_loop(weights, graph):
+    """Incremental exact decode == restated synthesize.py loop: integer-exact attention trajectory, Y within 1e-3.
+    T = 100 > 85 so the full AudioDec dependency cone is exercised."""
+    T = 100
+    eng = engine_for(weights, max_T=T)
+    eng.set_decode_graph(graph)
+    h = hp.replace(max_T=T)
+    L = synthetic_text(h, B=3, seed=21)
+    Y, mx = eng.text2mel(dev(L))
+    Yr, _, trajr = O.synthesize(L, weights, h, np.float32, run_ssrn=False)
+    np.testing.assert_array_equal(mx.cpu().numpy(), trajr)
+    err = maxabs(Y.cpu().numpy(), Yr)
+    assert err < TOL, f"decode max-abs {err}"
+    assert trajr.max() > 10
+
+
+def test_decode_golden_config1(weights):
+    """Config 1 of BASELINE.json (Harvard sentence 1) against the committed fixture."""
+    g = np.load(os.path.join(GOLD, "config1_harvard1.npz"))
+    T = int(g["max_T"])
+    eng = engine_for(weights, max_T=T)
+    Y, mx = eng.text2mel(dev(g["L"]))
+    np.testing.assert_array_equal(mx.cpu().numpy(), g["traj"])
+    assert maxabs(Y.cpu().numpy(), g["Y"]) < TOL
+
+
+def test_reference_loop_driver_equals_fast_path(weights):
+    """synthesize.py's literal loop on the drop-in network functions == the one-call incremental decoder."""
+    from dc_tts_amd.synthesize import synthesize, synthesize_reference_loop
+    T = 90
+    eng = engine_for(weights, max_T=T)
+    L = dev(synthetic_text(hp.replace(max_T=T), B=2, seed=33))
+    Y1, Z1, t1 = synthesize(L, eng)
+    Y2, Z2, t2 = synthesize_reference_loop(L, eng)
+    assert torch.equal(t1, t2)
+    assert float((Y1 - Y2).abs().max()) < 1e-4 and float((Z1 - Z2).abs().max()) < 1e-3
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE configs[1], [3])
+def test_full_size_properties(weights):
+    """B=32, N=180, T=210 (configs[1]/[3] shard): determinism, shard independence, monotone attention, ranges,
+    and oracle agreement on two of the utterances."""
+    eng = engine_for(weights)
+    eng.set_decode_graph(True)
+    Lh = synthetic_text(hp, B=32, seed=1234)
+    L = dev(Lh)
+    Y, Z, mx = eng.synthesize(L)
+    Y2, Z2, mx2 = eng.synthesize(L)
+    assert torch.equal(Y, Y2) and torch.equal(Z, Z2) and torch.equal(mx, mx2)          # run-to-run bitwise
+    Ya, Za, mxa = eng.synthesize(L[:16].contiguous())
+    Yb, Zb, mxb = eng.synthesize(L[16:].contiguous())
+    assert torch.equal(torch.cat((Ya, Yb)), Y) and torch.equal(torch.cat((Za, Zb)), Z)  # shards == whole batch, bitwise
+    m = mx.cpu().numpy()
+    dm = np.diff(m, axis=1)
+    assert m.min() >= 0 and m.max() < hp.max_N and dm.min() >= 0 and dm.max() <= hp.attention_win_size - 1
+    assert tuple(Z.shape) == (32, 4 * hp.max_T, hp.n_linear)
+    z = Z.cpu().numpy()
+    assert np.isfinite(z).all() and z.min() >= 0 and z.max() <= 1
+    Yr, Zr, trajr = O.synthesize(Lh[:2], weights, hp, np.float32)
+    np.testing.assert_array_equal(m[:2], trajr)
+    assert maxabs(Y[:2].cpu().numpy(), Yr) < TOL and maxabs(z[:2], Zr) < TOL
+
+
+def test_long_form_shape(weights):
+    """configs[4] shape class: max_T = 1000 (one GPU's share, B = 8); cone / history indexing far beyond 210."""
+    T = 1000
+    eng = engine_for(weights, max_T=T)
+    eng.set_decode_graph(True)
+    L = dev(synthetic_text(hp, B=8, seed=77))
+    Y, mx = eng.text2mel(L)
+    Y2, mx2 = eng.text2mel(L)
+    assert torch.equal(Y, Y2) and torch.equal(mx, mx2)
+    m = mx.cpu().numpy()
+    assert (np.diff(m, axis=1) >= 0).all() and m.max() < hp.max_N
+    y = Y.cpu().numpy()
+    assert np.isfinite(y).all() and y.min() >= 0 and y.max() <= 1
+    # prefix property of a causal autoregressive decoder: the first 210 frames equal the T=210 run
+    e2 = engine_for(weights)
+    Ys, _ = e2.text2mel(L)
+    assert torch.equal(Ys, Y[:, :hp.max_T])
