@@ -53,6 +53,9 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  dc_tts_amd has no CPU or PyTorch fallback path.")
+    # torch ships its own libamdhip64; it must be the ONE HIP runtime in the process (loading /opt/rocm's copy
+    # first gives this library a second runtime that sees no device), so import torch before dlopen.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)          # AttributeError here = header / library out of sync
