@@ -35,6 +35,7 @@ SYMBOLS = {
     "dctts_text2mel_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dctts_synthesize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dctts_set_decode_graph": (c_int, [c_void_p, c_int]),
+    "dctts_set_decode_mode": (c_int, [c_void_p, c_int]),
     "dctts_device_bytes": (c_size_t, [c_void_p]),
     "dctts_debug_layer": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dctts_prof_enable": (c_int, [c_void_p, c_int]),

@@ -13,6 +13,7 @@
 
 #include "../../include/dctts_hip.h"
 #include "attn_kernels.h"
+#include "decode_kernels.h"
 #include "hconv_kernel.h"
 
 using namespace dctts;
@@ -61,6 +62,8 @@ struct DevLayer {
   int ntaps = 1, cin = 0, cin_p = 0, tap_off[3] = {0, 0, 0}, cout = 0, act = ACT_NONE;
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
+  float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
+  bool hc = false;
 };
 
 struct View {            // a (B, rows, stride) activation buffer; row0 = index of t = 0 inside a batch item
@@ -82,6 +85,9 @@ struct dctts_ctx {
   std::map<std::string, Buf> ws;       // named workspaces; key includes the geometry
   std::string ws_geom_textenc, ws_geom_t2m, ws_geom_dec, ws_geom_ssrn;
   int use_graph = 0;
+  int decode_mode = 1;                 // 0 = v1 (fused kernels, one stream), 1 = v2 (split kernels, chain + bulk branches)
+  hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  std::vector<int> cone_host_len;
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;
   // profiling
   int prof_id = -1;
@@ -108,28 +114,34 @@ static int upload(dctts_ctx* c, const std::vector<float>& h, float** d) {
   return 0;
 }
 
-// Pack W(tap, c, col) into MFMA fragment order: [tile][kgroup][lane][4],
-// lane l, element i  <-  k = 8*kg + 4*(l>>5) + i,  column of tile / (l&31)   (hconv_kernel.h).
-static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p,
-                                 const ConvShape& s, int cout, bool hc) {
-  const int tiles = s.nt * s.nw, KG = ntaps * cin_p / 8;
+// Pack W(tap, c, col) into MFMA fragment order: [tile][kgroup][lane][4].
+//   MF = 32 (v_mfma_f32_32x32x2_f32): lane l, element i <- k = 8*kg + 4*(l>>5) + i, column l&31 of the tile
+//   MF = 16 (v_mfma_f32_16x16x4_f32): lane l, element i <- k = 16*kg + 4*(l>>4) + i, column l&15 of the tile
+// Tiles of a highway layer alternate gate (H1) / info (H2) blocks of the same MF channels.
+static std::vector<float> pack_bw(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p,
+                                  int tiles, int cout, bool hc, int MF) {
+  const int KGS = (MF == 32) ? 8 : 16, KG = ntaps * cin_p / KGS, sh = (MF == 32) ? 5 : 4;
   std::vector<float> out((size_t)tiles * KG * 256, 0.f);
   for (int gt = 0; gt < tiles; ++gt)
     for (int kg = 0; kg < KG; ++kg)
       for (int l = 0; l < 64; ++l) {
         int col;
-        if (hc) { const int ch = (gt / 2) * 32 + (l & 31); col = ch < cout ? (gt & 1) * cout + ch : -1; }
-        else    { const int ch = gt * 32 + (l & 31);       col = ch < cout ? ch : -1; }
+        if (hc) { const int ch = (gt / 2) * MF + (l & (MF - 1)); col = ch < cout ? (gt & 1) * cout + ch : -1; }
+        else    { const int ch = gt * MF + (l & (MF - 1));       col = ch < cout ? ch : -1; }
         if (col < 0) continue;
         for (int i = 0; i < 4; ++i) {
-          const int k = kg * 8 + 4 * (l >> 5) + i, tap = k / cin_p, cc = k % cin_p;
+          const int k = kg * KGS + 4 * (l >> sh) + i, tap = k / cin_p, cc = k % cin_p;
           if (cc < cin_real) out[(((size_t)gt * KG + kg) * 64 + l) * 4 + i] = W(tap, cc, col);
         }
       }
   return out;
 }
+static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p,
+                                 const ConvShape& s, int cout, bool hc) {
+  return pack_bw(W, ntaps, cin_real, cin_p, s.nt * s.nw, cout, hc, 32);
+}
 
-static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L) {
+static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L, bool dec = false) {
   const HostTensor *k, *b, *be, *ga;
   CHK(get_w(c, scope + "/conv1d/kernel", {1, cin_real, cout}, &k));
   CHK(get_w(c, scope + "/conv1d/bias", {cout}, &b));
@@ -141,11 +153,12 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
   const float* kv = k->v.data();
   auto W = [=](int, int cc, int col) { return kv[(size_t)cc * cout + col]; };
   CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
+  if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 31) / 32), cout, false, 16), &L->wp16));
   CHK(upload(c, b->v, &L->bias)); CHK(upload(c, ga->v, &L->g1)); CHK(upload(c, be->v, &L->b1));
   return 0;
 }
 
-static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rate, bool causal, DevLayer* L) {
+static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rate, bool causal, DevLayer* L, bool dec = false) {
   const HostTensor *kw, *b, *b1, *g1, *b2, *g2;
   CHK(get_w(c, scope + "/conv1d/kernel", {k, C, 2 * C}, &kw));
   CHK(get_w(c, scope + "/conv1d/bias", {2 * C}, &b));
@@ -162,6 +175,8 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
   const float* kv = kw->v.data();
   auto W = [=](int tap, int cc, int col) { return kv[((size_t)tap * C + cc) * (2 * C) + col]; };
   CHK(upload(c, pack_b(W, k, C, L->cin_p, L->shape, C, true), &L->wp));
+  if (dec) CHK(upload(c, pack_bw(W, k, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16));
+  L->hc = true;
   CHK(upload(c, b->v, &L->bias));
   CHK(upload(c, g1->v, &L->g1)); CHK(upload(c, b1->v, &L->b1));
   CHK(upload(c, g2->v, &L->g2)); CHK(upload(c, b2->v, &L->b2));
@@ -235,6 +250,9 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  if (c->s_bulk) (void)hipStreamDestroy(c->s_bulk);
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
   free_ws(c);
   for (void* p : c->wallocs) (void)hipFree(p);
   for (int* p : c->cone_dev) (void)hipFree(p);
@@ -280,22 +298,22 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
   {
     const std::string s = "Text2Mel/AudioEnc/";
     int i = 1; DevLayer L;
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.n_mels, g.n_mels, d, ACT_RELU, &L)); c->audioenc.push_back(L);
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_RELU, &L)); c->audioenc.push_back(L);
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_NONE, &L)); c->audioenc.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.n_mels, g.n_mels, d, ACT_RELU, &L, true)); c->audioenc.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_RELU, &L, true)); c->audioenc.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_NONE, &L, true)); c->audioenc.push_back(L);
     for (int rep = 0; rep < 2; ++rep) for (int j = 0, r = 1; j < 4; ++j, r *= 3) {
-      snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, r, true, &L)); c->audioenc.push_back(L); }
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, 3, true, &L)); c->audioenc.push_back(L); }
+      snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, r, true, &L, true)); c->audioenc.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, 3, true, &L, true)); c->audioenc.push_back(L); }
   }
   // ---- AudioDec (networks.py:157-212), causal
   {
     const std::string s = "Text2Mel/AudioDec/";
     int i = 1; DevLayer L;
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * d, 2 * d, d, ACT_NONE, &L)); c->audiodec.push_back(L);
-    for (int j = 0, r = 1; j < 4; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, r, true, &L)); c->audiodec.push_back(L); }
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, 1, true, &L)); c->audiodec.push_back(L); }
-    for (int rep = 0; rep < 3; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_RELU, &L)); c->audiodec.push_back(L); }
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, g.n_mels, ACT_SIGMOID, &L)); c->audiodec.push_back(L);
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * d, 2 * d, d, ACT_NONE, &L, true)); c->audiodec.push_back(L);
+    for (int j = 0, r = 1; j < 4; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, r, true, &L, true)); c->audiodec.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, d, 3, 1, true, &L, true)); c->audiodec.push_back(L); }
+    for (int rep = 0; rep < 3; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, d, ACT_RELU, &L, true)); c->audiodec.push_back(L); }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, d, d, g.n_mels, ACT_SIGMOID, &L, true)); c->audiodec.push_back(L);
     auto cone = audiodec_cone(c->audiodec);
     for (auto& v : cone) {
       int* dp = nullptr;
@@ -535,6 +553,7 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
 // ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)
 struct DecodeWs {
   View kv, ypad, rbuf, logits; std::vector<View> ae, ad; int* pm_all; int* step;
+  std::vector<float*> pe, pd, pb;      // pre-norm rows: AudioEnc chain [B][np], AudioDec chain [B][np], AudioDec bulk [B*Rb][np]
 };
 
 static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
@@ -550,9 +569,18 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
   CHK(ws_view(c, "dec.rbuf", B, PAD + T, PAD, 2 * d, &w->rbuf));
   CHK(ws_view(c, "dec.logits", B, T, 0, nm, &w->logits));
   w->ae.resize(c->audioenc.size()); w->ad.resize(c->audiodec.size());
+  void* p;
   for (size_t i = 0; i < w->ae.size(); ++i) CHK(ws_view(c, "dec.ae" + std::to_string(i), B, PAD + T, PAD, d, &w->ae[i]));
   for (size_t i = 0; i + 1 < w->ad.size(); ++i) CHK(ws_view(c, "dec.ad" + std::to_string(i), B, PAD + T, PAD, d, &w->ad[i]));
-  void* p;
+  w->pe.resize(c->audioenc.size()); w->pd.resize(c->audiodec.size()); w->pb.resize(c->audiodec.size());
+  for (size_t i = 0; i < w->pe.size(); ++i) { const int np = c->audioenc[i].hc ? 2 * d : c->audioenc[i].cout; CHK(ws_get(c, "dec.pe" + std::to_string(i), (size_t)B * np * sizeof(float), &p)); w->pe[i] = (float*)p; }
+  for (size_t i = 0; i < w->pd.size(); ++i) {
+    const int np = c->audiodec[i].hc ? 2 * d : c->audiodec[i].cout;
+    CHK(ws_get(c, "dec.pd" + std::to_string(i), (size_t)B * np * sizeof(float), &p)); w->pd[i] = (float*)p;
+    const int Rb = c->cone_len[i] - 1;
+    w->pb[i] = nullptr;
+    if (Rb > 0) { CHK(ws_get(c, "dec.pb" + std::to_string(i), (size_t)B * Rb * np * sizeof(float), &p)); w->pb[i] = (float*)p; }
+  }
   CHK(ws_get(c, "dec.pm", (size_t)(T + 1) * B * sizeof(int), &p)); w->pm_all = (int*)p;
   CHK(ws_get(c, "dec.step", 64, &p)); w->step = (int*)p;
   return 0;
@@ -593,15 +621,138 @@ static int decode_step_launch(dctts_ctx* c, const DecodeWs& w, int B, int N, hip
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ decode v2: split kernels, chain + bulk
+static size_t hsplit_smem(int MF, int ntaps, int cin_p) {
+  const size_t a = (size_t)ntaps * MF * (cin_p + 4) * sizeof(float);
+  const size_t r = (size_t)8 * 2 * (MF == 32 ? 16 : 4) * 64 * sizeof(float);
+  return a > r ? a : r;
+}
+
+static RowNorm make_norm(const DevLayer& prod, const float* P, const View* res) {
+  RowNorm n; memset(&n, 0, sizeof(n));
+  n.P = P; n.np = prod.hc ? 2 * prod.cout : prod.cout;
+  n.g1 = prod.g1; n.b1 = prod.b1; n.g2 = prod.g2; n.b2 = prod.b2; n.act = prod.act;
+  if (res) { n.res = res->p; n.res_bstride = res->bstride; n.res_row0 = res->row0; n.res_stride = res->stride; }
+  return n;
+}
+
+// One split GEMM launch.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
+static int run_split(int MF, const DevLayer& L, int B, int R, const int* offs, const int* step, int pro, const RowNorm* nrm,
+                     const View* xmat, const View& xsrc, float* pout, hipStream_t st) {
+  SplitParams p; memset(&p, 0, sizeof(p));
+  p.M = B * R; p.R = R; p.b0 = 0; p.offs = offs; p.step = step;
+  p.pro = pro; if (nrm) p.nrm = *nrm;
+  if (xmat) { p.xmat = xmat->p; p.xm_bstride = xmat->bstride; p.xm_row0 = xmat->row0; p.xm_stride = xmat->stride; }
+  p.xsrc = xsrc.p; p.xs_bstride = xsrc.bstride; p.xs_row0 = xsrc.row0; p.xs_stride = xsrc.stride;
+  p.ntaps = L.ntaps; for (int j = 0; j < 3; ++j) p.tap_off[j] = L.tap_off[j];
+  p.cin = L.cin; p.cin_p = L.cin_p;
+  p.wp = (MF == 16) ? L.wp16 : L.wp; p.bias = L.bias; p.cout = L.cout; p.hc = L.hc ? 1 : 0;
+  p.np_out = L.hc ? 2 * L.cout : L.cout; p.pout = pout;
+  const int groups = L.hc ? L.cout / MF : (L.cout + 2 * MF - 1) / (2 * MF);
+  const dim3 grid((p.M + MF - 1) / MF, groups);
+  const size_t sm = hsplit_smem(MF, L.ntaps, L.cin_p);
+  if (MF == 16) hipLaunchKernelGGL(hsplit_kernel<16>, grid, dim3(512), sm, st, p);
+  else          hipLaunchKernelGGL(hsplit_kernel<32>, grid, dim3(512), sm, st, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int decode_v2_init(dctts_ctx* c) {
+  if (c->s_bulk) return 0;
+  HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  return 0;
+}
+
+static int decode_step_launch_v2(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t sm, hipStream_t sb) {
+  const int d = c->cfg.d;
+  const std::vector<DevLayer>& AE = c->audioenc; const std::vector<DevLayer>& AD = c->audiodec;
+  // ---- fork: the bulk branch (cone rows at offsets < 0) depends only on earlier frames and the current window
+  HIPCHK(hipEventRecord(c->ev_fork, sm));
+  HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
+  {
+    AttnWinParams a;
+    a.Qh = w.ae.back().p; a.q_bstride = w.ae.back().bstride; a.q_row0 = w.ae.back().row0; a.q_stride = d;
+    a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N;
+    a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
+    a.step = w.step; a.offs = c->cone_dev[0] + 1; a.R = c->cone_len[0] - 1;
+    a.pm_all = w.pm_all; a.B = B;
+    a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0;
+    hipLaunchKernelGGL(attention_window_kernel, dim3((a.R + 3) / 4, B), dim3(256), 0, sb, a);
+    HIPCHK(hipGetLastError());
+    for (size_t i = 0; i < AD.size(); ++i) {
+      const int Rb = c->cone_len[i] - 1;
+      if (Rb <= 0) break;
+      const View& src = (i == 0) ? w.rbuf : w.ad[i - 1];
+      CHK(run_split(32, AD[i], B, Rb, c->cone_dev[i] + 1, w.step, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb));
+      LnRowsParams q; memset(&q, 0, sizeof(q));
+      q.M = B * Rb; q.R = Rb; q.b0 = 0; q.offs = c->cone_dev[i] + 1; q.step = w.step; q.hc = AD[i].hc ? 1 : 0;
+      q.nrm = make_norm(AD[i], w.pb[i], AD[i].hc ? &src : nullptr);
+      q.x = w.ad[i].p; q.x_bstride = w.ad[i].bstride; q.x_row0 = w.ad[i].row0; q.x_stride = w.ad[i].stride;
+      hipLaunchKernelGGL(ln_rows_kernel, dim3((q.M + 3) / 4), dim3(256), 0, sb, q);
+      HIPCHK(hipGetLastError());
+    }
+  }
+  HIPCHK(hipEventRecord(c->ev_join, sb));
+  // ---- chain: AudioEnc for the newest frame (13 dependent layers, 16-row x 16-channel workgroups)
+  for (size_t i = 0; i < AE.size(); ++i) {
+    if (i == 0) {
+      CHK(run_split(16, AE[0], B, 1, nullptr, w.step, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm));
+    } else {
+      const RowNorm n = make_norm(AE[i - 1], w.pe[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr);
+      CHK(run_split(16, AE[i], B, 1, nullptr, w.step, AE[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ae[i - 1], w.ae[i - 1], w.pe[i], sm));
+    }
+  }
+  // ---- newest-frame attention: rebuild Q[j], materialise it, 3-key softmax, R[j], arg-max -> next window
+  {
+    AttnRow0Params a; memset(&a, 0, sizeof(a));
+    const size_t la = AE.size() - 1;
+    a.Bg = B; a.b0 = 0; a.B = B; a.step = w.step;
+    a.nrm = make_norm(AE[la], w.pe[la], &w.ae[la - 1]);
+    a.qhist = w.ae[la].p; a.q_bstride = w.ae[la].bstride; a.q_row0 = w.ae[la].row0; a.q_stride = d;
+    a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N; a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
+    a.pm_all = w.pm_all; a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0;
+    hipLaunchKernelGGL(attention_row0_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
+    HIPCHK(hipGetLastError());
+  }
+  // ---- chain: AudioDec row j; its taps at offsets < 0 come from the bulk branch -> join first
+  HIPCHK(hipStreamWaitEvent(sm, c->ev_join, 0));
+  for (size_t i = 0; i < AD.size(); ++i) {
+    if (i == 0) {
+      CHK(run_split(16, AD[0], B, 1, nullptr, w.step, PRO_RAW, nullptr, nullptr, w.rbuf, w.pd[0], sm));
+    } else {
+      const RowNorm n = make_norm(AD[i - 1], w.pd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr);
+      CHK(run_split(16, AD[i], B, 1, nullptr, w.step, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm));
+    }
+  }
+  {
+    const DevLayer& Ll = AD.back();
+    FinalizeParams f; memset(&f, 0, sizeof(f));
+    f.Bg = B; f.b0 = 0; f.step = w.step; f.P = w.pd[AD.size() - 1]; f.np = Ll.cout; f.g = Ll.g1; f.be = Ll.b1; f.n = Ll.cout;
+    f.ypad = w.ypad.p; f.y_bstride = w.ypad.bstride; f.y_row0 = w.ypad.row0 + 1; f.y_stride = w.ypad.stride;
+    f.logits = w.logits.p; f.l_bstride = w.logits.bstride; f.l_stride = w.logits.stride;
+    hipLaunchKernelGGL(finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, f);
+    HIPCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, sm, w.step);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, hipStream_t st) {
   if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
+  if (c->decode_mode == 1) CHK(decode_v2_init(c));
   CHK(textenc_into(c, L, B, N, &w.kv, st));
   HIPCHK(hipMemsetAsync(w.step, 0, sizeof(int), st));
   HIPCHK(hipMemsetAsync(w.pm_all, 0, (size_t)B * sizeof(int), st));      // prev_max_attentions = zeros (synthesize.py:46)
   if (c->use_graph) {
-    const std::string g = geom("graph", B, T, N);
+    const std::string g = geom(c->decode_mode == 1 ? "graph2" : "graph1", B, T, N);
     if (!c->graph_exec || c->graph_geom != g) {
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
@@ -609,7 +760,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
       HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
       const int prof_keep = c->prof_id; c->prof_id = -1;
-      int rc = decode_step_launch(c, w, B, N, cs);
+      int rc = c->decode_mode == 1 ? decode_step_launch_v2(c, w, B, N, cs, c->s_bulk) : decode_step_launch(c, w, B, N, cs);
       c->prof_id = prof_keep;
       hipError_t e = hipStreamEndCapture(cs, &c->graph);
       if (rc != 0) { (void)hipStreamDestroy(cs); return rc; }
@@ -620,7 +771,10 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     }
     for (int j = 0; j < T; ++j) HIPCHK(hipGraphLaunch(c->graph_exec, st));
   } else {
-    for (int j = 0; j < T; ++j) CHK(decode_step_launch(c, w, B, N, st));
+    for (int j = 0; j < T; ++j) {
+      if (c->decode_mode == 1) CHK(decode_step_launch_v2(c, w, B, N, st, c->s_bulk));
+      else CHK(decode_step_launch(c, w, B, N, st));
+    }
   }
   const int nm = c->cfg.n_mels;
   HIPCHK(hipMemcpy2DAsync(Y, (size_t)T * nm * sizeof(float), w.ypad.p + (w.ypad.row0 + 1) * nm,
@@ -649,6 +803,12 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   c->use_graph = enable ? 1 : 0;
+  return 0;
+}
+
+extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 1) return fail(DCTTS_ERR_ARG, "decode mode must be 0 or 1");
+  c->decode_mode = mode;
   return 0;
 }
 

@@ -80,6 +80,9 @@ class Engine:
     def set_decode_graph(self, enable: bool):
         self._ok(self.lib.dctts_set_decode_graph(self._h, int(bool(enable))))
 
+    def set_decode_mode(self, mode: int):
+        self._ok(self.lib.dctts_set_decode_mode(self._h, int(mode)))
+
     def device_bytes(self) -> int:
         return int(self.lib.dctts_device_bytes(self._h))
 

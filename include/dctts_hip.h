@@ -89,6 +89,12 @@ int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, floa
 /* Decode launch mode: 0 = one kernel launch per layer per step (eager), 1 = one hipGraph replay per step. */
 int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
+/* Decode algorithm form (results agree to fp32 re-association; both are the exact-parity incremental decode):
+ * 0 = fused full-row kernels on one stream (one workgroup per 32-row block),
+ * 1 = (default) column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone run as two
+ *     branches of the step (two streams / two graph branches). */
+int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
+
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
 size_t dctts_device_bytes(const dctts_ctx* ctx);
 

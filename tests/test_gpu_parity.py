@@ -198,16 +198,19 @@ def test_networks_surface_and_golden(weights):
 
 
 # ---------------------------------------------------------------- the autoregressive loop
+@pytest.mark.parametrize("mode", [1, 0])
 @pytest.mark.parametrize("graph", [False, True])
-def test_decode_vs_oracle_loop(weights, graph):
+def test_decode_vs_oracle_loop(weights, graph, mode):
     """Incremental exact decode == restated synthesize.py loop: integer-exact attention trajectory, Y within 1e-3.
     T = 100 > 85 so the full AudioDec dependency cone is exercised."""
     T = 100
     eng = engine_for(weights, max_T=T)
     eng.set_decode_graph(graph)
+    eng.set_decode_mode(mode)
     h = hp.replace(max_T=T)
     L = synthetic_text(h, B=3, seed=21)
     Y, mx = eng.text2mel(dev(L))
+    eng.set_decode_mode(1)
     Yr, _, trajr = O.synthesize(L, weights, h, np.float32, run_ssrn=False)
     np.testing.assert_array_equal(mx.cpu().numpy(), trajr)
     err = maxabs(Y.cpu().numpy(), Yr)
