@@ -14,10 +14,23 @@
 
 namespace dctts {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+// DPP reductions (no LDS crossbar): quad_perm / row_half_mirror / row_mirror leave the sum of each 16-lane row in
+// all of its lanes; the four row sums are then combined through v_readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);     // row_half_mirror
+  v = dpp_add<0x140>(v);     // row_mirror
   return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row16_sum(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
 
 // grid (T, B), block 256.  Q (B,T,d) / K,V (B,N,d) with arbitrary row strides (floats).
@@ -111,17 +124,17 @@ struct AttnWinParams {
   const float* Qh; long q_bstride; long q_row0; int q_stride;      // AudioEnc history (absolute time)
   const float* K; const float* V; int kv_stride; long kv_bstride;  // (B,N,*) rows
   int N, d, win;
-  const int* step; const int* offs; int R;
+  const int* step; int step_val; const int* offs; int R;
   const int* pm_all;     // (T+1, B) int32: row j = prev_max_attentions fed at step j
   int B;
-  float* rbuf; long r_bstride; long r_row0;                         // row stride 2d
+  float* rbuf; long r_bstride; long r_row0; long r_set;             // row stride 2d; r_set: parity set stride (0 = single)
 };
 
 __global__ void __launch_bounds__(256) attention_window_kernel(const AttnWinParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = blockIdx.x * 4 + wave, b = blockIdx.y;
   if (r >= p.R) return;
-  const int j = *p.step;
+  const int j = p.step_val + (p.step ? *p.step : 0);
   const int t = j + p.offs[r];
   if (t < 0) return;
   const int pm = p.pm_all[(long)j * p.B + b];
@@ -155,7 +168,7 @@ __global__ void __launch_bounds__(256) attention_window_kernel(const AttnWinPara
     const float a = e[k] * inv;
     o.x = fmaf(a, vv[k].x, o.x); o.y = fmaf(a, vv[k].y, o.y); o.z = fmaf(a, vv[k].z, o.z); o.w = fmaf(a, vv[k].w, o.w);
   }
-  float* rrow = p.rbuf + ((long)b * p.r_bstride + p.r_row0 + t) * (2 * p.d);
+  float* rrow = p.rbuf + (long)(j & 1) * p.r_set + ((long)b * p.r_bstride + p.r_row0 + t) * (2 * p.d);
   *reinterpret_cast<float4*>(rrow + c0) = o;
   *reinterpret_cast<float4*>(rrow + p.d + c0) = q;
   if (p.offs[r] == 0 && lane == 0) {

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -68,6 +69,7 @@ struct DevLayer {
 
 struct View {            // a (B, rows, stride) activation buffer; row0 = index of t = 0 inside a batch item
   float* p; long bstride; long row0; int stride;
+  long set = 0;          // floats between the two frame-parity copies of the buffer (0 = single copy)
 };
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
@@ -85,15 +87,21 @@ struct dctts_ctx {
   std::map<std::string, Buf> ws;       // named workspaces; key includes the geometry
   std::string ws_geom_textenc, ws_geom_t2m, ws_geom_dec, ws_geom_ssrn;
   int use_graph = 0;
-  int decode_mode = 1;                 // 0 = v1 (fused kernels, one stream), 1 = v2 (split kernels, chain + bulk branches)
-  hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  std::vector<int> cone_host_len;
-  hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;
+  int decode_mode = 1;                 // 0 = v1 (fused kernels, one stream), 1 = v2 (split kernels, chain + bulk streams)
+  hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // v1: one step, replayed T times
+  std::vector<hipGraphExec_t> chain_g, bulk_g; hipGraphExec_t pro_g = nullptr;   // v2: one small linear graph per frame and stream,
+  std::string graphs2_geom;                                                      //     frame index baked into every launch
+  int bulk_cap = 192;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
+  // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
+  long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
   // profiling
   int prof_id = -1;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
 };
 
+static void destroy_graphs2(dctts_ctx* c);
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -250,9 +258,11 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
+  destroy_graphs2(c);
+  for (int i = 0; i < 4; ++i) { if (c->ev_chain[i]) (void)hipEventDestroy(c->ev_chain[i]); if (c->ev_bulk[i]) (void)hipEventDestroy(c->ev_bulk[i]); }
   if (c->s_bulk) (void)hipStreamDestroy(c->s_bulk);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->trace_buf) (void)hipFree(c->trace_buf);
   free_ws(c);
   for (void* p : c->wallocs) (void)hipFree(p);
   for (int* p : c->cone_dev) (void)hipFree(p);
@@ -361,7 +371,14 @@ static int ws_get(dctts_ctx* c, const std::string& name, size_t bytes, void** ou
 static int ws_view(dctts_ctx* c, const std::string& name, int B, long rows, long row0, int stride, View* v) {
   void* p;
   CHK(ws_get(c, name, (size_t)B * rows * stride * sizeof(float), &p));
-  *v = View{(float*)p, rows, row0, stride};
+  *v = View{(float*)p, rows, row0, stride, 0};
+  return 0;
+}
+
+static int ws_view2(dctts_ctx* c, const std::string& name, int B, long rows, long row0, int stride, View* v) {   // two parity copies
+  void* p;
+  CHK(ws_get(c, name, (size_t)2 * B * rows * stride * sizeof(float), &p));
+  *v = View{(float*)p, rows, row0, stride, (long)B * rows * stride};
   return 0;
 }
 
@@ -553,6 +570,7 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
 // ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)
 struct DecodeWs {
   View kv, ypad, rbuf, logits; std::vector<View> ae, ad; int* pm_all; int* step;
+  std::vector<float*> se, sd;          // per-column-group partial LN statistics of pe / pd: [B][16][4]
   std::vector<float*> pe, pd, pb;      // pre-norm rows: AudioEnc chain [B][np], AudioDec chain [B][np], AudioDec bulk [B*Rb][np]
 };
 
@@ -562,17 +580,26 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
     (void)hipDeviceSynchronize(); drop_ws_prefix(c, "dec."); c->ws_geom_dec = g;
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    destroy_graphs2(c);
   }
   const int d = c->cfg.d, nm = c->cfg.n_mels;
+  const long rows = PAD + T + 2;
   // ypad row (PAD + t) holds S[t] = Y[t-1]  (train.py:51); row PAD is the zero frame fed at t = 0
-  CHK(ws_view(c, "dec.ypad", B, PAD + T + 1, PAD, nm, &w->ypad));
-  CHK(ws_view(c, "dec.rbuf", B, PAD + T, PAD, 2 * d, &w->rbuf));
+  CHK(ws_view(c, "dec.ypad", B, rows, PAD, nm, &w->ypad));
+  CHK(ws_view2(c, "dec.rbuf", B, rows, PAD, 2 * d, &w->rbuf));
   CHK(ws_view(c, "dec.logits", B, T, 0, nm, &w->logits));
   w->ae.resize(c->audioenc.size()); w->ad.resize(c->audiodec.size());
   void* p;
-  for (size_t i = 0; i < w->ae.size(); ++i) CHK(ws_view(c, "dec.ae" + std::to_string(i), B, PAD + T, PAD, d, &w->ae[i]));
-  for (size_t i = 0; i + 1 < w->ad.size(); ++i) CHK(ws_view(c, "dec.ad" + std::to_string(i), B, PAD + T, PAD, d, &w->ad[i]));
+  for (size_t i = 0; i < w->ae.size(); ++i) CHK(ws_view(c, "dec.ae" + std::to_string(i), B, rows, PAD, d, &w->ae[i]));
+  for (size_t i = 0; i + 1 < w->ad.size(); ++i) {
+    // layers whose cone reaches rows < j are rewritten by the bulk stream one frame ahead: two parity copies
+    if (c->cone_len[i] > 1) CHK(ws_view2(c, "dec.ad" + std::to_string(i), B, rows, PAD, d, &w->ad[i]));
+    else CHK(ws_view(c, "dec.ad" + std::to_string(i), B, rows, PAD, d, &w->ad[i]));
+  }
   w->pe.resize(c->audioenc.size()); w->pd.resize(c->audiodec.size()); w->pb.resize(c->audiodec.size());
+  w->se.resize(c->audioenc.size()); w->sd.resize(c->audiodec.size());
+  for (size_t i = 0; i < w->se.size(); ++i) { CHK(ws_get(c, "dec.se" + std::to_string(i), (size_t)B * 64 * sizeof(float), &p)); w->se[i] = (float*)p; }
+  for (size_t i = 0; i < w->sd.size(); ++i) { CHK(ws_get(c, "dec.sd" + std::to_string(i), (size_t)B * 64 * sizeof(float), &p)); w->sd[i] = (float*)p; }
   for (size_t i = 0; i < w->pe.size(); ++i) { const int np = c->audioenc[i].hc ? 2 * d : c->audioenc[i].cout; CHK(ws_get(c, "dec.pe" + std::to_string(i), (size_t)B * np * sizeof(float), &p)); w->pe[i] = (float*)p; }
   for (size_t i = 0; i < w->pd.size(); ++i) {
     const int np = c->audiodec[i].hc ? 2 * d : c->audiodec[i].cout;
@@ -581,11 +608,12 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
     w->pb[i] = nullptr;
     if (Rb > 0) { CHK(ws_get(c, "dec.pb" + std::to_string(i), (size_t)B * Rb * np * sizeof(float), &p)); w->pb[i] = (float*)p; }
   }
-  CHK(ws_get(c, "dec.pm", (size_t)(T + 1) * B * sizeof(int), &p)); w->pm_all = (int*)p;
-  CHK(ws_get(c, "dec.step", 64, &p)); w->step = (int*)p;
+  CHK(ws_get(c, "dec.pm", (size_t)(T + 2) * B * sizeof(int), &p)); w->pm_all = (int*)p;
+  CHK(ws_get(c, "dec.step", 256, &p)); w->step = (int*)p;
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ decode v1: fused kernels, one stream
 static int decode_step_launch(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t st) {
   const int d = c->cfg.d;
   // AudioEnc: one new row per utterance, taps read the per-layer history
@@ -597,9 +625,9 @@ static int decode_step_launch(dctts_ctx* c, const DecodeWs& w, int B, int N, hip
   a.Qh = w.ae.back().p; a.q_bstride = w.ae.back().bstride; a.q_row0 = w.ae.back().row0; a.q_stride = d;
   a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N;
   a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
-  a.step = w.step; a.offs = c->cone_dev[0]; a.R = c->cone_len[0];
+  a.step = w.step; a.step_val = 0; a.offs = c->cone_dev[0]; a.R = c->cone_len[0];
   a.pm_all = w.pm_all; a.B = B;
-  a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0;
+  a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0; a.r_set = 0;
   hipLaunchKernelGGL(attention_window_kernel, dim3((a.R + 3) / 4, B), dim3(256), 0, st, a);
   HIPCHK(hipGetLastError());
   // AudioDec dependency cone
@@ -621,39 +649,45 @@ static int decode_step_launch(dctts_ctx* c, const DecodeWs& w, int B, int N, hip
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ decode v2: split kernels, two streams
+static dctts_ctx* g_trace_ctx = nullptr;
 
-// ------------------------------------------------------------------------------------------------ decode v2: split kernels, chain + bulk
-static size_t hsplit_smem(int MF, int ntaps, int cin_p) {
-  const size_t a = (size_t)ntaps * MF * (cin_p + 4) * sizeof(float);
-  const size_t r = (size_t)8 * 2 * (MF == 32 ? 16 : 4) * 64 * sizeof(float);
-  return a > r ? a : r;
+static size_t hsplit_smem(int MF) {
+  return (size_t)8 * 2 * (MF == 32 ? 16 : 4) * 64 * sizeof(float);      // split-K reduction buffer
 }
 
 static RowNorm make_norm(const DevLayer& prod, const float* P, const View* res) {
   RowNorm n; memset(&n, 0, sizeof(n));
   n.P = P; n.np = prod.hc ? 2 * prod.cout : prod.cout;
   n.g1 = prod.g1; n.b1 = prod.b1; n.g2 = prod.g2; n.b2 = prod.b2; n.act = prod.act;
-  if (res) { n.res = res->p; n.res_bstride = res->bstride; n.res_row0 = res->row0; n.res_stride = res->stride; }
+  if (res) { n.res = res->p; n.res_bstride = res->bstride; n.res_row0 = res->row0; n.res_stride = res->stride; n.res_set = res->set; }
   return n;
 }
 
-// One split GEMM launch.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
-static int run_split(int MF, const DevLayer& L, int B, int R, const int* offs, const int* step, int pro, const RowNorm* nrm,
-                     const View* xmat, const View& xsrc, float* pout, hipStream_t st) {
+// One split GEMM launch for frame `frame`.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
+static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, const int* offs, int frame, int pro, const RowNorm* nrm,
+                     const View* xmat, const View& xsrc, float* pout, hipStream_t st,
+                     const float* stats_in = nullptr, float* stats_out = nullptr) {
   SplitParams p; memset(&p, 0, sizeof(p));
-  p.M = B * R; p.R = R; p.b0 = 0; p.offs = offs; p.step = step;
+  p.M = B * R; p.R = R; p.b0 = 0; p.offs = offs; p.step = nullptr; p.step_val = frame;
   p.pro = pro; if (nrm) p.nrm = *nrm;
-  if (xmat) { p.xmat = xmat->p; p.xm_bstride = xmat->bstride; p.xm_row0 = xmat->row0; p.xm_stride = xmat->stride; }
-  p.xsrc = xsrc.p; p.xs_bstride = xsrc.bstride; p.xs_row0 = xsrc.row0; p.xs_stride = xsrc.stride;
+  if (xmat) { p.xmat = xmat->p; p.xm_bstride = xmat->bstride; p.xm_row0 = xmat->row0; p.xm_stride = xmat->stride; p.xm_set = xmat->set; }
+  p.xsrc = xsrc.p; p.xs_bstride = xsrc.bstride; p.xs_row0 = xsrc.row0; p.xs_stride = xsrc.stride; p.xs_set = xsrc.set;
   p.ntaps = L.ntaps; for (int j = 0; j < 3; ++j) p.tap_off[j] = L.tap_off[j];
   p.cin = L.cin; p.cin_p = L.cin_p;
   p.wp = (MF == 16) ? L.wp16 : L.wp; p.bias = L.bias; p.cout = L.cout; p.hc = L.hc ? 1 : 0;
-  p.np_out = L.hc ? 2 * L.cout : L.cout; p.pout = pout;
+  p.np_out = L.hc ? 2 * L.cout : L.cout; p.pout = pout; p.stats_in = stats_in; p.stats_out = stats_out;
+  if (pro != PRO_RAW && (MF != 16 || L.cin_p != 256 || !stats_in))
+    return fail(DCTTS_ERR_STATE, "split kernel: LN prologue needs the 16-row form, 256 input channels and producer statistics");
+  if (L.ntaps > 1 && L.cin_p != 256) return fail(DCTTS_ERR_STATE, "split kernel: multi-tap layers must have 256 input channels");
+  if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++);
   const int groups = L.hc ? L.cout / MF : (L.cout + 2 * MF - 1) / (2 * MF);
-  const dim3 grid((p.M + MF - 1) / MF, groups);
-  const size_t sm = hsplit_smem(MF, L.ntaps, L.cin_p);
-  if (MF == 16) hipLaunchKernelGGL(hsplit_kernel<16>, grid, dim3(512), sm, st, p);
-  else          hipLaunchKernelGGL(hsplit_kernel<32>, grid, dim3(512), sm, st, p);
+  p.ngroups = groups;
+  int nblk = ((p.M + MF - 1) / MF) * groups;
+  if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
+  const size_t sm = hsplit_smem(MF);
+  if (MF == 16) hipLaunchKernelGGL(hsplit_kernel<16>, dim3(nblk), dim3(512), sm, st, p);
+  else          hipLaunchKernelGGL(hsplit_kernel<32>, dim3(nblk), dim3(512), sm, st, p);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -662,84 +696,125 @@ static int decode_v2_init(dctts_ctx* c) {
   if (c->s_bulk) return 0;
   HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], hipEventDisableTiming)); }
+  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   return 0;
 }
 
-static int decode_step_launch_v2(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t sm, hipStream_t sb) {
+// AudioEnc for frame j (13 dependent 16-row x 16-channel-group launches), then the newest-frame attention:
+// rebuild Q[j], materialise it, 3-key softmax, R[j], arg-max -> the window of frame j+1.
+static int v2_audioenc_attn(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm) {
   const int d = c->cfg.d;
-  const std::vector<DevLayer>& AE = c->audioenc; const std::vector<DevLayer>& AD = c->audiodec;
-  // ---- fork: the bulk branch (cone rows at offsets < 0) depends only on earlier frames and the current window
-  HIPCHK(hipEventRecord(c->ev_fork, sm));
-  HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
-  {
-    AttnWinParams a;
-    a.Qh = w.ae.back().p; a.q_bstride = w.ae.back().bstride; a.q_row0 = w.ae.back().row0; a.q_stride = d;
-    a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N;
-    a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
-    a.step = w.step; a.offs = c->cone_dev[0] + 1; a.R = c->cone_len[0] - 1;
-    a.pm_all = w.pm_all; a.B = B;
-    a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0;
-    hipLaunchKernelGGL(attention_window_kernel, dim3((a.R + 3) / 4, B), dim3(256), 0, sb, a);
-    HIPCHK(hipGetLastError());
-    for (size_t i = 0; i < AD.size(); ++i) {
-      const int Rb = c->cone_len[i] - 1;
-      if (Rb <= 0) break;
-      const View& src = (i == 0) ? w.rbuf : w.ad[i - 1];
-      CHK(run_split(32, AD[i], B, Rb, c->cone_dev[i] + 1, w.step, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb));
-      LnRowsParams q; memset(&q, 0, sizeof(q));
-      q.M = B * Rb; q.R = Rb; q.b0 = 0; q.offs = c->cone_dev[i] + 1; q.step = w.step; q.hc = AD[i].hc ? 1 : 0;
-      q.nrm = make_norm(AD[i], w.pb[i], AD[i].hc ? &src : nullptr);
-      q.x = w.ad[i].p; q.x_bstride = w.ad[i].bstride; q.x_row0 = w.ad[i].row0; q.x_stride = w.ad[i].stride;
-      hipLaunchKernelGGL(ln_rows_kernel, dim3((q.M + 3) / 4), dim3(256), 0, sb, q);
-      HIPCHK(hipGetLastError());
-    }
-  }
-  HIPCHK(hipEventRecord(c->ev_join, sb));
-  // ---- chain: AudioEnc for the newest frame (13 dependent layers, 16-row x 16-channel workgroups)
+  const std::vector<DevLayer>& AE = c->audioenc;
   for (size_t i = 0; i < AE.size(); ++i) {
     if (i == 0) {
-      CHK(run_split(16, AE[0], B, 1, nullptr, w.step, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm));
+      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
     } else {
       const RowNorm n = make_norm(AE[i - 1], w.pe[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr);
-      CHK(run_split(16, AE[i], B, 1, nullptr, w.step, AE[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ae[i - 1], w.ae[i - 1], w.pe[i], sm));
+      CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, AE[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ae[i - 1], w.ae[i - 1], w.pe[i], sm, w.se[i - 1], w.se[i]));
     }
   }
-  // ---- newest-frame attention: rebuild Q[j], materialise it, 3-key softmax, R[j], arg-max -> next window
-  {
-    AttnRow0Params a; memset(&a, 0, sizeof(a));
-    const size_t la = AE.size() - 1;
-    a.Bg = B; a.b0 = 0; a.B = B; a.step = w.step;
-    a.nrm = make_norm(AE[la], w.pe[la], &w.ae[la - 1]);
-    a.qhist = w.ae[la].p; a.q_bstride = w.ae[la].bstride; a.q_row0 = w.ae[la].row0; a.q_stride = d;
-    a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N; a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
-    a.pm_all = w.pm_all; a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0;
-    hipLaunchKernelGGL(attention_row0_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
+  AttnRow0Params a; memset(&a, 0, sizeof(a));
+  const size_t la = AE.size() - 1;
+  a.Bg = B; a.b0 = 0; a.B = B; a.step = nullptr; a.step_val = j;
+  a.nrm = make_norm(AE[la], w.pe[la], &w.ae[la - 1]);
+  a.qhist = w.ae[la].p; a.q_bstride = w.ae[la].bstride; a.q_row0 = w.ae[la].row0; a.q_stride = d;
+  a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N; a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
+  a.pm_all = w.pm_all; a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0; a.r_set = w.rbuf.set;
+  hipLaunchKernelGGL(attention_row0_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// The decode loop runs as two concurrent streams (DESIGN.md "decode pipeline"):
+//   chain stream, piece j : AudioDec chain for frame j -> mel frame j -> AudioEnc chain + attention for frame j+1
+//   bulk  stream, piece f : the cone rows (offsets < 0) of frame f, re-evaluated with frame f's window, written into
+//                           parity copy f&1 of the cone buffers.  Needs attention(f-1) = end of chain piece f-2 and
+//                           must finish before chain piece f: it overlaps chain piece f-1.
+// The frame index is passed by value: no device-side counter, no dependent load at kernel start.
+static int v2_bulk_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, hipStream_t sb) {
+  const int d = c->cfg.d;
+  const std::vector<DevLayer>& AD = c->audiodec;
+  AttnWinParams a;
+  a.Qh = w.ae.back().p; a.q_bstride = w.ae.back().bstride; a.q_row0 = w.ae.back().row0; a.q_stride = d;
+  a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N;
+  a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
+  a.step = nullptr; a.step_val = f; a.offs = c->cone_dev[0] + 1; a.R = c->cone_len[0] - 1;
+  a.pm_all = w.pm_all; a.B = B;
+  a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0; a.r_set = w.rbuf.set;
+  hipLaunchKernelGGL(attention_window_kernel, dim3((a.R + 3) / 4, B), dim3(256), 0, sb, a);
+  HIPCHK(hipGetLastError());
+  for (size_t i = 0; i < AD.size(); ++i) {
+    const int Rb = c->cone_len[i] - 1;
+    if (Rb <= 0) break;
+    const View& src = (i == 0) ? w.rbuf : w.ad[i - 1];
+    CHK(run_split(c, 32, AD[i], B, Rb, c->cone_dev[i] + 1, f, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb));
+    LnRowsParams q; memset(&q, 0, sizeof(q));
+    q.M = B * Rb; q.R = Rb; q.b0 = 0; q.offs = c->cone_dev[i] + 1; q.step = nullptr; q.step_val = f; q.hc = AD[i].hc ? 1 : 0;
+    q.nrm = make_norm(AD[i], w.pb[i], AD[i].hc ? &src : nullptr);
+    q.x = w.ad[i].p; q.x_bstride = w.ad[i].bstride; q.x_row0 = w.ad[i].row0; q.x_stride = w.ad[i].stride; q.x_set = w.ad[i].set;
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((q.M + 3) / 4), dim3(256), 0, sb, q);
     HIPCHK(hipGetLastError());
   }
-  // ---- chain: AudioDec row j; its taps at offsets < 0 come from the bulk branch -> join first
-  HIPCHK(hipStreamWaitEvent(sm, c->ev_join, 0));
+  return 0;
+}
+
+static int v2_chain_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, bool with_next, hipStream_t sm) {
+  const std::vector<DevLayer>& AD = c->audiodec;
   for (size_t i = 0; i < AD.size(); ++i) {
     if (i == 0) {
-      CHK(run_split(16, AD[0], B, 1, nullptr, w.step, PRO_RAW, nullptr, nullptr, w.rbuf, w.pd[0], sm));
+      CHK(run_split(c, 16, AD[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.rbuf, w.pd[0], sm, nullptr, w.sd[0]));
     } else {
       const RowNorm n = make_norm(AD[i - 1], w.pd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr);
-      CHK(run_split(16, AD[i], B, 1, nullptr, w.step, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm));
+      CHK(run_split(c, 16, AD[i], B, 1, nullptr, j, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm, w.sd[i - 1], w.sd[i]));
     }
   }
-  {
-    const DevLayer& Ll = AD.back();
-    FinalizeParams f; memset(&f, 0, sizeof(f));
-    f.Bg = B; f.b0 = 0; f.step = w.step; f.P = w.pd[AD.size() - 1]; f.np = Ll.cout; f.g = Ll.g1; f.be = Ll.b1; f.n = Ll.cout;
-    f.ypad = w.ypad.p; f.y_bstride = w.ypad.bstride; f.y_row0 = w.ypad.row0 + 1; f.y_stride = w.ypad.stride;
-    f.logits = w.logits.p; f.l_bstride = w.logits.bstride; f.l_stride = w.logits.stride;
-    hipLaunchKernelGGL(finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, f);
-    HIPCHK(hipGetLastError());
-  }
-  hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, sm, w.step);
+  const DevLayer& Ll = AD.back();
+  FinalizeParams f; memset(&f, 0, sizeof(f));
+  f.Bg = B; f.b0 = 0; f.step = nullptr; f.step_val = j; f.P = w.pd[AD.size() - 1]; f.np = Ll.cout; f.g = Ll.g1; f.be = Ll.b1; f.n = Ll.cout;
+  f.ypad = w.ypad.p; f.y_bstride = w.ypad.bstride; f.y_row0 = w.ypad.row0 + 1; f.y_stride = w.ypad.stride;
+  f.logits = w.logits.p; f.l_bstride = w.logits.bstride; f.l_stride = w.logits.stride;
+  hipLaunchKernelGGL(finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, f);
   HIPCHK(hipGetLastError());
+  if (with_next) CHK(v2_audioenc_attn(c, w, B, N, j + 1, sm));
+  return 0;
+}
+
+static void destroy_graphs2(dctts_ctx* c) {
+  for (hipGraphExec_t g : c->chain_g) if (g) (void)hipGraphExecDestroy(g);
+  for (hipGraphExec_t g : c->bulk_g) if (g) (void)hipGraphExecDestroy(g);
+  if (c->pro_g) (void)hipGraphExecDestroy(c->pro_g);
+  c->pro_g = nullptr;
+  c->chain_g.clear(); c->bulk_g.clear(); c->graphs2_geom.clear();
+}
+
+template <typename F>
+static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
+  hipGraph_t gr = nullptr;
+  HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+  const int rc = body();
+  const hipError_t e = hipStreamEndCapture(cs, &gr);
+  if (rc != 0) { if (gr) (void)hipGraphDestroy(gr); return rc; }
+  HIPCHK(e);
+  HIPCHK(hipGraphInstantiate(out, gr, nullptr, nullptr, 0));
+  (void)hipGraphDestroy(gr);
+  return 0;
+}
+
+static int write_trace(dctts_ctx* c, int j) {
+  std::vector<long long> h(64 * 8);
+  HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  FILE* f = fopen("gpurun_out/decode_trace.txt", "w");
+  if (!f) return 0;
+  long long t0 = 0; for (int k = 0; k < c->trace_n; ++k) if (h[8 * k] && (!t0 || h[8 * k] < t0)) t0 = h[8 * k];
+  fprintf(f, "# chain launches (hsplit_kernel<16>) of chain piece %d, workgroup 0 thread 0, microseconds since first entry (100 MHz wall clock)\n", j);
+  fprintf(f, "# idx entry rowinfo loads_issued centre_rebuilt kloop_done reduce_sync end\n");
+  for (int k = 0; k < c->trace_n; ++k) {
+    fprintf(f, "%2d", k);
+    for (int q = 0; q < 7; ++q) fprintf(f, " %8.2f", (h[8 * k + q] - t0) / 100.0);
+    fprintf(f, "\n");
+  }
+  fclose(f);
   return 0;
 }
 
@@ -747,12 +822,65 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
-  if (c->decode_mode == 1) CHK(decode_v2_init(c));
+  const bool v2 = (c->decode_mode == 1);
+  if (v2) CHK(decode_v2_init(c));
+  if (!v2) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // v1 uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
-  HIPCHK(hipMemsetAsync(w.step, 0, sizeof(int), st));
+  HIPCHK(hipMemsetAsync(w.step, 0, 256, st));                              // v1's device-side frame counter
   HIPCHK(hipMemsetAsync(w.pm_all, 0, (size_t)B * sizeof(int), st));      // prev_max_attentions = zeros (synthesize.py:46)
-  if (c->use_graph) {
-    const std::string g = geom(c->decode_mode == 1 ? "graph2" : "graph1", B, T, N);
+  if (v2) {
+    hipStream_t sb = c->s_bulk;
+    const bool gr = c->use_graph != 0;
+    if (gr) {
+      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)w.kv.p);
+      if (c->chain_g.empty() || c->graphs2_geom != g) {
+        destroy_graphs2(c);
+        hipStream_t cs;
+        HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        const int prof_keep = c->prof_id; c->prof_id = -1;
+        c->chain_g.assign(T, nullptr); c->bulk_g.assign(T, nullptr);
+        int rc = capture_piece(cs, &c->pro_g, [&]() { return v2_audioenc_attn(c, w, B, N, 0, cs); });   // frame 0's AudioEnc + attention
+        for (int j = 0; j < T && rc == 0; ++j) {
+          rc = capture_piece(cs, &c->chain_g[j], [&]() { return v2_chain_piece(c, w, B, N, j, j + 1 < T, cs); });
+          if (rc == 0 && j >= 1) rc = capture_piece(cs, &c->bulk_g[j], [&]() { return v2_bulk_piece(c, w, B, N, j, cs); });
+        }
+        c->prof_id = prof_keep;
+        HIPCHK(hipStreamDestroy(cs));
+        if (rc != 0) { destroy_graphs2(c); return rc; }
+        c->graphs2_geom = g;
+      }
+    }
+    const char* tenv = getenv("DCTTS_TRACE");
+    const int tstep = (tenv && !gr) ? atoi(tenv) : -1;
+    // the bulk stream joins the caller's stream at the start (TextEnc, resets)
+    HIPCHK(hipEventRecord(c->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
+    // pipeline prologue = chain piece -1: frame 0's AudioEnc + attention
+    if (gr) HIPCHK(hipGraphLaunch(c->pro_g, st)); else CHK(v2_audioenc_attn(c, w, B, N, 0, st));
+    HIPCHK(hipEventRecord(c->ev_chain[3], st));
+    for (int j = 0; j < T; ++j) {
+      // bulk piece f = j+1 needs attention(j) (end of chain piece j-1) and overlaps chain piece j
+      if (j + 1 < T) {
+        HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));
+        if (gr) HIPCHK(hipGraphLaunch(c->bulk_g[j + 1], sb)); else CHK(v2_bulk_piece(c, w, B, N, j + 1, sb));
+        HIPCHK(hipEventRecord(c->ev_bulk[(j + 1) & 3], sb));
+      }
+      if (j >= 1) HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0));      // chain piece j reads frame j's cone rows
+      if (j == tstep) {
+        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 8 * sizeof(long long))); }
+        HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 8 * sizeof(long long), st));
+        c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
+      }
+      if (gr) HIPCHK(hipGraphLaunch(c->chain_g[j], st)); else CHK(v2_chain_piece(c, w, B, N, j, j + 1 < T, st));
+      HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
+      if (c->trace_on) {
+        c->trace_on = false; g_trace_ctx = nullptr;
+        HIPCHK(hipStreamSynchronize(st));
+        CHK(write_trace(c, j));
+      }
+    }
+  } else if (c->use_graph) {
+    const std::string g = geom("graph1", B, T, N);
     if (!c->graph_exec || c->graph_geom != g) {
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
@@ -760,7 +888,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
       HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
       const int prof_keep = c->prof_id; c->prof_id = -1;
-      int rc = c->decode_mode == 1 ? decode_step_launch_v2(c, w, B, N, cs, c->s_bulk) : decode_step_launch(c, w, B, N, cs);
+      int rc = decode_step_launch(c, w, B, N, cs);
       c->prof_id = prof_keep;
       hipError_t e = hipStreamEndCapture(cs, &c->graph);
       if (rc != 0) { (void)hipStreamDestroy(cs); return rc; }
@@ -771,10 +899,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     }
     for (int j = 0; j < T; ++j) HIPCHK(hipGraphLaunch(c->graph_exec, st));
   } else {
-    for (int j = 0; j < T; ++j) {
-      if (c->decode_mode == 1) CHK(decode_step_launch_v2(c, w, B, N, st, c->s_bulk));
-      else CHK(decode_step_launch(c, w, B, N, st));
-    }
+    for (int j = 0; j < T; ++j) CHK(decode_step_launch(c, w, B, N, st));
   }
   const int nm = c->cfg.n_mels;
   HIPCHK(hipMemcpy2DAsync(Y, (size_t)T * nm * sizeof(float), w.ypad.p + (w.ypad.row0 + 1) * nm,

@@ -1,22 +1,26 @@
-// decode_kernels.h -- latency-oriented kernels for one step of the Text2Mel autoregressive loop
+// decode_kernels.h -- latency-oriented kernels for one frame of the Text2Mel autoregressive loop
 // (synthesize.py:47-54) on gfx950.
 //
-// Why a second kernel family: in a decode step every AudioEnc layer and the tail of the AudioDec cone
-// see only B (= 32) rows.  A workgroup that owns all output columns of a row block (hconv_kernel.h, the
-// throughput form) then leaves 255 of 256 CUs idle and takes ~75 us per layer.  Here the output columns
-// are split across workgroups (one 2-tile column group each) and K is split across the 8 waves of a
-// workgroup, so a 32-row layer becomes 16-32 short workgroups.  Layer-norm needs whole rows, so it is
-// DEFERRED: the GEMM writes pre-norm values P, and whoever consumes a row normalises it:
-//   * chain layers (the newest frame j): the consumer's prologue normalises + gates its 16 centre rows
-//     from P (wave per row, two-pass statistics in registers) while staging its A tile into LDS, and the
-//     first column group materialises those rows into the layer's absolute-time history buffer;
+// Why a second kernel family: in a decode step every AudioEnc layer and the newest-frame rows of the
+// AudioDec cone see only B (= 32) rows.  A workgroup that owns all output columns of a row block
+// (hconv_kernel.h, the throughput form) then leaves 255 of 256 CUs idle and takes ~75 us per layer.
+// Here the output columns are split across workgroups (one 2-tile column group each) and K is split
+// across the 8 waves of a workgroup, so a 32-row layer becomes 32 short workgroups.
+//
+// Layer-norm needs whole rows, so it is DEFERRED.  The GEMM writes pre-norm values P plus, per output row
+// and 16-column group, the partial statistics (mean_g, M2_g); whoever consumes a row rebuilds it:
+//   * chain layers (the newest frame j): the consumer Chan-combines the 16 partials of each of its centre
+//     rows (exact two-pass quality), applies LN (+act) or LN + sigmoid gate + highway mix elementwise to the
+//     A fragments it holds in registers, and the first column group materialises the rebuilt rows into the
+//     layer's absolute-time history buffer;
 //   * bulk layers (cone rows at offsets < 0, independent of frame j): a row kernel (ln_rows_kernel).
 //
-// hsplit_kernel<MF>: MF = 32 -> 32 rows x 2 tiles of v_mfma_f32_32x32x2_f32   (bulk cone layers)
+// hsplit_kernel<MF>: MF = 32 -> 32 rows x 2 tiles of v_mfma_f32_32x32x2_f32   (bulk cone layers, persistent items)
 //                    MF = 16 -> 16 rows x 2 tiles of v_mfma_f32_16x16x4_f32   (chain layers)
-// A is staged once per workgroup into LDS ([tap][row][Cin+4], conflict-free ds_read_b128); B comes from
-// HBM/L2 in MFMA fragment order (one coalesced 1 KiB load per wave per four MFMAs); the 8 partial
-// accumulators are reduced through LDS (reusing the A region) in a fixed order -> deterministic.
+// A fragments are loaded straight from global memory into registers in MFMA operand layout (no LDS staging:
+// no wave shares another wave's K slice); B comes in pre-packed fragment order (one coalesced 1 KiB load per
+// wave per four MFMAs); every load of a work item is issued before the first use; the 8 partial accumulators
+// are reduced through LDS in a fixed order -> deterministic.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,15 +40,19 @@ enum { PRO_RAW = 0, PRO_LN_C = 1, PRO_LN_HC = 2 };
 struct RowNorm {
   const float* P; int np;                  // pre-norm rows [prow][np]  (np = 256 for C, 512 for HC)
   const float* g1; const float* b1; const float* g2; const float* b2; int act;
-  const float* res; long res_bstride; long res_row0; int res_stride;   // highway residual X_{l-1}[b][t] (HC)
+  const float* res; long res_bstride; long res_row0; int res_stride; long res_set;   // highway residual X_{l-1}[b][t] (HC)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// uniform base + unsigned 32-bit element offset: selects the SGPR-base / VGPR-offset addressing mode (one VGPR per address)
+__device__ __forceinline__ float4 ld4u(const float* base, unsigned off) { return *reinterpret_cast<const float4*>(base + off); }
+// latency-critical prologue math: hardware exp / rcp / rsq (about 1 ulp) instead of the long IEEE sequences
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float rsqrt_fast(float x) { return __builtin_amdgcn_rsqf(x); }
 
-// One wave normalises one 256-channel row; lane owns channels 4*lane .. 4*lane+3.
-__device__ __forceinline__ float4 norm_row_c(const RowNorm& n, long prow, int lane) {
+// One wave normalises one 256-channel row; lane owns channels 4*lane .. 4*lane+3 (two-pass statistics, DPP sums).
+__device__ __forceinline__ float4 norm_c_regs(const RowNorm& n, const float4 x, int lane) {
   const int c = lane * 4;
-  const float4 x = ld4(n.P + prow * n.np + c);
   const float mean = wave_sum(x.x + x.y + x.z + x.w) * (1.0f / 256.0f);
   const float4 d = make_float4(x.x - mean, x.y - mean, x.z - mean, x.w - mean);
   const float var = wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * (1.0f / 256.0f);
@@ -55,10 +63,8 @@ __device__ __forceinline__ float4 norm_row_c(const RowNorm& n, long prow, int la
   return y;
 }
 
-__device__ __forceinline__ float4 norm_row_hc(const RowNorm& n, long prow, int b, int t, int lane) {
+__device__ __forceinline__ float4 norm_hc_regs(const RowNorm& n, const float4 h1, const float4 h2, const float4 xr, int lane) {
   const int c = lane * 4;
-  const float4 h1 = ld4(n.P + prow * n.np + c), h2 = ld4(n.P + prow * n.np + 256 + c);
-  const float4 xr = ld4(n.res + ((long)b * n.res_bstride + n.res_row0 + t) * n.res_stride + c);
   const float m1 = wave_sum(h1.x + h1.y + h1.z + h1.w) * (1.0f / 256.0f);
   const float m2 = wave_sum(h2.x + h2.y + h2.z + h2.w) * (1.0f / 256.0f);
   const float4 d1 = make_float4(h1.x - m1, h1.y - m1, h1.z - m1, h1.w - m1);
@@ -75,162 +81,302 @@ __device__ __forceinline__ float4 norm_row_hc(const RowNorm& n, long prow, int b
   return o;
 }
 
+__device__ __forceinline__ float4 norm_row_c(const RowNorm& n, long prow, int lane) {
+  return norm_c_regs(n, ld4(n.P + prow * n.np + lane * 4), lane);
+}
+
+// par = frame parity selecting the residual's buffer copy (0 when the residual buffer is single)
+__device__ __forceinline__ float4 norm_row_hc(const RowNorm& n, long prow, int b, int t, int lane, long par = 0) {
+  const int c = lane * 4;
+  const float4 h1 = ld4(n.P + prow * n.np + c), h2 = ld4(n.P + prow * n.np + 256 + c);
+  const float4 xr = ld4(n.res + par * n.res_set + ((long)b * n.res_bstride + n.res_row0 + t) * n.res_stride + c);
+  return norm_hc_regs(n, h1, h2, xr, lane);
+}
+
 struct SplitParams {
-  // ---- row mapping: m in [0,M) -> b = b0 + m / R, r = m % R, t = *step + (offs ? offs[r] : 0); rows with t < 0 are skipped
-  int M, R, b0; const int* offs; const int* step;
-  // ---- centre tap (row t itself): PRO_RAW reads xsrc; PRO_LN_* rebuilds it from pre-norm rows (index b*R + r)
-  int pro; RowNorm nrm;
-  float* xmat; long xm_bstride; long xm_row0; int xm_stride;    // where column group 0 materialises the rebuilt row
+  // ---- row mapping: m in [0,M) -> b = b0 + m / R, r = m % R, t = frame + (offs ? offs[r] : 0); rows with t < 0 are skipped
+  int M, R, b0; const int* offs; const int* step; int step_val;   // frame = step_val + (step ? *step : 0)
+  int ngroups;                                                   // column groups; work items = row tiles x ngroups, grid-strided
+  // ---- centre tap (row t itself): PRO_RAW reads xsrc; PRO_LN_* rebuilds it from pre-norm rows (index b*R + r) using the
+  //      producer's per-column-group partial statistics `stats_in` [prow][16 groups][4] = (mean1, M2_1, mean2, M2_2)
+  int pro; RowNorm nrm; const float* stats_in;
+  float* xmat; long xm_bstride; long xm_row0; int xm_stride; long xm_set;   // where column group 0 materialises the rebuilt row
   // ---- tap source (absolute-time activation buffer): all taps when PRO_RAW, the non-centre taps otherwise
-  const float* xsrc; long xs_bstride; long xs_row0; int xs_stride;
+  const float* xsrc; long xs_bstride; long xs_row0; int xs_stride; long xs_set;
   int ntaps; int tap_off[3]; int cin; int cin_p;
   // ---- weights / output
   const float* wp; const float* bias; int cout; int hc; int np_out;
   float* pout;                                                   // pre-norm rows [b*R + r][np_out]
+  float* stats_out;                                              // optional partial statistics of pout (16-row form only)
+  long long* dbg;                                                // optional: 8 wall-clock (100 MHz) stamps of workgroup 0
 };
+// *_set: buffers written by the bulk branch exist twice (frame parity); set stride in floats, 0 = single buffer.
+
+// Sum over the four lanes l, l^16, l^32, l^48 (the lanes that share an A-operand row in the 16x16x4 layout), on the
+// VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two registers.
+__device__ __forceinline__ float xrow4_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  const float s = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+  return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
+
+// Chan-combine the 16 per-group partials (mean_g, M2_g over 16 channels each) of one row: exact two-pass quality.
+// Each of the row's four lanes holds four groups (st[0..3]); h selects (x,y) = H1 / (z,w) = H2.
+__device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, float& mean, float& rstd) {
+  float sm = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sm += h ? st[g].z : st[g].x;
+  mean = xrow4_sum(sm) * (1.0f / 16.0f);
+  float m2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { const float dm = (h ? st[g].z : st[g].x) - mean; m2 += (h ? st[g].w : st[g].y) + 16.0f * dm * dm; }
+  rstd = rsqrt_fast(xrow4_sum(m2) * (1.0f / 256.0f) + 1e-12f);
+}
 
 template <int MF>
 __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
-  constexpr int BM = MF;
   constexpr int KGS = (MF == 32) ? 8 : 16;          // k per k-group (4 MFMAs)
   constexpr int NJ = (MF == 32) ? 16 : 4;           // accumulator registers per tile
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ int s_b[BM], s_t[BM];
-  __shared__ long s_prow[BM];
+  constexpr int NGMAX = (MF == 32) ? 12 : 6;        // k-groups per wave at K = 768
+  constexpr int BD = (MF == 32) ? 4 : 6;            // B prefetch ring depth (k-groups)
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // split-K reduction only
+  __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, grp = blockIdx.y;
-  const int LDS_S = p.cin_p + 4;
-  const int step = *p.step;
+  const bool tr = p.dbg && blockIdx.x == 0 && tid == 0;
+  if (tr) p.dbg[0] = wall_clock64();
+  const int step = p.step_val + (p.step ? *p.step : 0);
+  const long par = step & 1;
+  const int KG = p.ntaps * p.cin_p / KGS;
+  const int ntile = (p.M + MF - 1) / MF;
+  const int nitems = ntile * p.ngroups;
+  const int arow = lane & (MF - 1);
+  const int aq = (MF == 32) ? (lane >> 5) : (lane >> 4);
+  const int c4 = aq * 4;
+  const bool ln = (MF == 16) && (p.pro != PRO_RAW);
+  const int ctap = (p.ntaps == 1) ? 0 : ((p.tap_off[0] == 0) ? 0 : ((p.tap_off[1] == 0) ? 1 : 2));
 
-  if (tid < BM) {
-    const int m = m0 + tid;
-    int b = -1, t = -1; long prow = -1;
-    if (m < p.M) {
-      const int bl = m / p.R, r = m - bl * p.R;
-      b = p.b0 + bl;
-      t = step + (p.offs ? p.offs[r] : 0);
-      prow = (long)b * p.R + r;
-      if (t < 0) b = -1;
+  // Persistent over work items: the bulk branch launches fewer workgroups than CUs so that the latency-critical
+  // chain branch always finds free CUs; the chain itself has exactly one item per workgroup.
+  for (int item = blockIdx.x; item < nitems; item += (MF == 32 ? (int)gridDim.x : nitems)) {
+    const int tile_x = item / p.ngroups, grp = item - tile_x * p.ngroups;
+    const int m0 = tile_x * MF;
+
+    // ---- B fragments: wave w owns k-groups w, w+8, ...; independent of A, so issue first
+    const float* wb = p.wp + lane * 4;
+    const unsigned w0o = (unsigned)(grp * 2) * (unsigned)KG * 256u, w1o = w0o + (unsigned)KG * 256u;
+    float4 bq0[BD], bq1[BD];
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      const int g = wave + 8 * i;
+      bq0[i] = make_float4(0.f, 0.f, 0.f, 0.f); bq1[i] = bq0[i];
+      if (g < KG) { bq0[i] = ld4u(wb, w0o + (unsigned)g * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)g * 256u); }
     }
-    s_b[tid] = b; s_t[tid] = t; s_prow[tid] = prow;
-  }
-  __syncthreads();
 
-  // ---- stage the A tile: wave per (tap, row)
-  for (int idx = wave; idx < p.ntaps * BM; idx += 8) {
-    const int tap = idx / BM, row = idx - tap * BM;
-    float* dst = smem + (long)idx * LDS_S;
-    const int b = s_b[row], t = s_t[row];
-    const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
-    if (b < 0) {
-      for (int c = lane * 4; c < p.cin_p; c += 256) *reinterpret_cast<float4*>(dst + c) = make_float4(0.f, 0.f, 0.f, 0.f);
-    } else if (toff == 0 && p.pro != PRO_RAW) {
-      const float4 x = (p.pro == PRO_LN_C) ? norm_row_c(p.nrm, s_prow[row], lane) : norm_row_hc(p.nrm, s_prow[row], b, t, lane);
-      *reinterpret_cast<float4*>(dst + lane * 4) = x;
-      if (grp == 0 && p.xmat) *reinterpret_cast<float4*>(p.xmat + ((long)b * p.xm_bstride + p.xm_row0 + t) * p.xm_stride + lane * 4) = x;
-    } else {
-      const float* src = p.xsrc + ((long)b * p.xs_bstride + p.xs_row0 + t + toff) * p.xs_stride;
-      for (int c = lane * 4; c < p.cin_p; c += 256) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < p.cin) v = ld4(src + c);
-        *reinterpret_cast<float4*>(dst + c) = v;
+    // ---- this lane's A row (MFMA A operand: lane -> row lane % MF, k sub-block lane / MF)
+    int b = 0, t = 0; long prow = -1; bool valid = false;
+    {
+      const int m = m0 + arow;
+      if (m < p.M) {
+        int bl = m, r = 0;
+        if (p.R != 1) { bl = m / p.R; r = m - bl * p.R; }
+        b = p.b0 + bl;
+        t = step + (p.offs ? p.offs[r] : 0);
+        prow = (long)b * p.R + r;
+        valid = (t >= 0);
+      }
+      if (wave == 0 && aq == 0) s_prow[arow] = valid ? prow : -1;
+    }
+    if (tr) p.dbg[1] = wall_clock64();
+
+    // ---- A fragments straight from global memory: every load of the item is in flight before the first use.
+    //      Loads are unconditional (skipped rows read row 0 and are zeroed afterwards) so that no exec-mask branches
+    //      serialise them; addresses are uniform base + 32-bit offset.  ntaps > 1 implies cin_p == 256 (tap = shift).
+    const unsigned xs_row = valid ? (unsigned)(par * p.xs_set + ((long)b * p.xs_bstride + p.xs_row0 + t) * p.xs_stride) : (unsigned)(p.xs_row0 * p.xs_stride);
+    const unsigned p_row = valid ? (unsigned)(prow * p.nrm.np) : 0u;
+    const unsigned rs_row = valid ? (unsigned)(par * p.nrm.res_set + ((long)b * p.nrm.res_bstride + p.nrm.res_row0 + t) * p.nrm.res_stride) : 0u;
+    float4 av[NGMAX];
+    float4 h2v[2], rsv[2], g1v[2], b1v[2], g2v[2], b2v[2];   // centre-tap extras of the (at most two) centre k-groups of a wave
+    float4 st[4];
+#pragma unroll
+    for (int i = 0; i < NGMAX; ++i) {
+      const int g = wave + 8 * i;
+      av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < KG) {
+        const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+        const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
+        if (ln && tap == ctap) {
+          if constexpr (MF == 16) {
+            g1v[i & 1] = ld4u(p.nrm.g1, c); b1v[i & 1] = ld4u(p.nrm.b1, c);
+            av[i] = ld4u(p.nrm.P, p_row + c);
+            if (p.pro == PRO_LN_HC) {
+              g2v[i & 1] = ld4u(p.nrm.g2, c); b2v[i & 1] = ld4u(p.nrm.b2, c);
+              h2v[i & 1] = ld4u(p.nrm.P, p_row + 256 + c);
+              rsv[i & 1] = ld4u(p.nrm.res, rs_row + c);
+            }
+          }
+        } else if (c < p.cin) {            // uniform per 16-lane row group; pad columns stay zero
+          av[i] = ld4u(p.xsrc, xs_row + (unsigned)(toff * p.xs_stride) + c);
+        }
       }
     }
-  }
-  __syncthreads();
-
-  // ---- K loop: wave w owns k-groups w, w+8, ...
-  const int KG = p.ntaps * p.cin_p / KGS;
-  const float4* w0 = reinterpret_cast<const float4*>(p.wp) + ((long)(grp * 2) * KG) * 64 + lane;
-  const float4* w1 = w0 + (long)KG * 64;
-  const int arow = (MF == 32) ? (lane & 31) : (lane & 15);
-  const int aq = (MF == 32) ? (lane >> 5) : (lane >> 4);
-  typedef typename std::conditional<MF == 32, f32x16, f32x4>::type acc_t;
-  acc_t acc0, acc1;
+    if constexpr (MF == 16) {
+      if (ln) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
-  int g = wave;
-  float4 bq0 = make_float4(0.f, 0.f, 0.f, 0.f), bq1 = bq0;
-  if (g < KG) { bq0 = w0[(long)g * 64]; bq1 = w1[(long)g * 64]; }
-  for (; g < KG; g += 8) {
-    const int k0 = g * KGS;
-    const int tap = k0 / p.cin_p, koff = k0 - tap * p.cin_p;
-    const float4 a = *reinterpret_cast<const float4*>(smem + ((long)tap * BM + arow) * LDS_S + koff + aq * 4);
-    const int gn = (g + 8 < KG) ? g + 8 : g;
-    const float4 n0 = w0[(long)gn * 64], n1 = w1[(long)gn * 64];
-    if constexpr (MF == 32) {
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq1.w, acc1, 0, 0, 0);
-    } else {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq1.x, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq1.y, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq1.z, acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq1.w, acc1, 0, 0, 0);
+        for (int g = 0; g < 4; ++g) st[g] = ld4u(p.stats_in, (valid ? (unsigned)(prow * 64) : 0u) + (aq * 4 + g) * 4);
+      }
     }
-    bq0 = n0; bq1 = n1;
-  }
-  __syncthreads();                    // every wave is done reading the A tile: reuse it for the reduction
+    if (tr) p.dbg[2] = wall_clock64();
+    if (!valid) {
+#pragma unroll
+      for (int i = 0; i < NGMAX; ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 
-  // red[wave][tile][j][lane]
+    // ---- rebuild the centre-tap values: LN (+ act) or LN + sigmoid gate + highway mix, elementwise given the row statistics
+    if constexpr (MF == 16) {
+      if (ln) {
+        float m1, r1, m2 = 0.f, r2 = 0.f;
+        combine_stats(st, 0, m1, r1);                 // every lane takes part in the cross-lane sums (ln is uniform)
+        if (p.pro == PRO_LN_HC) combine_stats(st, 1, m2, r2);
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    smem[((wave * 2 + 0) * NJ + j) * 64 + lane] = acc0[j];
-    smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
-  }
-  __syncthreads();
-  for (int e = tid; e < 2 * NJ * 64; e += 512) {
-    const int l = e & 63, j = (e >> 6) % NJ, tile = e / (64 * NJ);
-    float v = 0.f;
+        for (int i = 0; i < NGMAX; ++i) {
+          const int g = wave + 8 * i;
+          if (g < KG) {
+            const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+            if (tap == ctap) {
+              const float4 g1 = g1v[i & 1], b1 = b1v[i & 1];
+              float4 x = av[i];
+              x.x = (x.x - m1) * r1 * g1.x + b1.x; x.y = (x.y - m1) * r1 * g1.y + b1.y;
+              x.z = (x.z - m1) * r1 * g1.z + b1.z; x.w = (x.w - m1) * r1 * g1.w + b1.w;
+              if (p.pro == PRO_LN_HC) {
+                const float4 g2 = g2v[i & 1], b2 = b2v[i & 1];
+                const float4 h2 = h2v[i & 1], xr = rsv[i & 1];
+                { const float s_ = sigmoid_fast(x.x); x.x = s_ * ((h2.x - m2) * r2 * g2.x + b2.x) + (1.0f - s_) * xr.x; }
+                { const float s_ = sigmoid_fast(x.y); x.y = s_ * ((h2.y - m2) * r2 * g2.y + b2.y) + (1.0f - s_) * xr.y; }
+                { const float s_ = sigmoid_fast(x.z); x.z = s_ * ((h2.z - m2) * r2 * g2.z + b2.z) + (1.0f - s_) * xr.z; }
+                { const float s_ = sigmoid_fast(x.w); x.w = s_ * ((h2.w - m2) * r2 * g2.w + b2.w) + (1.0f - s_) * xr.w; }
+              } else if (p.nrm.act == ACT_RELU) {
+                x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+              }
+              if (!valid) x = make_float4(0.f, 0.f, 0.f, 0.f);
+              av[i] = x;
+              if (valid && grp == 0 && p.xmat)
+                *reinterpret_cast<float4*>(p.xmat + par * p.xm_set + ((long)b * p.xm_bstride + p.xm_row0 + t) * p.xm_stride + c) = x;
+            }
+          }
+        }
+      }
+    }
+    if (tr) p.dbg[3] = wall_clock64();
+
+    // ---- K loop (fully unrolled so the register arrays are statically indexed)
+    typedef typename std::conditional<MF == 32, f32x16, f32x4>::type acc_t;
+    acc_t acc0, acc1;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v += smem[((w * 2 + tile) * NJ + j) * 64 + l];
-    int row, col;
-    if constexpr (MF == 32) { row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5); col = l & 31; }
-    else          { row = (l >> 4) * 4 + j;                      col = l & 15; }
-    if (s_b[row] < 0) continue;
-    int pcol; bool ok;
-    if (p.hc) { const int c = grp * MF + col; ok = c < p.cout; pcol = tile * p.cout + c; }
-    else      { pcol = (grp * 2 + tile) * MF + col; ok = pcol < p.cout; }
-    if (ok) p.pout[s_prow[row] * p.np_out + pcol] = v + p.bias[pcol];
+    for (int j = 0; j < NJ; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NGMAX; ++i) {
+      const int g = wave + 8 * i;
+      if (g < KG) {
+        const float4 a = av[i];
+        const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
+        if (i + BD < NGMAX) {
+          const int gn = g + 8 * BD;
+          if (gn < KG) { bq0[i % BD] = ld4u(wb, w0o + (unsigned)gn * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gn * 256u); }
+        }
+        if constexpr (MF == 32) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+        } else {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+        }
+      }
+    }
+    if (tr) p.dbg[4] = wall_clock64();
+
+    // ---- split-K reduction through LDS: red[wave][tile][j][lane], summed in a fixed order (deterministic)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      smem[((wave * 2 + 0) * NJ + j) * 64 + lane] = acc0[j];
+      smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
+    }
+    __syncthreads();
+    if (tr) p.dbg[5] = wall_clock64();
+    for (int e = tid; e < 2 * NJ * 64; e += 512) {
+      const int l = e & 63, j = (e >> 6) % NJ, tile = e / (64 * NJ);
+      float v_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v_ += smem[((w * 2 + tile) * NJ + j) * 64 + l];
+      int row, col;
+      if constexpr (MF == 32) { row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5); col = l & 31; }
+      else                    { row = (l >> 4) * 4 + j;                      col = l & 15; }
+      const long orow = s_prow[row];
+      int pcol; bool ok;
+      if (p.hc) { const int c = grp * MF + col; ok = c < p.cout; pcol = tile * p.cout + c; }
+      else      { pcol = (grp * 2 + tile) * MF + col; ok = pcol < p.cout; }
+      if (ok) v_ += p.bias[pcol];
+      if (ok && orow >= 0) p.pout[orow * p.np_out + pcol] = v_;
+      if constexpr (MF == 16) {
+        // partial LN statistics of this 16-column group: a DPP row (16 lanes) holds one output row's 16 columns
+        if (p.stats_out) {
+          const float mg = row16_sum(ok ? v_ : 0.f) * (1.0f / 16.0f);
+          const float dv = ok ? v_ - mg : 0.f;
+          const float m2g = row16_sum(dv * dv);
+          if (ok && orow >= 0 && col == 0) {
+            const int G = p.hc ? grp : grp * 2 + tile;
+            float* so = p.stats_out + (orow * 16 + G) * 4 + (p.hc ? tile * 2 : 0);
+            so[0] = mg; so[1] = m2g;
+          }
+        }
+      }
+    }
+    if (tr) p.dbg[6] = wall_clock64();
+    if (MF == 32 && item + (int)gridDim.x < nitems) __syncthreads();      // s_prow / smem are reused by the next item
   }
 }
 
-// Row kernel for the bulk branch: X[b][t] = act/ gate (LN(P[b*R + r])) for cone rows at offsets < 0.
+// Row kernel for the bulk branch: X[b][t] = act / gate (LN(P[b*R + r])) for cone rows at offsets < 0.
 // grid ceil(M/4), block 256 (wave per row).
 struct LnRowsParams {
-  int M, R, b0; const int* offs; const int* step;
+  int M, R, b0; const int* offs; const int* step; int step_val;
   int hc; RowNorm nrm;
-  float* x; long x_bstride; long x_row0; int x_stride;
+  float* x; long x_bstride; long x_row0; int x_stride; long x_set;
 };
 
 __global__ void __launch_bounds__(256) ln_rows_kernel(const LnRowsParams p) {
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= p.M) return;
   const int bl = m / p.R, r = m - bl * p.R, b = p.b0 + bl;
-  const int t = *p.step + (p.offs ? p.offs[r] : 0);
+  const int step = p.step_val + (p.step ? *p.step : 0);
+  const long par = step & 1;
+  const int t = step + (p.offs ? p.offs[r] : 0);
   if (t < 0) return;
   const long prow = (long)b * p.R + r;
-  const float4 x = p.hc ? norm_row_hc(p.nrm, prow, b, t, lane) : norm_row_c(p.nrm, prow, lane);
-  *reinterpret_cast<float4*>(p.x + ((long)b * p.x_bstride + p.x_row0 + t) * p.x_stride + lane * 4) = x;
+  const float4 x = p.hc ? norm_row_hc(p.nrm, prow, b, t, lane, par) : norm_row_c(p.nrm, prow, lane);
+  *reinterpret_cast<float4*>(p.x + par * p.x_set + ((long)b * p.x_bstride + p.x_row0 + t) * p.x_stride + lane * 4) = x;
 }
 
 // Newest-frame attention (row offset 0): rebuilds Q[j] from AudioEnc's last pre-norm rows, materialises it
-// into the Q history, runs the 3-key windowed softmax, writes R[j] and the arg-max for the next step.
+// into the Q history, runs the 3-key windowed softmax, writes R[j] and the arg-max for the next frame.
 // grid ceil(Bg/4), block 256 (wave per utterance).
 struct AttnRow0Params {
-  int Bg, b0, B; const int* step;
+  int Bg, b0, B; const int* step; int step_val;
   RowNorm nrm;                                              // Q[j] = gate(LN(P_last[b]))  (R == 1: prow = b)
   float* qhist; long q_bstride; long q_row0; int q_stride;
   const float* K; const float* V; int kv_stride; long kv_bstride; int N, d, win;
   int* pm_all;
-  float* rbuf; long r_bstride; long r_row0;
+  float* rbuf; long r_bstride; long r_row0; long r_set;
 };
 
 __global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Params p) {
   const int lane = threadIdx.x & 63, bl = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bl >= p.Bg) return;
-  const int b = p.b0 + bl, j = *p.step, c0 = lane * 4;
+  const int b = p.b0 + bl, j = p.step_val + (p.step ? *p.step : 0), c0 = lane * 4;
   const float4 q = norm_row_hc(p.nrm, (long)b, b, j, lane);
   *reinterpret_cast<float4*>(p.qhist + ((long)b * p.q_bstride + p.q_row0 + j) * p.q_stride + c0) = q;
   const int pm = p.pm_all[(long)j * p.B + b];
@@ -261,7 +407,7 @@ __global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Param
     const float a = e[k] * inv;
     o.x = fmaf(a, vv[k].x, o.x); o.y = fmaf(a, vv[k].y, o.y); o.z = fmaf(a, vv[k].z, o.z); o.w = fmaf(a, vv[k].w, o.w);
   }
-  float* rrow = p.rbuf + ((long)b * p.r_bstride + p.r_row0 + j) * (2 * p.d);
+  float* rrow = p.rbuf + (long)(j & 1) * p.r_set + ((long)b * p.r_bstride + p.r_row0 + j) * (2 * p.d);
   *reinterpret_cast<float4*>(rrow + c0) = o;
   *reinterpret_cast<float4*>(rrow + p.d + c0) = q;
   if (lane == 0) p.pm_all[(long)(j + 1) * p.B + b] = pm + am;
@@ -270,7 +416,7 @@ __global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Param
 // End of the chain: mel frame j = sigmoid(LN(P_last[b])) over n_mels channels -> S[j+1] (ypad row j+1) and the
 // raw logits.  grid ceil(Bg/4), block 256 (wave per utterance).  n_mels <= 128.
 struct FinalizeParams {
-  int Bg, b0; const int* step;
+  int Bg, b0; const int* step; int step_val;
   const float* P; int np; const float* g; const float* be; int n;
   float* ypad; long y_bstride; long y_row0; int y_stride;       // y_row0 already includes the +1 shift (train.py:51)
   float* logits; long l_bstride; int l_stride;
@@ -279,7 +425,7 @@ struct FinalizeParams {
 __global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
   const int lane = threadIdx.x & 63, bl = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (bl >= p.Bg) return;
-  const int b = p.b0 + bl, j = *p.step;
+  const int b = p.b0 + bl, j = p.step_val + (p.step ? *p.step : 0);
   const float* row = p.P + (long)b * p.np;
   const int c0 = lane, c1 = lane + 64;
   const float x0 = (c0 < p.n) ? row[c0] : 0.f, x1 = (c1 < p.n) ? row[c1] : 0.f;
