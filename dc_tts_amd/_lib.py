@@ -38,6 +38,7 @@ SYMBOLS = {
     "dctts_set_decode_mode": (c_int, [c_void_p, c_int]),
     "dctts_device_bytes": (c_size_t, [c_void_p]),
     "dctts_debug_layer": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "dctts_debug_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "dctts_prof_enable": (c_int, [c_void_p, c_int]),
     "dctts_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
 }

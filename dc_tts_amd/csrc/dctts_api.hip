@@ -972,6 +972,17 @@ extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const
   return run_conv(c, L, vi, nullptr, vo, rm, st);
 }
 
+
+// Calibration aid for the HBM counters (FETCH_SIZE / WRITE_SIZE): a float4 grid-stride copy of known size.
+__global__ void __launch_bounds__(256) calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream) {
+  hipLaunchKernelGGL(calib_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, nfloats / 4);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ profiling aid
 extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");

@@ -104,6 +104,9 @@ size_t dctts_device_bytes(const dctts_ctx* ctx);
  * each D layer occupying two consecutive indices.  Synchronises (allocates a scratch copy of X). */
 int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X, int B, int T, float* out, void* stream);
 
+/* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
+int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
+
 /* Measurement aid for bench.py's roofline object: HIP events are recorded on the launch stream
  * around every launch of the conv kernel instantiation `kernel_id` = epi*10000 + NT*100 + NW
  * (epi 0 = C, 1 = HC) while enabled.  collect() synchronises those events, returns the number of
