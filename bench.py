@@ -139,6 +139,12 @@ def main():
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None, "kernel": "hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11/HC_12, 1024ch k=3, fused LN+gate)",
                 "launches": n_launch, "avg_launch_ms": None, "flop_per_launch": flops_per_launch}
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if B == 32 and T == 210 and os.path.exists(tj):
+            # HBM bytes per launch of this kernel from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+            # collected separately with rocprofv3 --pmc (profiles/r01_pmc_traffic.md); bench.py cannot read counters itself
+            roof["traffic"] = json.load(open(tj))["hbm_bytes_per_launch"]
+            roof["traffic_unit"] = "bytes/launch (PMC, separate pass)"
         if n_launch > 0:
             avg_ms = dom_ms / n_launch
             ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
