@@ -64,6 +64,8 @@ struct DevLayer {
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
+  float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for rowmlp_kernel
+  int cin_real = 0;
   bool hc = false;
 };
 
@@ -93,6 +95,7 @@ struct dctts_ctx {
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // v1: one step, replayed T times
   std::vector<hipGraphExec_t> chain_g, bulk_g; hipGraphExec_t pro_g = nullptr;   // v2: one small linear graph per frame and stream,
   std::string graphs2_geom;                                                      //     frame index baked into every launch
+  int fuse_mlp = 1;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch
   int bulk_cap = 192;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
@@ -162,6 +165,8 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
   auto W = [=](int, int cc, int col) { return kv[(size_t)cc * cout + col]; };
   CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 31) / 32), cout, false, 16), &L->wp16));
+  if (dec) CHK(upload(c, k->v, &L->wraw));
+  L->cin_real = cin_real;
   CHK(upload(c, b->v, &L->bias)); CHK(upload(c, ga->v, &L->g1)); CHK(upload(c, be->v, &L->b1));
   return 0;
 }
@@ -701,13 +706,52 @@ static int decode_v2_init(dctts_ctx* c) {
   return 0;
 }
 
+// rowmlp launch: layers NETA[a0, a1) then NETB[b0_, b1) (either range may be empty) as one per-row MLP for `frame`.
+static int run_rowmlp(dctts_ctx* c, const DecodeWs& w, int B, int frame, bool tail, bool head, hipStream_t st) {
+  const std::vector<DevLayer>& AD = c->audiodec; const std::vector<DevLayer>& AE = c->audioenc;
+  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
+  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
+  RowMlpParams p; memset(&p, 0, sizeof(p));
+  p.B = B; p.b0 = 0; p.frame = frame; p.mel_layer = -1;
+  int n = 0;
+  auto add = [&](const DevLayer& L) {
+    RowMlpLayer& m = p.L[n++];
+    m.w = L.wraw; m.bias = L.bias; m.g = L.g1; m.be = L.b1; m.cin = L.cin_real; m.cout = L.cout; m.act = (L.act == ACT_RELU) ? ACT_RELU : ACT_NONE;
+  };
+  if (tail) {
+    const RowNorm nr = make_norm(AD[lh], w.pd[lh], &w.ad[lh - 1]);
+    p.pro = PRO_LN_HC; p.nrm = nr;
+    for (size_t i = lh + 1; i < AD.size(); ++i) add(AD[i]);
+    p.mel_layer = n - 1;
+    p.ypad = w.ypad.p; p.y_bstride = w.ypad.bstride; p.y_row0 = w.ypad.row0 + 1; p.y_stride = w.ypad.stride;
+    p.logits = w.logits.p; p.l_bstride = w.logits.bstride; p.l_stride = w.logits.stride;
+  } else {
+    p.pro = PRO_RAW; p.xsrc = w.ypad.p; p.xs_bstride = w.ypad.bstride; p.xs_row0 = w.ypad.row0; p.xs_stride = w.ypad.stride; p.cin0 = c->cfg.n_mels;
+  }
+  if (head) {
+    for (size_t i = 0; i < nh; ++i) add(AE[i]);
+    p.xout = w.ae[nh - 1].p; p.xo_bstride = w.ae[nh - 1].bstride; p.xo_row0 = w.ae[nh - 1].row0; p.xo_stride = w.ae[nh - 1].stride;
+    p.xo_frame_add = tail ? 1 : 0;                             // after the tail the head works on frame + 1
+  }
+  p.nlayers = n;
+  if (n < 1 || n > 8) return fail(DCTTS_ERR_STATE, "rowmlp: 1..8 layers");
+  for (int i = 0; i < n; ++i) if (!p.L[i].w || (p.L[i].cin & 7) || (p.L[i].cout & 3) || p.L[i].cin > 256 || p.L[i].cout > 256) return fail(DCTTS_ERR_STATE, "rowmlp: unsupported layer shape");
+  hipLaunchKernelGGL(rowmlp_kernel, dim3(B), dim3(512), 0, st, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// AudioEnc highway layers for frame j (the k=1 head has already written its C_3 row), then the newest-frame attention.
 // AudioEnc for frame j (13 dependent 16-row x 16-channel-group launches), then the newest-frame attention:
 // rebuild Q[j], materialise it, 3-key softmax, R[j], arg-max -> the window of frame j+1.
-static int v2_audioenc_attn(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm) {
+static int v2_audioenc_attn(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm, bool head_done = false) {
   const int d = c->cfg.d;
   const std::vector<DevLayer>& AE = c->audioenc;
-  for (size_t i = 0; i < AE.size(); ++i) {
-    if (i == 0) {
+  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;
+  for (size_t i = head_done ? nh : 0; i < AE.size(); ++i) {
+    if (head_done && i == nh) {       // C_3's row was materialised by rowmlp: every tap of HC_4 is a raw history row
+      CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ae[i - 1], w.pe[i], sm, nullptr, w.se[i]));
+    } else if (i == 0) {
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
     } else {
       const RowNorm n = make_norm(AE[i - 1], w.pe[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr);
@@ -761,13 +805,21 @@ static int v2_bulk_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, h
 
 static int v2_chain_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, bool with_next, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->audiodec;
-  for (size_t i = 0; i < AD.size(); ++i) {
+  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;
+  const size_t nsplit = c->fuse_mlp ? lh + 1 : AD.size();
+  for (size_t i = 0; i < nsplit; ++i) {
     if (i == 0) {
       CHK(run_split(c, 16, AD[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.rbuf, w.pd[0], sm, nullptr, w.sd[0]));
     } else {
       const RowNorm n = make_norm(AD[i - 1], w.pd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr);
       CHK(run_split(c, 16, AD[i], B, 1, nullptr, j, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm, w.sd[i - 1], w.sd[i]));
     }
+  }
+  if (c->fuse_mlp) {
+    // C_8..C_11 + sigmoid (mel frame j) and, for the next frame, AudioEnc C_1..C_3: one per-row MLP launch
+    CHK(run_rowmlp(c, w, B, j, true, with_next, sm));
+    if (with_next) CHK(v2_audioenc_attn(c, w, B, N, j + 1, sm, true));
+    return 0;
   }
   const DevLayer& Ll = AD.back();
   FinalizeParams f; memset(&f, 0, sizeof(f));
@@ -832,14 +884,16 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     hipStream_t sb = c->s_bulk;
     const bool gr = c->use_graph != 0;
     if (gr) {
-      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)w.kv.p);
+      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->fuse_mlp) + ":" + std::to_string((size_t)w.kv.p);
       if (c->chain_g.empty() || c->graphs2_geom != g) {
         destroy_graphs2(c);
         hipStream_t cs;
         HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         const int prof_keep = c->prof_id; c->prof_id = -1;
         c->chain_g.assign(T, nullptr); c->bulk_g.assign(T, nullptr);
-        int rc = capture_piece(cs, &c->pro_g, [&]() { return v2_audioenc_attn(c, w, B, N, 0, cs); });   // frame 0's AudioEnc + attention
+        int rc = capture_piece(cs, &c->pro_g, [&]() {                                               // frame 0's AudioEnc + attention
+          if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, cs)); return v2_audioenc_attn(c, w, B, N, 0, cs, true); }
+          return v2_audioenc_attn(c, w, B, N, 0, cs); });
         for (int j = 0; j < T && rc == 0; ++j) {
           rc = capture_piece(cs, &c->chain_g[j], [&]() { return v2_chain_piece(c, w, B, N, j, j + 1 < T, cs); });
           if (rc == 0 && j >= 1) rc = capture_piece(cs, &c->bulk_g[j], [&]() { return v2_bulk_piece(c, w, B, N, j, cs); });
@@ -856,7 +910,9 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
     // pipeline prologue = chain piece -1: frame 0's AudioEnc + attention
-    if (gr) HIPCHK(hipGraphLaunch(c->pro_g, st)); else CHK(v2_audioenc_attn(c, w, B, N, 0, st));
+    if (gr) HIPCHK(hipGraphLaunch(c->pro_g, st));
+    else if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, st)); CHK(v2_audioenc_attn(c, w, B, N, 0, st, true)); }
+    else CHK(v2_audioenc_attn(c, w, B, N, 0, st));
     HIPCHK(hipEventRecord(c->ev_chain[3], st));
     for (int j = 0; j < T; ++j) {
       // bulk piece f = j+1 needs attention(j) (end of chain piece j-1) and overlaps chain piece j
@@ -932,8 +988,9 @@ extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
 }
 
 extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 1) return fail(DCTTS_ERR_ARG, "decode mode must be 0 or 1");
-  c->decode_mode = mode;
+  if (!c || mode < 0 || mode > 2) return fail(DCTTS_ERR_ARG, "decode mode must be 0, 1 or 2");
+  c->decode_mode = mode ? 1 : 0;
+  c->fuse_mlp = (mode == 2) ? 0 : 1;
   return 0;
 }
 

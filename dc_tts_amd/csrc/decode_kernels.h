@@ -413,6 +413,89 @@ __global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Param
   if (lane == 0) p.pm_all[(long)(j + 1) * p.B + b] = pm + am;
 }
 
+// Row-per-workgroup chain of k=1 conv layers (a per-row MLP): AudioDec C_8..C_11 + sigmoid (mel frame j), then
+// AudioEnc C_1..C_3 of frame j+1 on the frame just produced -- seven dependent layers in ONE launch.
+// One workgroup = one utterance row.  64 k MACs per layer are trivial, so plain VALU FMAs: wave w owns a K slice,
+// lane owns 4 output channels, weights stay in TF layout (Cin, Cout) and stream as coalesced 1 KiB wave loads
+// (256 KB per layer through one CU ~ 2 us: the bound); partial sums meet in LDS; layer-norm is done by wave 0
+// (lane = 4 channels, DPP sums), so no statistics ever leave the workgroup.
+struct RowMlpLayer { const float* w; const float* bias; const float* g; const float* be; int cin; int cout; int act; int pad_; };
+struct RowMlpParams {
+  int B, b0, frame;
+  int pro; RowNorm nrm;                                        // PRO_LN_HC: input row rebuilt from pre-norm rows (prow = b); PRO_RAW: xsrc row
+  const float* xsrc; long xs_bstride; long xs_row0; int xs_stride; int cin0;
+  int nlayers; RowMlpLayer L[8];
+  int mel_layer;                                               // index of the layer whose LN output is the mel logits (-1: none)
+  float* ypad; long y_bstride; long y_row0; int y_stride;      // sigmoid(logits) -> row y_row0 + frame (y_row0 includes the +1 shift)
+  float* logits; long l_bstride; int l_stride;
+  float* xout; long xo_bstride; long xo_row0; int xo_stride; int xo_frame_add;   // last layer's activation row -> frame + xo_frame_add
+};
+
+__global__ void __launch_bounds__(512) rowmlp_kernel(const RowMlpParams p) {
+  __shared__ __attribute__((aligned(16))) float xs[256];        // current layer input
+  __shared__ __attribute__((aligned(16))) float part[8 * 256];  // per-wave partial sums
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = p.b0 + blockIdx.x;
+  const int c = lane * 4;
+  if (wave == 0) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.pro == PRO_LN_HC) x = norm_row_hc(p.nrm, (long)b, b, p.frame, lane, p.frame & 1);
+    else if (c < p.cin0) x = ld4(p.xsrc + ((long)b * p.xs_bstride + p.xs_row0 + p.frame) * p.xs_stride + c);
+    *reinterpret_cast<float4*>(&xs[c]) = x;
+  }
+  __syncthreads();
+  for (int l = 0; l < p.nlayers; ++l) {
+    const RowMlpLayer& Ly = p.L[l];
+    // ---- partial products: wave w owns k in [w*kw, (w+1)*kw); cin is a multiple of 8 (80, 256)
+    const int kw = Ly.cin >> 3, k0 = wave * kw;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < Ly.cout) {
+      const float* wp = Ly.w + (long)k0 * Ly.cout + c;
+      for (int kk = 0; kk < kw; kk += 8) {
+        float4 wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (kk + u < kw) wv[u] = ld4(wp + (long)(kk + u) * Ly.cout);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (kk + u < kw) {
+          const float xk = xs[k0 + kk + u];
+          acc.x = fmaf(xk, wv[u].x, acc.x); acc.y = fmaf(xk, wv[u].y, acc.y); acc.z = fmaf(xk, wv[u].z, acc.z); acc.w = fmaf(xk, wv[u].w, acc.w);
+        }
+      }
+    }
+    *reinterpret_cast<float4*>(&part[wave * 256 + c]) = acc;
+    __syncthreads();
+    // ---- wave 0: reduce the 8 partials, bias, layer-norm over cout, activation; becomes the next layer's input
+    if (wave == 0) {
+      const bool in = c < Ly.cout;
+      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) {
+        y = ld4(Ly.bias + c);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const float4 q = *reinterpret_cast<const float4*>(&part[w * 256 + c]); y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w; }
+      }
+      const float invn = 1.0f / (float)Ly.cout;
+      const float mean = wave_sum(y.x + y.y + y.z + y.w) * invn;
+      float4 d = in ? make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float rs = 1.0f / sqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * invn + 1e-12f);
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) {
+        const float4 g = ld4(Ly.g + c), be = ld4(Ly.be + c);
+        o = make_float4(d.x * rs * g.x + be.x, d.y * rs * g.y + be.y, d.z * rs * g.z + be.z, d.w * rs * g.w + be.w);
+        if (Ly.act == ACT_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (l == p.mel_layer) {
+          *reinterpret_cast<float4*>(p.logits + ((long)b * p.l_bstride + p.frame) * p.l_stride + c) = o;
+          o = make_float4(sigmoidf_(o.x), sigmoidf_(o.y), sigmoidf_(o.z), sigmoidf_(o.w));
+          *reinterpret_cast<float4*>(p.ypad + ((long)b * p.y_bstride + p.y_row0 + p.frame) * p.y_stride + c) = o;
+        }
+        if (l + 1 == p.nlayers && p.xout)
+          *reinterpret_cast<float4*>(p.xout + ((long)b * p.xo_bstride + p.xo_row0 + p.frame + p.xo_frame_add) * p.xo_stride + c) = o;
+      }
+      *reinterpret_cast<float4*>(&xs[c]) = o;                   // channels >= cout are zero: the next layer's K padding
+    }
+    __syncthreads();
+  }
+}
+
 // End of the chain: mel frame j = sigmoid(LN(P_last[b])) over n_mels channels -> S[j+1] (ypad row j+1) and the
 // raw logits.  grid ceil(Bg/4), block 256 (wave per utterance).  n_mels <= 128.
 struct FinalizeParams {

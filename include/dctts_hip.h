@@ -91,8 +91,9 @@ int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
 /* Decode algorithm form (results agree to fp32 re-association; both are the exact-parity incremental decode):
  * 0 = fused full-row kernels on one stream (one workgroup per 32-row block),
- * 1 = (default) column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone run as two
- *     branches of the step (two streams / two graph branches). */
+ * 1 = (default) column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone run on two
+ *     streams; the k=1 layers around the mel frame (AudioDec C_8..C_11 + sigmoid, AudioEnc C_1..C_3) are one per-row launch,
+ * 2 = as 1 but every layer its own launch. */
 int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
 
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
