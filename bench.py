@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
     ap.add_argument("--max-T", type=int, default=210)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--decode-mode", type=int, default=1, help="1 = default, 2 = no k=1 fusion, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -85,6 +86,7 @@ def main():
     B, T = args.batch, hp.max_T
     W = synthetic_weights(hp, seed=1234, perturb=True)
     eng = Engine(W, hp, device=local, decode_graph=not args.no_graph)
+    eng.set_decode_mode(args.decode_mode)
     L = torch.from_numpy(synthetic_text(hp, B=B, seed=1234 + rank)).cuda()
 
     def barrier():

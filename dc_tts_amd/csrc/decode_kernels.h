@@ -419,6 +419,14 @@ __global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Param
 // lane owns 4 output channels, weights stay in TF layout (Cin, Cout) and stream as coalesced 1 KiB wave loads
 // (256 KB per layer through one CU ~ 2 us: the bound); partial sums meet in LDS; layer-norm is done by wave 0
 // (lane = 4 channels, DPP sums), so no statistics ever leave the workgroup.
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads() it does not drain
+// outstanding global loads (vmcnt), so loads issued before it keep flying.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 struct RowMlpLayer { const float* w; const float* bias; const float* g; const float* be; int cin; int cout; int act; int pad_; };
 struct RowMlpParams {
   int B, b0, frame;
@@ -437,6 +445,28 @@ __global__ void __launch_bounds__(512) rowmlp_kernel(const RowMlpParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = p.b0 + blockIdx.x;
   const int c = lane * 4;
+
+  // This wave's K slice of a layer's weights: up to 32 float4 per lane, ALL issued together (the layer is bound by
+  // streaming 256 KB through one CU; fewer loads in flight would make it latency-bound instead).
+  float4 wv[32];
+  auto load_w = [&](int l) {
+    const RowMlpLayer& Ly = p.L[l];
+    const int kw = Ly.cin >> 3;                                  // cin is a multiple of 8 (80, 256)
+    if (c < Ly.cout) {
+      const float* wp = Ly.w + (long)(wave * kw) * Ly.cout + c;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) if (u < kw) wv[u] = ld4(wp + (long)u * Ly.cout);
+    }
+  };
+  // bias / gamma / beta of a layer are needed by wave 0 right after the reduction: fetch them one layer ahead and BEFORE the
+  // weight prefetch (vmcnt retires in order: a late parameter load would wait behind 32 weight loads)
+  float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), pg = pb, pe = pb, nb = pb, ng = pb, ne = pb;
+  auto load_par = [&](int l, float4& b_, float4& g_, float4& e_) {
+    const RowMlpLayer& Ly = p.L[l];
+    if (wave == 0 && c < Ly.cout) { b_ = ld4(Ly.bias + c); g_ = ld4(Ly.g + c); e_ = ld4(Ly.be + c); }
+  };
+  load_par(0, pb, pg, pe);
+  load_w(0);
   if (wave == 0) {
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.pro == PRO_LN_HC) x = norm_row_hc(p.nrm, (long)b, b, p.frame, lane, p.frame & 1);
@@ -446,30 +476,24 @@ __global__ void __launch_bounds__(512) rowmlp_kernel(const RowMlpParams p) {
   __syncthreads();
   for (int l = 0; l < p.nlayers; ++l) {
     const RowMlpLayer& Ly = p.L[l];
-    // ---- partial products: wave w owns k in [w*kw, (w+1)*kw); cin is a multiple of 8 (80, 256)
     const int kw = Ly.cin >> 3, k0 = wave * kw;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c < Ly.cout) {
-      const float* wp = Ly.w + (long)k0 * Ly.cout + c;
-      for (int kk = 0; kk < kw; kk += 8) {
-        float4 wv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (kk + u < kw) wv[u] = ld4(wp + (long)(kk + u) * Ly.cout);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (kk + u < kw) {
-          const float xk = xs[k0 + kk + u];
-          acc.x = fmaf(xk, wv[u].x, acc.x); acc.y = fmaf(xk, wv[u].y, acc.y); acc.z = fmaf(xk, wv[u].z, acc.z); acc.w = fmaf(xk, wv[u].w, acc.w);
-        }
+      for (int u = 0; u < 32; ++u) if (u < kw) {
+        const float xk = xs[k0 + u];
+        acc.x = fmaf(xk, wv[u].x, acc.x); acc.y = fmaf(xk, wv[u].y, acc.y); acc.z = fmaf(xk, wv[u].z, acc.z); acc.w = fmaf(xk, wv[u].w, acc.w);
       }
     }
+    if (l + 1 < p.nlayers) { load_par(l + 1, nb, ng, ne); load_w(l + 1); }   // next layer's parameters + weights fly during the reduction + layer-norm
     *reinterpret_cast<float4*>(&part[wave * 256 + c]) = acc;
-    __syncthreads();
+    lds_barrier();      // LDS-only barrier: the prefetched weight loads stay in flight across it
     // ---- wave 0: reduce the 8 partials, bias, layer-norm over cout, activation; becomes the next layer's input
     if (wave == 0) {
       const bool in = c < Ly.cout;
       float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) {
-        y = ld4(Ly.bias + c);
+        y = pb;
 #pragma unroll
         for (int w = 0; w < 8; ++w) { const float4 q = *reinterpret_cast<const float4*>(&part[w * 256 + c]); y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w; }
       }
@@ -479,7 +503,7 @@ __global__ void __launch_bounds__(512) rowmlp_kernel(const RowMlpParams p) {
       const float rs = 1.0f / sqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * invn + 1e-12f);
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) {
-        const float4 g = ld4(Ly.g + c), be = ld4(Ly.be + c);
+        const float4 g = pg, be = pe;
         o = make_float4(d.x * rs * g.x + be.x, d.y * rs * g.y + be.y, d.z * rs * g.z + be.z, d.w * rs * g.w + be.w);
         if (Ly.act == ACT_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         if (l == p.mel_layer) {
@@ -492,7 +516,8 @@ __global__ void __launch_bounds__(512) rowmlp_kernel(const RowMlpParams p) {
       }
       *reinterpret_cast<float4*>(&xs[c]) = o;                   // channels >= cout are zero: the next layer's K padding
     }
-    __syncthreads();
+    pb = nb; pg = ng; pe = ne;
+    lds_barrier();      // LDS-only barrier: the prefetched weight loads stay in flight across it
   }
 }
 
