@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
     ap.add_argument("--max-T", type=int, default=210)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--decode-mode", type=int, default=1, help="1 = default, 2 = no k=1 fusion, 0 = fused full-row kernels")
+    ap.add_argument("--decode-mode", type=int, default=1, help="1 = default (split kernels, two streams), 2 = + fused k=1 row MLP, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

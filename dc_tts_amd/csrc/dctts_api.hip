@@ -64,7 +64,6 @@ struct DevLayer {
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
-  float* wp8 = nullptr;           // decode layers: 16x16x4 tiles holding 8 real columns each (half the weight bytes per workgroup)
   float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for rowmlp_kernel
   int cin_real = 0;
   bool hc = false;
@@ -96,9 +95,9 @@ struct dctts_ctx {
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // v1: one step, replayed T times
   std::vector<hipGraphExec_t> chain_g, bulk_g; hipGraphExec_t pro_g = nullptr;   // v2: one small linear graph per frame and stream,
   std::string graphs2_geom;                                                      //     frame index baked into every launch
-  int chain_cols = 8;                  // real output columns per chain MFMA tile (16 = full tile, 8 = half the weight bytes per workgroup)
   int chain_rows = 8;                  // rows per chain workgroup (16 = full MFMA tile; 8 halves the activation bytes each CU pulls)
-  int fuse_mlp = 1;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch
+  int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
+                                       //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
   int bulk_cap = 192;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
@@ -132,19 +131,16 @@ static int upload(dctts_ctx* c, const std::vector<float>& h, float** d) {
 //   MF = 32 (v_mfma_f32_32x32x2_f32): lane l, element i <- k = 8*kg + 4*(l>>5) + i, column l&31 of the tile
 //   MF = 16 (v_mfma_f32_16x16x4_f32): lane l, element i <- k = 16*kg + 4*(l>>4) + i, column l&15 of the tile
 // Tiles of a highway layer alternate gate (H1) / info (H2) blocks of the same MF channels.
-// gc = real columns per tile (gc < MF: the remaining columns of every tile are zero padding).
 static std::vector<float> pack_bw(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p,
-                                  int tiles, int cout, bool hc, int MF, int gc = 0) {
-  if (gc <= 0) gc = MF;
+                                  int tiles, int cout, bool hc, int MF) {
   const int KGS = (MF == 32) ? 8 : 16, KG = ntaps * cin_p / KGS, sh = (MF == 32) ? 5 : 4;
   std::vector<float> out((size_t)tiles * KG * 256, 0.f);
   for (int gt = 0; gt < tiles; ++gt)
     for (int kg = 0; kg < KG; ++kg)
       for (int l = 0; l < 64; ++l) {
         int col;
-        const int lc = l & (MF - 1);
-        if (hc) { const int ch = (gt / 2) * gc + lc; col = (lc < gc && ch < cout) ? (gt & 1) * cout + ch : -1; }
-        else    { const int ch = gt * gc + lc;       col = (lc < gc && ch < cout) ? ch : -1; }
+        if (hc) { const int ch = (gt / 2) * MF + (l & (MF - 1)); col = ch < cout ? (gt & 1) * cout + ch : -1; }
+        else    { const int ch = gt * MF + (l & (MF - 1));       col = ch < cout ? ch : -1; }
         if (col < 0) continue;
         for (int i = 0; i < 4; ++i) {
           const int k = kg * KGS + 4 * (l >> sh) + i, tap = k / cin_p, cc = k % cin_p;
@@ -172,7 +168,6 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
   CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 31) / 32), cout, false, 16), &L->wp16));
   if (dec) CHK(upload(c, k->v, &L->wraw));
-  if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 15) / 16), cout, false, 16, 8), &L->wp8));
   L->cin_real = cin_real;
   CHK(upload(c, b->v, &L->bias)); CHK(upload(c, ga->v, &L->g1)); CHK(upload(c, be->v, &L->b1));
   return 0;
@@ -196,7 +191,6 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
   auto W = [=](int tap, int cc, int col) { return kv[((size_t)tap * C + cc) * (2 * C) + col]; };
   CHK(upload(c, pack_b(W, k, C, L->cin_p, L->shape, C, true), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, k, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16));
-  if (dec) CHK(upload(c, pack_bw(W, k, C, L->cin_p, 2 * (C / 8), C, true, 16, 8), &L->wp8));
   L->hc = true;
   CHK(upload(c, b->v, &L->bias));
   CHK(upload(c, g1->v, &L->g1)); CHK(upload(c, b1->v, &L->b1));
@@ -611,8 +605,8 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
   }
   w->pe.resize(c->audioenc.size()); w->pd.resize(c->audiodec.size()); w->pb.resize(c->audiodec.size());
   w->se.resize(c->audioenc.size()); w->sd.resize(c->audiodec.size());
-  for (size_t i = 0; i < w->se.size(); ++i) { CHK(ws_get(c, "dec.se" + std::to_string(i), (size_t)B * 128 * sizeof(float), &p)); w->se[i] = (float*)p; }
-  for (size_t i = 0; i < w->sd.size(); ++i) { CHK(ws_get(c, "dec.sd" + std::to_string(i), (size_t)B * 128 * sizeof(float), &p)); w->sd[i] = (float*)p; }
+  for (size_t i = 0; i < w->se.size(); ++i) { CHK(ws_get(c, "dec.se" + std::to_string(i), (size_t)B * 64 * sizeof(float), &p)); w->se[i] = (float*)p; }
+  for (size_t i = 0; i < w->sd.size(); ++i) { CHK(ws_get(c, "dec.sd" + std::to_string(i), (size_t)B * 64 * sizeof(float), &p)); w->sd[i] = (float*)p; }
   for (size_t i = 0; i < w->pe.size(); ++i) { const int np = c->audioenc[i].hc ? 2 * d : c->audioenc[i].cout; CHK(ws_get(c, "dec.pe" + std::to_string(i), (size_t)B * np * sizeof(float), &p)); w->pe[i] = (float*)p; }
   for (size_t i = 0; i < w->pd.size(); ++i) {
     const int np = c->audiodec[i].hc ? 2 * d : c->audiodec[i].cout;
@@ -688,18 +682,15 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   p.xsrc = xsrc.p; p.xs_bstride = xsrc.bstride; p.xs_row0 = xsrc.row0; p.xs_stride = xsrc.stride; p.xs_set = xsrc.set;
   p.ntaps = L.ntaps; for (int j = 0; j < 3; ++j) p.tap_off[j] = L.tap_off[j];
   p.cin = L.cin; p.cin_p = L.cin_p;
-  const int gc = (MF == 16) ? c->chain_cols : MF;
-  p.gcols = gc; p.gcols_in = c->chain_cols;
-  p.wp = (MF == 16) ? (gc == 8 ? L.wp8 : L.wp16) : L.wp; p.bias = L.bias; p.cout = L.cout; p.hc = L.hc ? 1 : 0;
+  p.wp = (MF == 16) ? L.wp16 : L.wp; p.bias = L.bias; p.cout = L.cout; p.hc = L.hc ? 1 : 0;
   p.np_out = L.hc ? 2 * L.cout : L.cout; p.pout = pout; p.stats_in = stats_in; p.stats_out = stats_out;
   if (pro != PRO_RAW && (MF != 16 || L.cin_p != 256 || !stats_in))
     return fail(DCTTS_ERR_STATE, "split kernel: LN prologue needs the 16-row form, 256 input channels and producer statistics");
   if (L.ntaps > 1 && L.cin_p != 256) return fail(DCTTS_ERR_STATE, "split kernel: multi-tap layers must have 256 input channels");
   if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++);
-  const int groups = L.hc ? L.cout / gc : (L.cout + 2 * gc - 1) / (2 * gc);
+  const int groups = L.hc ? L.cout / MF : (L.cout + 2 * MF - 1) / (2 * MF);
   p.ngroups = groups;
   p.tile_rows = (MF == 16) ? c->chain_rows : MF;
-  if (const char* e = getenv("DCTTS_DBG_KDIV")) p.dbg_kdiv = (MF == 16) ? atoi(e) : 0;
   int nblk = ((p.M + p.tile_rows - 1) / p.tile_rows) * groups;
   if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
   const size_t sm = hsplit_smem(MF);
@@ -888,7 +879,6 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
-  if (const char* e = getenv("DCTTS_CHAIN_COLS")) { const int r = atoi(e); if (r == 8 || r == 16) c->chain_cols = r; }
   if (v2) CHK(decode_v2_init(c));
   if (!v2) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // v1 uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
@@ -898,7 +888,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     hipStream_t sb = c->s_bulk;
     const bool gr = c->use_graph != 0;
     if (gr) {
-      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->fuse_mlp) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string(c->chain_cols) + ":" + std::to_string((size_t)w.kv.p);
+      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->fuse_mlp) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string((size_t)w.kv.p);
       if (c->chain_g.empty() || c->graphs2_geom != g) {
         destroy_graphs2(c);
         hipStream_t cs;
@@ -1004,7 +994,7 @@ extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
 extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return fail(DCTTS_ERR_ARG, "decode mode must be 0, 1 or 2");
   c->decode_mode = mode ? 1 : 0;
-  c->fuse_mlp = (mode == 2) ? 0 : 1;
+  c->fuse_mlp = (mode == 2) ? 1 : 0;
   return 0;
 }
 

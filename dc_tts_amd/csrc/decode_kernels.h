@@ -97,10 +97,8 @@ struct SplitParams {
   // ---- row mapping: m in [0,M) -> b = b0 + m / R, r = m % R, t = frame + (offs ? offs[r] : 0); rows with t < 0 are skipped
   int M, R, b0; const int* offs; const int* step; int step_val;   // frame = step_val + (step ? *step : 0)
   int ngroups;                                                   // column groups; work items = row tiles x ngroups, grid-strided
-  int tile_rows;                                                 // rows per work item (<= MF): fewer rows = fewer bytes per CU, more CUs
-  int gcols;                                                     // real output columns per MFMA tile (MF, or 8 of 16 in the chain: halves the
-                                                                 // weight bytes each CU pulls -- the chain is bound by bytes per CU, not MFMA)
-  int gcols_in;                                                  // same for the producer of stats_in: partials are per gcols_in channels
+  int tile_rows;                                                 // rows per work item (<= MF): the chain is bound by bytes pulled per CU
+                                                                 // (~30 GB/s each), so 8-row items on twice the CUs beat full 16-row tiles
   // ---- centre tap (row t itself): PRO_RAW reads xsrc; PRO_LN_* rebuilds it from pre-norm rows (index b*R + r) using the
   //      producer's per-column-group partial statistics `stats_in` [prow][16 groups][4] = (mean1, M2_1, mean2, M2_2)
   int pro; RowNorm nrm; const float* stats_in;
@@ -113,7 +111,6 @@ struct SplitParams {
   float* pout;                                                   // pre-norm rows [b*R + r][np_out]
   float* stats_out;                                              // optional partial statistics of pout (16-row form only)
   long long* dbg;                                                // optional: 8 wall-clock (100 MHz) stamps of workgroup 0
-  int dbg_kdiv;                                                  // TIMING EXPERIMENTS ONLY: process 1/dbg_kdiv of K (wrong results)
 };
 // *_set: buffers written by the bulk branch exist twice (frame parity); set stride in floats, 0 = single buffer.
 
@@ -126,19 +123,17 @@ __device__ __forceinline__ float xrow4_sum(float v) {
   return __uint_as_float(q[0]) + __uint_as_float(q[1]);
 }
 
-// Combine the per-group partials (mean_g, M2_g over n channels each; G = 256 / n groups) of one row into (mean, rstd).
-// Each of the row's four lanes streams its G/4 groups into three running sums per LN half, so no partial stays live:
-//   mean = S(mean_g) / G,   M2 = S(M2_g) + n * (S(mean_g^2) - G * mean^2)        (parallel-variance identity)
-// The within-group M2_g are exact two-pass values from the producer; only the small between-group term is formed
-// from sums of squares of group MEANS (|mean_g| = O(1), so its fp32 cancellation error is ~1e-6 of the variance).
-struct StatAcc { float s1, s2, s3; };
-__device__ __forceinline__ void stat_add(StatAcc& a, float m, float m2) { a.s1 += m; a.s2 = fmaf(m, m, a.s2); a.s3 += m2; }
-__device__ __forceinline__ void stat_finish(const StatAcc& a, float n, float& mean, float& rstd) {
-  const float G = 256.0f / n;
-  const float s1 = xrow4_sum(a.s1), s2 = xrow4_sum(a.s2), s3 = xrow4_sum(a.s3);
-  mean = s1 / G;
-  const float m2 = s3 + n * fmaxf(s2 - G * mean * mean, 0.f);
-  rstd = rsqrt_fast(m2 * (1.0f / 256.0f) + 1e-12f);
+// Chan-combine the 16 per-group partials (mean_g, M2_g over 16 channels each) of one row: exact two-pass quality.
+// Each of the row's four lanes holds four groups (st[0..3]); h selects (x,y) = H1 / (z,w) = H2.
+__device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, float& mean, float& rstd) {
+  float sm = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) sm += h ? st[g].z : st[g].x;
+  mean = xrow4_sum(sm) * (1.0f / 16.0f);
+  float m2 = 0.f;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) { const float dm = (h ? st[g].z : st[g].x) - mean; m2 += (h ? st[g].w : st[g].y) + 16.0f * dm * dm; }
+  rstd = rsqrt_fast(xrow4_sum(m2) * (1.0f / 256.0f) + 1e-12f);
 }
 
 template <int MF>
@@ -154,7 +149,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   if (tr) p.dbg[0] = wall_clock64();
   const int step = p.step_val + (p.step ? *p.step : 0);
   const long par = step & 1;
-  const int KG = p.ntaps * p.cin_p / KGS / (p.dbg_kdiv > 1 ? p.dbg_kdiv : 1);
+  const int KG = p.ntaps * p.cin_p / KGS;
   const int ntile = (p.M + p.tile_rows - 1) / p.tile_rows;
   const int nitems = ntile * p.ngroups;
   const int arow = lane & (MF - 1);
@@ -172,16 +167,12 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     // ---- B fragments: wave w owns k-groups w, w+8, ...; independent of A, so issue first
     const float* wb = p.wp + lane * 4;
     const unsigned w0o = (unsigned)(grp * 2) * (unsigned)KG * 256u, w1o = w0o + (unsigned)KG * 256u;
-    const bool bcol = (lane & (MF - 1)) < p.gcols;       // lanes whose B column is a real channel (others: packed zeros, not fetched)
     float4 bq0[BD], bq1[BD];
 #pragma unroll
-    for (int i = 0; i < BD; ++i) { bq0[i] = make_float4(0.f, 0.f, 0.f, 0.f); bq1[i] = bq0[i]; }
-    if (bcol) {
-#pragma unroll
-      for (int i = 0; i < BD; ++i) {
-        const int g = wave + 8 * i;
-        if (g < KG) { bq0[i] = ld4u(wb, w0o + (unsigned)g * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)g * 256u); }
-      }
+    for (int i = 0; i < BD; ++i) {
+      const int g = wave + 8 * i;
+      bq0[i] = make_float4(0.f, 0.f, 0.f, 0.f); bq1[i] = bq0[i];
+      if (g < KG) { bq0[i] = ld4u(wb, w0o + (unsigned)g * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)g * 256u); }
     }
 
     // ---- this lane's A row (MFMA A operand: lane -> row lane % MF, k sub-block lane / MF)
@@ -208,8 +199,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     const unsigned rs_row = valid ? (unsigned)(par * p.nrm.res_set + ((long)b * p.nrm.res_bstride + p.nrm.res_row0 + t) * p.nrm.res_stride) : 0u;
     float4 av[NGMAX];
     float4 h2v[2], rsv[2], g1v[2], b1v[2], g2v[2], b2v[2];   // centre-tap extras of the (at most two) centre k-groups of a wave
-    const int gpl = 64 / (p.gcols_in > 0 ? p.gcols_in : 16);   // statistics groups streamed by this lane
-    float4 st[8];
+    float4 st[4];
 #pragma unroll
     for (int i = 0; i < NGMAX; ++i) {
       const int g = wave + 8 * i;
@@ -235,7 +225,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     if constexpr (MF == 16) {
       if (ln) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) if (g < gpl) st[g] = ld4u(p.stats_in, (valid ? (unsigned)(prow * gpl * 16) : 0u) + (aq * gpl + g) * 4);
+        for (int g = 0; g < 4; ++g) st[g] = ld4u(p.stats_in, (valid ? (unsigned)(prow * 64) : 0u) + (aq * 4 + g) * 4);
       }
     }
     if (tr) p.dbg[2] = wall_clock64();
@@ -248,12 +238,8 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     if constexpr (MF == 16) {
       if (ln) {
         float m1, r1, m2 = 0.f, r2 = 0.f;
-        const float gn_ = (float)(p.gcols_in > 0 ? p.gcols_in : 16);
-        StatAcc a1 = {0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 8; ++g) if (g < gpl) { stat_add(a1, st[g].x, st[g].y); stat_add(a2, st[g].z, st[g].w); }
-        stat_finish(a1, gn_, m1, r1);                 // every lane takes part in the cross-lane sums (ln is uniform)
-        if (p.pro == PRO_LN_HC) stat_finish(a2, gn_, m2, r2);
+        combine_stats(st, 0, m1, r1);                 // every lane takes part in the cross-lane sums (ln is uniform)
+        if (p.pro == PRO_LN_HC) combine_stats(st, 1, m2, r2);
 #pragma unroll
         for (int i = 0; i < NGMAX; ++i) {
           const int g = wave + 8 * i;
@@ -298,7 +284,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
         if (i + BD < NGMAX) {
           const int gn = g + 8 * BD;
-          if (gn < KG && bcol) { bq0[i % BD] = ld4u(wb, w0o + (unsigned)gn * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gn * 256u); }
+          if (gn < KG) { bq0[i % BD] = ld4u(wb, w0o + (unsigned)gn * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gn * 256u); }
         }
         if constexpr (MF == 32) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
@@ -333,19 +319,19 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       else                    { row = (l >> 4) * 4 + j;                      col = l & 15; }
       const long orow = s_prow[row];
       int pcol; bool ok;
-      if (p.hc) { const int c = grp * p.gcols + col; ok = (col < p.gcols) && c < p.cout; pcol = tile * p.cout + c; }
-      else      { pcol = (grp * 2 + tile) * p.gcols + col; ok = (col < p.gcols) && pcol < p.cout; }
+      if (p.hc) { const int c = grp * MF + col; ok = c < p.cout; pcol = tile * p.cout + c; }
+      else      { pcol = (grp * 2 + tile) * MF + col; ok = pcol < p.cout; }
       if (ok) v_ += p.bias[pcol];
       if (ok && orow >= 0) p.pout[orow * p.np_out + pcol] = v_;
       if constexpr (MF == 16) {
         // partial LN statistics of this 16-column group: a DPP row (16 lanes) holds one output row's 16 columns
         if (p.stats_out) {
-          const float mg = row16_sum(ok ? v_ : 0.f) / (float)p.gcols;
+          const float mg = row16_sum(ok ? v_ : 0.f) * (1.0f / 16.0f);
           const float dv = ok ? v_ - mg : 0.f;
           const float m2g = row16_sum(dv * dv);
           if (ok && orow >= 0 && col == 0) {
             const int G = p.hc ? grp : grp * 2 + tile;
-            float* so = p.stats_out + (orow * (256 / p.gcols) + G) * 4 + (p.hc ? tile * 2 : 0);
+            float* so = p.stats_out + (orow * 16 + G) * 4 + (p.hc ? tile * 2 : 0);
             so[0] = mg; so[1] = m2g;
           }
         }

@@ -89,11 +89,11 @@ int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, floa
 /* Decode launch mode: 0 = one kernel launch per layer per step (eager), 1 = one hipGraph replay per step. */
 int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
-/* Decode algorithm form (results agree to fp32 re-association; both are the exact-parity incremental decode):
+/* Decode algorithm form (results agree to fp32 re-association; all are the exact-parity incremental decode):
  * 0 = fused full-row kernels on one stream (one workgroup per 32-row block),
- * 1 = (default) column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone run on two
- *     streams; the k=1 layers around the mel frame (AudioDec C_8..C_11 + sigmoid, AudioEnc C_1..C_3) are one per-row launch,
- * 2 = as 1 but every layer its own launch. */
+ * 1 = (default) column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone run on two streams,
+ * 2 = as 1, but the k=1 layers around the mel frame (AudioDec C_8..C_11 + sigmoid, next frame's AudioEnc C_1..C_3) run as one
+ *     row-per-workgroup launch (fewer launches, measured slower: bound by the bytes one CU can pull). */
 int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
 
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
