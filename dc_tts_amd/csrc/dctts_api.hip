@@ -98,7 +98,7 @@ struct dctts_ctx {
   int chain_rows = 8;                  // rows per chain workgroup (16 = full MFMA tile; 8 halves the activation bytes each CU pulls)
   int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
                                        //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
-  int bulk_cap = 192;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
+  int bulk_cap = 144;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
   // profiling
@@ -879,6 +879,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
+  if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   if (v2) CHK(decode_v2_init(c));
   if (!v2) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // v1 uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
