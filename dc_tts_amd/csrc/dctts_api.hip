@@ -75,6 +75,7 @@ struct View {            // a (B, rows, stride) activation buffer; row0 = index 
 };
 
 struct Buf { void* p = nullptr; size_t bytes = 0; };
+struct Arena { void* base = nullptr; size_t size = 0, used = 0; };
 
 struct dctts_ctx {
   dctts_config cfg;
@@ -82,6 +83,8 @@ struct dctts_ctx {
   std::map<std::string, HostTensor> hw;
   bool finalized = false;
   std::vector<void*> wallocs;
+  std::vector<Arena> warena;           // weights
+  std::map<std::string, std::vector<Arena>> wsarena;   // workspaces, one pool per geometry prefix ("dec.", "ssrn.", ...)
   size_t wbytes = 0;
   std::vector<DevLayer> textenc, audioenc, audiodec, ssrn;
   float* embed = nullptr;
@@ -118,11 +121,26 @@ static int get_w(dctts_ctx* c, const std::string& name, const std::vector<int64_
   return 0;
 }
 
+// Device memory comes from a few large arenas (bump allocation, 256-byte aligned) instead of hundreds of small hipMallocs:
+// every decode launch touches a different layer's weights and buffers, and with one allocation per tensor each launch
+// started with address-translation misses (large contiguous arenas map with big pages and stay within TLB reach).
+static const size_t ARENA_CHUNK = (size_t)512 << 20;
+static int arena_alloc(dctts_ctx* c, std::vector<Arena>& pool, size_t bytes, void** out) {
+  bytes = (bytes + 255) & ~(size_t)255;
+  for (Arena& a : pool) if (a.used + bytes <= a.size) { *out = (char*)a.base + a.used; a.used += bytes; return 0; }
+  Arena a; a.size = bytes > ARENA_CHUNK ? bytes : ARENA_CHUNK; a.used = bytes;
+  HIPCHK(hipMalloc(&a.base, a.size));
+  HIPCHK(hipMemset(a.base, 0, a.size));
+  pool.push_back(a);
+  *out = a.base;
+  return 0;
+}
+
 static int upload(dctts_ctx* c, const std::vector<float>& h, float** d) {
   void* p = nullptr;
-  HIPCHK(hipMalloc(&p, h.size() * sizeof(float)));
+  CHK(arena_alloc(c, c->warena, h.size() * sizeof(float), &p));
   HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
-  c->wallocs.push_back(p); c->wbytes += h.size() * sizeof(float);
+  c->wbytes += h.size() * sizeof(float);
   *d = (float*)p;
   return 0;
 }
@@ -256,7 +274,8 @@ extern "C" int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg
 }
 
 static void free_ws(dctts_ctx* c) {
-  for (auto& kv : c->ws) if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& kv : c->wsarena) for (Arena& a : kv.second) (void)hipFree(a.base);
+  c->wsarena.clear();
   c->ws.clear();
 }
 
@@ -272,6 +291,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   free_ws(c);
   for (void* p : c->wallocs) (void)hipFree(p);
+  for (Arena& a : c->warena) (void)hipFree(a.base);
   for (int* p : c->cone_dev) (void)hipFree(p);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
@@ -365,10 +385,10 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
 static int ws_get(dctts_ctx* c, const std::string& name, size_t bytes, void** out) {
   Buf& b = c->ws[name];
   if (b.bytes != bytes) {
-    if (b.p) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    HIPCHK(hipMalloc(&b.p, bytes));
-    HIPCHK(hipMemset(b.p, 0, bytes));      // pad rows/columns stay zero: kernels never write them
-    HIPCHK(hipDeviceSynchronize());
+    // new buffer (or a changed size: the old slice stays in the pool until its geometry prefix is dropped)
+    const std::string prefix = name.substr(0, name.find('.') + 1);
+    CHK(arena_alloc(c, c->wsarena[prefix], bytes, &b.p));      // arenas are zero-filled when created: pad rows/columns stay
+    HIPCHK(hipDeviceSynchronize());                            // zero because kernels never write them
     b.bytes = bytes;
   }
   *out = b.p;
@@ -390,8 +410,9 @@ static int ws_view2(dctts_ctx* c, const std::string& name, int B, long rows, lon
 }
 
 extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
-  size_t n = c->wbytes;
-  for (auto& kv : c->ws) n += kv.second.bytes;
+  size_t n = 0;
+  for (const Arena& a : c->warena) n += a.size;
+  for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
   return n;
 }
 
@@ -434,9 +455,11 @@ static std::string geom(const char* tag, int a, int b, int cdim = 0) {
 
 static void drop_ws_prefix(dctts_ctx* c, const std::string& prefix) {
   for (auto it = c->ws.begin(); it != c->ws.end();) {
-    if (it->first.compare(0, prefix.size(), prefix) == 0) { if (it->second.p) (void)hipFree(it->second.p); it = c->ws.erase(it); }
+    if (it->first.compare(0, prefix.size(), prefix) == 0) it = c->ws.erase(it);
     else ++it;
   }
+  auto pit = c->wsarena.find(prefix);
+  if (pit != c->wsarena.end()) { for (Arena& a : pit->second) (void)hipFree(a.base); c->wsarena.erase(pit); }
 }
 
 // ------------------------------------------------------------------------------------------------ TextEnc
