@@ -1,0 +1,225 @@
+"""Reader for TensorFlow V2 checkpoints ("tensor bundles": `<prefix>.index` + `<prefix>.data-XXXXX-of-YYYYY`), without
+TensorFlow -- so the reference's trained weights (`synthesize.py:32-40` restores `Text2Mel/*` from `logdir-1` and `SSRN/*`
+from `logdir-2`) can feed `dc_tts_amd.engine.Engine` directly.
+
+Formats implemented from their public specifications (TensorFlow is not installable here, so this reader is exercised
+against bundles produced by the spec-following writer in tests/test_tf_checkpoint.py, not against TF-written files):
+  * `.index` is a LevelDB-style sorted string table (tensorflow/core/lib/io/table): 48-byte footer = metaindex BlockHandle,
+    index BlockHandle (varint64 offset + size each), zero padding, magic 0xdb4775248b80fb57; every block is followed by a
+    5-byte trailer (compression type, masked crc32c); block entries are (shared, non_shared, value_len) varint32 triples with
+    prefix-compressed keys, then a restart array.  The index block maps to data blocks; data-block values are protobufs.
+  * key "" -> BundleHeaderProto {num_shards = 1, endianness = 2, version = 3}; every other key is a variable name ->
+    BundleEntryProto {dtype = 1, shape = 2 (TensorShapeProto: dim = 2 {size = 1}), shard_id = 3, offset = 4, size = 5,
+    crc32c = 6 (fixed32), slices = 7}.  Tensor bytes are raw little-endian at [offset, offset + size) of the shard file.
+"""
+import os
+import re
+import struct
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+TABLE_MAGIC = 0xDB4775248B80FB57
+_DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64}     # DT_FLOAT, DT_DOUBLE, DT_INT32, DT_INT64
+
+
+class CheckpointError(ValueError):
+    pass
+
+
+# ----------------------------------------------------------------------------- crc32c (Castagnoli), TF's masking
+def _make_crc_table():
+    tab = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+        tab.append(c)
+    return tab
+
+
+_CRC_TABLE = _make_crc_table()
+
+
+def crc32c(data: bytes, crc: int = 0) -> int:
+    c = crc ^ 0xFFFFFFFF
+    for b in data:
+        c = _CRC_TABLE[(c ^ b) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def mask_crc(c: int) -> int:
+    return (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ----------------------------------------------------------------------------- varints / protobuf wire format
+def _varint(buf: bytes, pos: int) -> Tuple[int, int]:
+    result, shift = 0, 0
+    while True:
+        if pos >= len(buf):
+            raise CheckpointError("truncated varint")
+        b = buf[pos]; pos += 1
+        result |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return result, pos
+        shift += 7
+        if shift > 70:
+            raise CheckpointError("varint too long")
+
+
+def _proto_fields(buf: bytes) -> Iterable[Tuple[int, int, object]]:
+    """Yield (field_number, wire_type, value) of one protobuf message (varint / fixed64 / bytes / fixed32)."""
+    pos = 0
+    while pos < len(buf):
+        key, pos = _varint(buf, pos)
+        field, wt = key >> 3, key & 7
+        if wt == 0:
+            v, pos = _varint(buf, pos)
+        elif wt == 1:
+            v = struct.unpack_from("<Q", buf, pos)[0]; pos += 8
+        elif wt == 2:
+            n, pos = _varint(buf, pos)
+            v = buf[pos:pos + n]; pos += n
+        elif wt == 5:
+            v = struct.unpack_from("<I", buf, pos)[0]; pos += 4
+        else:
+            raise CheckpointError(f"unsupported protobuf wire type {wt}")
+        yield field, wt, v
+
+
+def _parse_shape(buf: bytes) -> Tuple[int, ...]:
+    dims = []
+    for f, _, v in _proto_fields(buf):
+        if f == 2:                                   # repeated Dim dim = 2
+            size = 0
+            for f2, _, v2 in _proto_fields(v):
+                if f2 == 1:
+                    size = v2 if v2 < (1 << 63) else v2 - (1 << 64)
+            dims.append(size)
+    return tuple(dims)
+
+
+def _parse_entry(buf: bytes) -> dict:
+    e = dict(dtype=0, shape=(), shard_id=0, offset=0, size=0, crc32c=None, sliced=False)
+    for f, _, v in _proto_fields(buf):
+        if f == 1: e["dtype"] = v
+        elif f == 2: e["shape"] = _parse_shape(v)
+        elif f == 3: e["shard_id"] = v
+        elif f == 4: e["offset"] = v
+        elif f == 5: e["size"] = v
+        elif f == 6: e["crc32c"] = v
+        elif f == 7: e["sliced"] = True
+    return e
+
+
+# ----------------------------------------------------------------------------- sorted string table (.index)
+def _read_block(data: bytes, offset: int, size: int, verify: bool) -> bytes:
+    if offset + size + 5 > len(data):
+        raise CheckpointError("block handle outside the file")
+    body, ctype = data[offset:offset + size], data[offset + size]
+    if verify:
+        stored = struct.unpack_from("<I", data, offset + size + 1)[0]
+        if mask_crc(crc32c(data[offset:offset + size + 1])) != stored:
+            raise CheckpointError("block checksum mismatch")
+    if ctype != 0:
+        raise CheckpointError("compressed table blocks are not supported (TF's BundleWriter writes them uncompressed)")
+    return body
+
+
+def _block_entries(block: bytes) -> Iterable[Tuple[bytes, bytes]]:
+    if len(block) < 4:
+        raise CheckpointError("short block")
+    nrestarts = struct.unpack_from("<I", block, len(block) - 4)[0]
+    limit = len(block) - 4 - 4 * nrestarts
+    pos, key = 0, b""
+    while pos < limit:
+        shared, pos = _varint(block, pos)
+        non_shared, pos = _varint(block, pos)
+        vlen, pos = _varint(block, pos)
+        key = key[:shared] + block[pos:pos + non_shared]; pos += non_shared
+        yield key, block[pos:pos + vlen]; pos += vlen
+
+
+def read_index(path: str, verify: bool = True) -> Tuple[dict, Dict[str, dict]]:
+    """Parse `<prefix>.index` -> (header dict, {variable name: entry dict})."""
+    data = open(path, "rb").read()
+    if len(data) < 48:
+        raise CheckpointError("index file shorter than a table footer")
+    footer = data[-48:]
+    if struct.unpack_from("<Q", footer, 40)[0] != TABLE_MAGIC:
+        raise CheckpointError("bad table magic: not a TF V2 checkpoint index")
+    pos = 0
+    _mo, pos = _varint(footer, pos); _ms, pos = _varint(footer, pos)
+    io, pos = _varint(footer, pos); isz, pos = _varint(footer, pos)
+    header, entries = {"num_shards": 1, "endianness": 0, "version": None}, {}
+    for _k, handle in _block_entries(_read_block(data, io, isz, verify)):
+        bo, p2 = _varint(handle, 0); bs, _ = _varint(handle, p2)
+        for key, val in _block_entries(_read_block(data, bo, bs, verify)):
+            if key == b"":
+                for f, _, v in _proto_fields(val):
+                    if f == 1: header["num_shards"] = v
+                    elif f == 2: header["endianness"] = v
+            else:
+                entries[key.decode("utf-8")] = _parse_entry(val)
+    if header["endianness"] != 0:
+        raise CheckpointError("big-endian bundles are not supported")
+    return header, entries
+
+
+def read_checkpoint(prefix: str, names: Optional[Iterable[str]] = None, verify: bool = True,
+                    verify_tensors: bool = True) -> Dict[str, np.ndarray]:
+    """Load variables of the bundle `<prefix>` (e.g. logdir/LJ01-1/model_gs_800k) as numpy arrays.
+    `verify` checks the index blocks' checksums; `verify_tensors` additionally checks every tensor's crc32c (pure Python:
+    about a second per 2 MB, so load_reference_weights leaves it off for the 200 MB of network weights)."""
+    header, entries = read_index(prefix + ".index", verify)
+    want = set(names) if names is not None else None
+    shards: Dict[int, bytes] = {}
+    out: Dict[str, np.ndarray] = {}
+    for name, e in entries.items():
+        if want is not None and name not in want:
+            continue
+        if e["sliced"]:
+            raise CheckpointError(f"{name}: partitioned (sliced) variables are not supported")
+        if e["dtype"] not in _DTYPES:
+            raise CheckpointError(f"{name}: unsupported dtype enum {e['dtype']}")
+        sid = e["shard_id"]
+        if sid not in shards:
+            shards[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, header["num_shards"]), "rb").read()
+        raw = shards[sid][e["offset"]:e["offset"] + e["size"]]
+        dt = np.dtype(_DTYPES[e["dtype"]])
+        count = int(np.prod(e["shape"])) if e["shape"] else 1
+        if len(raw) != e["size"] or count * dt.itemsize != e["size"]:
+            raise CheckpointError(f"{name}: size {e['size']} does not match shape {e['shape']}")
+        if verify_tensors and e["crc32c"] is not None and mask_crc(crc32c(raw)) != e["crc32c"]:
+            raise CheckpointError(f"{name}: tensor checksum mismatch")
+        out[name] = np.frombuffer(raw, dtype=dt).reshape(e["shape"]).copy()
+    if want is not None and want - set(out):
+        raise CheckpointError(f"variables missing from {prefix}: {sorted(want - set(out))[:3]}")
+    return out
+
+
+def latest_checkpoint(logdir: str) -> str:
+    """tf.train.latest_checkpoint: the `checkpoint` state file names the newest prefix (synthesize.py:34,40)."""
+    state = os.path.join(logdir, "checkpoint")
+    m = re.search(r'^model_checkpoint_path:\s*"(.*)"', open(state).read(), re.M)
+    if not m:
+        raise CheckpointError(f"no model_checkpoint_path in {state}")
+    p = m.group(1)
+    return p if os.path.isabs(p) else os.path.join(logdir, p)
+
+
+def load_reference_weights(logdir: str, hp=None) -> Dict[str, np.ndarray]:
+    """What synthesize.py:32-40 restores: `Text2Mel/*` trainable variables from `<logdir>-1`, `SSRN/*` from `<logdir>-2`
+    (optimizer slots such as `.../Adam` are ignored).  Returns the dict `dc_tts_amd.engine.Engine` takes."""
+    from .hyperparams import hp as _hp
+    from .layers import variable_shapes
+    from .weights import check_weights
+    hp = hp or _hp
+    spec = variable_shapes(hp)
+    t2m = [n for n in spec if n.startswith("Text2Mel/")]
+    ssrn = [n for n in spec if n.startswith("SSRN/")]
+    W = read_checkpoint(latest_checkpoint(logdir + "-1"), t2m, verify_tensors=False)
+    W.update(read_checkpoint(latest_checkpoint(logdir + "-2"), ssrn, verify_tensors=False))
+    W = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in W.items()}
+    check_weights(W, hp)
+    return W

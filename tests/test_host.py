@@ -134,3 +134,25 @@ def test_sharding_world2_gloo(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARD_OK" in r.stdout
+
+
+def test_text_front_end_matches_reference_semantics(tmp_path):
+    """dc_tts_amd.data_load (product) vs the oracle's restatement and hand-checked strings (data_load.py:19-31,79-86)."""
+    from dc_tts_amd import data_load as D
+    from dc_tts_amd.hyperparams import hp
+    from oracle import dctts_ref as O
+    c2i, i2c = D.load_vocab()
+    assert c2i["P"] == 0 and c2i["E"] == 1 and c2i[" "] == 2 and i2c[31] == "?" and len(c2i) == 32
+    assert D.text_normalize("Crème  BRÛLÉE, 42 times!") == "creme brulee times "
+    lines = ["1. The birch canoe slid on the smooth planks.\n", "2. It's easy to tell the depth of a well.\n", "3. Déjà-vu?\n"]
+    L = D.encode_lines(lines)
+    np.testing.assert_array_equal(L, O.load_sentences(lines, hp))
+    assert "".join(i2c[i] for i in L[1] if i) == "it's easy to tell the depth of a well.E"
+    assert "".join(i2c[i] for i in L[2] if i) == "deja vu?E"
+    f = tmp_path / "sent.txt"
+    f.write_text("http://header.line\n" + "".join(lines), encoding="utf-8")
+    np.testing.assert_array_equal(D.load_data("synthesize", str(f)), L)
+    with pytest.raises(NotImplementedError):
+        D.load_data("train")
+    with pytest.raises(ValueError):
+        D.encode_lines(["1. " + "a" * 200])

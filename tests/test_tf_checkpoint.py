@@ -1,0 +1,121 @@
+"""TF V2 checkpoint (tensor bundle) reader, exercised against bundles written by the spec-following writer below
+(TensorFlow itself cannot be installed here; see dc_tts_amd/tf_checkpoint.py for the format references)."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from dc_tts_amd import tf_checkpoint as C
+
+
+def _vint(n):
+    out = bytearray()
+    while True:
+        b = n & 0x7F; n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b); return bytes(out)
+
+
+def _field(num, wt, payload):
+    return _vint((num << 3) | wt) + payload
+
+
+def _block(entries, restart_interval=4):
+    """LevelDB block with prefix compression and restart points."""
+    buf, restarts, prev = bytearray(), [], b""
+    for i, (k, v) in enumerate(entries):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(buf))
+        else:
+            while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                shared += 1
+        buf += _vint(shared) + _vint(len(k) - shared) + _vint(len(v)) + k[shared:] + v
+        prev = k
+    for r in restarts:
+        buf += struct.pack("<I", r)
+    buf += struct.pack("<I", len(restarts))
+    return bytes(buf)
+
+
+def write_bundle(prefix, tensors, keys_per_block=5, with_crc=True):
+    """Minimal TF tensor-bundle writer: one shard, uncompressed table blocks, masked crc32c everywhere."""
+    data = bytearray(); entries = []
+    dt_enum = {np.dtype(np.float32): 1, np.dtype(np.int32): 3, np.dtype(np.int64): 9}
+    for name in sorted(tensors):
+        a = np.ascontiguousarray(tensors[name]); raw = a.tobytes()
+        shape = b"".join(_field(2, 2, _vint(len(d)) + d) for d in (_field(1, 0, _vint(s)) for s in a.shape))
+        e = _field(1, 0, _vint(dt_enum[a.dtype])) + _field(2, 2, _vint(len(shape)) + shape) + _field(3, 0, _vint(0)) + \
+            _field(4, 0, _vint(len(data))) + _field(5, 0, _vint(len(raw)))
+        if with_crc:
+            e += _field(6, 5, struct.pack("<I", C.mask_crc(C.crc32c(raw))))
+        entries.append((name.encode(), e)); data += raw
+    header = _field(1, 0, _vint(1)) + _field(2, 0, _vint(0)) + _field(3, 2, _vint(2) + _field(1, 0, _vint(1)))
+    entries = [(b"", header)] + entries
+    out = bytearray(); index = []
+    def emit(block):
+        off = len(out); out.extend(block); trailer = b"\x00"
+        out.extend(trailer + struct.pack("<I", C.mask_crc(C.crc32c(block + trailer))))
+        return _vint(off) + _vint(len(block))
+    for i in range(0, len(entries), keys_per_block):
+        chunk = entries[i:i + keys_per_block]
+        index.append((chunk[-1][0] + b"\xff", emit(_block(chunk))))
+    meta = emit(_block([]))
+    idx = emit(_block(index, restart_interval=1))
+    footer = meta + idx
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", C.TABLE_MAGIC)
+    open(prefix + ".index", "wb").write(bytes(out))
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+
+
+def test_crc32c_known_answers():
+    assert C.crc32c(b"123456789") == 0xE3069283            # the standard CRC-32C check value
+    assert C.crc32c(b"\x00" * 32) == 0x8A9136AA             # RFC 3720 B.4
+
+
+def test_round_trip_and_errors(tmp_path):
+    rng = np.random.default_rng(0)
+    T = {"Text2Mel/TextEnc/embed_1/lookup_table": rng.standard_normal((32, 128)).astype(np.float32),
+         "Text2Mel/TextEnc/C_2/conv1d/kernel": rng.standard_normal((1, 128, 512)).astype(np.float32),
+         "Text2Mel/TextEnc/C_2/conv1d/kernel/Adam": np.zeros((1, 128, 512), np.float32),
+         "Text2Mel/TextEnc/C_2/conv1d/bias": rng.standard_normal(512).astype(np.float32),
+         "gs/global_step": np.array(800000, np.int32),
+         "SSRN/D_4/conv2d_transpose/kernel": rng.standard_normal((1, 3, 16, 16)).astype(np.float32)}
+    prefix = str(tmp_path / "model_gs_800k")
+    write_bundle(prefix, T)
+    header, entries = C.read_index(prefix + ".index")
+    assert header["num_shards"] == 1 and set(entries) == set(T)
+    assert entries["SSRN/D_4/conv2d_transpose/kernel"]["shape"] == (1, 3, 16, 16)
+    got = C.read_checkpoint(prefix)
+    for k in T:
+        np.testing.assert_array_equal(got[k], T[k])
+    sub = C.read_checkpoint(prefix, ["Text2Mel/TextEnc/C_2/conv1d/bias"])
+    assert list(sub) == ["Text2Mel/TextEnc/C_2/conv1d/bias"]
+    with pytest.raises(C.CheckpointError):
+        C.read_checkpoint(prefix, ["no/such/variable"])
+    raw = bytearray(open(prefix + ".data-00000-of-00001", "rb").read()); raw[10] ^= 0x40
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(raw))
+    with pytest.raises(C.CheckpointError):                  # corrupted tensor bytes: crc32c mismatch
+        C.read_checkpoint(prefix)
+    (tmp_path / "checkpoint").write_text('model_checkpoint_path: "model_gs_800k"\nall_model_checkpoint_paths: "model_gs_800k"\n')
+    assert C.latest_checkpoint(str(tmp_path)) == prefix
+
+
+def test_load_reference_weights_layout(tmp_path, weights):
+    """A full synthetic 'trained' checkpoint pair laid out like hp.logdir-1 / hp.logdir-2 -> the Engine's weight dict."""
+    from dc_tts_amd.hyperparams import hp
+    logdir = str(tmp_path / "LJ01")
+    for suffix, scope in (("-1", "Text2Mel/"), ("-2", "SSRN/")):
+        d = logdir + suffix; os.makedirs(d)
+        T = {k: v for k, v in weights.items() if k.startswith(scope)}
+        T[next(iter(T)) + "/Adam_1"] = np.zeros(3, np.float32)           # optimizer slot: must be ignored
+        T["gs/global_step"] = np.array(1, np.int32)
+        write_bundle(os.path.join(d, "model_gs_1k"), T, keys_per_block=16, with_crc=False)
+        open(os.path.join(d, "checkpoint"), "w").write('model_checkpoint_path: "model_gs_1k"\n')
+    W = C.load_reference_weights(logdir, hp)
+    assert set(W) == set(weights)
+    for k in weights:
+        np.testing.assert_array_equal(W[k], weights[k])
