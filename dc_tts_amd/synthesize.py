@@ -39,3 +39,40 @@ def synthesize_reference_loop(L: torch.Tensor, engine: Optional[Engine] = None):
         traj[:, j] = max_att[:, j]
     _zl, Z = eng.ssrn(Y, want_logits=False)                                          # :57
     return Y, Z, traj
+
+
+def main(argv=None):
+    """`python -m dc_tts_amd.synthesize --text harvard_sentences.txt [--logdir logdir/LJ01] --out samples`
+    = the reference's `python synthesize.py` up to the magnitude spectrograms (synthesize.py:21-57): the mel (Y) and linear
+    (Z) spectrograms are written as .npy per sentence; Griffin-Lim / wav writing (synthesize.py:59-64) is out of scope."""
+    import argparse
+    import os
+
+    import numpy as np
+
+    from .data_load import load_data
+    from .hyperparams import hp
+    from .weights import synthetic_weights
+    ap = argparse.ArgumentParser(description=main.__doc__)
+    ap.add_argument("--text", required=True, help="test file in the reference's format (header line, then '<n>. sentence')")
+    ap.add_argument("--logdir", default=None, help="prefix of the trained checkpoints (<logdir>-1 Text2Mel, <logdir>-2 SSRN); "
+                                                   "omitted: seeded synthetic weights")
+    ap.add_argument("--out", default="samples")
+    args = ap.parse_args(argv)
+    if args.logdir:
+        from .tf_checkpoint import load_reference_weights
+        W = load_reference_weights(args.logdir, hp)
+    else:
+        W = synthetic_weights(hp, seed=1234, perturb=True)
+    eng = Engine(W, hp)
+    L = load_data("synthesize", args.text, hp)
+    Y, Z, _ = eng.synthesize(torch.from_numpy(L).to(eng.device))
+    os.makedirs(args.out, exist_ok=True)
+    for i in range(L.shape[0]):
+        np.save(os.path.join(args.out, f"{i + 1}.mel.npy"), Y[i].cpu().numpy())
+        np.save(os.path.join(args.out, f"{i + 1}.mag.npy"), Z[i].cpu().numpy())
+    print(f"{L.shape[0]} sentences -> {args.out}/<n>.mel.npy ({tuple(Y.shape[1:])}), <n>.mag.npy ({tuple(Z.shape[1:])})")
+
+
+if __name__ == "__main__":
+    main()
