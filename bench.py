@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--decode-mode", type=int, default=1, help="1 = default (split kernels, two streams), 2 = + fused k=1 row MLP, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (plumbing test: ranks may share a GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,10 +74,15 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from dc_tts_amd.engine import Engine
     from dc_tts_amd.hyperparams import hp as hp0
@@ -110,8 +117,8 @@ def main():
     eng.prof_enable(-1)
     n_launch, dom_ms = eng.prof_collect()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # measurement only: no collective on the data path
         elapsed = float(t.item())
 
     # ---- untimed: per-phase breakdown (torch events on the launch stream)
