@@ -82,7 +82,6 @@ struct dctts_ctx {
   int device = 0;
   std::map<std::string, HostTensor> hw;
   bool finalized = false;
-  std::vector<void*> wallocs;
   std::vector<Arena> warena;           // weights
   std::map<std::string, std::vector<Arena>> wsarena;   // workspaces, one pool per geometry prefix ("dec.", "ssrn.", ...)
   size_t wbytes = 0;
@@ -290,7 +289,6 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   free_ws(c);
-  for (void* p : c->wallocs) (void)hipFree(p);
   for (Arena& a : c->warena) (void)hipFree(a.base);
   for (int* p : c->cone_dev) (void)hipFree(p);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
