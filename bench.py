@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
     ap.add_argument("--max-T", type=int, default=210)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-mode", type=int, default=1, help="0 eager, 1 bulk pieces as hipGraphs (default), 2 chain pieces too")
     ap.add_argument("--decode-mode", type=int, default=1, help="1 = default (split kernels, two streams), 2 = + fused k=1 row MLP, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (plumbing test: ranks may share a GPU)")
@@ -92,7 +93,7 @@ def main():
     hp = hp0.replace(max_T=args.max_T)
     B, T = args.batch, hp.max_T
     W = synthetic_weights(hp, seed=1234, perturb=True)
-    eng = Engine(W, hp, device=local, decode_graph=not args.no_graph)
+    eng = Engine(W, hp, device=local, decode_graph=0 if args.no_graph else args.graph_mode)
     eng.set_decode_mode(args.decode_mode)
     L = torch.from_numpy(synthetic_text(hp, B=B, seed=1234 + rank)).cuda()
 
@@ -167,7 +168,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded character ids, seeded random-init weights)",
             "config": {"workload": f"full Text2Mel autoregressive decode + SSRN, batch={B}/GPU, max_N={hp.max_N}, "
                                    f"max_T={T} mel frames -> ({B},{4 * T},{hp.n_linear}) per GPU; exact-parity incremental decode",
-                       "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_graph": not args.no_graph,
+                       "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_graph_mode": 0 if args.no_graph else args.graph_mode,
                        "sharding": f"{world} x {B} utterances, no collective"},
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),

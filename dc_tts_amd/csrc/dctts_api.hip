@@ -908,20 +908,24 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   HIPCHK(hipMemsetAsync(w.pm_all, 0, (size_t)B * sizeof(int), st));      // prev_max_attentions = zeros (synthesize.py:46)
   if (v2) {
     hipStream_t sb = c->s_bulk;
+    // use_graph: 0 = every launch eager; 1 = bulk pieces as per-frame graphs, chain launches eager (default: a graph launch per
+    // chain piece costs ~11 us of start-up on the critical path, the bulk's is hidden); 2 = both as graphs
     const bool gr = c->use_graph != 0;
+    const bool gr_chain = c->use_graph == 2;
     if (gr) {
-      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->fuse_mlp) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string((size_t)w.kv.p);
-      if (c->chain_g.empty() || c->graphs2_geom != g) {
+      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->fuse_mlp) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p);
+      if (c->bulk_g.empty() || c->graphs2_geom != g) {
         destroy_graphs2(c);
         hipStream_t cs;
         HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
         const int prof_keep = c->prof_id; c->prof_id = -1;
         c->chain_g.assign(T, nullptr); c->bulk_g.assign(T, nullptr);
-        int rc = capture_piece(cs, &c->pro_g, [&]() {                                               // frame 0's AudioEnc + attention
+        int rc = 0;
+        if (gr_chain) rc = capture_piece(cs, &c->pro_g, [&]() {                                     // frame 0's AudioEnc + attention
           if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, cs)); return v2_audioenc_attn(c, w, B, N, 0, cs, true); }
           return v2_audioenc_attn(c, w, B, N, 0, cs); });
         for (int j = 0; j < T && rc == 0; ++j) {
-          rc = capture_piece(cs, &c->chain_g[j], [&]() { return v2_chain_piece(c, w, B, N, j, j + 1 < T, cs); });
+          if (gr_chain) rc = capture_piece(cs, &c->chain_g[j], [&]() { return v2_chain_piece(c, w, B, N, j, j + 1 < T, cs); });
           if (rc == 0 && j >= 1) rc = capture_piece(cs, &c->bulk_g[j], [&]() { return v2_bulk_piece(c, w, B, N, j, cs); });
         }
         c->prof_id = prof_keep;
@@ -931,12 +935,12 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
       }
     }
     const char* tenv = getenv("DCTTS_TRACE");
-    const int tstep = (tenv && !gr) ? atoi(tenv) : -1;
+    const int tstep = (tenv && !gr_chain) ? atoi(tenv) : -1;
     // the bulk stream joins the caller's stream at the start (TextEnc, resets)
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
     // pipeline prologue = chain piece -1: frame 0's AudioEnc + attention
-    if (gr) HIPCHK(hipGraphLaunch(c->pro_g, st));
+    if (gr_chain) HIPCHK(hipGraphLaunch(c->pro_g, st));
     else if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, st)); CHK(v2_audioenc_attn(c, w, B, N, 0, st, true)); }
     else CHK(v2_audioenc_attn(c, w, B, N, 0, st));
     HIPCHK(hipEventRecord(c->ev_chain[3], st));
@@ -953,7 +957,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
         HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 8 * sizeof(long long), st));
         c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
       }
-      if (gr) HIPCHK(hipGraphLaunch(c->chain_g[j], st)); else CHK(v2_chain_piece(c, w, B, N, j, j + 1 < T, st));
+      if (gr_chain) HIPCHK(hipGraphLaunch(c->chain_g[j], st)); else CHK(v2_chain_piece(c, w, B, N, j, j + 1 < T, st));
       HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
       if (c->trace_on) {
         c->trace_on = false; g_trace_ctx = nullptr;
@@ -1008,8 +1012,8 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 }
 
 extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
-  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
-  c->use_graph = enable ? 1 : 0;
+  if (!c || enable < 0 || enable > 2) return fail(DCTTS_ERR_ARG, "decode graph mode must be 0, 1 or 2");
+  c->use_graph = enable;
   return 0;
 }
 

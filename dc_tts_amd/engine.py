@@ -77,8 +77,9 @@ class Engine:
         except Exception:
             pass
 
-    def set_decode_graph(self, enable: bool):
-        self._ok(self.lib.dctts_set_decode_graph(self._h, int(bool(enable))))
+    def set_decode_graph(self, enable):
+        """False/0: eager launches; True/1: side-stream work as per-frame hipGraphs (default); 2: chain pieces as graphs too."""
+        self._ok(self.lib.dctts_set_decode_graph(self._h, int(enable)))
 
     def set_decode_mode(self, mode: int):
         self._ok(self.lib.dctts_set_decode_mode(self._h, int(mode)))

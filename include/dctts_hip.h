@@ -86,7 +86,9 @@ int dctts_text2mel_decode(dctts_ctx* ctx, const int32_t* L, int B, int N, int T,
 int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y, float* Z,
                      int64_t* max_attentions, void* stream);
 
-/* Decode launch mode: 0 = one kernel launch per layer per step (eager), 1 = one hipGraph replay per step. */
+/* Decode launch mode: 0 = every launch eager; 1 (default) = the side-stream (bulk) work of each frame is one hipGraph launch,
+ * the latency-critical chain launches stay eager; 2 = chain pieces are per-frame hipGraphs too (decode mode 0: 1 and 2 both
+ * mean one graph replay per frame). */
 int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
 /* Decode algorithm form (results agree to fp32 re-association; all are the exact-parity incremental decode):
