@@ -122,6 +122,7 @@ def main():
     elapsed = t1 - t0
     eng.prof_enable(-1)
     n_launch, dom_ms = eng.prof_collect()
+    dom_rows = eng.prof_rows()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # measurement only: no collective on the data path
@@ -150,10 +151,13 @@ def main():
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         # roofline of the dominant kernel: algorithmic FLOPs of one launch = 2 * rows * K * N of the layer
         C = 2 * hp.c                                             # SSRN HC_11 / HC_12: 1024 -> 2048, k = 3
-        flops_per_launch = 2.0 * (B * 4 * T) * (3 * C) * (2 * C)
+        # rows per launch as the library reports them: the layer's B*4T rows minus the row tail that goes to hconv16_kernel
+        rows_per_launch = dom_rows / n_launch if n_launch else B * 4 * T
+        flops_per_launch = 2.0 * rows_per_launch * (3 * C) * (2 * C)
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None, "kernel": "hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11/HC_12, 1024ch k=3, fused LN+gate)",
-                "launches": n_launch, "avg_launch_ms": None, "flop_per_launch": flops_per_launch}
+                "launches": n_launch, "avg_launch_ms": None, "flop_per_launch": flops_per_launch,
+                "rows_per_launch": rows_per_launch, "layer_rows": B * 4 * T}
         tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if B == 32 and T == 210 and os.path.exists(tj):
             # HBM bytes per launch of this kernel from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),

@@ -16,6 +16,7 @@
 #include "attn_kernels.h"
 #include "decode_kernels.h"
 #include "hconv_kernel.h"
+#include "hconv16_kernel.h"
 
 using namespace dctts;
 
@@ -27,9 +28,9 @@ namespace dctts {
     return hipGetLastError();                                                          \
   }
 
-hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream) {
-  const dim3 grid((p.M + 31) / 32);
-  if (p.M <= 0) return hipSuccess;
+hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles) {
+  const dim3 grid(tiles >= 0 ? tiles : (p.M + 31) / 32);
+  if (p.M <= 0 || grid.x == 0) return hipSuccess;
   HCONV_CASE(EPI_HC, 2, 8)
   HCONV_CASE(EPI_HC, 4, 8)
   HCONV_CASE(EPI_HC, 8, 8)
@@ -38,6 +39,22 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
   HCONV_CASE(EPI_C, 2, 8)
   HCONV_CASE(EPI_C, 4, 8)
   HCONV_CASE(EPI_C, 3, 11)
+  return hipErrorInvalidConfiguration;
+}
+
+#define HCONV16_CASE(E, NT_, NW_)                                                                   \
+  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                   \
+    hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
+    return hipGetLastError();                                                                       \
+  }
+
+hipError_t launch_hconv16(const ConvShape& s, const ConvParams& p, int m_start, hipStream_t stream) {
+  if (p.M <= m_start) return hipSuccess;
+  const dim3 grid((p.M - m_start + 15) / 16);
+  HCONV16_CASE(EPI_HC, 8, 8)
+  HCONV16_CASE(EPI_HC, 16, 8)
+  HCONV16_CASE(EPI_C, 8, 8)
+  HCONV16_CASE(EPI_C, 6, 11)
   return hipErrorInvalidConfiguration;
 }
 
@@ -63,6 +80,8 @@ struct DevLayer {
   int ntaps = 1, cin = 0, cin_p = 0, tap_off[3] = {0, 0, 0}, cout = 0, act = ACT_NONE;
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
+  float* wp16r = nullptr;         // SSRN 4T-resolution layers: packing for hconv16_kernel (row-tail launches)
+  ConvShape shape16{0, 0, 0};
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
   float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for rowmlp_kernel
   int cin_real = 0;
@@ -100,6 +119,9 @@ struct dctts_ctx {
   int chain_rows = 8;                  // rows per chain workgroup (16 = full MFMA tile; 8 halves the activation bytes each CU pulls)
   int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
                                        //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
+  long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
+  int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
+  int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
   int bulk_cap = 144;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
@@ -171,7 +193,7 @@ static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, i
   return pack_bw(W, ntaps, cin_real, cin_p, s.nt * s.nw, cout, hc, 32);
 }
 
-static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L, bool dec = false) {
+static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L, bool dec = false, bool tail = false) {
   const HostTensor *k, *b, *be, *ga;
   CHK(get_w(c, scope + "/conv1d/kernel", {1, cin_real, cout}, &k));
   CHK(get_w(c, scope + "/conv1d/bias", {cout}, &b));
@@ -185,12 +207,16 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
   CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 31) / 32), cout, false, 16), &L->wp16));
   if (dec) CHK(upload(c, k->v, &L->wraw));
+  if (tail) {
+    L->shape16 = pick_shape16(EPI_C, cout);
+    CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, L->shape16.nt * L->shape16.nw, cout, false, 16), &L->wp16r));
+  }
   L->cin_real = cin_real;
   CHK(upload(c, b->v, &L->bias)); CHK(upload(c, ga->v, &L->g1)); CHK(upload(c, be->v, &L->b1));
   return 0;
 }
 
-static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rate, bool causal, DevLayer* L, bool dec = false) {
+static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rate, bool causal, DevLayer* L, bool dec = false, bool tail = false) {
   const HostTensor *kw, *b, *b1, *g1, *b2, *g2;
   CHK(get_w(c, scope + "/conv1d/kernel", {k, C, 2 * C}, &kw));
   CHK(get_w(c, scope + "/conv1d/bias", {2 * C}, &b));
@@ -208,6 +234,10 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
   auto W = [=](int tap, int cc, int col) { return kv[((size_t)tap * C + cc) * (2 * C) + col]; };
   CHK(upload(c, pack_b(W, k, C, L->cin_p, L->shape, C, true), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, k, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16));
+  if (tail) {
+    L->shape16 = pick_shape16(EPI_HC, C);
+    CHK(upload(c, pack_bw(W, k, C, L->cin_p, L->shape16.nt * L->shape16.nw, C, true, 16), &L->wp16r));
+  }
   L->hc = true;
   CHK(upload(c, b->v, &L->bias));
   CHK(upload(c, g1->v, &L->g1)); CHK(upload(c, b1->v, &L->b1));
@@ -268,6 +298,9 @@ extern "C" int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg
   HIPCHK(hipSetDevice(device));
   dctts_ctx* c = new dctts_ctx();
   c->cfg = *cfg; c->device = device;
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+  if (const char* e = getenv("DCTTS_TAIL_SPLIT")) c->tail_split = atoi(e);
   *out = c;
   return 0;
 }
@@ -365,13 +398,14 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L)); c->ssrn.push_back(L); }
     for (int rep = 0; rep < 2; ++rep) {
       snprintf(nm, 64, "D_%d", i++); L = DevLayer(); L2 = DevLayer(); CHK(make_D(c, s + nm, cc, &L, &L2)); c->ssrn.push_back(L); c->ssrn.push_back(L2);
-      for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L)); c->ssrn.push_back(L); }
+      for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L, false, rep == 1)); c->ssrn.push_back(L); }
     }
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, cc, cc, 2 * cc, ACT_NONE, &L)); c->ssrn.push_back(L);
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * cc, 3, 1, false, &L)); c->ssrn.push_back(L); }
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * cc, 2 * cc, F, ACT_NONE, &L)); c->ssrn.push_back(L);
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_RELU, &L)); c->ssrn.push_back(L); }
-    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_SIGMOID, &L)); c->ssrn.push_back(L);
+    // everything from HC_8 on runs at 4T rows: those layers also get the 16-row packing for the row-tail launch
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, cc, cc, 2 * cc, ACT_NONE, &L, false, true)); c->ssrn.push_back(L);
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * cc, 3, 1, false, &L, false, true)); c->ssrn.push_back(L); }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * cc, 2 * cc, F, ACT_NONE, &L, false, true)); c->ssrn.push_back(L);
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_RELU, &L, false, true)); c->ssrn.push_back(L); }
+    snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_SIGMOID, &L, false, true)); c->ssrn.push_back(L);
   }
   HIPCHK(hipDeviceSynchronize());
   c->hw.clear();
@@ -435,8 +469,15 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   const bool prof = (c->prof_id == kid);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-  HIPCHK(launch_hconv(L.shape, p, st));
-  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); }
+  // Row split (hconv16_kernel.h): exact rounds of 32-row items on hconv_kernel, a short tail on 16-row items.
+  int tiles32 = (p.M + 31) / 32, m_tail = p.M;
+  if (L.wp16r && c->tail_split) {
+    const int full = (tiles32 / c->n_cu) * c->n_cu;
+    if ((tiles32 - full) * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
+  }
+  HIPCHK(launch_hconv(L.shape, p, st, tiles32));
+  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
+  if (m_tail < p.M) { p.wp = L.wp16r; HIPCHK(launch_hconv16(L.shape16, p, m_tail, st)); }
   return 0;
 }
 
@@ -1073,6 +1114,7 @@ extern "C" int dctts_debug_copy(const float* src, float* dst, size_t nfloats, vo
 // ------------------------------------------------------------------------------------------------ profiling aid
 extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  if (kernel_id >= 0) c->prof_rows = 0;
   c->prof_id = kernel_id;
   return 0;
 }
@@ -1089,5 +1131,11 @@ extern "C" int dctts_prof_collect(dctts_ctx* c, int* launches, double* total_ms)
   }
   c->prof_ev.clear();
   *launches = n; *total_ms = tot;
+  return 0;
+}
+
+extern "C" int dctts_prof_rows(dctts_ctx* c, long long* rows) {
+  if (!c || !rows) return fail(DCTTS_ERR_ARG, "null argument");
+  *rows = c->prof_rows;
   return 0;
 }

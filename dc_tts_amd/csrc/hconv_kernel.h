@@ -306,6 +306,7 @@ inline ConvShape pick_shape(int epi, int cout) {
 
 inline int shape_tiles(const ConvShape& s) { return s.nt * s.nw; }
 
-hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream);
+// tiles < 0: all of ceil(M / 32); otherwise only the first `tiles` 32-row items (the rest belong to hconv16_kernel).
+hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles = -1);
 
 }  // namespace dctts

@@ -95,6 +95,12 @@ class Engine:
         self._ok(self.lib.dctts_prof_collect(self._h, ctypes.byref(n), ctypes.byref(ms)))
         return n.value, ms.value
 
+    def prof_rows(self) -> int:
+        """Output rows covered by the profiled launches since prof_enable (a layer may be split with a 16-row tail launch)."""
+        r = ctypes.c_longlong(0)
+        self._ok(self.lib.dctts_prof_rows(self._h, ctypes.byref(r)))
+        return r.value
+
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
 

@@ -116,6 +116,9 @@ int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream)
  * launches and their summed duration, and clears the list. */
 int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);
 int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
+/* Output rows those launches covered, summed since the last prof_enable (a layer's rows may be split between the
+ * 32-row kernel -- the one timed here -- and a 16-row tail launch, see csrc/hconv16_kernel.h). */
+int dctts_prof_rows(dctts_ctx* ctx, long long* rows);
 
 #ifdef __cplusplus
 }
