@@ -19,6 +19,13 @@ class Config(ctypes.Structure):
                 ("n_linear", c_int), ("max_N", c_int), ("attention_win_size", c_int)]
 
 
+class VocoderConfig(ctypes.Structure):
+    _fields_ = [("n_fft", c_int), ("hop_length", c_int), ("win_length", c_int), ("n_iter", c_int),
+                ("power", ctypes.c_float), ("preemphasis", ctypes.c_float), ("max_db", ctypes.c_float),
+                ("ref_db", ctypes.c_float), ("trim_top_db", ctypes.c_float), ("trim_frame_length", c_int),
+                ("trim_hop_length", c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/dctts_hip.h declares
 SYMBOLS = {
     "dctts_create": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(Config)]),
@@ -42,6 +49,11 @@ SYMBOLS = {
     "dctts_prof_enable": (c_int, [c_void_p, c_int]),
     "dctts_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
     "dctts_prof_rows": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong)]),
+    "dctts_vocoder_create": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.POINTER(VocoderConfig)]),
+    "dctts_vocoder_destroy": (c_int, [c_void_p]),
+    "dctts_vocoder_device_bytes": (c_size_t, [c_void_p]),
+    "dctts_spectrogram2wav": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dctts_griffin_lim": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

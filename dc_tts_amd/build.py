@@ -5,12 +5,12 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "dctts_api.hip")
+SRCS = [os.path.join(HERE, "csrc", "dctts_api.hip"), os.path.join(HERE, "csrc", "vocoder_api.hip")]
 OUT = os.path.join(HERE, "lib", "libdctts_hip.so")
 
 
 def _deps():
-    return [SRC] + glob.glob(os.path.join(HERE, "csrc", "*.h")) + \
+    return SRCS + glob.glob(os.path.join(HERE, "csrc", "*.h")) + \
         [os.path.join(os.path.dirname(HERE), "include", "dctts_hip.h")]
 
 
@@ -19,7 +19,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in _deps()):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", SRC, "-o", OUT]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + SRCS + ["-o", OUT]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/dctts_hip.h"
+#include "api_common.h"
 #include "attn_kernels.h"
 #include "decode_kernels.h"
 #include "hconv_kernel.h"
@@ -63,6 +64,7 @@ hipError_t launch_hconv16(const ConvShape& s, const ConvParams& p, int m_start, 
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+int dctts_set_error(int code, const std::string& msg) { return fail(code, msg); }
 #define HIPCHK(x)                                                                                   \
   do {                                                                                              \
     hipError_t e__ = (x);                                                                           \

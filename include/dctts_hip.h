@@ -120,6 +120,43 @@ int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
  * 32-row kernel -- the one timed here -- and a 16-row tail launch, see csrc/hconv16_kernel.h). */
 int dctts_prof_rows(dctts_ctx* ctx, long long* rows);
 
+/* ------------------------------------------------------------------------------------------------
+ * Vocoder tail: utils.py:67-114 `spectrogram2wav` / `griffin_lim` / `invert_spectrogram`, which
+ * synthesize.py:61-64 calls once per utterance on the CPU (librosa + scipy).  Here: a batch at a time on the GPU.
+ * It owns no weights, so it is its own handle.  Spectrogram tensors stay frame-major (B, F, 1 + n_fft/2) -- the layout
+ * dctts_ssrn_fwd writes (F = 4T) -- not librosa's (1 + n_fft/2, F). */
+typedef struct dctts_vocoder dctts_vocoder;
+
+/* hyperparams.py:13-24 + the librosa.effects.trim defaults the reference relies on (utils.py:92) */
+typedef struct {
+  int n_fft;            /* 2048 (the FFT kernels are specialised on it) */
+  int hop_length;       /* 275 */
+  int win_length;       /* 1102 */
+  int n_iter;           /* 50 */
+  float power;          /* 1.5 */
+  float preemphasis;    /* 0.97 */
+  float max_db;         /* 100 */
+  float ref_db;         /* 20 */
+  float trim_top_db;    /* 60 */
+  int trim_frame_length;/* 2048 */
+  int trim_hop_length;  /* 512 */
+} dctts_vocoder_config;
+
+int dctts_vocoder_create(dctts_vocoder** out, int device, const dctts_vocoder_config* cfg);
+int dctts_vocoder_destroy(dctts_vocoder* v);
+size_t dctts_vocoder_device_bytes(const dctts_vocoder* v);
+
+/* utils.py:67-94 spectrogram2wav for B utterances.  mag (B,F,1+n_fft/2): network output in [0,1] (Z).
+ * wav (B, hop_length*(F-1)) float32: de-normalise -> **power -> Griffin-Lim (n_iter) -> de-emphasis, NOT trimmed;
+ * bounds (B,2) int32 or NULL: [start, end) of librosa.effects.trim(wav) per utterance (the reference returns
+ * wav[start:end]).  Requires hop_length*(F-1) > n_fft/2 (reflect padding; librosa raises below that too). */
+int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, int F, float* wav, int32_t* bounds, void* stream);
+
+/* utils.py:96-106 griffin_lim on magnitudes.  spec (B,F,1+n_fft/2) (already de-normalised, any non-negative values);
+ * y (B, hop_length*(F-1)); X_best (B,F,1+n_fft/2,2) interleaved complex64 or NULL = the spectrogram*phase the last
+ * iteration produced (needs n_iter >= 1).  n_iter = 0 gives y = istft(spec). */
+int dctts_griffin_lim(dctts_vocoder* v, const float* spec, int B, int F, int n_iter, float* y, float* X_best, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
