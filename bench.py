@@ -22,6 +22,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 DOMINANT_KERNEL_ID = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
 
 
@@ -58,6 +59,57 @@ def cpu_baseline(hp, W, seconds_budget=25.0):
             "rtf": per_frame / hp.seconds_per_mel_frame}
 
 
+def vocoder_cpu_baseline(hp, mag1):
+    """oracle/vocoder_ref.spectrogram2wav (numpy restatement of utils.py:67-114; librosa is not installable) on ONE utterance."""
+    from oracle import vocoder_ref as V
+    t0 = time.perf_counter()
+    V.spectrogram2wav(mag1, hp, np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": (mag1.shape[0] / hp.r) / dt, "unit": "mel frames/s", "cores": 1, "kind": "port",
+            "sample": f"1 utterance ({mag1.shape[0]} linear frames, n_iter={hp.n_iter}), numpy fp32 FFTs, single thread",
+            "seconds_per_utterance": dt}
+
+
+def vocoder_section(hp, Z, ms_synth, with_cpu):
+    """Untimed extra (NOT part of `value`: BASELINE's metric excludes Griffin-Lim): the vocoder tail on the batch
+    the timed loop just produced, with the roofline of its dominant kernel."""
+    from dc_tts_amd.utils import Vocoder
+    B, F, nb = Z.shape
+    v = Vocoder(hp)
+    v.spectrogram2wav_device(Z); torch.cuda.synchronize()
+    reps = 3
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    v.prof_enable(True)
+    e0.record()
+    for _ in range(reps):
+        wav, bounds = v.spectrogram2wav_device(Z)
+    e1.record(); torch.cuda.synchronize()
+    v.prof_enable(False)
+    n_launch, it_ms = v.prof_collect()
+    ms = e0.elapsed_time(e1) / reps
+    L = hp.hop_length * (F - 1)
+    # algorithmic bytes of one gl_iter_wave_kernel launch: the signal in, the magnitudes in, the windowed frames out (fp32)
+    alg = 4.0 * B * (L + F * nb + F * hp.win_length)
+    avg = it_ms / max(n_launch, 1)
+    ach = alg / (avg * 1e-3) / 1e9 if n_launch else None
+    audio_s = B * L / hp.sr
+    out = {"ms_per_batch": round(ms, 3), "n_iter": hp.n_iter, "rtf": ms * 1e-3 / audio_s,
+           "mel_frames_per_s": round(B * (F // hp.r) / (ms * 1e-3), 1),
+           "end_to_end_ms_per_batch": round(ms_synth + ms, 3),
+           "end_to_end_mel_frames_per_s": round(B * (F // hp.r) / ((ms_synth + ms) * 1e-3), 1),
+           "roofline": {"bound": "hbm", "achieved": None if ach is None else round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": None if ach is None else round(ach / PEAK_HBM_GBPS, 4), "traffic": None,
+                        "kernel": "gl_iter_wave_kernel (one Griffin-Lim iteration: window, rfft, phase projection, irfft, window; "
+                                  "one wave per frame)", "launches": n_launch, "avg_launch_ms": round(avg, 4),
+                        "algorithmic_bytes_per_launch": alg,
+                        "note": "VALU-issue bound (~2.5 k wave instructions per frame), not HBM bound: see DESIGN.md"},
+           "device_bytes": v.device_bytes()}
+    if with_cpu:
+        out["cpu_baseline"] = vocoder_cpu_baseline(hp, Z[0].cpu().numpy())
+    v.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +121,7 @@ def main():
     ap.add_argument("--graph-mode", type=int, default=1, help="0 eager, 1 bulk pieces as hipGraphs (default), 2 chain pieces too")
     ap.add_argument("--decode-mode", type=int, default=1, help="1 = default (split kernels, two streams), 2 = + fused k=1 row MLP, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vocoder", action="store_true", help="skip the untimed vocoder-tail section (SURVEY 8f-2)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (plumbing test: ranks may share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -185,6 +238,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp, W)
+        if world == 1 and not args.no_vocoder:
+            out["vocoder"] = vocoder_section(hp, Z, elapsed / args.steps * 1e3, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -54,6 +54,8 @@ SYMBOLS = {
     "dctts_vocoder_device_bytes": (c_size_t, [c_void_p]),
     "dctts_spectrogram2wav": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dctts_griffin_lim": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "dctts_vocoder_prof_enable": (c_int, [c_void_p, c_int]),
+    "dctts_vocoder_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
 }
 
 _lib = None

@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/dctts_hip.h"
@@ -31,7 +33,10 @@ struct dctts_vocoder {
   float *window = nullptr, *wss = nullptr;
   float2 *w1024 = nullptr, *w2048 = nullptr;
   int wss_frames = 0;
+  int wave_kernel = 1;     // register budget of the iteration kernel: 1 = 3 waves/SIMD without spills, 2 = 4 waves/SIMD (DCTTS_VOC_WAVE)
   VBuf spec, X, fr0, fr1, yraw, pw;
+  bool prof = false;                                  // HIP events around every gl_iter_wave launch (dctts_vocoder_prof_*)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
 };
 
 static int vgrow(VBuf& b, size_t bytes) {
@@ -52,6 +57,7 @@ extern "C" int dctts_vocoder_create(dctts_vocoder** out, int device, const dctts
   VHIPCHK(hipSetDevice(device));
   dctts_vocoder* v = new dctts_vocoder();
   v->cfg = *cfg; v->device = device;
+  if (const char* e = getenv("DCTTS_VOC_WAVE")) v->wave_kernel = atoi(e);
   v->lpad = (cfg->n_fft - cfg->win_length) / 2;                      // librosa.util.pad_center
   v->frs = (cfg->win_length + 3) & ~3;
   // periodic Hann (scipy get_window('hann', win, fftbins=True)), evaluated in double, rounded once
@@ -75,6 +81,7 @@ extern "C" int dctts_vocoder_destroy(dctts_vocoder* v) {
   if (!v) return 0;
   (void)hipSetDevice(v->device);
   (void)hipDeviceSynchronize();
+  for (auto& e : v->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (VBuf* b : {&v->spec, &v->X, &v->fr0, &v->fr1, &v->yraw, &v->pw}) if (b->p) (void)hipFree(b->p);
   if (v->window) (void)hipFree(v->window);
   if (v->wss) (void)hipFree(v->wss);
@@ -113,30 +120,39 @@ static int geom(dctts_vocoder* v, int B, int F, VocGeom* g) {
   if (L > 0x3fffffff) return dctts_set_error(DCTTS_ERR_ARG, "utterance too long");
   VCHK(ensure_wss(v, F));
   g->F = F; g->L = (int)L; g->hop = v->cfg.hop_length; g->win = v->cfg.win_length; g->lpad = v->lpad; g->frs = v->frs;
-  g->window = v->window; g->wss = v->wss; g->w1024 = v->w1024; g->w2048 = v->w2048;
+  g->window = v->window; g->wss = v->wss; g->w1024 = v->w1024; g->w1024i = v->w1024; g->w2048 = v->w2048;
   g->tiny = std::numeric_limits<float>::min();
+  g->dmax = (v->cfg.win_length + v->cfg.hop_length - 1) / v->cfg.hop_length;
   return 0;
 }
 
-// utils.py:96-106 on device buffers.  spec (B,F,1025) magnitudes; leaves the final frames in *fr_final.
+// utils.py:96-106 on device buffers.  spec (B,F,1025) magnitudes -> y (B, L).
 static int run_griffin_lim(dctts_vocoder* v, const VocGeom& g, const float* spec, int B, int n_iter, float2* X_best,
-                           const float** fr_final, hipStream_t st) {
-  const size_t frb = (size_t)B * g.F * g.frs * sizeof(float);
-  VCHK(vgrow(v->fr0, frb)); VCHK(vgrow(v->fr1, frb));
-  float* fa = (float*)v->fr0.p; float* fb = (float*)v->fr1.p;
-  const dim3 grid(g.F, B);
-  hipLaunchKernelGGL(istft_frames_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float2*)nullptr, spec, fa);
+                           float* y, hipStream_t st) {
+  VCHK(vgrow(v->fr0, (size_t)B * g.F * g.frs * sizeof(float)));
+  float* fr = (float*)v->fr0.p;
+  const dim3 grid(g.F, B), ogrid((g.L + 255) / 256, B);
+  const int n_items = B * g.F, per_xcd = (n_items + 7) / 8;
+  hipLaunchKernelGGL(istft_frames_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float2*)nullptr, spec, fr);
+  hipLaunchKernelGGL(ola_kernel, ogrid, dim3(256), 0, st, g, (const float*)fr, y);
   for (int it = 0; it < n_iter; ++it) {
     if (X_best && it == n_iter - 1) {      // the caller wants the last X_best: un-fused pair for this iteration
-      hipLaunchKernelGGL(stft_phase_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float*)fa, spec, X_best);
-      hipLaunchKernelGGL(istft_frames_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float2*)X_best, spec, fb);
-    } else {
-      hipLaunchKernelGGL(gl_iter_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float*)fa, spec, fb);
+      hipLaunchKernelGGL(stft_phase_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float*)fr, spec, X_best);
+      VCHK(vgrow(v->fr1, (size_t)B * g.F * g.frs * sizeof(float)));
+      hipLaunchKernelGGL(istft_frames_kernel, grid, dim3(VOC_THREADS), 0, st, g, (const float2*)X_best, spec, (float*)v->fr1.p);
+      hipLaunchKernelGGL(ola_kernel, ogrid, dim3(256), 0, st, g, (const float*)v->fr1.p, y);
+      break;
     }
-    float* t = fa; fa = fb; fb = t;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (v->prof) { VHIPCHK(hipEventCreate(&e0)); VHIPCHK(hipEventCreate(&e1)); VHIPCHK(hipEventRecord(e0, st)); }
+    if (v->wave_kernel == 2)
+      hipLaunchKernelGGL(gl_iter_wave4_kernel, dim3(8 * per_xcd), dim3(64), 0, st, g, (const float*)y, spec, fr, n_items, per_xcd);
+    else
+      hipLaunchKernelGGL(gl_iter_wave_kernel, dim3(8 * per_xcd), dim3(64), 0, st, g, (const float*)y, spec, fr, n_items, per_xcd);
+    if (v->prof) { VHIPCHK(hipEventRecord(e1, st)); v->prof_ev.emplace_back(e0, e1); }
+    hipLaunchKernelGGL(ola_kernel, ogrid, dim3(256), 0, st, g, (const float*)fr, y);
   }
   VHIPCHK(hipGetLastError());
-  *fr_final = fa;
   return 0;
 }
 
@@ -148,10 +164,7 @@ extern "C" int dctts_griffin_lim(dctts_vocoder* v, const float* spec, int B, int
   VocGeom g;
   VCHK(geom(v, B, F, &g));
   hipStream_t st = (hipStream_t)stream;
-  const float* fr = nullptr;
-  VCHK(run_griffin_lim(v, g, spec, B, n_iter, (float2*)X_best, &fr, st));
-  hipLaunchKernelGGL(ola_kernel, dim3((g.L + 255) / 256, B), dim3(256), 0, st, g, fr, y);
-  VHIPCHK(hipGetLastError());
+  VCHK(run_griffin_lim(v, g, spec, B, n_iter, (float2*)X_best, y, st));
   return 0;
 }
 
@@ -166,9 +179,7 @@ extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, 
   VCHK(vgrow(v->yraw, (size_t)B * g.L * sizeof(float)));
   float* spec = (float*)v->spec.p; float* yraw = (float*)v->yraw.p;
   hipLaunchKernelGGL(denorm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mag, spec, n, v->cfg.max_db, v->cfg.ref_db, v->cfg.power);
-  const float* fr = nullptr;
-  VCHK(run_griffin_lim(v, g, spec, B, v->cfg.n_iter, nullptr, &fr, st));
-  hipLaunchKernelGGL(ola_kernel, dim3((g.L + 255) / 256, B), dim3(256), 0, st, g, fr, yraw);
+  VCHK(run_griffin_lim(v, g, spec, B, v->cfg.n_iter, nullptr, yraw, st));
   hipLaunchKernelGGL(deemph_kernel, dim3((g.L + DE_CHUNK - 1) / DE_CHUNK, B), dim3(256), 0, st, (const float*)yraw, wav, g.L, v->cfg.preemphasis);
   if (bounds) {
     const int flen = v->cfg.trim_frame_length, fhop = v->cfg.trim_hop_length;
@@ -179,6 +190,27 @@ extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, 
     hipLaunchKernelGGL(trim_bounds_kernel, dim3(B), dim3(256), 0, st, (const float*)v->pw.p, (int*)bounds, g.L, n_tf, fhop, v->cfg.trim_top_db);
   }
   VHIPCHK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_vocoder_prof_enable(dctts_vocoder* v, int enable) {
+  if (!v) return dctts_set_error(DCTTS_ERR_ARG, "null handle");
+  v->prof = enable != 0;
+  return 0;
+}
+
+extern "C" int dctts_vocoder_prof_collect(dctts_vocoder* v, int* launches, double* total_ms) {
+  if (!v || !launches || !total_ms) return dctts_set_error(DCTTS_ERR_ARG, "null argument");
+  double tot = 0; int n = 0;
+  for (auto& e : v->prof_ev) {
+    VHIPCHK(hipEventSynchronize(e.second));
+    float ms = 0.f;
+    VHIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
+    tot += ms; ++n;
+    (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+  }
+  v->prof_ev.clear();
+  *launches = n; *total_ms = tot;
   return 0;
 }
 

@@ -2,21 +2,22 @@
 // as HIP kernels for gfx950.  librosa.stft / istft are restated in oracle/vocoder_ref.py; these kernels follow that.
 //
 // Griffin-Lim is 50 x (istft -> stft -> keep the phase).  With n_fft = 2048, hop = 275, win = 1102 this is FFT + streaming
-// work (HBM / LDS bound, no MFMA):  one workgroup owns one frame of one utterance and runs the 2048-point real transform
-// as a 1024-point complex Stockham radix-4 FFT in LDS (5 passes, one butterfly per thread per pass).
-//
-//   istft_frames_kernel   X_best row (1025 complex) -> Hermitian pre-twist -> IFFT -> * window -> the 1102 samples under
-//                         the window, stored per frame (`fr`, (B, F, FRS)); nothing is overlap-added with atomics.
-//   stft_phase_kernel     gathers its 1102 windowed input samples straight from `fr` (overlap-add of <= 5 frames in frame
-//                         order / window sum-square, reflect padding at the ends = librosa center=True) -> FFT ->
-//                         post-twist -> est / max(1e-8,|est|) * magnitude -> X_best row.  The time signal never exists in
-//                         HBM between the two transforms.
-//   ola_kernel            final istft: the same gather, written out as the waveform.
+// work (no MFMA).  Per iteration two launches:
+//   gl_iter_wave_kernel   ONE WAVE PER FRAME: window * y -> 2048-point real FFT (a 1024-point complex FFT held in the wave's
+//                         registers, fft_wave.h) -> est / max(1e-8,|est|) * magnitude -> inverse FFT -> * window -> the 1102
+//                         samples under the window, stored per frame (`fr`, (B, F, FRS)).  The spectrum never touches HBM.
+//   ola_kernel            librosa.istft's overlap-add as a GATHER (<= 5 frames per output sample, summed in frame order,
+//                         divided by the window sum-square): deterministic, no atomics -> y (B, L).
+// Around them:
+//   istft_frames_kernel   first pass (real, zero-phase spectrum) and the X_best debug path: 256-thread radix-4 LDS FFT.
+//   stft_phase_kernel     X_best (B, F, 1025) complex out, for tests (the fused kernel never materialises it).
 //   deemph_kernel         scipy.signal.lfilter([1],[1,-a]) (utils.py:89) as a blocked linear-recurrence scan.
 //   frame_power_kernel / trim_bounds_kernel   librosa.effects.trim's [start, end) (utils.py:92).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "fft_wave.h"
 
 namespace dctts {
 
@@ -33,8 +34,11 @@ struct VocGeom {
   const float* window;     // (n_fft) padded periodic Hann
   const float* wss;        // (n_fft + hop*(F-1)) overlap-added squared window
   const float2* w1024;     // exp(-2 pi i m / 1024), m < 1024
+  const float2* w1024i;    // the same table through a second pointer: stops the compiler from keeping ~40 twiddles live (or
+                           // spilled) between the forward and the inverse transform of gl_iter_wave_kernel
   const float2* w2048;     // exp(-2 pi i k / 2048), k <= 1024
   float tiny;
+  int dmax;         // ceil(win / hop): frames f-dmax .. f+dmax can overlap frame f's window
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -150,77 +154,119 @@ __global__ void __launch_bounds__(VOC_THREADS) stft_phase_kernel(const VocGeom g
   }
 }
 
-// One whole Griffin-Lim iteration per launch (utils.py:100-103 + the istft of the next pass): frames_out[f] =
-// window * irfft(spec * phase(stft(istft(frames_in))))[f].  The spectrum row lives only in LDS; `fr_in` / `fr_out` ping-pong.
-__global__ void __launch_bounds__(VOC_THREADS) gl_iter_kernel(const VocGeom g, const float* __restrict__ fr_in,
-                                                              const float* __restrict__ spec, float* __restrict__ fr_out) {
-  __shared__ float2 s[2][VOC_M];
-  __shared__ float2 s_nyq;
-  const int tid = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
-  const float* fr_b = fr_in + (long)b * g.F * g.frs;
-  auto sample = [&](int i) -> float {
-    if (i < g.lpad || i >= g.lpad + g.win) return 0.f;
-    int n = f * g.hop + i - VOC_NFFT / 2;
-    if (n < 0) n = -n; else if (n >= g.L) n = 2 * (g.L - 1) - n;
-    return ola_sample(g, fr_b, n + VOC_NFFT / 2) * g.window[i];
-  };
+// The production form of one Griffin-Lim iteration (utils.py:100-103 + the windowed irfft of the next istft):
+//   frames_out[f] = window * irfft(spec[f] * phase(rfft(window * y_pad[f hop : f hop + n_fft])))
+// ONE WAVE PER FRAME (fft_wave.h): no workgroup barrier, the spectrum row never leaves registers / the wave's 8.7 KB exchange
+// buffer.  `y` is the overlap-added signal of the previous pass (ola_kernel) -- gathering it straight from the frames cost
+// ~4x the loads and ~2 k VALU instructions per frame, and this kernel is VALU-issue bound.  Workgroup w runs on XCD w % 8, so
+// items are dealt out to give each XCD a contiguous run of frames (neighbouring frames share 3/4 of their input in that L2).
+__device__ __forceinline__ void gl_iter_wave_body(const VocGeom& g, const float* __restrict__ y,
+                                                  const float* __restrict__ spec, float* __restrict__ fr_out,
+                                                  int n_items, int per_xcd) {
+  __shared__ float2 ex[FW_EX];
+  const int lane = threadIdx.x;
+  const int item = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || item >= n_items) return;
+  const int b = item / g.F, f = item - b * g.F;
+  const float* yb = y + (long)b * g.L;
+  const int n0 = f * g.hop - VOC_NFFT / 2;                  // signal index of frame sample 0 (librosa.stft, center=True)
+  const int q_lo = g.lpad >> 7, q_hi = (g.lpad + g.win - 1) >> 7;     // lane-strided slots 128 q .. 128 q + 127 that touch the window
+  float2 v[16];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = tid + r * VOC_THREADS;
-    s[0][n] = make_float2(sample(2 * n), sample(2 * n + 1));
+  for (int q = 0; q < 16; ++q) {
+    v[q] = make_float2(0.f, 0.f);
+    if (q >= q_lo && q <= q_hi) {                            // uniform
+      const int i0 = 2 * (lane + 64 * q);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = i0 + h;
+        float x = 0.f;
+        if (i >= g.lpad && i < g.lpad + g.win) {
+          int n = n0 + i;
+          if (n < 0) n = -n; else if (n >= g.L) n = 2 * (g.L - 1) - n;      // np.pad(mode="reflect")
+          x = yb[(unsigned)n] * g.window[(unsigned)i];
+        }
+        if (h == 0) v[q].x = x; else v[q].y = x;
+      }
+    }
   }
+  fw_passA_store<false>(v, ex, lane); __syncthreads();
+  fw_passB_load<false>(v, ex, lane, g.w1024); __syncthreads();
+  fw_passB_store(v, ex, lane); __syncthreads();
+  fw_passC_load<false>(v, ex, lane, g.w1024); __syncthreads();          // v[r] = Z[lane + 64 r]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ex[fw_base(lane) + 68 * r] = v[r];
+  if (lane == 0) ex[FW_N + FW_N / 16] = v[0];             // Z[M] = Z[0], where lane 0's "partner lane 64" formula looks for it
   __syncthreads();
-  fft1024<false>(s, g.w1024, tid);                       // Z in s[1]
-  const long row = ((long)b * g.F + f) * VOC_BINS;
-  for (int k = tid; k <= VOC_M; k += VOC_THREADS) {
-    const float2 a = s[1][k & (VOC_M - 1)], c = s[1][(VOC_M - k) & (VOC_M - 1)];
+  const float2* exp_ = ex + fw_base(64 - lane);            // Z[M - k], k = lane + 64 r, sits at fw_base(64 - lane) + 68 (15 - r)
+  const float* sp_row = spec + ((long)b * g.F + f) * VOC_BINS;
+  // Post-twist (Z -> est), phase projection and the inverse transform's pre-twist, all from the pair (Z[k], Z[M-k]):
+  //   est[k] = E + Dw/i,  est[M-k] = conj(E) + conj(Dw)/i   with E = (a + conj c)/2, Dw = W^k (a - conj c)/2
+  // so the lane that owns k rebuilds X_best[M-k] itself and no second exchange is needed.
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k = lane + 64 * r;
+    const float2 a = v[r], c = exp_[68 * (15 - r)];
+    const float2 w = g.w2048[(unsigned)k];
     const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
     const float2 D = make_float2(0.5f * (a.x - c.x), 0.5f * (a.y + c.y));
-    const float2 Dw = cmul(D, g.w2048[k]);
-    const float2 est = make_float2(E.x + Dw.y, E.y - Dw.x);
-    const float mag = fmaxf(1e-8f, hypotf(est.x, est.y));
-    const float sp = spec[row + k];
-    float2 xb = make_float2(sp * (est.x / mag), sp * (est.y / mag));
-    if (k == 0 || k == VOC_M) xb.y = 0.f;
-    if (k == VOC_M) s_nyq = xb; else s[0][k] = xb;        // X_best row -> s[0] (+ Nyquist)
+    const float2 Dw = fw_mul(D, w);
+    const float2 e1 = make_float2(E.x + Dw.y, E.y - Dw.x);                 // est[k]
+    const float2 e2 = make_float2(E.x - Dw.y, -(E.y + Dw.x));              // est[M-k]
+    // spec / max(1e-8, |est|) as spec * min(rsq(|est|^2), 1e8): v_rsq_f32 is ~1 ulp, an IEEE sqrt + divide costs ~25 instructions
+    const float s1 = sp_row[(unsigned)k] * fminf(__builtin_amdgcn_rsqf(fmaf(e1.x, e1.x, e1.y * e1.y)), 1e8f);
+    const float s2 = sp_row[(unsigned)(VOC_M - k)] * fminf(__builtin_amdgcn_rsqf(fmaf(e2.x, e2.x, e2.y * e2.y)), 1e8f);
+    const float2 x1 = make_float2(s1 * e1.x, k == 0 ? 0.f : s1 * e1.y);    // X_best[k]   (irfft drops Im of DC / Nyquist)
+    const float2 x2 = make_float2(s2 * e2.x, k == 0 ? 0.f : s2 * e2.y);    // X_best[M-k]
+    const float2 E2 = make_float2(0.5f * (x1.x + x2.x), 0.5f * (x1.y - x2.y));
+    const float2 D2 = make_float2(0.5f * (x1.x - x2.x), 0.5f * (x1.y + x2.y));
+    const float2 O2 = fw_mulc(D2, w);
+    v[r] = make_float2(E2.x - O2.y, E2.y + O2.x);
   }
   __syncthreads();
-  float2 a4[4], c4[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int k = tid + r * VOC_THREADS;
-    a4[r] = s[0][k];
-    c4[r] = (k == 0) ? s_nyq : s[0][VOC_M - k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int k = tid + r * VOC_THREADS;
-    const float2 a = a4[r], c = c4[r];
-    const float2 E = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
-    const float2 D = make_float2(0.5f * (a.x - c.x), 0.5f * (a.y + c.y));
-    const float2 O = cmulc(D, g.w2048[k]);
-    s[0][k] = make_float2(E.x - O.y, E.y + O.x);
-  }
-  __syncthreads();
-  fft1024<true>(s, g.w1024, tid);
+  fw_passA_store<true>(v, ex, lane); __syncthreads();
+  fw_passB_load<true>(v, ex, lane, g.w1024i); __syncthreads();
+  fw_passB_store(v, ex, lane); __syncthreads();
+  fw_passC_load<true>(v, ex, lane, g.w1024i);
   float* out = fr_out + ((long)b * g.F + f) * g.frs;
   const float inv = 1.0f / (float)VOC_M;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int n = tid + r * VOC_THREADS;
-    const float2 z = s[1][n];
+  for (int r = 0; r < 16; ++r) {
+    const int n = lane + 64 * r;
     const int i0 = 2 * n - g.lpad, i1 = i0 + 1;
-    if (i0 >= 0 && i0 < g.win) out[i0] = (z.x * inv) * g.window[2 * n];
-    if (i1 >= 0 && i1 < g.win) out[i1] = (z.y * inv) * g.window[2 * n + 1];
+    if (i0 >= 0 && i0 < g.win) out[(unsigned)i0] = (v[r].x * inv) * g.window[(unsigned)(2 * n)];
+    if (i1 >= 0 && i1 < g.win) out[(unsigned)i1] = (v[r].y * inv) * g.window[(unsigned)(2 * n + 1)];
   }
 }
+// Register budget: 168 VGPRs (3 waves / SIMD) holds the lane program without spills; the 128-VGPR build (4 waves / SIMD)
+// spills ~34 dwords.  Both are kept so the trade can be measured (DCTTS_VOC_WAVE = 1 | 2).
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+gl_iter_wave_kernel(const VocGeom g, const float* __restrict__ y, const float* __restrict__ spec, float* __restrict__ fr_out,
+                    int n_items, int per_xcd) { gl_iter_wave_body(g, y, spec, fr_out, n_items, per_xcd); }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+gl_iter_wave4_kernel(const VocGeom g, const float* __restrict__ y, const float* __restrict__ spec, float* __restrict__ fr_out,
+                     int n_items, int per_xcd) { gl_iter_wave_body(g, y, spec, fr_out, n_items, per_xcd); }
 
-// grid (ceil(L / 256), B): y (B, L) = istft(X)[n_fft/2 : -n_fft/2] from the stored frames.
+// grid (ceil(L / 256), B): y (B, L) = istft(X)[n_fft/2 : -n_fft/2] from the stored frames.  The frames that can reach a block of
+// 256 consecutive samples are a block-uniform range (scalar divisions, <= dmax + 2 of them); each lane just tests its index.
 __global__ void __launch_bounds__(256) ola_kernel(const VocGeom g, const float* __restrict__ fr, float* __restrict__ y) {
-  const int n = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y;
+  const int m0 = blockIdx.x * 256 + VOC_NFFT / 2;           // first y_full index of the block (uniform)
+  const int lo_num = m0 - (g.lpad + g.win - 1);
+  int q_lo = lo_num <= 0 ? 0 : (lo_num + g.hop - 1) / g.hop;
+  int q_hi = (m0 + 255 - g.lpad) / g.hop;
+  if (q_hi > g.F - 1) q_hi = g.F - 1;
+  const int n = blockIdx.x * 256 + threadIdx.x;
   if (n >= g.L) return;
-  y[(long)b * g.L + n] = ola_sample(g, fr + (long)b * g.F * g.frs, n + VOC_NFFT / 2);
+  const int m = n + VOC_NFFT / 2;
+  const float* fr_b = fr + (long)b * g.F * g.frs;
+  float acc = 0.f;
+  for (int q = q_lo; q <= q_hi; ++q) {                       // ascending frame order, as librosa.istft accumulates
+    const int idx = m - q * g.hop - g.lpad;
+    if (idx >= 0 && idx < g.win) acc = acc + fr_b[(long)q * g.frs + idx];
+  }
+  const float ws = g.wss[m];
+  y[(long)b * g.L + n] = ws > g.tiny ? acc / ws : acc;
 }
 
 // utils.py:79-86: spec = (10 ** ((clip(mag,0,1) * max_db - max_db + ref_db) * 0.05)) ** power

@@ -1,5 +1,5 @@
-"""Host driver shaped like the reference's ``synthesize.py:21-57`` (without Griffin-Lim / wav I/O,
-which are outside the metric).
+"""Host driver shaped like the reference's ``synthesize.py:21-64``.  The metric covers :45-57 (decode + SSRN);
+the Griffin-Lim tail (:59-64) runs on the GPU too (``dc_tts_amd/utils.py``) and is used by the CLI below.
 
 ``synthesize_reference_loop`` is the literal loop of synthesize.py:45-57 written against the drop-in
 ``networks`` surface -- 210 full-graph evaluations, exactly what a maintainer gets by swapping the
@@ -43,8 +43,9 @@ def synthesize_reference_loop(L: torch.Tensor, engine: Optional[Engine] = None):
 
 def main(argv=None):
     """`python -m dc_tts_amd.synthesize --text harvard_sentences.txt [--logdir logdir/LJ01] --out samples`
-    = the reference's `python synthesize.py` up to the magnitude spectrograms (synthesize.py:21-57): the mel (Y) and linear
-    (Z) spectrograms are written as .npy per sentence; Griffin-Lim / wav writing (synthesize.py:59-64) is out of scope."""
+    = the reference's `python synthesize.py` (synthesize.py:21-64): Text2Mel decode, SSRN, then `spectrogram2wav` per sentence
+    (on the GPU, dc_tts_amd/utils.py) written as `<out>/<n>.wav` with scipy.io.wavfile.write like synthesize.py:64.
+    `--save-spectrograms` also writes the mel (Y) and linear (Z) spectrograms as .npy."""
     import argparse
     import os
 
@@ -58,6 +59,8 @@ def main(argv=None):
     ap.add_argument("--logdir", default=None, help="prefix of the trained checkpoints (<logdir>-1 Text2Mel, <logdir>-2 SSRN); "
                                                    "omitted: seeded synthetic weights")
     ap.add_argument("--out", default="samples")
+    ap.add_argument("--save-spectrograms", action="store_true")
+    ap.add_argument("--no-wav", action="store_true", help="stop at the magnitude spectrograms (synthesize.py:57)")
     args = ap.parse_args(argv)
     if args.logdir:
         from .tf_checkpoint import load_reference_weights
@@ -68,10 +71,17 @@ def main(argv=None):
     L = load_data("synthesize", args.text, hp)
     Y, Z, _ = eng.synthesize(torch.from_numpy(L).to(eng.device))
     os.makedirs(args.out, exist_ok=True)
-    for i in range(L.shape[0]):
-        np.save(os.path.join(args.out, f"{i + 1}.mel.npy"), Y[i].cpu().numpy())
-        np.save(os.path.join(args.out, f"{i + 1}.mag.npy"), Z[i].cpu().numpy())
-    print(f"{L.shape[0]} sentences -> {args.out}/<n>.mel.npy ({tuple(Y.shape[1:])}), <n>.mag.npy ({tuple(Z.shape[1:])})")
+    if args.save_spectrograms or args.no_wav:
+        for i in range(L.shape[0]):
+            np.save(os.path.join(args.out, f"{i + 1}.mel.npy"), Y[i].cpu().numpy())
+            np.save(os.path.join(args.out, f"{i + 1}.mag.npy"), Z[i].cpu().numpy())
+    if not args.no_wav:
+        from scipy.io.wavfile import write
+        from .utils import spectrogram2wav
+        for i, wav in enumerate(spectrogram2wav(Z, hp)):                # synthesize.py:61-64
+            write(os.path.join(args.out, f"{i + 1}.wav"), hp.sr, wav)
+    print(f"{L.shape[0]} sentences -> {args.out}/ (mel {tuple(Y.shape[1:])}, mag {tuple(Z.shape[1:])}"
+          f"{'' if args.no_wav else ', <n>.wav at %d Hz' % hp.sr})")
 
 
 if __name__ == "__main__":

@@ -57,6 +57,15 @@ class Vocoder:
     def device_bytes(self) -> int:
         return int(self.lib.dctts_vocoder_device_bytes(self._h))
 
+    def prof_enable(self, enable: bool):
+        self._ok(self.lib.dctts_vocoder_prof_enable(self._h, int(bool(enable))))
+
+    def prof_collect(self) -> Tuple[int, float]:
+        """(launches, total ms) of the Griffin-Lim iteration kernel since prof_enable(True), by HIP events on the launch stream."""
+        n = ctypes.c_int(0); ms = ctypes.c_double(0.0)
+        self._ok(self.lib.dctts_vocoder_prof_collect(self._h, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
     def n_samples(self, F: int) -> int:
         """Length of librosa.istft's output for F frames: hop_length * (F - 1)."""
         return self.hp.hop_length * (F - 1)

@@ -157,6 +157,12 @@ int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, int F, floa
  * iteration produced (needs n_iter >= 1).  n_iter = 0 gives y = istft(spec). */
 int dctts_griffin_lim(dctts_vocoder* v, const float* spec, int B, int F, int n_iter, float* y, float* X_best, void* stream);
 
+/* Measurement aid (bench.py roofline of the vocoder): while enabled, HIP events are recorded on the launch stream around
+ * every launch of the Griffin-Lim iteration kernel (gl_iter_wave_kernel); collect() synchronises them, returns the number
+ * of launches and their summed duration, and clears the list. */
+int dctts_vocoder_prof_enable(dctts_vocoder* v, int enable);
+int dctts_vocoder_prof_collect(dctts_vocoder* v, int* launches, double* total_ms);
+
 #ifdef __cplusplus
 }
 #endif
