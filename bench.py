@@ -104,6 +104,10 @@ def vocoder_section(hp, Z, ms_synth, with_cpu):
                         "algorithmic_bytes_per_launch": alg,
                         "note": "VALU-issue bound (~2.5 k wave instructions per frame), not HBM bound: see DESIGN.md"},
            "device_bytes": v.device_bytes()}
+    tj = os.path.join(ROOT, "profiles", "r01_vocoder_pmc.json")
+    if B == 32 and F == 840 and os.path.exists(tj):           # PMC FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 passes
+        out["roofline"]["traffic"] = json.load(open(tj))["hbm_bytes_per_launch"]
+        out["roofline"]["traffic_unit"] = "bytes/launch (PMC, separate pass: profiles/r01_vocoder.md)"
     if with_cpu:
         out["cpu_baseline"] = vocoder_cpu_baseline(hp, Z[0].cpu().numpy())
     v.close()
