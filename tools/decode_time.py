@@ -1,0 +1,15 @@
+import sys, os, time, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+from dc_tts_amd.engine import Engine
+from dc_tts_amd.hyperparams import hp
+from dc_tts_amd.weights import synthetic_weights, synthetic_text
+T = 210
+eng = Engine(synthetic_weights(hp), hp, decode_graph=int(os.environ.get("GM", "1")))
+L = torch.from_numpy(synthetic_text(hp, B=32)).cuda()
+for _ in range(2): eng.text2mel(L)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(3): eng.text2mel(L)
+e1.record(); torch.cuda.synchronize()
+print("text2mel ms", e0.elapsed_time(e1) / 3, "us/frame", (e0.elapsed_time(e1) / 3 - 2.54) * 1e3 / T)
