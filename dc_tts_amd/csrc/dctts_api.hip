@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -982,6 +983,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     // the bulk stream joins the caller's stream at the start (TextEnc, resets)
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
+    const auto host_t0 = std::chrono::steady_clock::now();
     // pipeline prologue = chain piece -1: frame 0's AudioEnc + attention
     if (gr_chain) HIPCHK(hipGraphLaunch(c->pro_g, st));
     else if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, st)); CHK(v2_audioenc_attn(c, w, B, N, 0, st, true)); }
@@ -1007,6 +1009,10 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
         HIPCHK(hipStreamSynchronize(st));
         CHK(write_trace(c, j));
       }
+    }
+    if (getenv("DCTTS_HOSTTIME")) {
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
+      fprintf(stderr, "[dctts] decode: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
     }
   } else if (c->use_graph) {
     const std::string g = geom("graph1", B, T, N);

@@ -114,6 +114,23 @@ struct SplitParams {
 };
 // *_set: buffers written by the bulk branch exist twice (frame parity); set stride in floats, 0 = single buffer.
 
+// Kernel arguments arrive through scalar loads from the kernarg segment, and the compiler fetches a ~300-byte parameter struct
+// lazily: the chain kernel showed five s_load batches, each followed by s_waitcnt lgkmcnt(0), i.e. five serialised scalar
+// memory round trips (~2 us) before its first vector load.  Naming every field as an SGPR input of an empty asm at entry makes
+// the compiler fetch the whole struct in one batch.
+#define DCTTS_SGPR(x) asm volatile("" ::"s"(x))
+__device__ __forceinline__ void prefetch_params(const SplitParams& p) {
+  DCTTS_SGPR(p.M); DCTTS_SGPR(p.R); DCTTS_SGPR(p.b0); DCTTS_SGPR(p.offs); DCTTS_SGPR(p.step); DCTTS_SGPR(p.step_val);
+  DCTTS_SGPR(p.ngroups); DCTTS_SGPR(p.tile_rows); DCTTS_SGPR(p.pro);
+  DCTTS_SGPR(p.nrm.P); DCTTS_SGPR(p.nrm.np); DCTTS_SGPR(p.nrm.g1); DCTTS_SGPR(p.nrm.b1); DCTTS_SGPR(p.nrm.g2); DCTTS_SGPR(p.nrm.b2);
+  DCTTS_SGPR(p.nrm.act); DCTTS_SGPR(p.nrm.res); DCTTS_SGPR(p.nrm.res_bstride); DCTTS_SGPR(p.nrm.res_row0);
+  DCTTS_SGPR(p.nrm.res_stride); DCTTS_SGPR(p.nrm.res_set); DCTTS_SGPR(p.stats_in);
+  DCTTS_SGPR(p.xmat); DCTTS_SGPR(p.xm_bstride); DCTTS_SGPR(p.xm_row0); DCTTS_SGPR(p.xm_stride); DCTTS_SGPR(p.xm_set);
+  DCTTS_SGPR(p.xsrc); DCTTS_SGPR(p.xs_bstride); DCTTS_SGPR(p.xs_row0); DCTTS_SGPR(p.xs_stride); DCTTS_SGPR(p.xs_set);
+  DCTTS_SGPR(p.ntaps); DCTTS_SGPR(p.tap_off[0]); DCTTS_SGPR(p.tap_off[1]); DCTTS_SGPR(p.tap_off[2]); DCTTS_SGPR(p.cin); DCTTS_SGPR(p.cin_p);
+  DCTTS_SGPR(p.wp); DCTTS_SGPR(p.bias); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.hc); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.stats_out);
+}
+
 // Sum over the four lanes l, l^16, l^32, l^48 (the lanes that share an A-operand row in the 16x16x4 layout), on the
 // VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two registers.
 __device__ __forceinline__ float xrow4_sum(float v) {
@@ -145,6 +162,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];     // split-K reduction only
   __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if constexpr (MF == 16) prefetch_params(p);
   const bool tr = p.dbg && blockIdx.x == 0 && tid == 0;
   if (tr) p.dbg[0] = wall_clock64();
   const int step = p.step_val + (p.step ? *p.step : 0);
@@ -168,11 +186,14 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     const float* wb = p.wp + lane * 4;
     const unsigned w0o = (unsigned)(grp * 2) * (unsigned)KG * 256u, w1o = w0o + (unsigned)KG * 256u;
     float4 bq0[BD], bq1[BD];
+    // Loads are issued WITHOUT branches around them: a uniform `if (g < KG)` still compiles to a branch, and at every join the
+    // wait-count pass falls back to s_waitcnt vmcnt(0) when a register may have a load pending on one path -- the chain kernel
+    // then paid ~6 serialised memory round trips per layer (in-kernel stamps: 2.8 us from first to last issue).  k-groups past
+    // the end re-read the last one (clamped index); their A fragment is zero, so the duplicate weights contribute nothing.
 #pragma unroll
     for (int i = 0; i < BD; ++i) {
-      const int g = wave + 8 * i;
-      bq0[i] = make_float4(0.f, 0.f, 0.f, 0.f); bq1[i] = bq0[i];
-      if (g < KG) { bq0[i] = ld4u(wb, w0o + (unsigned)g * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)g * 256u); }
+      const int g = wave + 8 * i, gc = g < KG ? g : KG - 1;
+      bq0[i] = ld4u(wb, w0o + (unsigned)gc * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)gc * 256u);
     }
 
     // ---- this lane's A row (MFMA A operand: lane -> row lane % MF, k sub-block lane / MF)
@@ -200,38 +221,64 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     float4 av[NGMAX];
     float4 h2v[2], rsv[2], g1v[2], b1v[2], g2v[2], b2v[2];   // centre-tap extras of the (at most two) centre k-groups of a wave
     float4 st[4];
+    float biasv = 0.f;                                        // MF == 16: this thread's output column, fetched with everything else
+    if constexpr (MF == 16) {
+      // Branch-free issue (see above).  Addresses that a branch used to skip are redirected to something readable
+      // (the tap source's first row / the clamped column) and the value is discarded afterwards.
+      const bool hcpro = (p.pro == PRO_LN_HC);
 #pragma unroll
-    for (int i = 0; i < NGMAX; ++i) {
-      const int g = wave + 8 * i;
-      av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g < KG) {
-        const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+      for (int i = 0; i < NGMAX; ++i) {
+        const int g = wave + 8 * i, gc = g < KG ? g : KG - 1;
+        const int k0 = gc * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
         const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
-        if (ln && tap == ctap) {
-          if constexpr (MF == 16) {
-            g1v[i & 1] = ld4u(p.nrm.g1, c); b1v[i & 1] = ld4u(p.nrm.b1, c);
-            av[i] = ld4u(p.nrm.P, p_row + c);
-            if (p.pro == PRO_LN_HC) {
-              g2v[i & 1] = ld4u(p.nrm.g2, c); b2v[i & 1] = ld4u(p.nrm.b2, c);
-              h2v[i & 1] = ld4u(p.nrm.P, p_row + 256 + c);
-              rsv[i & 1] = ld4u(p.nrm.res, rs_row + c);
-            }
-          }
-        } else if (c < p.cin) {            // uniform per 16-lane row group; pad columns stay zero
-          av[i] = ld4u(p.xsrc, xs_row + (unsigned)(toff * p.xs_stride) + c);
+        const bool centre = ln && tap == ctap;                                  // uniform: a scalar select of the base pointer
+        const int cc = c < p.cin ? c : p.cin - 4;                               // pad columns of a narrow input: read in range, zeroed below
+        const float* base = centre ? p.nrm.P : p.xsrc;
+        const unsigned off = centre ? p_row + (unsigned)c : xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)cc;
+        av[i] = ld4u(base, off);
+      }
+      // the two centre k-groups of wave w are 16 ctap + w and 16 ctap + 8 + w  (i = 2 ctap + e): channel (8 e + w) 16 + c4
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned ce = ln ? (unsigned)((8 * e + wave) * 16 + c4) : 0u;
+        g1v[e] = ld4u(ln ? p.nrm.g1 : p.xsrc, ce); b1v[e] = ld4u(ln ? p.nrm.b1 : p.xsrc, ce);
+        g2v[e] = ld4u(hcpro ? p.nrm.g2 : p.xsrc, hcpro ? ce : 0u); b2v[e] = ld4u(hcpro ? p.nrm.b2 : p.xsrc, hcpro ? ce : 0u);
+        h2v[e] = ld4u(hcpro ? p.nrm.P : p.xsrc, hcpro ? p_row + 256u + ce : 0u);
+        rsv[e] = ld4u(hcpro ? p.nrm.res : p.xsrc, hcpro ? rs_row + ce : 0u);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) st[g] = ld4u(ln ? p.stats_in : p.xsrc, (ln && valid) ? (unsigned)(prow * 64) + (unsigned)((aq * 4 + g) * 4) : 0u);
+      {
+        const int l = tid & 63, tile = tid >> 8, col = l & 15;
+        const int pc = p.hc ? ((grp * MF + col) < p.cout ? tile * p.cout + grp * MF + col : 0)
+                            : (((grp * 2 + tile) * MF + col) < p.cout ? (grp * 2 + tile) * MF + col : 0);
+        biasv = p.bias[(unsigned)pc];
+      }
+      if (tr) p.dbg[2] = wall_clock64();
+      // discard what the redirected loads fetched
+#pragma unroll
+      for (int i = 0; i < NGMAX; ++i) {
+        const int g = wave + 8 * i;
+        const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+        const bool centre = ln && tap == ctap;
+        if (g >= KG || !valid || (!centre && c >= p.cin)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NGMAX; ++i) {
+        const int g = wave + 8 * i;
+        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < KG) {
+          const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+          const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
+          if (c < p.cin) av[i] = ld4u(p.xsrc, xs_row + (unsigned)(toff * p.xs_stride) + c);     // pad columns stay zero
         }
       }
-    }
-    if constexpr (MF == 16) {
-      if (ln) {
+      if (tr) p.dbg[2] = wall_clock64();
+      if (!valid) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) st[g] = ld4u(p.stats_in, (valid ? (unsigned)(prow * 64) : 0u) + (aq * 4 + g) * 4);
+        for (int i = 0; i < NGMAX; ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    }
-    if (tr) p.dbg[2] = wall_clock64();
-    if (!valid) {
-#pragma unroll
-      for (int i = 0; i < NGMAX; ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     // ---- rebuild the centre-tap values: LN (+ act) or LN + sigmoid gate + highway mix, elementwise given the row statistics
@@ -284,7 +331,8 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
         if (i + BD < NGMAX) {
           const int gn = g + 8 * BD;
-          if (gn < KG) { bq0[i % BD] = ld4u(wb, w0o + (unsigned)gn * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gn * 256u); }
+          const int gnc = gn < KG ? gn : KG - 1;
+          bq0[i % BD] = ld4u(wb, w0o + (unsigned)gnc * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gnc * 256u);
         }
         if constexpr (MF == 32) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
@@ -321,7 +369,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       int pcol; bool ok;
       if (p.hc) { const int c = grp * MF + col; ok = c < p.cout; pcol = tile * p.cout + c; }
       else      { pcol = (grp * 2 + tile) * MF + col; ok = pcol < p.cout; }
-      if (ok) v_ += p.bias[pcol];
+      if constexpr (MF == 16) { if (ok) v_ += biasv; } else { if (ok) v_ += p.bias[pcol]; }
       if (ok && orow >= 0) p.pout[orow * p.np_out + pcol] = v_;
       if constexpr (MF == 16) {
         // partial LN statistics of this 16-column group: a DPP row (16 lanes) holds one output row's 16 columns
