@@ -752,25 +752,40 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   if (pro != PRO_RAW && (MF != 16 || L.cin_p != 256 || !stats_in))
     return fail(DCTTS_ERR_STATE, "split kernel: LN prologue needs the 16-row form, 256 input channels and producer statistics");
   if (L.ntaps > 1 && L.cin_p != 256) return fail(DCTTS_ERR_STATE, "split kernel: multi-tap layers must have 256 input channels");
-  if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++);
+  if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) { p.dbg_wg = g_trace_ctx->trace_buf + 64 * 8 + 256 * g_trace_ctx->trace_n; p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++); }
   const int groups = L.hc ? L.cout / MF : (L.cout + 2 * MF - 1) / (2 * MF);
   p.ngroups = groups;
   p.tile_rows = (MF == 16) ? c->chain_rows : MF;
   int nblk = ((p.M + p.tile_rows - 1) / p.tile_rows) * groups;
   if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
   const size_t sm = hsplit_smem(MF);
-  if (MF == 16) hipLaunchKernelGGL(hsplit_kernel<16>, dim3(nblk), dim3(512), sm, st, p);
-  else          hipLaunchKernelGGL(hsplit_kernel<32>, dim3(nblk), dim3(512), sm, st, p);
+  if (MF == 16 && p.dbg) hipLaunchKernelGGL((hsplit_kernel<16, true>), dim3(nblk), dim3(512), sm, st, p);
+  else if (MF == 16) hipLaunchKernelGGL(hsplit_kernel<16>, dim3(nblk), dim3(512), sm, st, p);
+  else {
+    const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
+    if (kg == 96)      hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
+    else if (kg == 64) hipLaunchKernelGGL((hsplit_kernel<32, false, 8>), dim3(nblk), dim3(512), sm, st, p);
+    else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): K must be 512 or 768");
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 static int decode_v2_init(dctts_ctx* c) {
   if (c->s_bulk) return 0;
-  HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
+  {
+    // the bulk stream is throughput work that only has to finish within a frame period: lowest priority, so the dispatcher
+    // prefers the latency-critical chain launches (caller's stream) whenever both have workgroups ready
+    int lo = 0, hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const char* e = getenv("DCTTS_BULK_PRIO");
+    if (e && atoi(e) == 0) HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
+    else HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, lo));
+  }
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], hipEventDisableTiming)); }
-  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   return 0;
 }
 
@@ -922,7 +937,7 @@ static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
 }
 
 static int write_trace(dctts_ctx* c, int j) {
-  std::vector<long long> h(64 * 8);
+  std::vector<long long> h(64 * (8 + 256));
   HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   FILE* f = fopen("gpurun_out/decode_trace.txt", "w");
   if (!f) return 0;
@@ -932,6 +947,16 @@ static int write_trace(dctts_ctx* c, int j) {
   for (int k = 0; k < c->trace_n; ++k) {
     fprintf(f, "%2d", k);
     for (int q = 0; q < 7; ++q) fprintf(f, " %8.2f", (h[8 * k + q] - t0) / 100.0);
+    // all workgroups of the launch: first / last entry, first / last end
+    long long e0 = 0, e1 = 0, x0 = 0, x1 = 0; int nw = 0;
+    for (int wg = 0; wg < 128; ++wg) {
+      const long long en = h[64 * 8 + 256 * k + 2 * wg], ex = h[64 * 8 + 256 * k + 2 * wg + 1];
+      if (!en || !ex) continue;
+      if (!nw || en < e0) e0 = en; if (!nw || en > e1) e1 = en;
+      if (!nw || ex < x0) x0 = ex; if (!nw || ex > x1) x1 = ex;
+      ++nw;
+    }
+    if (nw) fprintf(f, "  | %3d wgs: entry %8.2f..%8.2f  end %8.2f..%8.2f", nw, (e0 - t0) / 100.0, (e1 - t0) / 100.0, (x0 - t0) / 100.0, (x1 - t0) / 100.0);
     fprintf(f, "\n");
   }
   fclose(f);
@@ -998,8 +1023,8 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
       }
       if (j >= 1) HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0));      // chain piece j reads frame j's cone rows
       if (j == tstep) {
-        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 8 * sizeof(long long))); }
-        HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 8 * sizeof(long long), st));
+        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * (8 + 256) * sizeof(long long))); }
+        HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * (8 + 256) * sizeof(long long), st));
         c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
       }
       if (gr_chain) HIPCHK(hipGraphLaunch(c->chain_g[j], st)); else CHK(v2_chain_piece(c, w, B, N, j, j + 1 < T, st));

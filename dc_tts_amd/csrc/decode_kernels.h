@@ -111,6 +111,7 @@ struct SplitParams {
   float* pout;                                                   // pre-norm rows [b*R + r][np_out]
   float* stats_out;                                              // optional partial statistics of pout (16-row form only)
   long long* dbg;                                                // optional: 8 wall-clock (100 MHz) stamps of workgroup 0
+  long long* dbg_wg;                                             // optional: (entry, end) stamps of every workgroup (<= 128)
 };
 // *_set: buffers written by the bulk branch exist twice (frame parity); set stride in floats, 0 = single buffer.
 
@@ -153,18 +154,24 @@ __device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, floa
   rstd = rsqrt_fast(xrow4_sum(m2) * (1.0f / 256.0f) + 1e-12f);
 }
 
-template <int MF>
+// TRACE = true compiles the wall-clock stamps in (DCTTS_TRACE).  They must NOT exist in the production instantiation even as
+// dead branches: a store that may be pending makes the wait-count pass treat vmcnt as out of order (mixed load / store events)
+// and every later wait on a load becomes s_waitcnt vmcnt(0) -- the bulk kernel's weight prefetch ring was serialised by it.
+// NG > 0 fixes the k-groups per wave at compile time (K = 64 NG for the 32-row form): the K loop is then straight-line code.
+// With a run-time `if (g < KG)` around each step, a prefetch issued inside a conditional block may or may not be followed by
+// younger loads, so the only safe wait for it is vmcnt(0) -- the counted waits the ring depends on need unconditional steps.
+template <int MF, bool TRACE = false, int NG = 0>
 __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   constexpr int KGS = (MF == 32) ? 8 : 16;          // k per k-group (4 MFMAs)
   constexpr int NJ = (MF == 32) ? 16 : 4;           // accumulator registers per tile
-  constexpr int NGMAX = (MF == 32) ? 12 : 6;        // k-groups per wave at K = 768
+  constexpr int NGMAX = NG > 0 ? NG : ((MF == 32) ? 12 : 6);   // k-groups per wave (12 / 6 at K = 768)
   constexpr int BD = (MF == 32) ? 4 : 6;            // B prefetch ring depth (k-groups)
   extern __shared__ __attribute__((aligned(16))) float smem[];     // split-K reduction only
   __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if constexpr (MF == 16) prefetch_params(p);
-  const bool tr = p.dbg && blockIdx.x == 0 && tid == 0;
-  if (tr) p.dbg[0] = wall_clock64();
+  prefetch_params(p);
+  const bool tr = TRACE && p.dbg && blockIdx.x == 0 && tid == 0;
+  if constexpr (TRACE) { if (tr) p.dbg[0] = wall_clock64(); if (p.dbg_wg && tid == 0 && blockIdx.x < 128) p.dbg_wg[2 * blockIdx.x] = wall_clock64(); }
   const int step = p.step_val + (p.step ? *p.step : 0);
   const long par = step & 1;
   const int KG = p.ntaps * p.cin_p / KGS;
@@ -210,7 +217,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       }
       if (wave == 0 && aq == 0) s_prow[arow] = valid ? prow : -1;
     }
-    if (tr) p.dbg[1] = wall_clock64();
+    if constexpr (TRACE) { if (tr) p.dbg[1] = wall_clock64(); }
 
     // ---- A fragments straight from global memory: every load of the item is in flight before the first use.
     //      Loads are unconditional (skipped rows read row 0 and are zeroed afterwards) so that no exec-mask branches
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
                             : (((grp * 2 + tile) * MF + col) < p.cout ? (grp * 2 + tile) * MF + col : 0);
         biasv = p.bias[(unsigned)pc];
       }
-      if (tr) p.dbg[2] = wall_clock64();
+      if constexpr (TRACE) { if (tr) p.dbg[2] = wall_clock64(); }
       // discard what the redirected loads fetched
 #pragma unroll
       for (int i = 0; i < NGMAX; ++i) {
@@ -264,20 +271,21 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         if (g >= KG || !valid || (!centre && c >= p.cin)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
+      // same branch-free issue as the 16-row form: clamped k-group / column, value discarded afterwards
+#pragma unroll
+      for (int i = 0; i < NGMAX; ++i) {
+        const int g = wave + 8 * i, gc = g < KG ? g : KG - 1;
+        const int k0 = gc * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+        const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
+        const int cc = c < p.cin ? c : p.cin - 4;
+        av[i] = ld4u(p.xsrc, xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)cc);
+      }
+      if constexpr (TRACE) { if (tr) p.dbg[2] = wall_clock64(); }
 #pragma unroll
       for (int i = 0; i < NGMAX; ++i) {
         const int g = wave + 8 * i;
-        av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < KG) {
-          const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
-          const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
-          if (c < p.cin) av[i] = ld4u(p.xsrc, xs_row + (unsigned)(toff * p.xs_stride) + c);     // pad columns stay zero
-        }
-      }
-      if (tr) p.dbg[2] = wall_clock64();
-      if (!valid) {
-#pragma unroll
-        for (int i = 0; i < NGMAX; ++i) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+        if (g >= KG || !valid || c >= p.cin) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);       // pad columns / skipped rows stay zero
       }
     }
 
@@ -316,7 +324,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         }
       }
     }
-    if (tr) p.dbg[3] = wall_clock64();
+    if constexpr (TRACE) { if (tr) p.dbg[3] = wall_clock64(); }
 
     // ---- K loop (fully unrolled so the register arrays are statically indexed)
     typedef typename std::conditional<MF == 32, f32x16, f32x4>::type acc_t;
@@ -326,14 +334,9 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
     for (int i = 0; i < NGMAX; ++i) {
       const int g = wave + 8 * i;
-      if (g < KG) {
+      if (NG > 0 || g < KG) {
         const float4 a = av[i];
         const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
-        if (i + BD < NGMAX) {
-          const int gn = g + 8 * BD;
-          const int gnc = gn < KG ? gn : KG - 1;
-          bq0[i % BD] = ld4u(wb, w0o + (unsigned)gnc * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gnc * 256u);
-        }
         if constexpr (MF == 32) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
@@ -345,9 +348,20 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
         }
+        // Refill the ring slot AFTER the MFMAs that read it were issued.  Issued before them (as it used to be) the refill is a
+        // write-after-read on live MFMA operands: the compiler loaded into a temporary and put s_waitcnt vmcnt(0) right behind
+        // every prefetch -- 16 serialised memory round trips per work item in the bulk kernel.
+        if (i + BD < NGMAX) {
+          const int gn = g + 8 * BD;
+          const int gnc = gn < KG ? gn : KG - 1;
+          bq0[i % BD] = ld4u(wb, w0o + (unsigned)gnc * 256u); bq1[i % BD] = ld4u(wb, w1o + (unsigned)gnc * 256u);
+          // keep the refill HERE: left alone, the machine scheduler sinks it to just before its consumer (4 steps later) to save
+          // registers, and the ring degenerates into load -> s_waitcnt vmcnt(0) -> use
+          if constexpr (NG > 0) __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
-    if (tr) p.dbg[4] = wall_clock64();
+    if constexpr (TRACE) { if (tr) p.dbg[4] = wall_clock64(); }
 
     // ---- split-K reduction through LDS: red[wave][tile][j][lane], summed in a fixed order (deterministic)
 #pragma unroll
@@ -356,7 +370,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
     }
     __syncthreads();
-    if (tr) p.dbg[5] = wall_clock64();
+    if constexpr (TRACE) { if (tr) p.dbg[5] = wall_clock64(); }
     for (int e = tid; e < 2 * NJ * 64; e += 512) {
       const int l = e & 63, j = (e >> 6) % NJ, tile = e / (64 * NJ);
       float v_ = 0.f;
@@ -385,7 +399,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         }
       }
     }
-    if (tr) p.dbg[6] = wall_clock64();
+    if constexpr (TRACE) { if (tr) p.dbg[6] = wall_clock64(); if (p.dbg_wg && tid == 0 && blockIdx.x < 128) p.dbg_wg[2 * blockIdx.x + 1] = wall_clock64(); }
     if (MF == 32 && item + (int)gridDim.x < nitems) __syncthreads();      // s_prow / smem are reused by the next item
   }
 }
