@@ -759,8 +759,17 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   int nblk = ((p.M + p.tile_rows - 1) / p.tile_rows) * groups;
   if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
   const size_t sm = hsplit_smem(MF);
-  if (MF == 16 && p.dbg) hipLaunchKernelGGL((hsplit_kernel<16, true>), dim3(nblk), dim3(512), sm, st, p);
-  else if (MF == 16) hipLaunchKernelGGL(hsplit_kernel<16>, dim3(nblk), dim3(512), sm, st, p);
+  // specialised 16-row forms: causal k = 3 over 256 channels (NT = 3), k = 1 over 256 channels (NT = 1); anything else is generic
+  const int nt = (MF != 16 || L.cin_p != 256 || L.cin != 256) ? 0 : (L.ntaps == 3 && L.tap_off[2] == 0) ? 3 : (L.ntaps == 1 ? 1 : 0);
+  if (MF == 16 && p.dbg) {
+    if (nt == 3)      hipLaunchKernelGGL((hsplit_kernel<16, true, 0, 3>), dim3(nblk), dim3(512), sm, st, p);
+    else if (nt == 1) hipLaunchKernelGGL((hsplit_kernel<16, true, 0, 1>), dim3(nblk), dim3(512), sm, st, p);
+    else              hipLaunchKernelGGL((hsplit_kernel<16, true, 0, 0>), dim3(nblk), dim3(512), sm, st, p);
+  } else if (MF == 16) {
+    if (nt == 3)      hipLaunchKernelGGL((hsplit_kernel<16, false, 0, 3>), dim3(nblk), dim3(512), sm, st, p);
+    else if (nt == 1) hipLaunchKernelGGL((hsplit_kernel<16, false, 0, 1>), dim3(nblk), dim3(512), sm, st, p);
+    else              hipLaunchKernelGGL((hsplit_kernel<16, false, 0, 0>), dim3(nblk), dim3(512), sm, st, p);
+  }
   else {
     const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
     if (kg == 96)      hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);

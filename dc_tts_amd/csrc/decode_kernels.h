@@ -160,12 +160,16 @@ __device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, floa
 // NG > 0 fixes the k-groups per wave at compile time (K = 64 NG for the 32-row form): the K loop is then straight-line code.
 // With a run-time `if (g < KG)` around each step, a prefetch issued inside a conditional block may or may not be followed by
 // younger loads, so the only safe wait for it is vmcnt(0) -- the counted waits the ring depends on need unconditional steps.
-template <int MF, bool TRACE = false, int NG = 0>
+// NT = 3 (16-row form): three causal taps over 256 channels, centre = tap 2 (every k = 3 layer of AudioEnc / AudioDec).  Wave w's
+// k-group i is then tap i >> 1, channels 128 (i & 1) + 16 w: compile-time per i, which removes ~150 select / compare
+// instructions from the stretch between kernel entry and the first load.  NT = 1: k = 1 over 256 channels: two k-groups per
+// wave instead of six clamped ones (the generic form re-reads the last group four times: 3x the load traffic of such a layer).
+template <int MF, bool TRACE = false, int NG = 0, int NT = 0>
 __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   constexpr int KGS = (MF == 32) ? 8 : 16;          // k per k-group (4 MFMAs)
   constexpr int NJ = (MF == 32) ? 16 : 4;           // accumulator registers per tile
-  constexpr int NGMAX = NG > 0 ? NG : ((MF == 32) ? 12 : 6);   // k-groups per wave (12 / 6 at K = 768)
-  constexpr int BD = (MF == 32) ? 4 : 6;            // B prefetch ring depth (k-groups)
+  constexpr int NGMAX = NG > 0 ? NG : ((MF == 32) ? 12 : (NT == 1 ? 2 : 6));   // k-groups per wave (12 / 6 at K = 768, 2 at K = 256)
+  constexpr int BD = (MF == 32) ? 4 : NGMAX;        // B prefetch ring depth (k-groups); the 16-row form holds all of them
   extern __shared__ __attribute__((aligned(16))) float smem[];     // split-K reduction only
   __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -181,7 +185,13 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   const int aq = (MF == 32) ? (lane >> 5) : (lane >> 4);
   const int c4 = aq * 4;
   const bool ln = (MF == 16) && (p.pro != PRO_RAW);
-  const int ctap = (p.ntaps == 1) ? 0 : ((p.tap_off[0] == 0) ? 0 : ((p.tap_off[1] == 0) ? 1 : 2));
+  const int ctap = (NT == 3) ? 2 : ((p.ntaps == 1) ? 0 : ((p.tap_off[0] == 0) ? 0 : ((p.tap_off[1] == 0) ? 1 : 2)));
+  // (tap, first channel) of this lane's fragment of k-group i / g
+  auto tap_c = [&](int i, int g, int& tap, int& c) {
+    if constexpr (NT == 3) { tap = i >> 1; c = 128 * (i & 1) + 16 * wave + c4; }
+    else if constexpr (NT == 1) { tap = 0; c = 128 * i + 16 * wave + c4; }
+    else { const int k0 = g * KGS; tap = (p.ntaps == 1) ? 0 : (k0 >> 8); c = k0 - tap * p.cin_p + c4; }
+  };
 
   // Persistent over work items: the bulk branch launches fewer workgroups than CUs so that the latency-critical
   // chain branch always finds free CUs; the chain itself has exactly one item per workgroup.
@@ -199,7 +209,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     // the end re-read the last one (clamped index); their A fragment is zero, so the duplicate weights contribute nothing.
 #pragma unroll
     for (int i = 0; i < BD; ++i) {
-      const int g = wave + 8 * i, gc = g < KG ? g : KG - 1;
+      const int g = wave + 8 * i, gc = (NT != 0 || g < KG) ? g : KG - 1;
       bq0[i] = ld4u(wb, w0o + (unsigned)gc * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)gc * 256u);
     }
 
@@ -235,11 +245,11 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       const bool hcpro = (p.pro == PRO_LN_HC);
 #pragma unroll
       for (int i = 0; i < NGMAX; ++i) {
-        const int g = wave + 8 * i, gc = g < KG ? g : KG - 1;
-        const int k0 = gc * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+        const int g = wave + 8 * i, gc = (NT != 0 || g < KG) ? g : KG - 1;
+        int tap, c; tap_c(i, gc, tap, c);
         const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
         const bool centre = ln && tap == ctap;                                  // uniform: a scalar select of the base pointer
-        const int cc = c < p.cin ? c : p.cin - 4;                               // pad columns of a narrow input: read in range, zeroed below
+        const int cc = (NT != 0 || c < p.cin) ? c : p.cin - 4;                  // pad columns of a narrow input: read in range, zeroed below
         const float* base = centre ? p.nrm.P : p.xsrc;
         const unsigned off = centre ? p_row + (unsigned)c : xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)cc;
         av[i] = ld4u(base, off);
@@ -266,9 +276,10 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
       for (int i = 0; i < NGMAX; ++i) {
         const int g = wave + 8 * i;
-        const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+        int tap, c; tap_c(i, g, tap, c);
         const bool centre = ln && tap == ctap;
-        if (g >= KG || !valid || (!centre && c >= p.cin)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (NT != 0) { if (!valid) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        else { if (g >= KG || !valid || (!centre && c >= p.cin)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
       }
     } else {
       // same branch-free issue as the 16-row form: clamped k-group / column, value discarded afterwards
@@ -298,8 +309,8 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
         for (int i = 0; i < NGMAX; ++i) {
           const int g = wave + 8 * i;
-          if (g < KG) {
-            const int k0 = g * KGS, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+          if (NT != 0 || g < KG) {
+            int tap, c; tap_c(i, g, tap, c);
             if (tap == ctap) {
               const float4 g1 = g1v[i & 1], b1 = b1v[i & 1];
               float4 x = av[i];
@@ -334,7 +345,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
     for (int i = 0; i < NGMAX; ++i) {
       const int g = wave + 8 * i;
-      if (NG > 0 || g < KG) {
+      if (NG > 0 || NT != 0 || g < KG) {
         const float4 a = av[i];
         const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
         if constexpr (MF == 32) {
