@@ -123,9 +123,10 @@ struct dctts_ctx {
   int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
                                        //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
+  int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
   int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
-  int bulk_cap = 144;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
+  int bulk_cap = 176;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
   // profiling
@@ -761,15 +762,19 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   const size_t sm = hsplit_smem(MF);
   // specialised 16-row forms: causal k = 3 over 256 channels (NT = 3), k = 1 over 256 channels (NT = 1); anything else is generic
   const int nt = (MF != 16 || L.cin_p != 256 || L.cin != 256) ? 0 : (L.ntaps == 3 && L.tap_off[2] == 0) ? 3 : (L.ntaps == 1 ? 1 : 0);
+  const bool one = (MF == 16) && c->chain_one;
+  if (one) nblk *= 2;
+#define DCTTS_LAUNCH16(TR, NTV)                                                                                          \
+  do {                                                                                                                   \
+    if (one) hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, true>), dim3(nblk), dim3(512), sm, st, p);                \
+    else     hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, false>), dim3(nblk), dim3(512), sm, st, p);               \
+  } while (0)
   if (MF == 16 && p.dbg) {
-    if (nt == 3)      hipLaunchKernelGGL((hsplit_kernel<16, true, 0, 3>), dim3(nblk), dim3(512), sm, st, p);
-    else if (nt == 1) hipLaunchKernelGGL((hsplit_kernel<16, true, 0, 1>), dim3(nblk), dim3(512), sm, st, p);
-    else              hipLaunchKernelGGL((hsplit_kernel<16, true, 0, 0>), dim3(nblk), dim3(512), sm, st, p);
+    if (nt == 3) DCTTS_LAUNCH16(true, 3); else if (nt == 1) DCTTS_LAUNCH16(true, 1); else DCTTS_LAUNCH16(true, 0);
   } else if (MF == 16) {
-    if (nt == 3)      hipLaunchKernelGGL((hsplit_kernel<16, false, 0, 3>), dim3(nblk), dim3(512), sm, st, p);
-    else if (nt == 1) hipLaunchKernelGGL((hsplit_kernel<16, false, 0, 1>), dim3(nblk), dim3(512), sm, st, p);
-    else              hipLaunchKernelGGL((hsplit_kernel<16, false, 0, 0>), dim3(nblk), dim3(512), sm, st, p);
+    if (nt == 3) DCTTS_LAUNCH16(false, 3); else if (nt == 1) DCTTS_LAUNCH16(false, 1); else DCTTS_LAUNCH16(false, 0);
   }
+#undef DCTTS_LAUNCH16
   else {
     const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
     if (kg == 96)      hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
@@ -978,6 +983,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
+  if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   if (v2) CHK(decode_v2_init(c));
   if (!v2) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // v1 uses one copy of every buffer

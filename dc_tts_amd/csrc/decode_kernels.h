@@ -164,7 +164,9 @@ __device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, floa
 // k-group i is then tap i >> 1, channels 128 (i & 1) + 16 w: compile-time per i, which removes ~150 select / compare
 // instructions from the stretch between kernel entry and the first load.  NT = 1: k = 1 over 256 channels: two k-groups per
 // wave instead of six clamped ones (the generic form re-reads the last group four times: 3x the load traffic of such a layer).
-template <int MF, bool TRACE = false, int NG = 0, int NT = 0>
+// ONE (16-row form): a workgroup owns ONE 16-column tile (gate or info) instead of the pair: twice the workgroups, half the
+// weight bytes and half the MFMAs per workgroup (the matrix pipe is shared by the two waves of a SIMD: 2 us -> 1 us).
+template <int MF, bool TRACE = false, int NG = 0, int NT = 0, bool ONE = false>
 __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   constexpr int KGS = (MF == 32) ? 8 : 16;          // k per k-group (4 MFMAs)
   constexpr int NJ = (MF == 32) ? 16 : 4;           // accumulator registers per tile
@@ -180,7 +182,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   const long par = step & 1;
   const int KG = p.ntaps * p.cin_p / KGS;
   const int ntile = (p.M + p.tile_rows - 1) / p.tile_rows;
-  const int nitems = ntile * p.ngroups;
+  const int nitems = ntile * p.ngroups * (ONE ? 2 : 1);
   const int arow = lane & (MF - 1);
   const int aq = (MF == 32) ? (lane >> 5) : (lane >> 4);
   const int c4 = aq * 4;
@@ -196,12 +198,13 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   // Persistent over work items: the bulk branch launches fewer workgroups than CUs so that the latency-critical
   // chain branch always finds free CUs; the chain itself has exactly one item per workgroup.
   for (int item = blockIdx.x; item < nitems; item += (MF == 32 ? (int)gridDim.x : nitems)) {
-    const int tile_x = item / p.ngroups, grp = item - tile_x * p.ngroups;
+    const int mytile = ONE ? (item & 1) : 0, rest = ONE ? (item >> 1) : item;
+    const int tile_x = rest / p.ngroups, grp = rest - tile_x * p.ngroups;
     const int m0 = tile_x * p.tile_rows;
 
     // ---- B fragments: wave w owns k-groups w, w+8, ...; independent of A, so issue first
     const float* wb = p.wp + lane * 4;
-    const unsigned w0o = (unsigned)(grp * 2) * (unsigned)KG * 256u, w1o = w0o + (unsigned)KG * 256u;
+    const unsigned w0o = (unsigned)(grp * 2 + mytile) * (unsigned)KG * 256u, w1o = w0o + (unsigned)KG * 256u;
     float4 bq0[BD], bq1[BD];
     // Loads are issued WITHOUT branches around them: a uniform `if (g < KG)` still compiles to a branch, and at every join the
     // wait-count pass falls back to s_waitcnt vmcnt(0) when a register may have a load pending on one path -- the chain kernel
@@ -210,7 +213,8 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
     for (int i = 0; i < BD; ++i) {
       const int g = wave + 8 * i, gc = (NT != 0 || g < KG) ? g : KG - 1;
-      bq0[i] = ld4u(wb, w0o + (unsigned)gc * 256u); bq1[i] = ld4u(wb, w1o + (unsigned)gc * 256u);
+      bq0[i] = ld4u(wb, w0o + (unsigned)gc * 256u);
+      if constexpr (!ONE) bq1[i] = ld4u(wb, w1o + (unsigned)gc * 256u); else bq1[i] = bq0[i];
     }
 
     // ---- this lane's A row (MFMA A operand: lane -> row lane % MF, k sub-block lane / MF)
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) st[g] = ld4u(ln ? p.stats_in : p.xsrc, (ln && valid) ? (unsigned)(prow * 64) + (unsigned)((aq * 4 + g) * 4) : 0u);
       {
-        const int l = tid & 63, tile = tid >> 8, col = l & 15;
+        const int l = tid & 63, tile = ONE ? mytile : (tid >> 8), col = l & 15;
         const int pc = p.hc ? ((grp * MF + col) < p.cout ? tile * p.cout + grp * MF + col : 0)
                             : (((grp * 2 + tile) * MF + col) < p.cout ? (grp * 2 + tile) * MF + col : 0);
         biasv = p.bias[(unsigned)pc];
@@ -328,7 +332,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
               }
               if (!valid) x = make_float4(0.f, 0.f, 0.f, 0.f);
               av[i] = x;
-              if (valid && grp == 0 && p.xmat)
+              if (valid && grp == 0 && mytile == 0 && p.xmat)
                 *reinterpret_cast<float4*>(p.xmat + par * p.xm_set + ((long)b * p.xm_bstride + p.xm_row0 + t) * p.xm_stride + c) = x;
             }
           }
@@ -354,10 +358,10 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
           acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
         } else {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0); if constexpr (!ONE) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0); if constexpr (!ONE) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0); if constexpr (!ONE) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0); if constexpr (!ONE) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
         }
         // Refill the ring slot AFTER the MFMAs that read it were issued.  Issued before them (as it used to be) the refill is a
         // write-after-read on live MFMA operands: the compiler loaded into a temporary and put s_waitcnt vmcnt(0) right behind
@@ -378,15 +382,15 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       smem[((wave * 2 + 0) * NJ + j) * 64 + lane] = acc0[j];
-      smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
+      if constexpr (!ONE) smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
     }
     __syncthreads();
     if constexpr (TRACE) { if (tr) p.dbg[5] = wall_clock64(); }
-    for (int e = tid; e < 2 * NJ * 64; e += 512) {
-      const int l = e & 63, j = (e >> 6) % NJ, tile = e / (64 * NJ);
+    for (int e = tid; e < (ONE ? 1 : 2) * NJ * 64; e += 512) {
+      const int l = e & 63, j = (e >> 6) % NJ, ltile = e / (64 * NJ), tile = ONE ? mytile : ltile;
       float v_ = 0.f;
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v_ += smem[((w * 2 + tile) * NJ + j) * 64 + l];
+      for (int w = 0; w < 8; ++w) v_ += smem[((w * 2 + ltile) * NJ + j) * 64 + l];
       int row, col;
       if constexpr (MF == 32) { row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5); col = l & 31; }
       else                    { row = (l >> 4) * 4 + j;                      col = l & 15; }
