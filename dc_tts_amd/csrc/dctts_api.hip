@@ -123,6 +123,7 @@ struct dctts_ctx {
   int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
                                        //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
+  int bulk_pipelined = 1;              // bulk contraction = hbulk_kernel (items software-pipelined); 0 = hsplit_kernel<32> (DCTTS_BULK_PIPE)
   int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
   int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
@@ -777,7 +778,10 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
 #undef DCTTS_LAUNCH16
   else {
     const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
-    if (kg == 96)      hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
+    const bool plain = (pro == PRO_RAW) && L.cin == L.cin_p && c->bulk_pipelined;   // hbulk_kernel: software-pipelined across items
+    if (kg == 96 && plain)      hipLaunchKernelGGL((hbulk_kernel<12>), dim3(nblk), dim3(512), sm, st, p);
+    else if (kg == 64 && plain) hipLaunchKernelGGL((hbulk_kernel<8>), dim3(nblk), dim3(512), sm, st, p);
+    else if (kg == 96) hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 64) hipLaunchKernelGGL((hsplit_kernel<32, false, 8>), dim3(nblk), dim3(512), sm, st, p);
     else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): K must be 512 or 768");
   }
@@ -800,6 +804,8 @@ static int decode_v2_init(dctts_ctx* c) {
   for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], hipEventDisableTiming)); }
   HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   return 0;
 }
 
@@ -983,6 +989,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
+  if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   if (v2) CHK(decode_v2_init(c));

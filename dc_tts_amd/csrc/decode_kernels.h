@@ -419,6 +419,131 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// hbulk_kernel: the bulk (cone) branch's contraction, software-pipelined across work items.  Same arithmetic and the same
+// summation order as hsplit_kernel<32> (32 rows x one gate/info pair of 32-column tiles, K split over 8 waves, fixed-order
+// LDS reduction), PRO_RAW only (its input rows are materialised by ln_rows_kernel).  What differs is the schedule:
+//   item n:  K loop | accumulators -> LDS | ISSUE item n+1's row info + A + first weight groups | barrier | epilogue of n
+// so the ~1.5 us a work item used to wait for its first loads, and the scalar set-up before them, overlap the reduction and
+// the stores of the previous one.  The epilogue issues no loads of its own (its two bias values ride along with the item's
+// loads): a load there would have to be waited for with vmcnt(0), i.e. behind everything just issued for the next item.
+template <int NG>
+__global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
+  constexpr int MF = 32, NJ = 16, BD = 4, KG = NG * 8;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ long s_prow[2][MF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  prefetch_params(p);
+  const int step = p.step_val + (p.step ? *p.step : 0);
+  const long par = step & 1;
+  const int ntile = (p.M + MF - 1) / MF;
+  const int nitems = ntile * p.ngroups;
+  const int arow = lane & 31, c4 = (lane >> 5) * 4;
+  const float* wb = p.wp + lane * 4;
+  const int ecol = lane & 31;                                  // this thread's output column inside a tile (epilogue)
+
+  float4 av[NG], bq0[BD], bq1[BD];
+  unsigned w0o = 0, w1o = 0;
+  bool valid = false;
+  int grp = 0;
+  float bias0 = 0.f, bias1 = 0.f;
+  // row info + every first load of `item`; results land in the variables above (they are dead once the K loop is done)
+  auto issue = [&](int item, int slot) {
+    const int tile_x = item / p.ngroups;
+    grp = item - tile_x * p.ngroups;
+    const int m0 = tile_x * MF;
+    w0o = (unsigned)(grp * 2) * (unsigned)KG * 256u; w1o = w0o + (unsigned)KG * 256u;
+#pragma unroll
+    for (int i = 0; i < BD; ++i) {
+      const unsigned g = (unsigned)(wave + 8 * i);
+      bq0[i] = ld4u(wb, w0o + g * 256u); bq1[i] = ld4u(wb, w1o + g * 256u);
+    }
+    int b = 0, t = 0; long prow = -1; valid = false;
+    const int m = m0 + arow;
+    if (m < p.M) {
+      int bl = m, r = 0;
+      if (p.R != 1) { bl = m / p.R; r = m - bl * p.R; }
+      b = p.b0 + bl;
+      t = step + (p.offs ? p.offs[r] : 0);
+      prow = (long)b * p.R + r;
+      valid = (t >= 0);
+    }
+    if (wave == 0 && lane < 32) s_prow[slot][arow] = valid ? prow : -1;
+    const unsigned xs_row = valid ? (unsigned)(par * p.xs_set + ((long)b * p.xs_bstride + p.xs_row0 + t) * p.xs_stride) : (unsigned)(p.xs_row0 * p.xs_stride);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int k0 = (wave + 8 * i) * 8, tap = (p.ntaps == 1) ? 0 : (k0 >> 8), c = k0 - tap * p.cin_p + c4;
+      const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
+      av[i] = ld4u(p.xsrc, xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)c);
+    }
+    {
+      const int c0 = p.hc ? grp * MF + ecol : (grp * 2) * MF + ecol, c1 = p.hc ? p.cout + grp * MF + ecol : (grp * 2 + 1) * MF + ecol;
+      const bool ok0 = p.hc ? (grp * MF + ecol) < p.cout : c0 < p.cout, ok1 = p.hc ? ok0 : c1 < p.cout;
+      bias0 = p.bias[ok0 ? (unsigned)c0 : 0u]; bias1 = p.bias[ok1 ? (unsigned)c1 : 0u];
+    }
+  };
+
+  int item = blockIdx.x, slot = 0;
+  if (item >= nitems) return;
+  issue(item, slot);
+  for (;;) {
+    const int grp_c = grp;
+    const float b0c = bias0, b1c = bias1;
+    const unsigned w0c = w0o, w1c = w1o;
+    const bool valid_c = valid;
+    typedef float f32x16_ __attribute__((ext_vector_type(16)));
+    f32x16_ acc0, acc1;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      float4 a = av[i];
+      if (!valid_c) a = make_float4(0.f, 0.f, 0.f, 0.f);           // skipped rows (t < 0) contribute nothing
+      const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc1, 0, 0, 0);
+      if (i + BD < NG) {                                            // refill the slot after the MFMAs that read it (see hsplit_kernel)
+        const unsigned gn = (unsigned)(wave + 8 * (i + BD));
+        bq0[i % BD] = ld4u(wb, w0c + gn * 256u); bq1[i % BD] = ld4u(wb, w1c + gn * 256u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      smem[((wave * 2 + 0) * NJ + j) * 64 + lane] = acc0[j];
+      smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
+    }
+    // next item's loads go out now; the last item re-issues itself (clamped) so that no branch surrounds the loads
+    const int next = item + (int)gridDim.x;
+    const bool more = next < nitems;
+    issue(more ? next : item, slot ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    // fully unrolled (4 elements per thread): a run-time loop here gets an s_waitcnt vmcnt(0) in its preheader (it contains
+    // stores), which would wait for everything just issued for the next item
+#pragma unroll
+    for (int q = 0; q < (2 * NJ * 64) / 512; ++q) {
+      const int e = tid + 512 * q;
+      const int l = e & 63, j = (e >> 6) % NJ, tile = e / (64 * NJ);
+      float v_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v_ += smem[((w * 2 + tile) * NJ + j) * 64 + l];
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * (l >> 5), col = l & 31;
+      const long orow = s_prow[slot][row];
+      int pcol; bool ok;
+      if (p.hc) { const int c = grp_c * MF + col; ok = c < p.cout; pcol = tile * p.cout + c; }
+      else      { pcol = (grp_c * 2 + tile) * MF + col; ok = pcol < p.cout; }
+      if (ok) v_ += tile ? b1c : b0c;
+      if (ok && orow >= 0) p.pout[orow * p.np_out + pcol] = v_;
+    }
+    if (!more) break;
+    __syncthreads();                                              // smem / s_prow[slot] are rewritten by the next round
+    item = next; slot ^= 1;
+  }
+}
+
 // Row kernel for the bulk branch: X[b][t] = act / gate (LN(P[b*R + r])) for cone rows at offsets < 0.
 // grid ceil(M/4), block 256 (wave per row).
 struct LnRowsParams {
