@@ -123,6 +123,7 @@ struct dctts_ctx {
   int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
                                        //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
+  int bulk_small_rows = 0;             // bulk layers with at most this many rows use the 16-row kernel form (DCTTS_BULK_SMALL, 0 = never)
   int bulk_pipelined = 1;              // bulk contraction = hbulk_kernel (items software-pipelined); 0 = hsplit_kernel<32> (DCTTS_BULK_PIPE)
   int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
@@ -741,7 +742,7 @@ static RowNorm make_norm(const DevLayer& prod, const float* P, const View* res) 
 // One split GEMM launch for frame `frame`.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
 static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, const int* offs, int frame, int pro, const RowNorm* nrm,
                      const View* xmat, const View& xsrc, float* pout, hipStream_t st,
-                     const float* stats_in = nullptr, float* stats_out = nullptr) {
+                     const float* stats_in = nullptr, float* stats_out = nullptr, int tile_rows16 = 0) {
   SplitParams p; memset(&p, 0, sizeof(p));
   p.M = B * R; p.R = R; p.b0 = 0; p.offs = offs; p.step = nullptr; p.step_val = frame;
   p.pro = pro; if (nrm) p.nrm = *nrm;
@@ -757,7 +758,7 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) { p.dbg_wg = g_trace_ctx->trace_buf + 64 * 8 + 256 * g_trace_ctx->trace_n; p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++); }
   const int groups = L.hc ? L.cout / MF : (L.cout + 2 * MF - 1) / (2 * MF);
   p.ngroups = groups;
-  p.tile_rows = (MF == 16) ? c->chain_rows : MF;
+  p.tile_rows = (MF == 16) ? (tile_rows16 ? tile_rows16 : c->chain_rows) : MF;
   int nblk = ((p.M + p.tile_rows - 1) / p.tile_rows) * groups;
   if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
   const size_t sm = hsplit_smem(MF);
@@ -895,7 +896,12 @@ static int v2_bulk_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, h
     const int Rb = c->cone_len[i] - 1;
     if (Rb <= 0) break;
     const View& src = (i == 0) ? w.rbuf : w.ad[i - 1];
-    CHK(run_split(c, 32, AD[i], B, Rb, c->cone_dev[i] + 1, f, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb));
+    // the last cone layers have few rows (14 / 4 / 2 per utterance): as 32-row items they are one latency-bound round of a
+    // handful of workgroups (~13 us); the 16-row chain form spreads them over (rows / 16) x 16 workgroups (~6 us)
+    if (B * Rb <= c->bulk_small_rows && AD[i].ntaps == 3)
+      CHK(run_split(c, 16, AD[i], B, Rb, c->cone_dev[i] + 1, f, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb, nullptr, nullptr, 16));
+    else
+      CHK(run_split(c, 32, AD[i], B, Rb, c->cone_dev[i] + 1, f, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb));
     LnRowsParams q; memset(&q, 0, sizeof(q));
     q.M = B * Rb; q.R = Rb; q.b0 = 0; q.offs = c->cone_dev[i] + 1; q.step = nullptr; q.step_val = f; q.hc = AD[i].hc ? 1 : 0;
     q.nrm = make_norm(AD[i], w.pb[i], AD[i].hc ? &src : nullptr);
@@ -989,6 +995,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
+  if (const char* e = getenv("DCTTS_BULK_SMALL")) c->bulk_small_rows = atoi(e);
   if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
