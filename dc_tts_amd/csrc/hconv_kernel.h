@@ -100,15 +100,17 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const int nch = p.ntaps * cpt;
   const int KG = nch * 4;                // k-groups of 8
 
-  auto load_chunk = [&](int ch) -> float4 {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int tap = ch / cpt;
-    const int c = (ch - tap * cpt) * 32 + lc4 * 4;
-    if (tid < 256 && my_inrow >= 0 && c < p.cin) {
-      const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
-      v = *reinterpret_cast<const float4*>(p.in + (my_inrow + toff) * (long)p.in_stride + c);
-    }
-    return v;
+  // Branch-free: a load inside a conditional block makes the wait-count pass fall back to s_waitcnt vmcnt(0) at the join (the
+  // weight prefetch behind it then drains twice per chunk).  Rows / columns that must read as zero are redirected to a readable
+  // address (row in_row0, column 0) and the value is discarded when it is stored to LDS; threads >= 256 load duplicates.
+  const bool row_ok = my_inrow >= 0;
+  const long safe_row = p.gather ? 0 : p.in_row0;
+  auto load_chunk = [&](int tap, int cit, bool& ok) -> float4 {          // cit = chunk index inside the tap
+    const int c = cit * 32 + lc4 * 4;
+    const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
+    ok = row_ok && c < p.cin;
+    const long row = row_ok ? my_inrow + toff : safe_row;
+    return *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
   };
 
   const float4* wq[NT];
@@ -122,8 +124,11 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-  float4 areg = load_chunk(0);
+  bool aok;
+  float4 areg = load_chunk(0, 0, aok);
+  if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) *reinterpret_cast<float4*>(&As[0][lrow * LDA + lc4 * 4]) = areg;
+  int ntap = 0, ncit = 0;                  // (tap, chunk in tap) of the chunk being prefetched
   float4 bcur[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) bcur[i] = wq[i][0];
@@ -131,7 +136,9 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 
   for (int ch = 0; ch < nch; ++ch) {
     const bool more = (ch + 1 < nch);
-    if (more) areg = load_chunk(ch + 1);
+    if (more) { if (++ncit == cpt) { ncit = 0; ++ntap; } }       // the last chunk re-reads itself: no branch around the load
+    areg = load_chunk(ntap, ncit, aok);
+    __builtin_amdgcn_sched_barrier(0);     // pin the prefetch here: the scheduler otherwise sinks it to the LDS store at the end
     const float* Ab = As[ch & 1];
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
@@ -152,6 +159,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) bcur[i] = bnext[i];
     }
+    if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (more && tid < 256) *reinterpret_cast<float4*>(&As[(ch + 1) & 1][lrow * LDA + lc4 * 4]) = areg;
     __syncthreads();
   }
