@@ -1,5 +1,5 @@
 // vocoder_kernels.h -- the reference's vocoder tail (utils.py:67-114: spectrogram2wav / griffin_lim / invert_spectrogram)
-// as HIP kernels for gfx950.  librosa.stft / istft are restated in oracle/vocoder_ref.py; these kernels follow that.
+// as HIP kernels for gfx950.  They follow the published librosa 0.6 stft / istft / effects.trim algorithms (the test oracle restates them on the CPU).
 //
 // Griffin-Lim is 50 x (istft -> stft -> keep the phase).  With n_fft = 2048, hop = 275, win = 1102 this is FFT + streaming
 // work (no MFMA).  Per iteration two launches:

@@ -217,6 +217,26 @@ def test_ssrn(weights):
     assert maxabs(Z.cpu().numpy(), Zr) < TOL and maxabs(lg.cpu().numpy(), lgr) < 5e-3
 
 
+def test_ssrn_only_batch128_config3(weights):
+    """BASELINE configs[2]: SSRN-only, batch 128, (128, 210, 80) -> (128, 840, 1025).  Determinism, agreement with the same
+    utterances run as shards of 32 (rows land on the 32-row or the 16-row MFMA kernel depending on the launch: fp32
+    reassociation, <= 1e-5), range, and the oracle on two utterances."""
+    eng = engine_for(weights)
+    rng = np.random.default_rng(128)
+    Yh = rng.random((128, hp.max_T, hp.n_mels), dtype=np.float32)
+    Y = dev(Yh)
+    Z = eng.ssrn(Y, want_logits=False)[1]
+    Z2 = eng.ssrn(Y, want_logits=False)[1]
+    assert tuple(Z.shape) == (128, 4 * hp.max_T, hp.n_linear) and torch.equal(Z, Z2)
+    for s0 in (0, 96):
+        Zs = eng.ssrn(Y[s0:s0 + 32].contiguous(), want_logits=False)[1]
+        assert float((Zs - Z[s0:s0 + 32]).abs().max()) < 1e-5
+    assert float(Z.min()) >= 0.0 and float(Z.max()) <= 1.0 and bool(torch.isfinite(Z).all())
+    idx = [5, 127]
+    _, Zr = O.SSRN(Yh[idx], weights, hp)
+    assert maxabs(Z[idx].cpu().numpy(), Zr) < TOL
+
+
 def test_networks_surface_and_golden(weights):
     """The reference-named functions on the committed golden inputs (tests/golden/networks_seed1234.npz)."""
     from dc_tts_amd import networks

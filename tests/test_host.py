@@ -49,13 +49,35 @@ def test_no_gpu_means_loud_failure(weights):
         networks.TextEnc(None, training=False)
 
 
+def test_vocoder_needs_gpu_and_validates_config():
+    """No CPU fallback for the vocoder either; argument checks answer before any HIP call (status code + message over the ABI)."""
+    import torch
+    from dc_tts_amd import _lib
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    bad = _lib.VocoderConfig(1024, 275, 1102, 50, 1.5, 0.97, 100.0, 20.0, 60.0, 2048, 512)        # n_fft the kernels are not built for
+    assert lib.dctts_vocoder_create(ctypes.byref(h), 0, ctypes.byref(bad)) == -1 and "n_fft" in _lib.last_error()
+    bad = _lib.VocoderConfig(2048, 2000, 1102, 50, 1.5, 0.97, 100.0, 20.0, 60.0, 2048, 512)       # hop > win
+    assert lib.dctts_vocoder_create(ctypes.byref(h), 0, ctypes.byref(bad)) == -1 and "hop_length" in _lib.last_error()
+    assert lib.dctts_vocoder_create(None, 0, None) == -1
+    assert lib.dctts_spectrogram2wav(None, None, 1, 8, None, None, None) == -1
+    assert lib.dctts_griffin_lim(None, None, 1, 8, 1, None, None, None) == -1
+    if not torch.cuda.is_available():
+        from dc_tts_amd.engine import DcttsError
+        from dc_tts_amd.utils import Vocoder, spectrogram2wav
+        with pytest.raises(DcttsError):
+            Vocoder()
+        with pytest.raises(DcttsError):
+            spectrogram2wav(np.zeros((8, 1025), np.float32))
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under dc_tts_amd/ may import it."""
     for dp, _, fs in os.walk(os.path.join(ROOT, "dc_tts_amd")):
         for f in fs:
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dp, f)).read()
-                assert "import oracle" not in src and "from oracle" not in src and "dctts_ref" not in src, os.path.join(dp, f)
+                assert "import oracle" not in src and "from oracle" not in src and "dctts_ref" not in src and "vocoder_ref" not in src, os.path.join(dp, f)
 
 
 def test_weights_container(weights):
