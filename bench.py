@@ -212,7 +212,7 @@ def main():
         rows_per_launch = dom_rows / n_launch if n_launch else B * 4 * T
         flops_per_launch = 2.0 * rows_per_launch * (3 * C) * (2 * C)
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "traffic": None, "kernel": "hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11/HC_12, 1024ch k=3, fused LN+gate)",
+                "traffic": None, "kernel": "hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11/HC_12, 1024ch k=3, fused LN+gate): the largest kernel by FLOPs (27 % of the pipeline); by time the latency-bound decode chain dominates, see phase_rooflines.decode",
                 "launches": n_launch, "avg_launch_ms": None, "flop_per_launch": flops_per_launch,
                 "rows_per_launch": rows_per_launch, "layer_rows": B * 4 * T}
         tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -227,6 +227,20 @@ def main():
             roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_ms=round(avg_ms, 4))
         # whole-pipeline algorithmic FLOPs per mel frame: TextEnc/T + AudioEnc + AudioDec cone + attention + SSRN
         flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6
+        # per-phase fractions of both roofs from SURVEY 8d's algorithmic work (FLOP and fp32 bytes per utterance) and the phase times
+        # above: by TIME the decode dominates and is latency-bound -- `roofline` below is the kernel that dominates by FLOPs
+        def _pr(flop_utt, bytes_utt, ms):
+            tf = B * flop_utt / (ms * 1e-3) / 1e12
+            gb = B * bytes_utt / (ms * 1e-3) / 1e9
+            return {"tflops": round(tf, 2), "frac_mfma": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_GBps": round(gb, 1),
+                    "frac_hbm": round(gb / PEAK_HBM_GBPS, 4)}
+        dec_ms = phases["text2mel_total_ms"] - phases["textenc_ms"]
+        phase_roof = {
+            "textenc": _pr(2 * 3.0789e9, 68.6e6 / B + 0.37e6, phases["textenc_ms"]),
+            "decode": dict(_pr(T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 / B + 125e3), dec_ms),
+                           bound="latency: 26 dependent launches per frame on the critical path (DESIGN.md section 4)"),
+            "ssrn": _pr(T * 187.310e6, 67200 + 3444000 + 113641532.0 / B, phases["ssrn_ms"]),
+        }
         out = {
             "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
             "rtf": rtf, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -238,7 +252,7 @@ def main():
                        "sharding": f"{world} x {B} utterances, no collective"},
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "phases": phases, "roofline": roof, "device_bytes": eng.device_bytes(),
+            "phases": phases, "phase_rooflines": phase_roof, "roofline": roof, "device_bytes": eng.device_bytes(),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp, W)
