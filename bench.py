@@ -195,7 +195,16 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
     phases = None
+    host_xfer = None
     if rank == 0:
+        # PCIe-inclusive figure (reported beside `value`, never as it): ids host->device + Z device->pinned host per batch
+        Lh = L.cpu().pin_memory()
+        Zh = torch.empty(Z.shape, dtype=Z.dtype, pin_memory=True)
+        def xfer():
+            L.copy_(Lh, non_blocking=True); Zh.copy_(Z, non_blocking=True)
+        ms_x = timed(xfer)
+        host_xfer = {"h2d_bytes": Lh.numel() * 4, "d2h_bytes": Z.numel() * 4, "ms_per_batch": round(ms_x, 3),
+                     "GBps": round(Z.numel() * 4 / (ms_x * 1e-3) / 1e9, 1)}
         ms_te = timed(lambda: eng.text_enc(L))
         ms_t2m = timed(lambda: eng.text2mel(L))
         ms_ssrn = timed(lambda: eng.ssrn(Y, want_logits=False))
@@ -253,6 +262,8 @@ def main():
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "phases": phases, "phase_rooflines": phase_roof, "roofline": roof, "device_bytes": eng.device_bytes(),
+            "host_transfer": dict(host_xfer, value_incl_transfer=round(world * B * T / ((elapsed / args.steps) + host_xfer["ms_per_batch"] * 1e-3), 1),
+                                  note="serial upper bound on the cost: the copy of batch n can overlap the compute of batch n+1"),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp, W)
