@@ -1174,6 +1174,22 @@ extern "C" int dctts_debug_copy(const float* src, float* dst, size_t nfloats, vo
 }
 
 // ------------------------------------------------------------------------------------------------ profiling aid
+// Measurement aid: a stream restricted to CUs [cu_first, cu_first + cu_count) (hipExtStreamCreateWithCUMask), to probe how the
+// throughput phases behave on a partition of the chip while the latency-bound decode runs on the rest.
+extern "C" int dctts_debug_stream_create(int cu_first, int cu_count, void** stream) {
+  if (!stream || cu_first < 0 || cu_count < 1 || cu_first + cu_count > 1024) return fail(DCTTS_ERR_ARG, "bad CU range");
+  uint32_t mask[32]; memset(mask, 0, sizeof(mask));
+  for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t s = nullptr;
+  HIPCHK(hipExtStreamCreateWithCUMask(&s, 32, mask));
+  *stream = (void*)s;
+  return 0;
+}
+extern "C" int dctts_debug_stream_destroy(void* stream) {
+  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   if (kernel_id >= 0) c->prof_rows = 0;

@@ -107,6 +107,11 @@ size_t dctts_device_bytes(const dctts_ctx* ctx);
  * each D layer occupying two consecutive indices.  Synchronises (allocates a scratch copy of X). */
 int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X, int B, int T, float* out, void* stream);
 
+/* Measurement aid: create / destroy a stream restricted to CUs [cu_first, cu_first + cu_count) (hipExtStreamCreateWithCUMask);
+ * any entry point above accepts it as `stream`. */
+int dctts_debug_stream_create(int cu_first, int cu_count, void** stream);
+int dctts_debug_stream_destroy(void* stream);
+
 /* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
 int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
 
