@@ -15,8 +15,15 @@
 //     layer's absolute-time history buffer;
 //   * bulk layers (cone rows at offsets < 0, independent of frame j): a row kernel (ln_rows_kernel).
 //
-// hsplit_kernel<MF>: MF = 32 -> 32 rows x 2 tiles of v_mfma_f32_32x32x2_f32   (bulk cone layers, persistent items)
-//                    MF = 16 -> 16 rows x 2 tiles of v_mfma_f32_16x16x4_f32   (chain layers)
+// hsplit_kernel<MF, TRACE, NG, NT, ONE>:
+//                    MF = 32 -> 32 rows x 2 tiles of v_mfma_f32_32x32x2_f32   (bulk cone layers, persistent items; the production
+//                               bulk kernel is hbulk_kernel<NG> below: the same arithmetic, software-pipelined across items)
+//                    MF = 16 -> 16 rows x 2 tiles of v_mfma_f32_16x16x4_f32   (chain layers; NT = 3 / 1 are the forms specialised
+//                               for causal k = 3 / k = 1 layers over 256 channels)
+// What the wait-count pass of the compiler needs in order NOT to serialise these kernels' loads (each point cost microseconds
+// per launch before it was found): no branch around a load (clamp the address, discard the value), no store -- not even a
+// dead debug stamp -- pending next to loads, prefetches refilled after their consumers and pinned with sched_barrier,
+// straight-line K loops, no run-time loop with stores between prefetch and use, kernel arguments fetched in one batch.
 // A fragments are loaded straight from global memory into registers in MFMA operand layout (no LDS staging:
 // no wave shares another wave's K slice); B comes in pre-packed fragment order (one coalesced 1 KiB load per
 // wave per four MFMAs); every load of a work item is issued before the first use; the 8 partial accumulators
