@@ -462,7 +462,7 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
                     int out_tmul = 1, int out_tadd = 0) {
   ConvParams p;
   memset(&p, 0, sizeof(p));
-  p.in = in.p; p.gather = gather; p.in_bstride = in.bstride; p.in_row0 = in.row0; p.in_stride = in.stride;
+  p.in = in.p; p.gather = gather; p.gather_n = c->cfg.vocab_size; p.in_bstride = in.bstride; p.in_row0 = in.row0; p.in_stride = in.stride;
   p.cin = L.cin; p.cin_p = L.cin_p; p.ntaps = L.ntaps;
   for (int j = 0; j < 3; ++j) p.tap_off[j] = L.tap_off[j];
   p.M = rm.B * rm.R; p.R = rm.R; p.offs = rm.offs; p.step = rm.step;

@@ -44,7 +44,12 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
       const int b = m / p.R, r = m - b * p.R;
       const int t = t_base + (p.offs ? p.offs[r] : r);
       if (t >= 0) {
-        inrow = p.gather ? (long)p.gather[m] : ((long)b * p.in_bstride + p.in_row0 + t);
+        if (p.gather) {       // embedding lookup (modules.py:13-42): an id outside the table reads row 0 (= the all-zero PAD row), never out of bounds
+          const int id = p.gather[m];
+          inrow = (id >= 0 && id < p.gather_n) ? id : 0;
+        } else {
+          inrow = (long)b * p.in_bstride + p.in_row0 + t;
+        }
         outrow = (long)b * p.out_bstride + p.out_row0 + (long)t * p.out_tmul + p.out_tadd;
         out2row = (long)b * p.out2_bstride + p.out2_row0 + t;
       }

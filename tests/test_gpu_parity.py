@@ -154,6 +154,18 @@ def test_textenc(weights):
     assert maxabs(K.cpu().numpy(), Kr) < TOL_INNER and maxabs(V.cpu().numpy(), Vr) < TOL_INNER
 
 
+def test_textenc_out_of_vocabulary_ids_read_the_pad_row(weights):
+    """Character ids outside the 32-entry table must not read out of bounds: they behave like PAD (row 0 = zeros), which is
+    what tf.nn.embedding_lookup does on a GPU (on a CPU it raises)."""
+    eng = engine_for(weights)
+    L = synthetic_text(hp, B=2, seed=6)
+    Lbad = L.copy(); Lbad[0, 3] = 77; Lbad[1, 10] = -5
+    Lpad = L.copy(); Lpad[0, 3] = 0; Lpad[1, 10] = 0
+    K1, V1 = eng.text_enc(dev(Lbad))
+    K2, V2 = eng.text_enc(dev(Lpad))
+    assert torch.equal(K1, K2) and torch.equal(V1, V2)
+
+
 def test_audioenc_and_causality(weights):
     eng = engine_for(weights)
     rng = np.random.default_rng(6)
