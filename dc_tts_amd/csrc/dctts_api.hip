@@ -123,6 +123,7 @@ struct dctts_ctx {
   int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
                                        //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
+  int fuse_mel = 1;                    // 1: mel finalisation as the prologue of the next frame's AudioEnc C_1 (DCTTS_FUSE_MEL)
   int bulk_small_rows = 0;             // bulk layers with at most this many rows use the 16-row kernel form (DCTTS_BULK_SMALL, 0 = never)
   int bulk_pipelined = 1;              // bulk contraction = hbulk_kernel (items software-pipelined); 0 = hsplit_kernel<32> (DCTTS_BULK_PIPE)
   int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
@@ -735,6 +736,7 @@ static RowNorm make_norm(const DevLayer& prod, const float* P, const View* res) 
   RowNorm n; memset(&n, 0, sizeof(n));
   n.P = P; n.np = prod.hc ? 2 * prod.cout : prod.cout;
   n.g1 = prod.g1; n.b1 = prod.b1; n.g2 = prod.g2; n.b2 = prod.b2; n.act = prod.act;
+  n.ngroups = (prod.cout + 15) / 16;
   if (res) { n.res = res->p; n.res_bstride = res->bstride; n.res_row0 = res->row0; n.res_stride = res->stride; n.res_set = res->set; }
   return n;
 }
@@ -742,8 +744,10 @@ static RowNorm make_norm(const DevLayer& prod, const float* P, const View* res) 
 // One split GEMM launch for frame `frame`.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
 static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, const int* offs, int frame, int pro, const RowNorm* nrm,
                      const View* xmat, const View& xsrc, float* pout, hipStream_t st,
-                     const float* stats_in = nullptr, float* stats_out = nullptr, int tile_rows16 = 0) {
+                     const float* stats_in = nullptr, float* stats_out = nullptr, int tile_rows16 = 0, const View* xmat2 = nullptr,
+                     int xm2_toff = 0) {
   SplitParams p; memset(&p, 0, sizeof(p));
+  if (xmat2) { p.xmat2 = xmat2->p; p.xm2_bstride = xmat2->bstride; p.xm2_stride = xmat2->stride; p.xm2_toff = xm2_toff; }
   p.M = B * R; p.R = R; p.b0 = 0; p.offs = offs; p.step = nullptr; p.step_val = frame;
   p.pro = pro; if (nrm) p.nrm = *nrm;
   if (xmat) { p.xmat = xmat->p; p.xm_bstride = xmat->bstride; p.xm_row0 = xmat->row0; p.xm_stride = xmat->stride; p.xm_set = xmat->set; }
@@ -752,7 +756,9 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   p.cin = L.cin; p.cin_p = L.cin_p;
   p.wp = (MF == 16) ? L.wp16 : L.wp; p.bias = L.bias; p.cout = L.cout; p.hc = L.hc ? 1 : 0;
   p.np_out = L.hc ? 2 * L.cout : L.cout; p.pout = pout; p.stats_in = stats_in; p.stats_out = stats_out;
-  if (pro != PRO_RAW && (MF != 16 || L.cin_p != 256 || !stats_in))
+  if (pro == PRO_MEL && (MF != 16 || L.ntaps != 1 || !stats_in || !nrm || nrm->np != L.cin))
+    return fail(DCTTS_ERR_STATE, "split kernel: the mel prologue feeds a k = 1 layer whose input width is the mel row");
+  if (pro != PRO_RAW && pro != PRO_MEL && (MF != 16 || L.cin_p != 256 || !stats_in))
     return fail(DCTTS_ERR_STATE, "split kernel: LN prologue needs the 16-row form, 256 input channels and producer statistics");
   if (L.ntaps > 1 && L.cin_p != 256) return fail(DCTTS_ERR_STATE, "split kernel: multi-tap layers must have 256 input channels");
   if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) { p.dbg_wg = g_trace_ctx->trace_buf + 64 * 8 + 256 * g_trace_ctx->trace_n; p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++); }
@@ -848,13 +854,23 @@ static int run_rowmlp(dctts_ctx* c, const DecodeWs& w, int B, int frame, bool ta
 // AudioEnc highway layers for frame j (the k=1 head has already written its C_3 row), then the newest-frame attention.
 // AudioEnc for frame j (13 dependent 16-row x 16-channel-group launches), then the newest-frame attention:
 // rebuild Q[j], materialise it, 3-key softmax, R[j], arg-max -> the window of frame j+1.
-static int v2_audioenc_attn(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm, bool head_done = false) {
+static int v2_audioenc_attn(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm, bool head_done = false,
+                            bool mel_pro = false, bool mel_only = false) {
   const int d = c->cfg.d;
   const std::vector<DevLayer>& AE = c->audioenc;
   size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;
   for (size_t i = head_done ? nh : 0; i < AE.size(); ++i) {
     if (head_done && i == nh) {       // C_3's row was materialised by rowmlp: every tap of HC_4 is a raw history row
       CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ae[i - 1], w.pe[i], sm, nullptr, w.se[i]));
+    } else if (i == 0 && mel_pro) {
+      // mel frame j-1 = sigmoid(LN(AudioDec C_11 pre-norm)) is rebuilt here, in AudioEnc C_1's prologue (no finalize launch);
+      // column group 0 writes it to S[j] (ypad) and its logits to row j-1
+      const std::vector<DevLayer>& AD = c->audiodec;
+      const size_t la = AD.size() - 1;
+      RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
+      n.act = ACT_SIGMOID;
+      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1));
+      if (mel_only) return 0;     // after the last frame only the mel row is wanted (same arithmetic as every other frame's)
     } else if (i == 0) {
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
     } else {
@@ -930,6 +946,7 @@ static int v2_chain_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, 
     if (with_next) CHK(v2_audioenc_attn(c, w, B, N, j + 1, sm, true));
     return 0;
   }
+  if (c->fuse_mel) return v2_audioenc_attn(c, w, B, N, j + 1, sm, false, true, !with_next);   // finalisation rides in AudioEnc C_1
   const DevLayer& Ll = AD.back();
   FinalizeParams f; memset(&f, 0, sizeof(f));
   f.Bg = B; f.b0 = 0; f.step = nullptr; f.step_val = j; f.P = w.pd[AD.size() - 1]; f.np = Ll.cout; f.g = Ll.g1; f.be = Ll.b1; f.n = Ll.cout;
@@ -995,6 +1012,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
+  if (const char* e = getenv("DCTTS_FUSE_MEL")) c->fuse_mel = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_SMALL")) c->bulk_small_rows = atoi(e);
   if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;

@@ -41,12 +41,13 @@ namespace dctts {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { PRO_RAW = 0, PRO_LN_C = 1, PRO_LN_HC = 2 };
+enum { PRO_RAW = 0, PRO_LN_C = 1, PRO_LN_HC = 2, PRO_MEL = 3 };   // PRO_MEL: LN over n_mels + sigmoid = the mel frame (chain: AudioDec C_11 -> AudioEnc C_1)
 
 // How to obtain one 256-channel activation row X[b][t] that exists only as pre-norm values P.
 struct RowNorm {
   const float* P; int np;                  // pre-norm rows [prow][np]  (np = 256 for C, 512 for HC)
   const float* g1; const float* b1; const float* g2; const float* b2; int act;
+  int ngroups;                             // 16-column statistic groups that exist for a row (16 for 256 channels, 5 for 80)
   const float* res; long res_bstride; long res_row0; int res_stride; long res_set;   // highway residual X_{l-1}[b][t] (HC)
 };
 
@@ -110,6 +111,7 @@ struct SplitParams {
   //      producer's per-column-group partial statistics `stats_in` [prow][16 groups][4] = (mean1, M2_1, mean2, M2_2)
   int pro; RowNorm nrm; const float* stats_in;
   float* xmat; long xm_bstride; long xm_row0; int xm_stride; long xm_set;   // where column group 0 materialises the rebuilt row
+  float* xmat2; long xm2_bstride; int xm2_stride; int xm2_toff;             // PRO_MEL: the pre-sigmoid logits row, at time t + xm2_toff
   // ---- tap source (absolute-time activation buffer): all taps when PRO_RAW, the non-centre taps otherwise
   const float* xsrc; long xs_bstride; long xs_row0; int xs_stride; long xs_set;
   int ntaps; int tap_off[3]; int cin; int cin_p;
@@ -127,12 +129,16 @@ struct SplitParams {
 // memory round trips (~2 us) before its first vector load.  Naming every field as an SGPR input of an empty asm at entry makes
 // the compiler fetch the whole struct in one batch.
 #define DCTTS_SGPR(x) asm volatile("" ::"s"(x))
+template <int NT>
 __device__ __forceinline__ void prefetch_params(const SplitParams& p) {
   DCTTS_SGPR(p.M); DCTTS_SGPR(p.R); DCTTS_SGPR(p.b0); DCTTS_SGPR(p.offs); DCTTS_SGPR(p.step); DCTTS_SGPR(p.step_val);
   DCTTS_SGPR(p.ngroups); DCTTS_SGPR(p.tile_rows); DCTTS_SGPR(p.pro);
   DCTTS_SGPR(p.nrm.P); DCTTS_SGPR(p.nrm.np); DCTTS_SGPR(p.nrm.g1); DCTTS_SGPR(p.nrm.b1); DCTTS_SGPR(p.nrm.g2); DCTTS_SGPR(p.nrm.b2);
   DCTTS_SGPR(p.nrm.act); DCTTS_SGPR(p.nrm.res); DCTTS_SGPR(p.nrm.res_bstride); DCTTS_SGPR(p.nrm.res_row0);
   DCTTS_SGPR(p.nrm.res_stride); DCTTS_SGPR(p.nrm.res_set); DCTTS_SGPR(p.stats_in);
+  if constexpr (NT == 0) {     // only the generic form can carry the mel prologue; the specialised ones are at the SGPR limit already
+    DCTTS_SGPR(p.xmat2); DCTTS_SGPR(p.xm2_bstride); DCTTS_SGPR(p.xm2_stride); DCTTS_SGPR(p.xm2_toff); DCTTS_SGPR(p.nrm.ngroups);
+  }
   DCTTS_SGPR(p.xmat); DCTTS_SGPR(p.xm_bstride); DCTTS_SGPR(p.xm_row0); DCTTS_SGPR(p.xm_stride); DCTTS_SGPR(p.xm_set);
   DCTTS_SGPR(p.xsrc); DCTTS_SGPR(p.xs_bstride); DCTTS_SGPR(p.xs_row0); DCTTS_SGPR(p.xs_stride); DCTTS_SGPR(p.xs_set);
   DCTTS_SGPR(p.ntaps); DCTTS_SGPR(p.tap_off[0]); DCTTS_SGPR(p.tap_off[1]); DCTTS_SGPR(p.tap_off[2]); DCTTS_SGPR(p.cin); DCTTS_SGPR(p.cin_p);
@@ -150,15 +156,21 @@ __device__ __forceinline__ float xrow4_sum(float v) {
 
 // Chan-combine the 16 per-group partials (mean_g, M2_g over 16 channels each) of one row: exact two-pass quality.
 // Each of the row's four lanes holds four groups (st[0..3]); h selects (x,y) = H1 / (z,w) = H2.
-__device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, float& mean, float& rstd) {
+__device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, float& mean, float& rstd, int ngr = 16, int g0 = 0) {
+  // ngr < 16 (a row of 16 ngr channels): this lane's groups are g0 .. g0+3; groups >= ngr do not exist (their slots hold zeros)
+  const float inv_g = 1.0f / (float)ngr;
   float sm = 0.f;
 #pragma unroll
   for (int g = 0; g < 4; ++g) sm += h ? st[g].z : st[g].x;
-  mean = xrow4_sum(sm) * (1.0f / 16.0f);
+  mean = xrow4_sum(sm) * inv_g;
   float m2 = 0.f;
 #pragma unroll
-  for (int g = 0; g < 4; ++g) { const float dm = (h ? st[g].z : st[g].x) - mean; m2 += (h ? st[g].w : st[g].y) + 16.0f * dm * dm; }
-  rstd = rsqrt_fast(xrow4_sum(m2) * (1.0f / 256.0f) + 1e-12f);
+  for (int g = 0; g < 4; ++g) {
+    const float dm = (h ? st[g].z : st[g].x) - mean;
+    const float t = (h ? st[g].w : st[g].y) + 16.0f * dm * dm;
+    m2 += (g0 + g < ngr) ? t : 0.f;
+  }
+  rstd = rsqrt_fast(xrow4_sum(m2) * (inv_g * (1.0f / 16.0f)) + 1e-12f);
 }
 
 // TRACE = true compiles the wall-clock stamps in (DCTTS_TRACE).  They must NOT exist in the production instantiation even as
@@ -182,7 +194,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];     // split-K reduction only
   __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  prefetch_params(p);
+  prefetch_params<NT>(p);
   const bool tr = TRACE && p.dbg && blockIdx.x == 0 && tid == 0;
   if constexpr (TRACE) { if (tr) p.dbg[0] = wall_clock64(); if (p.dbg_wg && tid == 0 && blockIdx.x < 128) p.dbg_wg[2 * blockIdx.x] = wall_clock64(); }
   const int step = p.step_val + (p.step ? *p.step : 0);
@@ -262,13 +274,14 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         const bool centre = ln && tap == ctap;                                  // uniform: a scalar select of the base pointer
         const int cc = (NT != 0 || c < p.cin) ? c : p.cin - 4;                  // pad columns of a narrow input: read in range, zeroed below
         const float* base = centre ? p.nrm.P : p.xsrc;
-        const unsigned off = centre ? p_row + (unsigned)c : xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)cc;
+        const unsigned off = centre ? p_row + (unsigned)cc : xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)cc;
         av[i] = ld4u(base, off);
       }
       // the two centre k-groups of wave w are 16 ctap + w and 16 ctap + 8 + w  (i = 2 ctap + e): channel (8 e + w) 16 + c4
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const unsigned ce = ln ? (unsigned)((8 * e + wave) * 16 + c4) : 0u;
+        const int ce_ = (8 * e + wave) * 16 + c4;
+        const unsigned ce = ln ? (unsigned)((NT != 0 || ce_ < p.cin) ? ce_ : p.cin - 4) : 0u;
         g1v[e] = ld4u(ln ? p.nrm.g1 : p.xsrc, ce); b1v[e] = ld4u(ln ? p.nrm.b1 : p.xsrc, ce);
         g2v[e] = ld4u(hcpro ? p.nrm.g2 : p.xsrc, hcpro ? ce : 0u); b2v[e] = ld4u(hcpro ? p.nrm.b2 : p.xsrc, hcpro ? ce : 0u);
         h2v[e] = ld4u(hcpro ? p.nrm.P : p.xsrc, hcpro ? p_row + 256u + ce : 0u);
@@ -290,7 +303,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         int tap, c; tap_c(i, g, tap, c);
         const bool centre = ln && tap == ctap;
         if constexpr (NT != 0) { if (!valid) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        else { if (g >= KG || !valid || (!centre && c >= p.cin)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        else { if (g >= KG || !valid || c >= p.cin) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
       }
     } else {
       // same branch-free issue as the 16-row form: clamped k-group / column, value discarded afterwards
@@ -315,7 +328,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     if constexpr (MF == 16) {
       if (ln) {
         float m1, r1, m2 = 0.f, r2 = 0.f;
-        combine_stats(st, 0, m1, r1);                 // every lane takes part in the cross-lane sums (ln is uniform)
+        combine_stats(st, 0, m1, r1, NT == 0 ? p.nrm.ngroups : 16, aq * 4);   // every lane takes part in the cross-lane sums (ln is uniform)
         if (p.pro == PRO_LN_HC) combine_stats(st, 1, m2, r2);
 #pragma unroll
         for (int i = 0; i < NGMAX; ++i) {
@@ -336,10 +349,15 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
                 { const float s_ = sigmoid_fast(x.w); x.w = s_ * ((h2.w - m2) * r2 * g2.w + b2.w) + (1.0f - s_) * xr.w; }
               } else if (p.nrm.act == ACT_RELU) {
                 x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
+              } else if (NT == 0 && p.nrm.act == ACT_SIGMOID) {         // PRO_MEL: x = the logits of the mel frame (networks.py:210)
+                if (valid && grp == 0 && mytile == 0 && p.xmat2 && c < p.cin)
+                  *reinterpret_cast<float4*>(p.xmat2 + ((long)b * p.xm2_bstride + t + p.xm2_toff) * p.xm2_stride + c) = x;
+                x.x = sigmoidf_(x.x); x.y = sigmoidf_(x.y); x.z = sigmoidf_(x.z); x.w = sigmoidf_(x.w);
               }
+              if (NT == 0 && c >= p.cin) x = make_float4(0.f, 0.f, 0.f, 0.f);      // K padding of a narrow input
               if (!valid) x = make_float4(0.f, 0.f, 0.f, 0.f);
               av[i] = x;
-              if (valid && grp == 0 && mytile == 0 && p.xmat)
+              if (valid && grp == 0 && mytile == 0 && p.xmat && (NT != 0 || c < p.cin))
                 *reinterpret_cast<float4*>(p.xmat + par * p.xm_set + ((long)b * p.xm_bstride + p.xm_row0 + t) * p.xm_stride + c) = x;
             }
           }
@@ -440,7 +458,7 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ long s_prow[2][MF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  prefetch_params(p);
+  prefetch_params<1>(p);
   const int step = p.step_val + (p.step ? *p.step : 0);
   const long par = step & 1;
   const int ntile = (p.M + MF - 1) / MF;
