@@ -247,7 +247,7 @@ def main():
         phase_roof = {
             "textenc": _pr(2 * 3.0789e9, 68.6e6 / B + 0.37e6, phases["textenc_ms"]),
             "decode": dict(_pr(T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 / B + 125e3), dec_ms),
-                           bound="latency: 26 dependent launches per frame on the critical path (DESIGN.md section 4)"),
+                           bound="latency: 25 dependent launches per frame on the critical path (DESIGN.md section 4)"),
             "ssrn": _pr(T * 187.310e6, 67200 + 3444000 + 113641532.0 / B, phases["ssrn_ms"]),
         }
         out = {
