@@ -769,7 +769,10 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
   const size_t sm = hsplit_smem(MF);
   // specialised 16-row forms: causal k = 3 over 256 channels (NT = 3), k = 1 over 256 channels (NT = 1); anything else is generic
-  const int nt = (MF != 16 || L.cin_p != 256 || L.cin != 256) ? 0 : (L.ntaps == 3 && L.tap_off[2] == 0) ? 3 : (L.ntaps == 1 ? 1 : 0);
+  int nt = 0;
+  if (MF == 16 && L.cin == L.cin_p && L.cin_p == 256) nt = (L.ntaps == 3 && L.tap_off[2] == 0) ? 3 : (L.ntaps == 1 ? 1 : 0);
+  else if (MF == 16 && L.ntaps == 1 && L.cin == L.cin_p && L.cin_p == 512) nt = 2;
+  else if (MF == 16 && L.ntaps == 1 && L.cin_p <= 128) nt = 4;
   const bool one = (MF == 16) && c->chain_one;
   if (one) nblk *= 2;
 #define DCTTS_LAUNCH16(TR, NTV)                                                                                          \
@@ -778,9 +781,11 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
     else     hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, false>), dim3(nblk), dim3(512), sm, st, p);               \
   } while (0)
   if (MF == 16 && p.dbg) {
-    if (nt == 3) DCTTS_LAUNCH16(true, 3); else if (nt == 1) DCTTS_LAUNCH16(true, 1); else DCTTS_LAUNCH16(true, 0);
+    if (nt == 3) DCTTS_LAUNCH16(true, 3); else if (nt == 1) DCTTS_LAUNCH16(true, 1); else if (nt == 2) DCTTS_LAUNCH16(true, 2);
+    else if (nt == 4) DCTTS_LAUNCH16(true, 4); else DCTTS_LAUNCH16(true, 0);
   } else if (MF == 16) {
-    if (nt == 3) DCTTS_LAUNCH16(false, 3); else if (nt == 1) DCTTS_LAUNCH16(false, 1); else DCTTS_LAUNCH16(false, 0);
+    if (nt == 3) DCTTS_LAUNCH16(false, 3); else if (nt == 1) DCTTS_LAUNCH16(false, 1); else if (nt == 2) DCTTS_LAUNCH16(false, 2);
+    else if (nt == 4) DCTTS_LAUNCH16(false, 4); else DCTTS_LAUNCH16(false, 0);
   }
 #undef DCTTS_LAUNCH16
   else {

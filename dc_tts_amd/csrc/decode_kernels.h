@@ -136,7 +136,7 @@ __device__ __forceinline__ void prefetch_params(const SplitParams& p) {
   DCTTS_SGPR(p.nrm.P); DCTTS_SGPR(p.nrm.np); DCTTS_SGPR(p.nrm.g1); DCTTS_SGPR(p.nrm.b1); DCTTS_SGPR(p.nrm.g2); DCTTS_SGPR(p.nrm.b2);
   DCTTS_SGPR(p.nrm.act); DCTTS_SGPR(p.nrm.res); DCTTS_SGPR(p.nrm.res_bstride); DCTTS_SGPR(p.nrm.res_row0);
   DCTTS_SGPR(p.nrm.res_stride); DCTTS_SGPR(p.nrm.res_set); DCTTS_SGPR(p.stats_in);
-  if constexpr (NT == 0) {     // only the generic form can carry the mel prologue; the specialised ones are at the SGPR limit already
+  if constexpr (NT == 0 || NT == 4) {     // only the narrow / generic forms can carry the mel prologue; the others are at the SGPR limit already
     DCTTS_SGPR(p.xmat2); DCTTS_SGPR(p.xm2_bstride); DCTTS_SGPR(p.xm2_stride); DCTTS_SGPR(p.xm2_toff); DCTTS_SGPR(p.nrm.ngroups);
   }
   DCTTS_SGPR(p.xmat); DCTTS_SGPR(p.xm_bstride); DCTTS_SGPR(p.xm_row0); DCTTS_SGPR(p.xm_stride); DCTTS_SGPR(p.xm_set);
@@ -183,13 +183,16 @@ __device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, floa
 // k-group i is then tap i >> 1, channels 128 (i & 1) + 16 w: compile-time per i, which removes ~150 select / compare
 // instructions from the stretch between kernel entry and the first load.  NT = 1: k = 1 over 256 channels: two k-groups per
 // wave instead of six clamped ones (the generic form re-reads the last group four times: 3x the load traffic of such a layer).
+// NT = 2: k = 1 over 512 channels (AudioDec C_1: four k-groups per wave).  NT = 4: k = 1 over <= 128 channels (AudioEnc C_1 on
+// the 80-channel mel row: one k-group per wave, some waves and columns are padding, so it keeps the clamps).
 // ONE (16-row form): a workgroup owns ONE 16-column tile (gate or info) instead of the pair: twice the workgroups, half the
 // weight bytes and half the MFMAs per workgroup (the matrix pipe is shared by the two waves of a SIMD: 2 us -> 1 us).
 template <int MF, bool TRACE = false, int NG = 0, int NT = 0, bool ONE = false>
 __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   constexpr int KGS = (MF == 32) ? 8 : 16;          // k per k-group (4 MFMAs)
   constexpr int NJ = (MF == 32) ? 16 : 4;           // accumulator registers per tile
-  constexpr int NGMAX = NG > 0 ? NG : ((MF == 32) ? 12 : (NT == 1 ? 2 : 6));   // k-groups per wave (12 / 6 at K = 768, 2 at K = 256)
+  constexpr int NGMAX = NG > 0 ? NG : ((MF == 32) ? 12 : (NT == 1 ? 2 : (NT == 2 ? 4 : (NT == 4 ? 1 : 6))));   // k-groups per wave
+  constexpr bool FULL = (NT == 1 || NT == 2 || NT == 3);    // every k-group / channel of the form exists: no clamps, no padding
   constexpr int BD = (MF == 32) ? 4 : NGMAX;        // B prefetch ring depth (k-groups); the 16-row form holds all of them
   extern __shared__ __attribute__((aligned(16))) float smem[];     // split-K reduction only
   __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
@@ -210,7 +213,8 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   // (tap, first channel) of this lane's fragment of k-group i / g
   auto tap_c = [&](int i, int g, int& tap, int& c) {
     if constexpr (NT == 3) { tap = i >> 1; c = 128 * (i & 1) + 16 * wave + c4; }
-    else if constexpr (NT == 1) { tap = 0; c = 128 * i + 16 * wave + c4; }
+    else if constexpr (NT == 1 || NT == 2) { tap = 0; c = 128 * i + 16 * wave + c4; }
+    else if constexpr (NT == 4) { tap = 0; c = 16 * g + c4; }
     else { const int k0 = g * KGS; tap = (p.ntaps == 1) ? 0 : (k0 >> 8); c = k0 - tap * p.cin_p + c4; }
   };
 
@@ -231,7 +235,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     // the end re-read the last one (clamped index); their A fragment is zero, so the duplicate weights contribute nothing.
 #pragma unroll
     for (int i = 0; i < BD; ++i) {
-      const int g = wave + 8 * i, gc = (NT != 0 || g < KG) ? g : KG - 1;
+      const int g = wave + 8 * i, gc = (FULL || g < KG) ? g : KG - 1;
       bq0[i] = ld4u(wb, w0o + (unsigned)gc * 256u);
       if constexpr (!ONE) bq1[i] = ld4u(wb, w1o + (unsigned)gc * 256u); else bq1[i] = bq0[i];
     }
@@ -268,11 +272,11 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       const bool hcpro = (p.pro == PRO_LN_HC);
 #pragma unroll
       for (int i = 0; i < NGMAX; ++i) {
-        const int g = wave + 8 * i, gc = (NT != 0 || g < KG) ? g : KG - 1;
+        const int g = wave + 8 * i, gc = (FULL || g < KG) ? g : KG - 1;
         int tap, c; tap_c(i, gc, tap, c);
         const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
         const bool centre = ln && tap == ctap;                                  // uniform: a scalar select of the base pointer
-        const int cc = (NT != 0 || c < p.cin) ? c : p.cin - 4;                  // pad columns of a narrow input: read in range, zeroed below
+        const int cc = (FULL || c < p.cin) ? c : p.cin - 4;                  // pad columns of a narrow input: read in range, zeroed below
         const float* base = centre ? p.nrm.P : p.xsrc;
         const unsigned off = centre ? p_row + (unsigned)cc : xs_row + (unsigned)(toff * p.xs_stride) + (unsigned)cc;
         av[i] = ld4u(base, off);
@@ -281,7 +285,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int ce_ = (8 * e + wave) * 16 + c4;
-        const unsigned ce = ln ? (unsigned)((NT != 0 || ce_ < p.cin) ? ce_ : p.cin - 4) : 0u;
+        const unsigned ce = ln ? (unsigned)((FULL || ce_ < p.cin) ? ce_ : p.cin - 4) : 0u;
         g1v[e] = ld4u(ln ? p.nrm.g1 : p.xsrc, ce); b1v[e] = ld4u(ln ? p.nrm.b1 : p.xsrc, ce);
         g2v[e] = ld4u(hcpro ? p.nrm.g2 : p.xsrc, hcpro ? ce : 0u); b2v[e] = ld4u(hcpro ? p.nrm.b2 : p.xsrc, hcpro ? ce : 0u);
         h2v[e] = ld4u(hcpro ? p.nrm.P : p.xsrc, hcpro ? p_row + 256u + ce : 0u);
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         const int g = wave + 8 * i;
         int tap, c; tap_c(i, g, tap, c);
         const bool centre = ln && tap == ctap;
-        if constexpr (NT != 0) { if (!valid) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if constexpr (FULL) { if (!valid) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         else { if (g >= KG || !valid || c >= p.cin) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
       }
     } else {
@@ -328,12 +332,12 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     if constexpr (MF == 16) {
       if (ln) {
         float m1, r1, m2 = 0.f, r2 = 0.f;
-        combine_stats(st, 0, m1, r1, NT == 0 ? p.nrm.ngroups : 16, aq * 4);   // every lane takes part in the cross-lane sums (ln is uniform)
+        combine_stats(st, 0, m1, r1, FULL ? 16 : p.nrm.ngroups, aq * 4);   // every lane takes part in the cross-lane sums (ln is uniform)
         if (p.pro == PRO_LN_HC) combine_stats(st, 1, m2, r2);
 #pragma unroll
         for (int i = 0; i < NGMAX; ++i) {
           const int g = wave + 8 * i;
-          if (NT != 0 || g < KG) {
+          if (FULL || g < KG) {
             int tap, c; tap_c(i, g, tap, c);
             if (tap == ctap) {
               const float4 g1 = g1v[i & 1], b1 = b1v[i & 1];
@@ -349,15 +353,15 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
                 { const float s_ = sigmoid_fast(x.w); x.w = s_ * ((h2.w - m2) * r2 * g2.w + b2.w) + (1.0f - s_) * xr.w; }
               } else if (p.nrm.act == ACT_RELU) {
                 x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f);
-              } else if (NT == 0 && p.nrm.act == ACT_SIGMOID) {         // PRO_MEL: x = the logits of the mel frame (networks.py:210)
+              } else if (!FULL && p.nrm.act == ACT_SIGMOID) {         // PRO_MEL: x = the logits of the mel frame (networks.py:210)
                 if (valid && grp == 0 && mytile == 0 && p.xmat2 && c < p.cin)
                   *reinterpret_cast<float4*>(p.xmat2 + ((long)b * p.xm2_bstride + t + p.xm2_toff) * p.xm2_stride + c) = x;
                 x.x = sigmoidf_(x.x); x.y = sigmoidf_(x.y); x.z = sigmoidf_(x.z); x.w = sigmoidf_(x.w);
               }
-              if (NT == 0 && c >= p.cin) x = make_float4(0.f, 0.f, 0.f, 0.f);      // K padding of a narrow input
+              if (!FULL && c >= p.cin) x = make_float4(0.f, 0.f, 0.f, 0.f);      // K padding of a narrow input
               if (!valid) x = make_float4(0.f, 0.f, 0.f, 0.f);
               av[i] = x;
-              if (valid && grp == 0 && mytile == 0 && p.xmat && (NT != 0 || c < p.cin))
+              if (valid && grp == 0 && mytile == 0 && p.xmat && (FULL || c < p.cin))
                 *reinterpret_cast<float4*>(p.xmat + par * p.xm_set + ((long)b * p.xm_bstride + p.xm_row0 + t) * p.xm_stride + c) = x;
             }
           }
@@ -374,7 +378,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 #pragma unroll
     for (int i = 0; i < NGMAX; ++i) {
       const int g = wave + 8 * i;
-      if (NG > 0 || NT != 0 || g < KG) {
+      if (NG > 0 || FULL || g < KG) {
         const float4 a = av[i];
         const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
         if constexpr (MF == 32) {
