@@ -338,6 +338,20 @@ def test_full_size_properties(weights):
     assert maxabs(Y[:2].cpu().numpy(), Yr) < TOL and maxabs(z[:2], Zr) < TOL
 
 
+def test_ragged_batch_sizes(weights):
+    """Batch sizes that do not fill the 8-row chain tiles / 32-row bulk tiles (B = 3, 33): Text2Mel output and the attention
+    trajectory of every utterance are bitwise those of the same utterance decoded in another batch composition."""
+    T = 24
+    eng = engine_for(weights, max_T=T)
+    L = dev(synthetic_text(hp.replace(max_T=T), B=33, seed=404))
+    Y33, m33 = eng.text2mel(L)
+    Y32, m32 = eng.text2mel(L[:32].contiguous())
+    Y3, m3 = eng.text2mel(L[30:33].contiguous())
+    assert torch.equal(Y33[:32], Y32) and torch.equal(m33[:32], m32)
+    assert torch.equal(Y33[30:33], Y3) and torch.equal(m33[30:33], m3)
+    assert bool(torch.isfinite(Y33).all())
+
+
 def test_long_form_shape(weights):
     """configs[4] shape class: max_T = 1000 (one GPU's share, B = 8); cone / history indexing far beyond 210."""
     T = 1000
