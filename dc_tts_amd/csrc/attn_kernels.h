@@ -73,23 +73,25 @@ __global__ void __launch_bounds__(256) attention_full_kernel(const AttnFullParam
     lg[n] = a;
   }
   __syncthreads();
-  // max, first-index argmax
+  // (value desc, index asc) arg-max reduction over the workgroup; result in s_red[0] / s_arg
+  __shared__ float s_mx[4]; __shared__ int s_am[4];
+  auto block_argmax = [&](float mx, int am) {
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ov = __shfl_xor(mx, o); const int oi = __shfl_xor(am, o);
+      if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
+    }
+    if ((tid & 63) == 0) { s_mx[tid >> 6] = mx; s_am[tid >> 6] = am; }
+    __syncthreads();
+    if (tid == 0) {
+      float m = s_mx[0]; int a = s_am[0];
+      for (int w = 1; w < 4; ++w) if (s_mx[w] > m || (s_mx[w] == m && s_am[w] < a)) { m = s_mx[w]; a = s_am[w]; }
+      s_red[0] = m; s_arg = a;
+    }
+    __syncthreads();
+  };
   float mx = -INFINITY; int am = 0x7fffffff;
   for (int n = tid; n < p.N; n += 256) { const float v = lg[n]; if (v > mx) { mx = v; am = n; } }
-  // wave reduce (value desc, index asc)
-  for (int o = 32; o >= 1; o >>= 1) {
-    const float ov = __shfl_xor(mx, o); const int oi = __shfl_xor(am, o);
-    if (ov > mx || (ov == mx && oi < am)) { mx = ov; am = oi; }
-  }
-  __shared__ float s_mx[4]; __shared__ int s_am[4];
-  if ((tid & 63) == 0) { s_mx[tid >> 6] = mx; s_am[tid >> 6] = am; }
-  __syncthreads();
-  if (tid == 0) {
-    float m = s_mx[0]; int a = s_am[0];
-    for (int w = 1; w < 4; ++w) if (s_mx[w] > m || (s_mx[w] == m && s_am[w] < a)) { m = s_mx[w]; a = s_am[w]; }
-    s_red[0] = m; s_arg = a;
-  }
-  __syncthreads();
+  block_argmax(mx, am);
   mx = s_red[0];
   float se = 0.f;
   for (int n = tid; n < p.N; n += 256) { const float e = expf(lg[n] - mx); lg[n] = e; se += e; }
@@ -98,11 +100,15 @@ __global__ void __launch_bounds__(256) attention_full_kernel(const AttnFullParam
   if ((tid & 63) == 0) s_red[4 + (tid >> 6)] = se;
   __syncthreads();
   const float inv = 1.0f / (s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+  // tf.argmax runs on the POST-softmax row (networks.py:148-149), first index on ties: softmax is only weakly monotone in fp32
+  float pmx = -INFINITY; int pam = 0x7fffffff;
   for (int n = tid; n < p.N; n += 256) {
     const float a = lg[n] * inv; lg[n] = a;
+    if (a > pmx) { pmx = a; pam = n; }
     if (p.align) p.align[((long)b * p.N + n) * p.T + t] = a;
   }
   __syncthreads();
+  block_argmax(pmx, pam);
   if (tid == 0 && p.maxatt) p.maxatt[(long)b * p.T + t] = (long long)s_arg;
   float* rrow = p.R + ((long)b * p.T + t) * (2 * p.d);
   for (int c = tid; c < p.d; c += 256) {
@@ -155,13 +161,17 @@ __global__ void __launch_bounds__(256) attention_window_kernel(const AttnWinPara
       lg[k] = wave_sum(a) * scale;
     }
   }
-  float mx = lg[0]; int am = 0;
+  float mx = lg[0];
 #pragma unroll
-  for (int k = 1; k < 3; ++k) if (lg[k] > mx) { mx = lg[k]; am = k; }
+  for (int k = 1; k < 3; ++k) mx = fmaxf(mx, lg[k]);
   float e[3], se = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { e[k] = (k < nk) ? expf(lg[k] - mx) : 0.f; se += e[k]; }
   const float inv = 1.0f / se;
+  // tf.argmax of the POST-softmax row, first index on ties (networks.py:148-149)
+  int am = 0; float pbest = e[0] * inv;
+#pragma unroll
+  for (int k = 1; k < 3; ++k) { const float a = e[k] * inv; if (a > pbest) { pbest = a; am = k; } }
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
@@ -172,7 +182,6 @@ __global__ void __launch_bounds__(256) attention_window_kernel(const AttnWinPara
   *reinterpret_cast<float4*>(rrow + c0) = o;
   *reinterpret_cast<float4*>(rrow + p.d + c0) = q;
   if (p.offs[r] == 0 && lane == 0) {
-    // argmax over the post-softmax row, first index on ties (tf.argmax): softmax is monotone in the logit.
     const_cast<int*>(p.pm_all)[(long)(j + 1) * p.B + b] = pm + am;
   }
 }

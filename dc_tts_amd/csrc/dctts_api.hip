@@ -17,6 +17,7 @@
 #include "api_common.h"
 #include "attn_kernels.h"
 #include "decode_kernels.h"
+#include "decode3_kernels.h"
 #include "hconv_kernel.h"
 #include "hconv16_kernel.h"
 
@@ -53,6 +54,7 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
 hipError_t launch_hconv16(const ConvShape& s, const ConvParams& p, int m_start, hipStream_t stream) {
   if (p.M <= m_start) return hipSuccess;
   const dim3 grid((p.M - m_start + 15) / 16);
+  HCONV16_CASE(EPI_HC, 4, 8)
   HCONV16_CASE(EPI_HC, 8, 8)
   HCONV16_CASE(EPI_HC, 16, 8)
   HCONV16_CASE(EPI_C, 8, 8)
@@ -87,6 +89,8 @@ struct DevLayer {
   ConvShape shape16{0, 0, 0};
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
   float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for rowmlp_kernel
+  float* wp16c = nullptr;         // decode causal k=3 layers (v3): centre tap only, 16x16x4 tiles (the chain contracts K = 256)
+  float* wpp = nullptr;           // decode causal k=3 layers (v3): the two older taps, 32x32x2 tiles (presum GEMM, K = 512)
   int cin_real = 0;
   bool hc = false;
 };
@@ -113,7 +117,19 @@ struct dctts_ctx {
   std::map<std::string, Buf> ws;       // named workspaces; key includes the geometry
   std::string ws_geom_textenc, ws_geom_t2m, ws_geom_dec, ws_geom_ssrn;
   int use_graph = 0;
-  int decode_mode = 1;                 // 0 = v1 (fused kernels, one stream), 1 = v2 (split kernels, chain + bulk streams)
+  int decode_mode = 3;                 // 0 = v1 (fused kernels, one stream), 1 = v2 (split kernels, chain + bulk streams),
+                                       // 3 = v3 (v2 + hoisted taps: the chain contracts only centre taps, AudioDec C_1 is a row op)
+  // ---- decode v3
+  std::vector<DevLayer> ae_c, ad_c;    // chain view of AudioEnc / AudioDec: k=3 layers reduced to their centre tap (k=1 layers unchanged)
+  std::vector<DevLayer> ae_p;          // presum view of AudioEnc's k=3 layers (taps -2d, -d; K = 512); entries of k=1 layers are unused
+  DevLayer ad_c1q, ad_vw;              // AudioDec C_1 split by input rows: Q half (chain, 16-row tiles), A.V half (V . W_top precompute)
+  std::vector<int*> cone3_dev;         // per AudioDec layer: cone offsets < 0 (descending) followed by 0 (the presum row)
+  int* iota_dev = nullptr; int iota_n = 0;
+  hipEvent_t ev_aepre[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;
+  void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
+  int bulk3_fused = 0;                 // v3 bulk layers with more rows: 1 = full-row 16-row items with fused LN (hconv16_kernel), 0 = hbulk + ln_rows
+  int bulk3_small_rows = 16;           // v3 bulk layers with at most this many rows per utterance (incl. the presum row) use the 16-row kernel form
   hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr};
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // v1: one step, replayed T times
@@ -241,6 +257,11 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
   auto W = [=](int tap, int cc, int col) { return kv[((size_t)tap * C + cc) * (2 * C) + col]; };
   CHK(upload(c, pack_b(W, k, C, L->cin_p, L->shape, C, true), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, k, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16));
+  if (dec && k == 3 && causal) {
+    auto Wc = [=](int, int cc, int col) { return kv[((size_t)2 * C + cc) * (2 * C) + col]; };        // tap 2 sees x[t]
+    CHK(upload(c, pack_bw(Wc, 1, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16c));
+    CHK(upload(c, pack_bw(W, 2, C, L->cin_p, L->shape.nt * L->shape.nw, C, true, 32), &L->wpp));   // taps 0, 1 see x[t-2d], x[t-d]
+  }
   if (tail) {
     L->shape16 = pick_shape16(EPI_HC, C);
     CHK(upload(c, pack_bw(W, k, C, L->cin_p, L->shape16.nt * L->shape16.nw, C, true, 16), &L->wp16r));
@@ -302,6 +323,9 @@ extern "C" const char* dctts_last_error(void) { return g_err.c_str(); }
 extern "C" int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg) {
   if (!out || !cfg) return fail(DCTTS_ERR_ARG, "null argument");
   if (cfg->d != 256) return fail(DCTTS_ERR_ARG, "attention kernels are specialised for d == 256");
+  if (cfg->attention_win_size < 1 || cfg->attention_win_size > MAXWIN)
+    return fail(DCTTS_ERR_ARG, "attention_win_size must be 1..3: the decode attention kernels are unrolled for a 3-key window (hyperparams.py:32)");
+  if (cfg->max_N < 1 || cfg->n_mels < 4 || cfg->n_mels > 128 || (cfg->n_mels & 3)) return fail(DCTTS_ERR_ARG, "unsupported max_N / n_mels");
   HIPCHK(hipSetDevice(device));
   dctts_ctx* c = new dctts_ctx();
   c->cfg = *cfg; c->device = device;
@@ -331,6 +355,10 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   free_ws(c);
   for (Arena& a : c->warena) (void)hipFree(a.base);
   for (int* p : c->cone_dev) (void)hipFree(p);
+  for (int* p : c->cone3_dev) (void)hipFree(p);
+  if (c->iota_dev) (void)hipFree(c->iota_dev);
+  if (c->aepre_tab) (void)hipFree(c->aepre_tab);
+  for (int i = 0; i < 4; ++i) if (c->ev_aepre[i]) (void)hipEventDestroy(c->ev_aepre[i]);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;
@@ -395,7 +423,30 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
       HIPCHK(hipMalloc((void**)&dp, v.size() * sizeof(int)));
       HIPCHK(hipMemcpy(dp, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
       c->cone_dev.push_back(dp); c->cone_len.push_back((int)v.size());
+      std::vector<int> v3(v.begin() + 1, v.end()); v3.push_back(0);       // v[0] == 0: the newest row goes last (presum row)
+      HIPCHK(hipMalloc((void**)&dp, v3.size() * sizeof(int)));
+      HIPCHK(hipMemcpy(dp, v3.data(), v3.size() * sizeof(int), hipMemcpyHostToDevice));
+      c->cone3_dev.push_back(dp);
     }
+    // ---- decode v3 views
+    auto centre = [](const DevLayer& L) { DevLayer x = L; if (L.wp16c) { x.ntaps = 1; x.tap_off[0] = x.tap_off[1] = x.tap_off[2] = 0; x.wp16 = L.wp16c; } return x; };
+    auto older = [](const DevLayer& L) { DevLayer x = L; if (L.wpp) { x.ntaps = 2; x.tap_off[2] = 0; x.wp = L.wpp; } return x; };
+    for (const DevLayer& L : c->audioenc) { c->ae_c.push_back(centre(L)); c->ae_p.push_back(older(L)); }
+    for (const DevLayer& L : c->audiodec) c->ad_c.push_back(centre(L));
+    const HostTensor* k1;
+    CHK(get_w(c, s + "C_1/conv1d/kernel", {1, 2 * d, d}, &k1));
+    const float* kv = k1->v.data();
+    auto Wtop = [=](int, int cc, int col) { return kv[(size_t)cc * d + col]; };              // rows that multiply A.V (networks.py:150-151)
+    auto Wbot = [=](int, int cc, int col) { return kv[(size_t)(d + cc) * d + col]; };        // rows that multiply Q
+    c->ad_c1q = c->audiodec[0]; c->ad_c1q.cin = c->ad_c1q.cin_p = c->ad_c1q.cin_real = d; c->ad_c1q.wp = nullptr; c->ad_c1q.wraw = nullptr;
+    CHK(upload(c, pack_bw(Wbot, 1, d, d, 2 * ((d + 31) / 32), d, false, 16), &c->ad_c1q.wp16));
+    c->ad_vw = c->ad_c1q; c->ad_vw.wp16 = nullptr;
+    CHK(upload(c, pack_bw(Wtop, 1, d, d, (d + 31) / 32, d, false, 32), &c->ad_vw.wp));
+    CHK(upload(c, std::vector<float>(d, 0.f), &c->ad_vw.bias));
+    c->iota_n = g.max_N > 1024 ? g.max_N : 1024;
+    std::vector<int> io(c->iota_n); for (int q = 0; q < c->iota_n; ++q) io[q] = q;
+    HIPCHK(hipMalloc((void**)&c->iota_dev, io.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(c->iota_dev, io.data(), io.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   // ---- SSRN (networks.py:214-292), SAME
   {
@@ -648,6 +699,12 @@ struct DecodeWs {
   View kv, ypad, rbuf, logits; std::vector<View> ae, ad; int* pm_all; int* step;
   std::vector<float*> se, sd;          // per-column-group partial LN statistics of pe / pd: [B][16][4]
   std::vector<float*> pe, pd, pb;      // pre-norm rows: AudioEnc chain [B][np], AudioDec chain [B][np], AudioDec bulk [B*Rb][np]
+  // v3
+  float* vw = nullptr;                 // V . W_top  [B*N][d]
+  View c1q;                            // Q[t] . W_bot, absolute time
+  std::vector<float*> pse;             // AudioEnc presums per k=3 layer [B][2d] (bias + older taps of the next row)
+  std::vector<float*> pb3; long pb3_set[16] = {0};   // AudioDec cone pre-norm rows + presum row, two parity copies: [2][B*(Rb+1)][np]
+  float* ps0 = nullptr;                // AudioDec C_1 presum [B][d] (attnq_kernel)
 };
 
 static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
@@ -686,6 +743,20 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
   }
   CHK(ws_get(c, "dec.pm", (size_t)(T + 2) * B * sizeof(int), &p)); w->pm_all = (int*)p;
   CHK(ws_get(c, "dec.step", 256, &p)); w->step = (int*)p;
+  if (c->decode_mode == 3) {
+    CHK(ws_get(c, "dec.vw", (size_t)B * N * d * sizeof(float), &p)); w->vw = (float*)p;
+    CHK(ws_view(c, "dec.c1q", B, rows, PAD, d, &w->c1q));
+    CHK(ws_get(c, "dec.ps0", (size_t)B * d * sizeof(float), &p)); w->ps0 = (float*)p;
+    w->pse.assign(c->audioenc.size(), nullptr);
+    for (size_t i = 0; i < w->pse.size(); ++i)
+      if (c->audioenc[i].wpp) { CHK(ws_get(c, "dec.pse" + std::to_string(i), (size_t)B * 2 * d * sizeof(float), &p)); w->pse[i] = (float*)p; }
+    w->pb3.assign(c->audiodec.size(), nullptr);
+    for (size_t i = 0; i < w->pb3.size(); ++i) {
+      if (!c->audiodec[i].wpp) continue;
+      const size_t n = (size_t)B * c->cone_len[i] * 2 * d;          // cone_len rows: (cone_len - 1) bulk rows + the presum row
+      CHK(ws_get(c, "dec.pb3_" + std::to_string(i), 2 * n * sizeof(float), &p)); w->pb3[i] = (float*)p; w->pb3_set[i] = (long)n;
+    }
+  }
   return 0;
 }
 
@@ -741,12 +812,24 @@ static RowNorm make_norm(const DevLayer& prod, const float* P, const View* res) 
   return n;
 }
 
+struct SplitExtra {                     // decode v3 additions to a split launch
+  const float* presum = nullptr; int presum_rstride = 0;   // chain: per-row presum replaces the bias
+  const View* raw = nullptr;                                // chain: bare contraction -> raw[b][frame]
+  int mask_last = 0;                                        // bulk: the last row of every utterance is a presum row
+};
+
 // One split GEMM launch for frame `frame`.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
 static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, const int* offs, int frame, int pro, const RowNorm* nrm,
                      const View* xmat, const View& xsrc, float* pout, hipStream_t st,
                      const float* stats_in = nullptr, float* stats_out = nullptr, int tile_rows16 = 0, const View* xmat2 = nullptr,
-                     int xm2_toff = 0) {
+                     int xm2_toff = 0, const SplitExtra* ex = nullptr) {
   SplitParams p; memset(&p, 0, sizeof(p));
+  if (ex) {
+    p.presum = ex->presum; p.presum_rstride = ex->presum_rstride; p.mask_last = ex->mask_last;
+    if (ex->raw) { p.raw_out = ex->raw->p; p.raw_bstride = ex->raw->bstride; p.raw_row0 = ex->raw->row0; p.raw_stride = ex->raw->stride; }
+    if ((ex->presum || ex->raw) && (MF != 16 || R != 1)) return fail(DCTTS_ERR_STATE, "split kernel: presum / raw output belong to the chain (16-row form, one row per utterance)");
+    if (ex->mask_last && (L.ntaps != 3 || L.cin_p != 256 || L.tap_off[2] != 0 || pro != PRO_RAW)) return fail(DCTTS_ERR_STATE, "split kernel: presum rows belong to a causal 3-tap layer over 256 channels");
+  }
   if (xmat2) { p.xmat2 = xmat2->p; p.xm2_bstride = xmat2->bstride; p.xm2_stride = xmat2->stride; p.xm2_toff = xm2_toff; }
   p.M = B * R; p.R = R; p.b0 = 0; p.offs = offs; p.step = nullptr; p.step_val = frame;
   p.pro = pro; if (nrm) p.nrm = *nrm;
@@ -773,6 +856,7 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   if (MF == 16 && L.cin == L.cin_p && L.cin_p == 256) nt = (L.ntaps == 3 && L.tap_off[2] == 0) ? 3 : (L.ntaps == 1 ? 1 : 0);
   else if (MF == 16 && L.ntaps == 1 && L.cin == L.cin_p && L.cin_p == 512) nt = 2;
   else if (MF == 16 && L.ntaps == 1 && L.cin_p <= 128) nt = 4;
+  if (ex && (ex->presum || ex->raw) && nt != 1) return fail(DCTTS_ERR_STATE, "split kernel: presum / raw output need the k = 1 x 256-channel chain form");
   const bool one = (MF == 16) && c->chain_one;
   if (one) nblk *= 2;
 #define DCTTS_LAUNCH16(TR, NTV)                                                                                          \
@@ -791,8 +875,10 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   else {
     const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
     const bool plain = (pro == PRO_RAW) && L.cin == L.cin_p && c->bulk_pipelined;   // hbulk_kernel: software-pipelined across items
+    if (ex && ex->mask_last && !(kg == 96 && plain)) return fail(DCTTS_ERR_STATE, "split kernel: presum rows need hbulk_kernel<12>");
     if (kg == 96 && plain)      hipLaunchKernelGGL((hbulk_kernel<12>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 64 && plain) hipLaunchKernelGGL((hbulk_kernel<8>), dim3(nblk), dim3(512), sm, st, p);
+    else if (kg == 32 && plain) hipLaunchKernelGGL((hbulk_kernel<4>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 96) hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 64) hipLaunchKernelGGL((hsplit_kernel<32, false, 8>), dim3(nblk), dim3(512), sm, st, p);
     else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): K must be 512 or 768");
@@ -818,6 +904,9 @@ static int decode_v2_init(dctts_ctx* c) {
   HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)hbulk_group_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_aepre[i], hipEventDisableTiming));
   return 0;
 }
 
@@ -969,6 +1058,8 @@ static void destroy_graphs2(dctts_ctx* c) {
   if (c->pro_g) (void)hipGraphExecDestroy(c->pro_g);
   c->pro_g = nullptr;
   c->chain_g.clear(); c->bulk_g.clear(); c->graphs2_geom.clear();
+  for (hipGraphExec_t g : c->bulk3_g) if (g) (void)hipGraphExecDestroy(g);
+  c->bulk3_g.clear(); c->graphs3_geom.clear();
 }
 
 template <typename F>
@@ -1011,23 +1102,257 @@ static int write_trace(dctts_ctx* c, int j) {
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ decode v3: hoisted taps (decode3_kernels.h)
+// chain piece j (j = -1 .. T-1), caller's stream:
+//     AudioDec HC_2 .. C_11 of frame j  [j >= 0; needs bulk piece j]
+//     AudioEnc C_1 .. HC_13 of frame j+1 (C_1's prologue finalises mel frame j) [needs the AudioEnc presums of bulk piece j+1]
+//     attnq(j+1): Q[j+1], window of frame j+2, C_1's presum;  AudioDec C_1 of frame j+1 (K = 256 on Q[j+1]; also C1Q[j+1])
+// bulk piece f (f = 0 .. T-1), side stream, after chain piece f-2, overlapping chain piece f-1:
+//     AudioEnc presums for row f (one grouped launch) | C_1 cone rows (rowc1_kernel) | per k=3 AudioDec layer: cone rows + the
+//     presum row of frame f in one GEMM, then LN / gate of the cone rows.
+static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
+  const std::string g = std::to_string(B) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back());
+  if (c->aepre_tab && c->aepre_geom == g) return 0;
+  std::vector<SplitParams> tab;
+  const std::vector<DevLayer>& AP = c->ae_p;
+  for (size_t i = 0; i < AP.size(); ++i) {
+    if (!AP[i].wpp) continue;
+    const DevLayer& L = AP[i];
+    if (i == 0 || L.cin_p != 256 || L.cout != 256) return fail(DCTTS_ERR_STATE, "v3: AudioEnc k=3 layers must be 256 -> 2 x 256");
+    SplitParams p; memset(&p, 0, sizeof(p));
+    p.M = B; p.R = 1; p.ngroups = L.cout / 32; p.tile_rows = 32; p.pro = PRO_RAW;
+    const View& x = w.ae[i - 1];
+    p.xsrc = x.p; p.xs_bstride = x.bstride; p.xs_row0 = x.row0; p.xs_stride = x.stride; p.xs_set = 0;
+    p.ntaps = 2; p.tap_off[0] = L.tap_off[0]; p.tap_off[1] = L.tap_off[1]; p.cin = L.cin; p.cin_p = L.cin_p;
+    p.wp = L.wpp; p.bias = L.bias; p.cout = L.cout; p.hc = 1; p.np_out = 2 * L.cout; p.pout = w.pse[i];
+    tab.push_back(p);
+  }
+  if (tab.empty()) return fail(DCTTS_ERR_STATE, "v3: no causal k=3 AudioEnc layers");
+  (void)hipDeviceSynchronize();
+  if (c->aepre_tab) (void)hipFree(c->aepre_tab);
+  HIPCHK(hipMalloc(&c->aepre_tab, tab.size() * sizeof(SplitParams)));
+  HIPCHK(hipMemcpy(c->aepre_tab, tab.data(), tab.size() * sizeof(SplitParams), hipMemcpyHostToDevice));
+  c->aepre_layers = (int)tab.size(); c->aepre_geom = g;
+  return 0;
+}
+
+static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st) {
+  const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
+  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, (const SplitParams*)c->aepre_tab, ipl, f);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int v3_vw(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t st) {
+  if (N > c->iota_n) return fail(DCTTS_ERR_ARG, "decode: N too large");
+  const int d = c->cfg.d;
+  const View v{w.kv.p + d, (long)N, 0, 2 * d, 0};                    // V = channels d..2d of TextEnc's output rows
+  return run_split(c, 32, c->ad_vw, B, N, c->iota_dev, 0, PRO_RAW, nullptr, nullptr, v, w.vw, st);
+}
+
+static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, hipStream_t sb) {
+  const int d = c->cfg.d;
+  const std::vector<DevLayer>& AD = c->audiodec;
+  const int par = f & 1;
+  if (c->cone_len[0] > 1) {
+    RowC1Params q; memset(&q, 0, sizeof(q));
+    q.B = B; q.R = c->cone_len[0] - 1; q.offs = c->cone3_dev[0]; q.frame = f;
+    q.Qh = w.ae.back().p; q.q_bstride = w.ae.back().bstride; q.q_row0 = w.ae.back().row0; q.q_stride = d;
+    q.K = w.kv.p; q.k_stride = 2 * d; q.VW = w.vw; q.vw_stride = d; q.kv_bstride = N;
+    q.C1Q = w.c1q.p; q.c_bstride = w.c1q.bstride; q.c_row0 = w.c1q.row0; q.c_stride = w.c1q.stride;
+    q.bias = AD[0].bias; q.g = AD[0].g1; q.be = AD[0].b1;
+    q.N = N; q.d = d; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
+    q.x = w.ad[0].p; q.x_bstride = w.ad[0].bstride; q.x_row0 = w.ad[0].row0; q.x_stride = w.ad[0].stride; q.x_set = w.ad[0].set;
+    hipLaunchKernelGGL(rowc1_kernel, dim3((q.R + 3) / 4, B), dim3(256), 0, sb, q);
+    HIPCHK(hipGetLastError());
+  }
+  for (size_t i = 1; i < AD.size(); ++i) {
+    if (!AD[i].wpp) continue;
+    const int R = c->cone_len[i], Rb = R - 1;                          // Rb cone rows at offsets < 0, then the presum row (offset 0)
+    float* pout = w.pb3[i] + (long)par * w.pb3_set[i];
+    if (R > c->bulk3_small_rows && c->bulk3_fused) {
+      // many rows (HC_2, HC_3): 16-row x ALL-column items with the layer-norm / gate in the epilogue (hconv16_kernel): one round of
+      // MFMA-bound workgroups, no pre-norm round trip and no separate row pass; presum rows leave through presum_out
+      ConvParams q; memset(&q, 0, sizeof(q));
+      const View& in = w.ad[i - 1]; const View& out = w.ad[i];
+      q.in = in.p + (long)par * in.set; q.in_bstride = in.bstride; q.in_row0 = in.row0; q.in_stride = in.stride;
+      q.cin = AD[i].cin; q.cin_p = AD[i].cin_p; q.ntaps = AD[i].ntaps;
+      for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = AD[i].tap_off[t3];
+      q.M = B * R; q.R = R; q.offs = c->cone3_dev[i]; q.step = nullptr; q.t_base_val = f;
+      q.wp = AD[i].wp16; q.bias = AD[i].bias; q.g1 = AD[i].g1; q.b1 = AD[i].b1; q.g2 = AD[i].g2; q.b2 = AD[i].b2; q.cout = AD[i].cout;
+      q.out = out.p + (long)par * out.set; q.out_bstride = out.bstride; q.out_row0 = out.row0; q.out_stride = out.stride; q.out_tmul = 1;
+      q.act = ACT_NONE;
+      q.presum_out = pout + (long)(R - 1) * 2 * AD[i].cout; q.presum_rstride = (long)R * 2 * AD[i].cout;
+      HIPCHK(launch_hconv16(ConvShape{EPI_HC, 2 * AD[i].cout / 16 / 8, 8}, q, 0, sb));
+      continue;
+    }
+    SplitExtra ex; ex.mask_last = 1;
+    // few rows (the last cone layers): 16-row x 16-channel-group items spread them over (rows / 16) x 16 short workgroups instead
+    // of one latency-bound round of a handful of 32-row items
+    const int mf = (R <= c->bulk3_small_rows) ? 16 : 32;          // by rows per utterance, not by B: results stay bitwise shard-invariant
+    CHK(run_split(c, mf, AD[i], B, R, c->cone3_dev[i], f, PRO_RAW, nullptr, nullptr, w.ad[i - 1], pout, sb, nullptr, nullptr, 16, nullptr, 0, &ex));
+    if (Rb <= 0) continue;
+    LnRowsParams q; memset(&q, 0, sizeof(q));
+    q.M = B * Rb; q.R = Rb; q.Rp = R; q.b0 = 0; q.offs = c->cone3_dev[i]; q.step = nullptr; q.step_val = f; q.hc = 1;
+    q.nrm = make_norm(AD[i], pout, &w.ad[i - 1]);
+    q.x = w.ad[i].p; q.x_bstride = w.ad[i].bstride; q.x_row0 = w.ad[i].row0; q.x_stride = w.ad[i].stride; q.x_set = w.ad[i].set;
+    hipLaunchKernelGGL(ln_rows_kernel, dim3((q.M + 3) / 4), dim3(256), 0, sb, q);
+    HIPCHK(hipGetLastError());
+  }
+  return 0;
+}
+
+// AudioDec HC_2 .. C_11 for frame j (its C_1 ran at the end of the previous chain piece)
+static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
+  const std::vector<DevLayer>& AD = c->ad_c;
+  const int par = j & 1;
+  for (size_t i = 1; i < AD.size(); ++i) {
+    const RowNorm n = make_norm(AD[i - 1], w.pd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr);
+    SplitExtra ex;
+    if (AD[i].wp16c) { ex.presum = w.pb3[i] + (long)par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout; ex.presum_rstride = c->cone_len[i] * 2 * AD[i].cout; }
+    CHK(run_split(c, 16, AD[i], B, 1, nullptr, j, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm, w.sd[i - 1], w.sd[i],
+                  0, nullptr, 0, &ex));
+  }
+  return 0;
+}
+
+// AudioEnc for frame j (C_1's prologue finalises mel frame j-1 when j > 0), attention row j, AudioDec C_1 of frame j.
+static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm, hipEvent_t aepre) {
+  const int d = c->cfg.d;
+  const std::vector<DevLayer>& AE = c->ae_c;
+  const std::vector<DevLayer>& AD = c->ad_c;
+  for (size_t i = 0; i < AE.size(); ++i) {
+    if (i == 0 && j > 0) {
+      const size_t la = AD.size() - 1;
+      RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
+      n.act = ACT_SIGMOID;
+      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1));
+    } else if (i == 0) {
+      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
+    } else {
+      const RowNorm n = make_norm(AE[i - 1], w.pe[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr);
+      SplitExtra ex;
+      if (AE[i].wp16c) {
+        ex.presum = w.pse[i]; ex.presum_rstride = 2 * AE[i].cout;
+        if (aepre) { HIPCHK(hipStreamWaitEvent(sm, aepre, 0)); aepre = nullptr; }   // first consumer of this frame's AudioEnc presums
+      }
+      CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, AE[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ae[i - 1], w.ae[i - 1], w.pe[i], sm, w.se[i - 1], w.se[i],
+                    0, nullptr, 0, &ex));
+    }
+  }
+  const size_t la = AE.size() - 1;
+  AttnQParams a; memset(&a, 0, sizeof(a));
+  a.B = B; a.frame = j;
+  a.nrm = make_norm(AE[la], w.pe[la], &w.ae[la - 1]);
+  a.qhist = w.ae[la].p; a.q_bstride = w.ae[la].bstride; a.q_row0 = w.ae[la].row0; a.q_stride = d;
+  a.K = w.kv.p; a.k_stride = 2 * d; a.VW = w.vw; a.vw_stride = d; a.kv_bstride = N;
+  a.bias = c->audiodec[0].bias; a.N = N; a.d = d; a.win = c->cfg.attention_win_size; a.pm_all = w.pm_all; a.presum = w.ps0;
+  hipLaunchKernelGGL(attnq_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
+  HIPCHK(hipGetLastError());
+  SplitExtra ex; ex.presum = w.ps0; ex.presum_rstride = d; ex.raw = &w.c1q;
+  return run_split(c, 16, c->ad_c1q, B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ae[la], w.pd[0], sm, nullptr, w.sd[0], 0, nullptr, 0, &ex);
+}
+
+// the last frame's mel row: same arithmetic as every other frame's (AudioEnc C_1's prologue), without the rest of the piece
+static int v3_final_mel(dctts_ctx* c, const DecodeWs& w, int B, int T, hipStream_t sm) {
+  const std::vector<DevLayer>& AD = c->ad_c;
+  const size_t la = AD.size() - 1;
+  RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
+  n.act = ACT_SIGMOID;
+  return run_split(c, 16, c->ae_c[0], B, 1, nullptr, T, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1);
+}
+
+static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
+  CHK(decode_v2_init(c));
+  CHK(v3_aepre_table(c, w, B));
+  hipStream_t sb = c->s_bulk;
+  const bool gr = c->use_graph != 0;
+  if (gr) {
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
+    if (c->bulk3_g.empty() || c->graphs3_geom != g) {
+      destroy_graphs2(c);
+      hipStream_t cs;
+      HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+      const int prof_keep = c->prof_id; c->prof_id = -1;
+      c->bulk3_g.assign(T, nullptr);
+      int rc = 0;
+      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, f, cs); });
+      c->prof_id = prof_keep;
+      HIPCHK(hipStreamDestroy(cs));
+      if (rc != 0) { destroy_graphs2(c); return rc; }
+      c->graphs3_geom = g;
+    }
+  }
+  CHK(v3_vw(c, w, B, N, st));                                              // V . W_top, once per batch
+  HIPCHK(hipEventRecord(c->ev_fork, st));
+  HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
+  const int skip = getenv("DCTTS_V3_SKIP") ? atoi(getenv("DCTTS_V3_SKIP")) : 0;   // timing experiments only: 1 = no bulk work, 2 = no chain work
+  auto bulk_piece = [&](int f) -> int {
+    if (skip == 1) { HIPCHK(hipEventRecord(c->ev_aepre[f & 3], sb)); HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb)); return 0; }
+    CHK(v3_aepre(c, B, f, sb));
+    HIPCHK(hipEventRecord(c->ev_aepre[f & 3], sb));
+    if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, f, sb));
+    HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb));
+    return 0;
+  };
+  const char* tenv = getenv("DCTTS_TRACE");
+  const int tstep = tenv ? atoi(tenv) : -1;
+  const auto host_t0 = std::chrono::steady_clock::now();
+  CHK(bulk_piece(0));
+  CHK(v3_chain_enc(c, w, B, N, 0, st, c->ev_aepre[0]));                  // chain piece -1
+  HIPCHK(hipEventRecord(c->ev_chain[3], st));
+  for (int j = 0; j < T; ++j) {
+    if (j + 1 < T) {
+      HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));        // bulk piece j+1 needs attnq(j) / C1Q[j]: end of chain piece j-1
+      CHK(bulk_piece(j + 1));
+    }
+    HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0));
+    if (j == tstep) {
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * (8 + 256) * sizeof(long long))); }
+      HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * (8 + 256) * sizeof(long long), st));
+      c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
+    }
+    if (skip != 2) {
+    CHK(v3_chain_dec(c, w, B, j, st));
+    if (j + 1 < T) CHK(v3_chain_enc(c, w, B, N, j + 1, st, c->ev_aepre[(j + 1) & 3]));
+    else CHK(v3_final_mel(c, w, B, T, st));
+    }
+    HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
+    if (c->trace_on) {
+      c->trace_on = false; g_trace_ctx = nullptr;
+      HIPCHK(hipStreamSynchronize(st));
+      CHK(write_trace(c, j));
+    }
+  }
+  if (getenv("DCTTS_HOSTTIME")) {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
+    fprintf(stderr, "[dctts] decode v3: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
+  }
+  return 0;
+}
+
 static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, hipStream_t st) {
   if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
-  const bool v2 = (c->decode_mode == 1);
+  const bool v2 = (c->decode_mode == 1), v3 = (c->decode_mode == 3);
   if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
   if (const char* e = getenv("DCTTS_FUSE_MEL")) c->fuse_mel = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_SMALL")) c->bulk_small_rows = atoi(e);
+  if (const char* e = getenv("DCTTS_BULK3_SMALL")) c->bulk3_small_rows = atoi(e);
+  if (const char* e = getenv("DCTTS_BULK3_FUSED")) c->bulk3_fused = atoi(e);
   if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   if (v2) CHK(decode_v2_init(c));
-  if (!v2) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // v1 uses one copy of every buffer
+  if (!v2 && !v3) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }     // v1 uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
   HIPCHK(hipMemsetAsync(w.step, 0, 256, st));                              // v1's device-side frame counter
   HIPCHK(hipMemsetAsync(w.pm_all, 0, (size_t)B * sizeof(int), st));      // prev_max_attentions = zeros (synthesize.py:46)
-  if (v2) {
+  if (v3) {
+    CHK(decode_v3(c, w, B, N, T, st));
+  } else if (v2) {
     hipStream_t sb = c->s_bulk;
     // use_graph: 0 = every launch eager; 1 = bulk pieces as per-frame graphs, chain launches eager (default: a graph launch per
     // chain piece costs ~11 us of start-up on the critical path, the bulk's is hidden); 2 = both as graphs
@@ -1092,7 +1417,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
       fprintf(stderr, "[dctts] decode: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
     }
   } else if (c->use_graph) {
-    const std::string g = geom("graph1", B, T, N);
+    const std::string g = geom("graph1", B, T, N) + ":" + std::to_string((size_t)w.kv.p);   // the captured launches bake in the TextEnc output pointer
     if (!c->graph_exec || c->graph_geom != g) {
       if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
@@ -1144,8 +1469,8 @@ extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
 }
 
 extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 2) return fail(DCTTS_ERR_ARG, "decode mode must be 0, 1 or 2");
-  c->decode_mode = mode ? 1 : 0;
+  if (!c || mode < 0 || mode > 3) return fail(DCTTS_ERR_ARG, "decode mode must be 0, 1, 2 or 3");
+  c->decode_mode = (mode == 3) ? 3 : (mode ? 1 : 0);
   c->fuse_mlp = (mode == 2) ? 1 : 0;
   return 0;
 }

@@ -119,6 +119,10 @@ struct SplitParams {
   const float* wp; const float* bias; int cout; int hc; int np_out;
   float* pout;                                                   // pre-norm rows [b*R + r][np_out]
   float* stats_out;                                              // optional partial statistics of pout (16-row form only)
+  // ---- decode v3 (hoisted taps): the chain contracts only the centre tap; everything else arrives as a per-row presum
+  const float* presum; int presum_rstride;                       // 16-row form, R == 1: bias + older taps of row b at presum[b * rstride + col] (replaces bias)
+  float* raw_out; long raw_bstride; long raw_row0; int raw_stride;   // 16-row form, R == 1: the bare contraction (no bias / presum) -> raw_out[b][t][col]
+  int mask_last;                                                 // hbulk_kernel<12>: row r == R-1 of every utterance is a presum row (centre tap contributes 0)
   long long* dbg;                                                // optional: 8 wall-clock (100 MHz) stamps of workgroup 0
   long long* dbg_wg;                                             // optional: (entry, end) stamps of every workgroup (<= 128)
 };
@@ -143,6 +147,9 @@ __device__ __forceinline__ void prefetch_params(const SplitParams& p) {
   DCTTS_SGPR(p.xsrc); DCTTS_SGPR(p.xs_bstride); DCTTS_SGPR(p.xs_row0); DCTTS_SGPR(p.xs_stride); DCTTS_SGPR(p.xs_set);
   DCTTS_SGPR(p.ntaps); DCTTS_SGPR(p.tap_off[0]); DCTTS_SGPR(p.tap_off[1]); DCTTS_SGPR(p.tap_off[2]); DCTTS_SGPR(p.cin); DCTTS_SGPR(p.cin_p);
   DCTTS_SGPR(p.wp); DCTTS_SGPR(p.bias); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.hc); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.stats_out);
+  if constexpr (NT == 1) {
+    DCTTS_SGPR(p.presum); DCTTS_SGPR(p.presum_rstride); DCTTS_SGPR(p.raw_out); DCTTS_SGPR(p.raw_bstride); DCTTS_SGPR(p.raw_row0); DCTTS_SGPR(p.raw_stride);
+  }
 }
 
 // Sum over the four lanes l, l^16, l^32, l^48 (the lanes that share an A-operand row in the 16x16x4 layout), on the
@@ -241,7 +248,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     }
 
     // ---- this lane's A row (MFMA A operand: lane -> row lane % MF, k sub-block lane / MF)
-    int b = 0, t = 0; long prow = -1; bool valid = false;
+    int b = 0, t = 0; long prow = -1; bool valid = false, cmask = false;
     {
       const int m = m0 + arow;
       if (arow < p.tile_rows && m < p.M) {
@@ -251,6 +258,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         t = step + (p.offs ? p.offs[r] : 0);
         prow = (long)b * p.R + r;
         valid = (t >= 0);
+        cmask = (NT == 3) && p.mask_last && (r == p.R - 1);     // v3 presum row: the chain contracts its centre tap
       }
       if (wave == 0 && aq == 0) s_prow[arow] = valid ? prow : -1;
     }
@@ -297,7 +305,17 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         const int l = tid & 63, tile = ONE ? mytile : (tid >> 8), col = l & 15;
         const int pc = p.hc ? ((grp * MF + col) < p.cout ? tile * p.cout + grp * MF + col : 0)
                             : (((grp * 2 + tile) * MF + col) < p.cout ? (grp * 2 + tile) * MF + col : 0);
-        biasv = p.bias[(unsigned)pc];
+        if constexpr (NT == 1) {
+          // v3: the per-row presum (bias + the older taps, computed off the critical path) takes the place of the bias.
+          // Epilogue element of this thread: row (l >> 4) * 4 + ((tid >> 6) & 3) of the tile; R == 1, so the row index is b.
+          const int erow = (l >> 4) * 4 + ((tid >> 6) & 3), em = m0 + erow;
+          const bool eok = erow < p.tile_rows && em < p.M;
+          const bool ps = p.presum != nullptr;                                       // uniform: scalar select of base and offset
+          const unsigned boff = ps ? (eok ? (unsigned)((p.b0 + em) * p.presum_rstride + pc) : 0u) : (unsigned)pc;
+          biasv = (ps ? p.presum : p.bias)[boff];
+        } else {
+          biasv = p.bias[(unsigned)pc];
+        }
       }
       if constexpr (TRACE) { if (tr) p.dbg[2] = wall_clock64(); }
       // discard what the redirected loads fetched
@@ -306,7 +324,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         const int g = wave + 8 * i;
         int tap, c; tap_c(i, g, tap, c);
         const bool centre = ln && tap == ctap;
-        if constexpr (FULL) { if (!valid) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if constexpr (FULL) { if (!valid || (NT == 3 && tap == 2 && cmask)) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
         else { if (g >= KG || !valid || c >= p.cin) av[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
       }
     } else {
@@ -427,6 +445,9 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
       int pcol; bool ok;
       if (p.hc) { const int c = grp * MF + col; ok = c < p.cout; pcol = tile * p.cout + c; }
       else      { pcol = (grp * 2 + tile) * MF + col; ok = pcol < p.cout; }
+      if constexpr (MF == 16 && NT == 1) {
+        if (p.raw_out && ok && orow >= 0) p.raw_out[((long)orow * p.raw_bstride + p.raw_row0 + step) * p.raw_stride + pcol] = v_;
+      }
       if constexpr (MF == 16) { if (ok) v_ += biasv; } else { if (ok) v_ += p.bias[pcol]; }
       if (ok && orow >= 0) p.pout[orow * p.np_out + pcol] = v_;
       if constexpr (MF == 16) {
@@ -456,24 +477,19 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 // so the ~1.5 us a work item used to wait for its first loads, and the scalar set-up before them, overlap the reduction and
 // the stores of the previous one.  The epilogue issues no loads of its own (its two bias values ride along with the item's
 // loads): a load there would have to be waited for with vmcnt(0), i.e. behind everything just issued for the next item.
-template <int NG>
-__global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
+template <int NG, typename PT>
+__device__ __forceinline__ void hbulk_body(const PT& p, const int step, const int item0, const int item_stride, const int nitems,
+                                           float* smem, long (*s_prow)[32]) {
   constexpr int MF = 32, NJ = 16, BD = 4, KG = NG * 8;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  __shared__ long s_prow[2][MF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  prefetch_params<1>(p);
-  const int step = p.step_val + (p.step ? *p.step : 0);
   const long par = step & 1;
-  const int ntile = (p.M + MF - 1) / MF;
-  const int nitems = ntile * p.ngroups;
   const int arow = lane & 31, c4 = (lane >> 5) * 4;
   const float* wb = p.wp + lane * 4;
   const int ecol = lane & 31;                                  // this thread's output column inside a tile (epilogue)
 
   float4 av[NG], bq0[BD], bq1[BD];
   unsigned w0o = 0, w1o = 0;
-  bool valid = false;
+  bool valid = false, cmask = false;
   int grp = 0;
   float bias0 = 0.f, bias1 = 0.f;
   // row info + every first load of `item`; results land in the variables above (they are dead once the K loop is done)
@@ -484,10 +500,10 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
     w0o = (unsigned)(grp * 2) * (unsigned)KG * 256u; w1o = w0o + (unsigned)KG * 256u;
 #pragma unroll
     for (int i = 0; i < BD; ++i) {
-      const unsigned g = (unsigned)(wave + 8 * i);
+      const unsigned g = (unsigned)(wave + 8 * (i < NG ? i : NG - 1));
       bq0[i] = ld4u(wb, w0o + g * 256u); bq1[i] = ld4u(wb, w1o + g * 256u);
     }
-    int b = 0, t = 0; long prow = -1; valid = false;
+    int b = 0, t = 0; long prow = -1; valid = false; cmask = false;
     const int m = m0 + arow;
     if (m < p.M) {
       int bl = m, r = 0;
@@ -496,6 +512,7 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
       t = step + (p.offs ? p.offs[r] : 0);
       prow = (long)b * p.R + r;
       valid = (t >= 0);
+      cmask = p.mask_last && (r == p.R - 1);                   // presum row: the centre tap is contracted by the chain, not here
     }
     if (wave == 0 && lane < 32) s_prow[slot][arow] = valid ? prow : -1;
     const unsigned xs_row = valid ? (unsigned)(par * p.xs_set + ((long)b * p.xs_bstride + p.xs_row0 + t) * p.xs_stride) : (unsigned)(p.xs_row0 * p.xs_stride);
@@ -512,14 +529,14 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
     }
   };
 
-  int item = blockIdx.x, slot = 0;
+  int item = item0, slot = 0;
   if (item >= nitems) return;
   issue(item, slot);
   for (;;) {
     const int grp_c = grp;
     const float b0c = bias0, b1c = bias1;
     const unsigned w0c = w0o, w1c = w1o;
-    const bool valid_c = valid;
+    const bool valid_c = valid, cmask_c = cmask;
     typedef float f32x16_ __attribute__((ext_vector_type(16)));
     f32x16_ acc0, acc1;
 #pragma unroll
@@ -528,6 +545,7 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
     for (int i = 0; i < NG; ++i) {
       float4 a = av[i];
       if (!valid_c) a = make_float4(0.f, 0.f, 0.f, 0.f);           // skipped rows (t < 0) contribute nothing
+      if (NG == 12 && i >= 8) { if (cmask_c) a = make_float4(0.f, 0.f, 0.f, 0.f); }   // k-groups 64..95 = tap 2 (the centre) of a 3 x 256 layer
       const float4 b0 = bq0[i % BD], b1 = bq1[i % BD];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc1, 0, 0, 0);
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc1, 0, 0, 0);
@@ -545,7 +563,7 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
       smem[((wave * 2 + 1) * NJ + j) * 64 + lane] = acc1[j];
     }
     // next item's loads go out now; the last item re-issues itself (clamped) so that no branch surrounds the loads
-    const int next = item + (int)gridDim.x;
+    const int next = item + item_stride;
     const bool more = next < nitems;
     issue(more ? next : item, slot ^ 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -573,10 +591,34 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
   }
 }
 
+template <int NG>
+__global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ long s_prow[2][32];
+  prefetch_params<3>(p);
+  const int step = p.step_val + (p.step ? *p.step : 0);
+  const int nitems = ((p.M + 31) / 32) * p.ngroups;
+  hbulk_body<NG, SplitParams>(p, step, blockIdx.x, gridDim.x, nitems, smem, s_prow);
+}
+
+// Several independent layers of the same shape in ONE launch (v3: the presums of AudioEnc's ten causal k = 3 layers for the
+// next frame).  tab[layer] is a frame-independent descriptor in device memory; the frame index is a kernel argument.
+// grid = nlayers * items_per_layer, one item per workgroup.
+typedef const __attribute__((address_space(4))) SplitParams ConstSplitParams;   // constant address space: uniform field reads are scalar loads
+template <int NG>
+__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ long s_prow[2][32];
+  const int layer = blockIdx.x / items_per_layer, item = blockIdx.x - layer * items_per_layer;
+  ConstSplitParams& p = *((ConstSplitParams*)tab + layer);
+  hbulk_body<NG, ConstSplitParams>(p, step, item, items_per_layer, items_per_layer, smem, s_prow);
+}
+
 // Row kernel for the bulk branch: X[b][t] = act / gate (LN(P[b*R + r])) for cone rows at offsets < 0.
 // grid ceil(M/4), block 256 (wave per row).
 struct LnRowsParams {
   int M, R, b0; const int* offs; const int* step; int step_val;
+  int Rp;                                  // rows per utterance in P (0 = R; v3: R + 1, the last P row of an utterance is the chain's presum)
   int hc; RowNorm nrm;
   float* x; long x_bstride; long x_row0; int x_stride; long x_set;
 };
@@ -589,7 +631,7 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnRowsParams p) {
   const long par = step & 1;
   const int t = step + (p.offs ? p.offs[r] : 0);
   if (t < 0) return;
-  const long prow = (long)b * p.R + r;
+  const long prow = (long)b * (p.Rp ? p.Rp : p.R) + r;
   const float4 x = p.hc ? norm_row_hc(p.nrm, prow, b, t, lane, par) : norm_row_c(p.nrm, prow, lane);
   *reinterpret_cast<float4*>(p.x + par * p.x_set + ((long)b * p.x_bstride + p.x_row0 + t) * p.x_stride + lane * 4) = x;
 }
@@ -627,13 +669,18 @@ __global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Param
       lg[k] = wave_sum(a) * scale;
     }
   }
-  float mx = lg[0]; int am = 0;
+  float mx = lg[0];
 #pragma unroll
-  for (int k = 1; k < 3; ++k) if (lg[k] > mx) { mx = lg[k]; am = k; }
+  for (int k = 1; k < 3; ++k) mx = fmaxf(mx, lg[k]);
   float e[3], se = 0.f;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { e[k] = (k < nk) ? expf(lg[k] - mx) : 0.f; se += e[k]; }
   const float inv = 1.0f / se;
+  // tf.argmax of the POST-softmax row, first index on ties (networks.py:148-149): two logits an ulp apart can give equal
+  // probabilities, and the reference then keeps the lower index
+  int am = 0; float pbest = e[0] * inv;
+#pragma unroll
+  for (int k = 1; k < 3; ++k) { const float a = e[k] * inv; if (a > pbest) { pbest = a; am = k; } }
   float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int k = 0; k < 3; ++k) {

@@ -31,19 +31,21 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
   __shared__ long s_inrow[16];
   __shared__ long s_outrow[16];
   __shared__ long s_out2row[16];
+  __shared__ long s_pre[16];             // >= 0: presum row, value = utterance index (decode v3)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int arow = lane & 15, aq = lane >> 4;
   const int m0 = m_start + blockIdx.x * 16;
-  const int t_base = p.step ? *p.step : 0;
+  const int t_base = p.step ? *p.step : p.t_base_val;
 
   if (tid < 16) {
     const int m = m0 + tid;
-    long inrow = -1, outrow = -1, out2row = -1;
+    long inrow = -1, outrow = -1, out2row = -1, pre = -1;
     if (m < p.M) {
       const int b = m / p.R, r = m - b * p.R;
       const int t = t_base + (p.offs ? p.offs[r] : r);
       if (t >= 0) {
+        if (p.presum_out && r == p.R - 1) pre = b;
         if (p.gather) {       // embedding lookup (modules.py:13-42): an id outside the table reads row 0 (= the all-zero PAD row), never out of bounds
           const int id = p.gather[m];
           inrow = (id >= 0 && id < p.gather_n) ? id : 0;
@@ -54,13 +56,14 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
         out2row = (long)b * p.out2_bstride + p.out2_row0 + t;
       }
     }
-    s_inrow[tid] = inrow; s_outrow[tid] = outrow; s_out2row[tid] = out2row;
+    s_inrow[tid] = inrow; s_outrow[tid] = outrow; s_out2row[tid] = out2row; s_pre[tid] = pre;
   }
   __syncthreads();
 
   // ---- A loader: thread (lrow, lc4) moves one float4 per chunk (16 rows x 32 channels)
   const int lrow = (tid >> 3) & 15, lc4 = tid & 7;
   const long my_inrow = s_inrow[lrow];
+  const int mask_tap = (s_pre[lrow] >= 0) ? p.ntaps - 1 : -1;        // a presum row leaves its last (centre) tap to the chain
   const int cpt = p.cin_p >> 5;
   const int nch = p.ntaps * cpt;
   const int KG = nch * 2;                // k-groups of 16
@@ -69,7 +72,7 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int tap = ch / cpt;
     const int c = (ch - tap * cpt) * 32 + lc4 * 4;
-    if (tid < 128 && my_inrow >= 0 && c < p.cin) {
+    if (tid < 128 && my_inrow >= 0 && c < p.cin && tap != mask_tap) {
       const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
       v = *reinterpret_cast<const float4*>(p.in + (my_inrow + toff) * (long)p.in_stride + c);
     }
@@ -202,6 +205,11 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
         const int row = aq * 4 + j;
         const long orow = s_outrow[row];
         if (orow < 0) continue;
+        if (s_pre[row] >= 0) {                                       // presum row: bias + older taps, un-normalised, for the chain
+          float* pr = p.presum_out + s_pre[row] * p.presum_rstride;
+          pr[ch_] = acc[2 * k][j]; pr[C + ch_] = acc[2 * k + 1][j];
+          continue;
+        }
         const float y1 = (acc[2 * k][j] - mean[0][j]) * rstd[0][j] * g1 + b1;
         const float y2 = (acc[2 * k + 1][j] - mean[1][j]) * rstd[1][j] * g2 + b2;
         const float gt = sigmoidf_(y1);

@@ -57,6 +57,10 @@ struct ConvParams {
   int out_zero_to;        // columns [cout, out_zero_to) of each output row are written as 0
   float* out2; long out2_bstride; long out2_row0; int out2_stride;   // optional pre-activation copy (logits)
   int act;
+  // ---- decode v3 (hconv16_kernel only): frame index by value, and presum rows
+  int t_base_val;         // t_base when step == nullptr
+  float* presum_out;      // when set: row r == R-1 of every utterance is a PRESUM row -- its last tap is not contracted (the decode chain
+  long presum_rstride;    //   does that) and bias + the older taps go, un-normalised, to presum_out[b * presum_rstride + column]
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }

@@ -92,3 +92,98 @@ def incremental_decode(L, W, hp, dtype=np.float32, frozen_R=False):
         Ypad[:, PAD + j + 1, :] = Y[:, j, :]
         p = traj[:, j].copy()
     return Y, traj
+
+
+def incremental_decode_v3(L, W, hp, dtype=np.float32, stats=None):
+    """numpy MODEL of the round-2 decode data flow (decode3_kernels.h / dctts_api.hip: decode v3).  Same arithmetic as
+    ``incremental_decode`` up to fp32 re-association, organised the way the HIP path computes it:
+
+    * AudioDec C_1 never sees R.  With W1 = [W_top ; W_bot] (networks.py:167-174 applied to R = [A.V ; Q], :150-151)
+        C_1pre[t] = bias + sum_k a_k(t) * VW[p+k] + C1Q[t],   VW[n] = V[n] . W_top  (once per batch),
+                                                              C1Q[t] = Q[t] . W_bot (once per frame, window-independent)
+      so re-evaluating C_1 over the 84 older cone rows with a new window is a row operation, not a GEMM.
+    * every causal k=3 layer's newest row is  presum + x[t] . W[2]  where  presum = bias + x[t-2d] . W[0] + x[t-d] . W[1]
+      only reads rows that are final (AudioEnc) or computed by the bulk of the same frame (AudioDec cone rows < j):
+      the two older taps leave the latency-critical chain.
+    ``stats`` (dict) receives the minimum top-2 gap of the newest row's window logits."""
+    B, T, d = L.shape[0], hp.max_T, hp.d
+    K, V = O.TextEnc(L, W, hp, dtype)
+    ae, ad = audioenc_layers(hp), audiodec_layers(hp)
+    cone = audiodec_cone(hp)
+    Pe = O._Scoped(W, "Text2Mel/AudioEnc", dtype)
+    Pd = O._Scoped(W, "Text2Mel/AudioDec", dtype)
+    W1 = Pd["C_1/conv1d/kernel"][0]                              # (2d, d)
+    VW = V @ W1[:d]                                               # (B, N, d)
+    b1 = Pd["C_1/conv1d/bias"]
+    Ypad = np.zeros((B, PAD + T + 1, hp.n_mels), dtype)
+    AE = [np.zeros((B, PAD + T, l.cout), dtype) for l in ae]
+    C1Q = np.zeros((B, PAD + T, d), dtype)
+    AD = [np.zeros((B, PAD + T, l.cout), dtype) for l in ad]
+    Y = np.zeros((B, T, hp.n_mels), dtype)
+    traj = np.zeros((B, T), np.int64)
+    p = np.zeros((B,), np.int64)
+    scale = dtype(1.0 / np.sqrt(dtype(d)))
+    min_gap = np.inf
+
+    def hc_from_pre(l, P, pre, xres):
+        C = l.cout
+        H1 = O.sigmoid(O.normalize(pre[..., :C], P[l.scope + "/H1/gamma"], P[l.scope + "/H1/beta"]))
+        H2 = O.normalize(pre[..., C:], P[l.scope + "/H2/gamma"], P[l.scope + "/H2/beta"])
+        return H1 * H2 + (1.0 - H1) * xres
+
+    def presum(l, P, inbuf, t):
+        Wk = P[l.scope + "/conv1d/kernel"]
+        return P[l.scope + "/conv1d/bias"] + inbuf[:, PAD + t - 2 * l.rate, :] @ Wk[0] + inbuf[:, PAD + t - l.rate, :] @ Wk[1]
+
+    def attn_weights(b, rows):
+        n0 = int(p[b]); n1 = min(n0 + hp.attention_win_size, hp.max_N)
+        q = AE[-1][b, PAD + np.asarray(rows), :]
+        lg = (q @ K[b, n0:n1, :].T) * scale
+        e = np.exp(lg - lg.max(-1, keepdims=True))
+        return n0, n1, lg, e / e.sum(-1, keepdims=True)
+
+    for j in range(T):
+        # ---- chain: AudioEnc row j (presums read final history rows only)
+        src = Ypad
+        for li, l in enumerate(ae):
+            if l.kind == "C":
+                AE[li][:, PAD + j, :] = _layer_rows(l, Pe, src, [j], dtype)[:, 0, :]
+            else:
+                pre = presum(l, Pe, src, j) + src[:, PAD + j, :] @ Pe[l.scope + "/conv1d/kernel"][2]
+                AE[li][:, PAD + j, :] = hc_from_pre(l, Pe, pre, src[:, PAD + j, :])
+            src = AE[li]
+        # ---- chain: attention row j -> next window, C_1 presum; C_1's GEMM is Q[j] . W_bot only
+        C1Q[:, PAD + j, :] = AE[-1][:, PAD + j, :] @ W1[d:]
+        pre0 = np.zeros((B, d), dtype)
+        for b in range(B):
+            n0, n1, lg, a = attn_weights(b, [j])
+            traj[b, j] = n0 + int(np.argmax(a[0]))                # argmax over the post-softmax row (networks.py:149)
+            if n1 - n0 > 1:
+                s = np.sort(lg[0].astype(np.float64)); min_gap = min(min_gap, s[-1] - s[-2])
+            pre0[b] = b1 + a[0] @ VW[b, n0:n1, :]
+        # ---- bulk of frame j: cone rows at offsets < 0 with the CURRENT window (p = prev_max fed at step j)
+        rows = [j + o for o in cone[0] if o < 0 and j + o >= 0]
+        if rows:
+            for b in range(B):
+                n0, n1, lg, a = attn_weights(b, rows)
+                pre = b1 + a @ VW[b, n0:n1, :] + C1Q[b, PAD + np.asarray(rows), :]
+                AD[0][b, PAD + np.asarray(rows), :] = O.normalize(pre, Pd["C_1/normalize/gamma"], Pd["C_1/normalize/beta"])
+        for li in range(1, len(ad)):
+            rows_l = [j + o for o in cone[li] if o < 0 and j + o >= 0]
+            if rows_l:
+                AD[li][:, PAD + np.asarray(rows_l), :] = _layer_rows(ad[li], Pd, AD[li - 1], rows_l, dtype)
+        # ---- chain: AudioDec row j
+        AD[0][:, PAD + j, :] = O.normalize(pre0 + C1Q[:, PAD + j, :], Pd["C_1/normalize/gamma"], Pd["C_1/normalize/beta"])
+        for li in range(1, len(ad)):
+            l = ad[li]
+            if l.kind == "C":
+                AD[li][:, PAD + j, :] = _layer_rows(l, Pd, AD[li - 1], [j], dtype)[:, 0, :]
+            else:
+                pre = presum(l, Pd, AD[li - 1], j) + AD[li - 1][:, PAD + j, :] @ Pd[l.scope + "/conv1d/kernel"][2]
+                AD[li][:, PAD + j, :] = hc_from_pre(l, Pd, pre, AD[li - 1][:, PAD + j, :])
+        Y[:, j, :] = O.sigmoid(AD[-1][:, PAD + j, :])
+        Ypad[:, PAD + j + 1, :] = Y[:, j, :]
+        p = traj[:, j].copy()
+    if stats is not None:
+        stats["min_top2_logit_gap"] = float(min_gap)
+    return Y, traj

@@ -160,6 +160,46 @@ def test_incremental_model_equals_reference_loop(weights):
     assert np.abs(Y - Yf).max() > 1e-2                       # the 'obvious' cache is a different function
 
 
+def short_text(h, B, seed):
+    """(B, h.max_N) ids for a tiny max_N (the attention window must run into the end of the text within a short decode)."""
+    rng = np.random.default_rng(seed)
+    L = rng.integers(2, len(h.vocab), (B, h.max_N)).astype(np.int32)
+    L[:, -1] = 1
+    return L
+
+
+def test_v3_model_equals_reference_loop(weights):
+    """Round-2 decode data flow (tests/algo_model.incremental_decode_v3: AudioDec C_1 as a row operation on V.W_top / Q.W_bot,
+    the two older taps of every causal k=3 layer as presums) == the restated synthesize.py loop, fp64: the reorganisation is
+    exact algebra, not an approximation."""
+    from algo_model import incremental_decode_v3
+    from dc_tts_amd.weights import synthetic_text
+    h = hp.replace(max_T=100)
+    L = synthetic_text(h, B=2, seed=7)
+    Y, _, traj = O.synthesize(L, weights, h, np.float64, run_ssrn=False)
+    st = {}
+    Y3, traj3 = incremental_decode_v3(L, weights, h, np.float64, stats=st)
+    np.testing.assert_array_equal(traj, traj3)
+    assert np.abs(Y - Y3).max() < 1e-9
+    assert st["min_top2_logit_gap"] > 0
+
+
+def test_end_of_text_window_clipping_models(weights):
+    """networks.py:142-147 once prev_max >= max_N - 2: the window is clipped to 2, then 1 key.  A 10-character text saturates
+    within ~40 frames; both incremental models must follow the restated loop through and beyond saturation (fp32, trajectory
+    integer-exact)."""
+    from algo_model import incremental_decode, incremental_decode_v3
+    h = hp.replace(max_N=10, max_T=90)
+    L = short_text(h, 2, 11)
+    Y, _, traj = O.synthesize(L, weights, h, np.float32, run_ssrn=False)
+    assert traj.max() == h.max_N - 1 and (traj[:, -1] == h.max_N - 1).all()
+    assert (traj == h.max_N - 2).any()                       # the 2-key window was visited too
+    for fn in (incremental_decode, incremental_decode_v3):
+        Yi, ti = fn(L, weights, h, np.float32)
+        np.testing.assert_array_equal(traj, ti)
+        assert np.abs(Y - Yi).max() < 1e-4
+
+
 # ---------------------------------------------------------------- golden fixtures
 def _gold(name):
     path = os.path.join(GOLD, name)

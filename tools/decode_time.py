@@ -5,6 +5,7 @@ from dc_tts_amd.hyperparams import hp
 from dc_tts_amd.weights import synthetic_weights, synthetic_text
 T = 210
 eng = Engine(synthetic_weights(hp), hp, decode_graph=int(os.environ.get("GM", "1")))
+eng.set_decode_mode(int(os.environ.get("DM", "3")))
 L = torch.from_numpy(synthetic_text(hp, B=32)).cuda()
 for _ in range(2): eng.text2mel(L)
 torch.cuda.synchronize()
