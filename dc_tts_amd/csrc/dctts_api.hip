@@ -3,6 +3,7 @@
 // synthesize.py:45-57.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -91,6 +92,7 @@ struct DevLayer {
   float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for rowmlp_kernel
   float* wp16c = nullptr;         // decode causal k=3 layers (v3): centre tap only, 16x16x4 tiles (the chain contracts K = 256)
   float* wpp = nullptr;           // decode causal k=3 layers (v3): the two older taps, 32x32x2 tiles (presum GEMM, K = 512)
+  bool tap2 = false;              // v3 chain view of a dilation-1 AudioEnc layer: the chain contracts taps -1 and 0 (K = 512), the presum holds tap -2 only
   int cin_real = 0;
   bool hc = false;
 };
@@ -123,11 +125,14 @@ struct dctts_ctx {
   std::vector<DevLayer> ae_c, ad_c;    // chain view of AudioEnc / AudioDec: k=3 layers reduced to their centre tap (k=1 layers unchanged)
   std::vector<DevLayer> ae_p;          // presum view of AudioEnc's k=3 layers (taps -2d, -d; K = 512); entries of k=1 layers are unused
   DevLayer ad_c1q, ad_vw;              // AudioDec C_1 split by input rows: Q half (chain, 16-row tiles), A.V half (V . W_top precompute)
+  DevLayer hc2_wt[3], hc2_wt2[3];      // AudioDec HC_2 as a row operation (rowhc2_kernel): diag(gamma_C1) W2[q], K = 256 / zero-padded to K = 512
+  float* hc2_consts = nullptr;         // [3 taps][beta1 . W2[q], b1 . Wt_q, 1^T Wt_q][512]
+  float* zeros512 = nullptr;
   std::vector<int*> cone3_dev;         // per AudioDec layer: cone offsets < 0 (descending) followed by 0 (the presum row)
   int* iota_dev = nullptr; int iota_n = 0;
-  hipEvent_t ev_aepre[4] = {nullptr, nullptr, nullptr, nullptr};
-  std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;
+  std::vector<hipGraphExec_t> bulk3_g, chain3_g; std::string graphs3_geom;
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
+  int hc2_rowop = 1;                   // v3: AudioDec HC_2's cone rows as a row operation on cached products (0: GEMM + LN pass; DCTTS_HC2_ROWOP)
   int bulk3_fused = 0;                 // v3 bulk layers with more rows: 1 = full-row 16-row items with fused LN (hconv16_kernel), 0 = hbulk + ln_rows
   int bulk3_small_rows = 16;           // v3 bulk layers with at most this many rows per utterance (incl. the presum row) use the 16-row kernel form
   hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
@@ -358,7 +363,6 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   for (int* p : c->cone3_dev) (void)hipFree(p);
   if (c->iota_dev) (void)hipFree(c->iota_dev);
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
-  for (int i = 0; i < 4; ++i) if (c->ev_aepre[i]) (void)hipEventDestroy(c->ev_aepre[i]);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;
@@ -432,6 +436,22 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     auto centre = [](const DevLayer& L) { DevLayer x = L; if (L.wp16c) { x.ntaps = 1; x.tap_off[0] = x.tap_off[1] = x.tap_off[2] = 0; x.wp16 = L.wp16c; } return x; };
     auto older = [](const DevLayer& L) { DevLayer x = L; if (L.wpp) { x.ntaps = 2; x.tap_off[2] = 0; x.wp = L.wpp; } return x; };
     for (const DevLayer& L : c->audioenc) { c->ae_c.push_back(centre(L)); c->ae_p.push_back(older(L)); }
+    // AudioEnc layers of dilation 1: tap -1 reads the row the chain produced one frame earlier, so it stays in the chain (K = 512)
+    // and the presum -- computed a whole chain piece ahead, inside the bulk graph -- carries bias + tap -2 only
+    for (size_t i = 0; i < c->audioenc.size(); ++i) {
+      const DevLayer& L = c->audioenc[i];
+      if (!L.wpp || L.tap_off[1] != -1) continue;
+      char sc[96]; snprintf(sc, 96, "Text2Mel/AudioEnc/HC_%d/conv1d/kernel", (int)i + 1);
+      const HostTensor* kw; const int C = L.cout;
+      CHK(get_w(c, sc, {3, C, 2 * C}, &kw));
+      const float* kv2 = kw->v.data();
+      auto W12 = [=](int tap, int cc, int col) { return kv2[((size_t)(tap + 1) * C + cc) * (2 * C) + col]; };
+      auto W0z = [=](int tap, int cc, int col) { return tap == 0 ? kv2[((size_t)cc) * (2 * C) + col] : 0.f; };
+      DevLayer& X = c->ae_c[i]; X.ntaps = 2; X.tap2 = true;
+      CHK(upload(c, pack_bw(W12, 2, C, L.cin_p, 2 * (C / 16), C, true, 16), &X.wp16));
+      DevLayer& Pz = c->ae_p[i]; Pz.tap_off[0] = Pz.tap_off[1] = -2;
+      CHK(upload(c, pack_bw(W0z, 2, C, L.cin_p, L.shape.nt * L.shape.nw, C, true, 32), &Pz.wpp));
+    }
     for (const DevLayer& L : c->audiodec) c->ad_c.push_back(centre(L));
     const HostTensor* k1;
     CHK(get_w(c, s + "C_1/conv1d/kernel", {1, 2 * d, d}, &k1));
@@ -443,6 +463,34 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     c->ad_vw = c->ad_c1q; c->ad_vw.wp16 = nullptr;
     CHK(upload(c, pack_bw(Wtop, 1, d, d, (d + 31) / 32, d, false, 32), &c->ad_vw.wp));
     CHK(upload(c, std::vector<float>(d, 0.f), &c->ad_vw.bias));
+    {
+      // HC_2 as a row operation (decode3_kernels.h: rowhc2_kernel)
+      const HostTensor *k2, *ga1, *be1, *bi1;
+      CHK(get_w(c, s + "HC_2/conv1d/kernel", {3, d, 2 * d}, &k2));
+      CHK(get_w(c, s + "C_1/normalize/gamma", {d}, &ga1)); CHK(get_w(c, s + "C_1/normalize/beta", {d}, &be1)); CHK(get_w(c, s + "C_1/conv1d/bias", {d}, &bi1));
+      const float* w2 = k2->v.data(); const float* gam = ga1->v.data();
+      std::vector<float> consts((size_t)3 * 3 * 2 * d, 0.f);
+      for (int q = 0; q < 3; ++q)
+        for (int cc = 0; cc < d; ++cc)
+          for (int col = 0; col < 2 * d; ++col) {
+            const double wv = w2[((size_t)q * d + cc) * (2 * d) + col], wt = (double)gam[cc] * wv;
+            consts[((size_t)q * 3 + 0) * 2 * d + col] += (float)((double)be1->v[cc] * wv);
+            consts[((size_t)q * 3 + 1) * 2 * d + col] += (float)((double)bi1->v[cc] * wt);
+            consts[((size_t)q * 3 + 2) * 2 * d + col] += (float)wt;
+          }
+      CHK(upload(c, consts, &c->hc2_consts));
+      CHK(upload(c, std::vector<float>(2 * d, 0.f), &c->zeros512));
+      for (int q = 0; q < 3; ++q) {
+        auto Wt = [=](int tap, int cc, int col) { return tap == 0 ? gam[cc] * w2[((size_t)q * d + cc) * (2 * d) + col] : 0.f; };
+        DevLayer L = c->audiodec[1];
+        L.ntaps = 1; L.tap_off[0] = L.tap_off[1] = L.tap_off[2] = 0; L.bias = c->zeros512; L.wp16 = L.wp16c = L.wpp = nullptr;
+        CHK(upload(c, pack_bw(Wt, 1, d, d, L.shape.nt * L.shape.nw, d, true, 32), &L.wp));
+        c->hc2_wt[q] = L;
+        L.ntaps = 2;
+        CHK(upload(c, pack_bw(Wt, 2, d, d, L.shape.nt * L.shape.nw, d, true, 32), &L.wp));
+        c->hc2_wt2[q] = L;
+      }
+    }
     c->iota_n = g.max_N > 1024 ? g.max_N : 1024;
     std::vector<int> io(c->iota_n); for (int q = 0; q < c->iota_n; ++q) io[q] = q;
     HIPCHK(hipMalloc((void**)&c->iota_dev, io.size() * sizeof(int)));
@@ -702,9 +750,12 @@ struct DecodeWs {
   // v3
   float* vw = nullptr;                 // V . W_top  [B*N][d]
   View c1q;                            // Q[t] . W_bot, absolute time
-  std::vector<float*> pse;             // AudioEnc presums per k=3 layer [B][2d] (bias + older taps of the next row)
+  std::vector<float*> pse; long pse_set = 0;   // AudioEnc presums per k=3 layer, two parity copies [2][B][2d] (bias + older taps of row f in copy f & 1)
   std::vector<float*> pb3; long pb3_set[16] = {0};   // AudioDec cone pre-norm rows + presum row, two parity copies: [2][B*(Rb+1)][np]
   float* ps0 = nullptr;                // AudioDec C_1 presum [B][d] (attnq_kernel)
+  float* vww = nullptr;                // VW . diag(gamma1) W2[q]  [B*N][3][2d]  (rowhc2_kernel)
+  View c1qw;                           // C1Q[t] . diag(gamma1) W2[q], absolute time, stride 3 * 2d
+  View scal;                           // rowc1_kernel's per-row scalars, absolute time, stride 8
 };
 
 static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
@@ -747,9 +798,13 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
     CHK(ws_get(c, "dec.vw", (size_t)B * N * d * sizeof(float), &p)); w->vw = (float*)p;
     CHK(ws_view(c, "dec.c1q", B, rows, PAD, d, &w->c1q));
     CHK(ws_get(c, "dec.ps0", (size_t)B * d * sizeof(float), &p)); w->ps0 = (float*)p;
+    CHK(ws_get(c, "dec.vww", (size_t)B * N * 6 * d * sizeof(float), &p)); w->vww = (float*)p;
+    CHK(ws_view(c, "dec.c1qw", B, rows, PAD, 6 * d, &w->c1qw));
+    CHK(ws_view(c, "dec.scal", B, rows, PAD, 8, &w->scal));
     w->pse.assign(c->audioenc.size(), nullptr);
     for (size_t i = 0; i < w->pse.size(); ++i)
-      if (c->audioenc[i].wpp) { CHK(ws_get(c, "dec.pse" + std::to_string(i), (size_t)B * 2 * d * sizeof(float), &p)); w->pse[i] = (float*)p; }
+      if (c->audioenc[i].wpp) { CHK(ws_get(c, "dec.pse" + std::to_string(i), (size_t)2 * B * 2 * d * sizeof(float), &p)); w->pse[i] = (float*)p; }
+    w->pse_set = (long)B * 2 * d;
     w->pb3.assign(c->audiodec.size(), nullptr);
     for (size_t i = 0; i < w->pb3.size(); ++i) {
       if (!c->audiodec[i].wpp) continue;
@@ -816,6 +871,7 @@ struct SplitExtra {                     // decode v3 additions to a split launch
   const float* presum = nullptr; int presum_rstride = 0;   // chain: per-row presum replaces the bias
   const View* raw = nullptr;                                // chain: bare contraction -> raw[b][frame]
   int mask_last = 0;                                        // bulk: the last row of every utterance is a presum row
+  int np_out = 0;                                           // bulk: floats per output row when the output is a slice of wider rows
 };
 
 // One split GEMM launch for frame `frame`.  MF = 16: chain (newest frame, R = 1, offs = null); MF = 32: bulk (cone rows at offsets < 0).
@@ -826,6 +882,7 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   SplitParams p; memset(&p, 0, sizeof(p));
   if (ex) {
     p.presum = ex->presum; p.presum_rstride = ex->presum_rstride; p.mask_last = ex->mask_last;
+    if (ex->np_out && MF != 32) return fail(DCTTS_ERR_STATE, "split kernel: output slices belong to the 32-row form");
     if (ex->raw) { p.raw_out = ex->raw->p; p.raw_bstride = ex->raw->bstride; p.raw_row0 = ex->raw->row0; p.raw_stride = ex->raw->stride; }
     if ((ex->presum || ex->raw) && (MF != 16 || R != 1)) return fail(DCTTS_ERR_STATE, "split kernel: presum / raw output belong to the chain (16-row form, one row per utterance)");
     if (ex->mask_last && (L.ntaps != 3 || L.cin_p != 256 || L.tap_off[2] != 0 || pro != PRO_RAW)) return fail(DCTTS_ERR_STATE, "split kernel: presum rows belong to a causal 3-tap layer over 256 channels");
@@ -838,7 +895,7 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   p.ntaps = L.ntaps; for (int j = 0; j < 3; ++j) p.tap_off[j] = L.tap_off[j];
   p.cin = L.cin; p.cin_p = L.cin_p;
   p.wp = (MF == 16) ? L.wp16 : L.wp; p.bias = L.bias; p.cout = L.cout; p.hc = L.hc ? 1 : 0;
-  p.np_out = L.hc ? 2 * L.cout : L.cout; p.pout = pout; p.stats_in = stats_in; p.stats_out = stats_out;
+  p.np_out = (ex && ex->np_out) ? ex->np_out : (L.hc ? 2 * L.cout : L.cout); p.pout = pout; p.stats_in = stats_in; p.stats_out = stats_out;
   if (pro == PRO_MEL && (MF != 16 || L.ntaps != 1 || !stats_in || !nrm || nrm->np != L.cin))
     return fail(DCTTS_ERR_STATE, "split kernel: the mel prologue feeds a k = 1 layer whose input width is the mel row");
   if (pro != PRO_RAW && pro != PRO_MEL && (MF != 16 || L.cin_p != 256 || !stats_in))
@@ -859,10 +916,14 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   if (ex && (ex->presum || ex->raw) && nt != 1) return fail(DCTTS_ERR_STATE, "split kernel: presum / raw output need the k = 1 x 256-channel chain form");
   const bool one = (MF == 16) && c->chain_one;
   if (one) nblk *= 2;
+  // the chain-only forms (NT = 1, 2, 4 without ONE) take a (column groups, row tiles) grid and assume one row per utterance
+  const bool chainrow = (MF == 16) && (nt == 1 || nt == 2 || nt == 4) && !one;
+  if (chainrow && (R != 1 || offs)) return fail(DCTTS_ERR_STATE, "split kernel: the chain forms take one row per utterance and no offset table");
+  const dim3 grid16 = chainrow ? dim3(groups, (p.M + p.tile_rows - 1) / p.tile_rows) : dim3(nblk);
 #define DCTTS_LAUNCH16(TR, NTV)                                                                                          \
   do {                                                                                                                   \
-    if (one) hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, true>), dim3(nblk), dim3(512), sm, st, p);                \
-    else     hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, false>), dim3(nblk), dim3(512), sm, st, p);               \
+    if (one) hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, true>), grid16, dim3(512), sm, st, p);                    \
+    else     hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, false>), grid16, dim3(512), sm, st, p);                   \
   } while (0)
   if (MF == 16 && p.dbg) {
     if (nt == 3) DCTTS_LAUNCH16(true, 3); else if (nt == 1) DCTTS_LAUNCH16(true, 1); else if (nt == 2) DCTTS_LAUNCH16(true, 2);
@@ -898,15 +959,16 @@ static int decode_v2_init(dctts_ctx* c) {
     if (e && atoi(e) == 0) HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
     else HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, lo));
   }
-  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], hipEventDisableTiming)); }
+  // the two streams hand data to each other through device memory only: device-scope release on the event markers (no system-scope flush)
+  const unsigned evf = (getenv("DCTTS_EV_SYS") ? 0u : (unsigned)hipEventReleaseToDevice) | hipEventDisableTiming;
+  HIPCHK(hipEventCreateWithFlags(&c->ev_fork, evf));
+  for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], evf)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], evf)); }
   HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_group_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_aepre[i], hipEventDisableTiming));
   return 0;
 }
 
@@ -1059,7 +1121,8 @@ static void destroy_graphs2(dctts_ctx* c) {
   c->pro_g = nullptr;
   c->chain_g.clear(); c->bulk_g.clear(); c->graphs2_geom.clear();
   for (hipGraphExec_t g : c->bulk3_g) if (g) (void)hipGraphExecDestroy(g);
-  c->bulk3_g.clear(); c->graphs3_geom.clear();
+  for (hipGraphExec_t g : c->chain3_g) if (g) (void)hipGraphExecDestroy(g);
+  c->bulk3_g.clear(); c->chain3_g.clear(); c->graphs3_geom.clear();
 }
 
 template <typename F>
@@ -1112,34 +1175,50 @@ static int write_trace(dctts_ctx* c, int j) {
 //     AudioEnc presums for row f (one grouped launch) | C_1 cone rows (rowc1_kernel) | per k=3 AudioDec layer: cone rows + the
 //     presum row of frame f in one GEMM, then LN / gate of the cone rows.
 static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
-  const std::string g = std::to_string(B) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back());
+  const std::string g = std::to_string(B) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p);
   if (c->aepre_tab && c->aepre_geom == g) return 0;
   std::vector<SplitParams> tab;
   const std::vector<DevLayer>& AP = c->ae_p;
-  for (size_t i = 0; i < AP.size(); ++i) {
-    if (!AP[i].wpp) continue;
-    const DevLayer& L = AP[i];
-    if (i == 0 || L.cin_p != 256 || L.cout != 256) return fail(DCTTS_ERR_STATE, "v3: AudioEnc k=3 layers must be 256 -> 2 x 256");
-    SplitParams p; memset(&p, 0, sizeof(p));
-    p.M = B; p.R = 1; p.ngroups = L.cout / 32; p.tile_rows = 32; p.pro = PRO_RAW;
-    const View& x = w.ae[i - 1];
-    p.xsrc = x.p; p.xs_bstride = x.bstride; p.xs_row0 = x.row0; p.xs_stride = x.stride; p.xs_set = 0;
-    p.ntaps = 2; p.tap_off[0] = L.tap_off[0]; p.tap_off[1] = L.tap_off[1]; p.cin = L.cin; p.cin_p = L.cin_p;
-    p.wp = L.wpp; p.bias = L.bias; p.cout = L.cout; p.hc = 1; p.np_out = 2 * L.cout; p.pout = w.pse[i];
-    tab.push_back(p);
-  }
+  for (int par = 0; par < 2; ++par)
+    for (size_t i = 0; i < AP.size(); ++i) {
+      if (!AP[i].wpp) continue;
+      const DevLayer& L = AP[i];
+      if (i == 0 || L.cin_p != 256 || L.cout != 256) return fail(DCTTS_ERR_STATE, "v3: AudioEnc k=3 layers must be 256 -> 2 x 256");
+      SplitParams p; memset(&p, 0, sizeof(p));
+      p.M = B; p.R = 1; p.ngroups = L.cout / 32; p.tile_rows = 32; p.pro = PRO_RAW;
+      const View& x = w.ae[i - 1];
+      p.xsrc = x.p; p.xs_bstride = x.bstride; p.xs_row0 = x.row0; p.xs_stride = x.stride; p.xs_set = 0;
+      p.ntaps = 2; p.tap_off[0] = L.tap_off[0]; p.tap_off[1] = L.tap_off[1]; p.cin = L.cin; p.cin_p = L.cin_p;
+      p.wp = L.wpp; p.bias = L.bias; p.cout = L.cout; p.hc = 1; p.np_out = 2 * L.cout; p.pout = w.pse[i] + par * w.pse_set;
+      tab.push_back(p);
+      if (i + 1 == AP.size()) {
+        // riding in the same launch: the newest row of the C1Q . diag(gamma1) W2[q] cache (row f-1 when the launch's step is f+1)
+        for (int q = 0; q < 3; ++q) {
+          const DevLayer& H = c->hc2_wt2[q];
+          SplitParams h; memset(&h, 0, sizeof(h));
+          h.M = B; h.R = 1; h.ngroups = H.cout / 32; h.tile_rows = 32; h.pro = PRO_RAW;
+          h.xsrc = w.c1q.p; h.xs_bstride = w.c1q.bstride; h.xs_row0 = w.c1q.row0; h.xs_stride = w.c1q.stride; h.xs_set = 0;
+          h.ntaps = 2; h.tap_off[0] = h.tap_off[1] = -2; h.cin = H.cin; h.cin_p = H.cin_p;
+          h.wp = H.wp; h.bias = H.bias; h.cout = H.cout; h.hc = 1; h.np_out = 6 * H.cout; h.pout = w.c1qw.p + (long)q * 2 * H.cout;
+          h.abs_bstride = w.c1qw.bstride; h.abs_row0 = w.c1qw.row0; h.abs_toff = -2;
+          tab.push_back(h);
+        }
+      }
+    }
   if (tab.empty()) return fail(DCTTS_ERR_STATE, "v3: no causal k=3 AudioEnc layers");
   (void)hipDeviceSynchronize();
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
   HIPCHK(hipMalloc(&c->aepre_tab, tab.size() * sizeof(SplitParams)));
   HIPCHK(hipMemcpy(c->aepre_tab, tab.data(), tab.size() * sizeof(SplitParams), hipMemcpyHostToDevice));
-  c->aepre_layers = (int)tab.size(); c->aepre_geom = g;
+  c->aepre_layers = (int)tab.size() / 2; c->aepre_geom = g;
   return 0;
 }
 
+// AudioEnc presums for row f (into parity copy f & 1): bias + the taps that are final a whole chain piece before row f is computed
 static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st) {
   const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
-  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, (const SplitParams*)c->aepre_tab, ipl, f);
+  const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * c->aepre_layers;
+  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1148,13 +1227,21 @@ static int v3_vw(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t st) 
   if (N > c->iota_n) return fail(DCTTS_ERR_ARG, "decode: N too large");
   const int d = c->cfg.d;
   const View v{w.kv.p + d, (long)N, 0, 2 * d, 0};                    // V = channels d..2d of TextEnc's output rows
-  return run_split(c, 32, c->ad_vw, B, N, c->iota_dev, 0, PRO_RAW, nullptr, nullptr, v, w.vw, st);
+  CHK(run_split(c, 32, c->ad_vw, B, N, c->iota_dev, 0, PRO_RAW, nullptr, nullptr, v, w.vw, st));
+  const View vw{w.vw, (long)N, 0, d, 0};
+  SplitExtra ex; ex.np_out = 6 * d;
+  for (int q = 0; q < 3; ++q)                                           // VWW[n][q] = VW[n] . diag(gamma1) W2[q]
+    CHK(run_split(c, 32, c->hc2_wt[q], B, N, c->iota_dev, 0, PRO_RAW, nullptr, nullptr, vw, w.vww + (long)q * 2 * d, st, nullptr, nullptr, 0, nullptr, 0, &ex));
+  return 0;
 }
 
-static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, hipStream_t sb) {
+static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, int f, hipStream_t sb) {
   const int d = c->cfg.d;
   const std::vector<DevLayer>& AD = c->audiodec;
   const int par = f & 1;
+  // one grouped launch: AudioEnc presums of row f+1 (consumed by chain piece f; inputs are rows <= f-1) and the newest row (f-1) of
+  // the C1Q . diag(gamma1) W2 cache that rowhc2_kernel reads below
+  CHK(v3_aepre(c, B, f + 1, sb));
   if (c->cone_len[0] > 1) {
     RowC1Params q; memset(&q, 0, sizeof(q));
     q.B = B; q.R = c->cone_len[0] - 1; q.offs = c->cone3_dev[0]; q.frame = f;
@@ -1164,10 +1251,30 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, hi
     q.bias = AD[0].bias; q.g = AD[0].g1; q.be = AD[0].b1;
     q.N = N; q.d = d; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
     q.x = w.ad[0].p; q.x_bstride = w.ad[0].bstride; q.x_row0 = w.ad[0].row0; q.x_stride = w.ad[0].stride; q.x_set = w.ad[0].set;
+    q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
     hipLaunchKernelGGL(rowc1_kernel, dim3((q.R + 3) / 4, B), dim3(256), 0, sb, q);
     HIPCHK(hipGetLastError());
   }
-  for (size_t i = 1; i < AD.size(); ++i) {
+  size_t first_gemm = 1;
+  if (c->hc2_rowop && AD.size() > 1 && AD[1].wpp && AD[1].tap_off[1] == -1) {
+    // HC_2 over its cone rows + its presum row: a row operation on the cached V.W / Q.W products (no GEMM, no separate LN pass)
+    RowHc2Params q; memset(&q, 0, sizeof(q));
+    const int R = c->cone_len[1];
+    q.B = B; q.R = R; q.offs = c->cone3_dev[1]; q.frame = f;
+    for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = AD[1].tap_off[t3];
+    q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
+    q.VWW = w.vww; q.kv_bstride = N;
+    q.C1QW = w.c1qw.p; q.c_bstride = w.c1qw.bstride; q.c_row0 = w.c1qw.row0;
+    q.consts = c->hc2_consts; q.bias = AD[1].bias; q.g1 = AD[1].g1; q.b1 = AD[1].b1; q.g2 = AD[1].g2; q.b2 = AD[1].b2;
+    q.x1 = w.ad[0].p; q.x1_bstride = w.ad[0].bstride; q.x1_row0 = w.ad[0].row0; q.x1_stride = w.ad[0].stride; q.x1_set = w.ad[0].set;
+    q.x2 = w.ad[1].p; q.x2_bstride = w.ad[1].bstride; q.x2_row0 = w.ad[1].row0; q.x2_stride = w.ad[1].stride; q.x2_set = w.ad[1].set;
+    q.presum = w.pb3[1] + (long)par * w.pb3_set[1] + (long)(R - 1) * 2 * AD[1].cout; q.presum_rstride = (long)R * 2 * AD[1].cout;
+    q.N = N; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
+    hipLaunchKernelGGL(rowhc2_kernel, dim3((R + 3) / 4, B), dim3(256), 0, sb, q);
+    HIPCHK(hipGetLastError());
+    first_gemm = 2;
+  }
+  for (size_t i = first_gemm; i < AD.size(); ++i) {
     if (!AD[i].wpp) continue;
     const int R = c->cone_len[i], Rb = R - 1;                          // Rb cone rows at offsets < 0, then the presum row (offset 0)
     float* pout = w.pb3[i] + (long)par * w.pb3_set[i];
@@ -1203,22 +1310,69 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, hi
   return 0;
 }
 
+
+// One v3 chain layer on chain3_kernel (256 input channels).  `prod` = the layer whose pre-norm rows `P` (+ partial statistics
+// `stats_in`) are this layer's input (nullptr: PRO_RAW, `xin` is the input row view); `res` = highway residual of `prod`;
+// `xmat` = where the rebuilt input row is kept.  The frame offset is folded into every base pointer here.
+static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLayer* prod, const float* P, const float* stats_in,
+                      const View* res, const View* xmat, const View* xin, float* pout, float* stats_out, const SplitExtra* ex, hipStream_t st) {
+  if (L.cin != 256 || L.cin_p != 256 || L.ntaps != (L.tap2 ? 2 : 1) || !L.wp16) return fail(DCTTS_ERR_STATE, "chain3: k = 1 over 256 channels");
+  if (L.tap2 && (!prod || !xmat || !L.hc)) return fail(DCTTS_ERR_STATE, "chain3: the tap -1 form is a highway layer fed by a rebuilt row");
+  Chain3Params p; memset(&p, 0, sizeof(p));
+  const long par = j & 1;
+  auto row = [&](const View& v) { return v.p + par * v.set + (v.row0 + j) * (long)v.stride; };
+  p.B = B;
+  int pro = PRO_RAW;
+  if (prod) {
+    pro = prod->hc ? PRO_LN_HC : PRO_LN_C;
+    p.P = P; p.p_bs = prod->hc ? 2 * prod->cout : prod->cout; p.stats = stats_in;
+    p.g1 = prod->g1; p.b1 = prod->b1; p.g2 = prod->g2; p.b2 = prod->b2; p.relu = (prod->act == ACT_RELU) ? 1 : 0;
+    if (prod->cout != 256 || !stats_in) return fail(DCTTS_ERR_STATE, "chain3: producer must emit 256 channels with statistics");
+    if (prod->hc) { if (!res) return fail(DCTTS_ERR_STATE, "chain3: highway producer needs its residual"); p.res = row(*res); p.res_bs = (int)(res->bstride * res->stride); }
+    if (xmat) { p.xm = row(*xmat); p.xm_bs = (int)(xmat->bstride * xmat->stride); }
+    if (L.tap2) { p.xt = row(*xmat) - xmat->stride; p.xt_bs = p.xm_bs; }          // the same history buffer, one time step back
+  } else {
+    if (!xin) return fail(DCTTS_ERR_STATE, "chain3: raw input row missing");
+    p.P = row(*xin); p.p_bs = (int)(xin->bstride * xin->stride);
+  }
+  p.wp = L.wp16; p.add = L.bias; p.add_bs = 0;
+  if (ex && ex->presum) { p.add = ex->presum; p.add_bs = ex->presum_rstride; }
+  if (ex && ex->raw) { p.raw = row(*ex->raw); p.raw_bs = (int)(ex->raw->bstride * ex->raw->stride); }
+  p.pout = pout; p.np_out = L.hc ? 2 * L.cout : L.cout; p.stats_out = stats_out; p.cout = L.cout;
+  const dim3 grid(L.hc ? L.cout / 16 : (L.cout + 31) / 32, (B + 7) / 8);
+#define C3(PRO_, HC_) hipLaunchKernelGGL((chain3_kernel<PRO_, HC_>), grid, dim3(512), 0, st, p)
+  if (pro == PRO_LN_HC && L.hc && !L.tap2 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) {   // DCTTS_TRACE: stamped instantiation
+    p.ts = g_trace_ctx->trace_buf + 8 * 64 * g_trace_ctx->trace_n++;
+    hipLaunchKernelGGL((chain3_kernel<PRO_LN_HC, true, false, true>), grid, dim3(512), 0, st, p);
+  } else
+  if (L.tap2 && pro == PRO_LN_C) hipLaunchKernelGGL((chain3_kernel<PRO_LN_C, true, true>), grid, dim3(512), 0, st, p);
+  else if (L.tap2 && pro == PRO_LN_HC) hipLaunchKernelGGL((chain3_kernel<PRO_LN_HC, true, true>), grid, dim3(512), 0, st, p);
+  else if (pro == PRO_RAW && !L.hc) C3(PRO_RAW, false);
+  else if (pro == PRO_LN_C && L.hc) C3(PRO_LN_C, true);
+  else if (pro == PRO_LN_C) C3(PRO_LN_C, false);
+  else if (pro == PRO_LN_HC && L.hc) C3(PRO_LN_HC, true);
+  else if (pro == PRO_LN_HC) C3(PRO_LN_HC, false);
+  else return fail(DCTTS_ERR_STATE, "chain3: unsupported layer form");
+#undef C3
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // AudioDec HC_2 .. C_11 for frame j (its C_1 ran at the end of the previous chain piece)
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
   const int par = j & 1;
   for (size_t i = 1; i < AD.size(); ++i) {
-    const RowNorm n = make_norm(AD[i - 1], w.pd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr);
     SplitExtra ex;
     if (AD[i].wp16c) { ex.presum = w.pb3[i] + (long)par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout; ex.presum_rstride = c->cone_len[i] * 2 * AD[i].cout; }
-    CHK(run_split(c, 16, AD[i], B, 1, nullptr, j, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm, w.sd[i - 1], w.sd[i],
-                  0, nullptr, 0, &ex));
+    CHK(run_chain3(c, AD[i], B, j, &AD[i - 1], w.pd[i - 1], w.sd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr, &w.ad[i - 1], nullptr,
+                   w.pd[i], w.sd[i], &ex, sm));
   }
   return 0;
 }
 
 // AudioEnc for frame j (C_1's prologue finalises mel frame j-1 when j > 0), attention row j, AudioDec C_1 of frame j.
-static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm, hipEvent_t aepre) {
+static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm) {
   const int d = c->cfg.d;
   const std::vector<DevLayer>& AE = c->ae_c;
   const std::vector<DevLayer>& AD = c->ad_c;
@@ -1231,14 +1385,10 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
     } else if (i == 0) {
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
     } else {
-      const RowNorm n = make_norm(AE[i - 1], w.pe[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr);
       SplitExtra ex;
-      if (AE[i].wp16c) {
-        ex.presum = w.pse[i]; ex.presum_rstride = 2 * AE[i].cout;
-        if (aepre) { HIPCHK(hipStreamWaitEvent(sm, aepre, 0)); aepre = nullptr; }   // first consumer of this frame's AudioEnc presums
-      }
-      CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, AE[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ae[i - 1], w.ae[i - 1], w.pe[i], sm, w.se[i - 1], w.se[i],
-                    0, nullptr, 0, &ex));
+      if (AE[i].wp16c) { ex.presum = w.pse[i] + (long)(j & 1) * w.pse_set; ex.presum_rstride = 2 * AE[i].cout; }
+      CHK(run_chain3(c, AE[i], B, j, &AE[i - 1], w.pe[i - 1], w.se[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr, &w.ae[i - 1], nullptr,
+                     w.pe[i], w.se[i], &ex, sm));
     }
   }
   const size_t la = AE.size() - 1;
@@ -1251,7 +1401,7 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
   hipLaunchKernelGGL(attnq_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
   HIPCHK(hipGetLastError());
   SplitExtra ex; ex.presum = w.ps0; ex.presum_rstride = d; ex.raw = &w.c1q;
-  return run_split(c, 16, c->ad_c1q, B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ae[la], w.pd[0], sm, nullptr, w.sd[0], 0, nullptr, 0, &ex);
+  return run_chain3(c, c->ad_c1q, B, j, nullptr, nullptr, nullptr, nullptr, nullptr, &w.ae[la], w.pd[0], w.sd[0], &ex, sm);
 }
 
 // the last frame's mel row: same arithmetic as every other frame's (AudioEnc C_1's prologue), without the rest of the piece
@@ -1263,21 +1413,58 @@ static int v3_final_mel(dctts_ctx* c, const DecodeWs& w, int B, int T, hipStream
   return run_split(c, 16, c->ae_c[0], B, 1, nullptr, T, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1);
 }
 
+static int write_trace3(dctts_ctx* c, int j) {
+  std::vector<long long> h(64 * 64 * 8);
+  HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+  const char* path = getenv("DCTTS_TRACE_FILE");
+  FILE* f = fopen(path ? path : "decode_trace.txt", "w");
+  if (!f) return 0;
+  long long t0 = 0;
+  for (int k = 0; k < c->trace_n; ++k) for (int wg = 0; wg < 64; ++wg) { const long long e = h[(k * 64 + wg) * 8]; if (e && (!t0 || e < t0)) t0 = e; }
+  fprintf(f, "# chain3_kernel<LN_HC, HC> launches of chain piece %d: microseconds (100 MHz wall clock) since the first entry of the piece\n", j);
+  fprintf(f, "# idx wgs | first_entry last_entry | median over workgroups of: entry->loads_issued ->landed ->mfma_done ->barrier ->end | last_end\n");
+  for (int k = 0; k < c->trace_n; ++k) {
+    std::vector<double> ph[5]; long long e0 = 0, e1 = 0, x1 = 0; int nw = 0;
+    for (int wg = 0; wg < 64; ++wg) {
+      const long long* o = &h[(k * 64 + wg) * 8];
+      if (!o[0] || !o[5]) continue;
+      if (!nw || o[0] < e0) e0 = o[0]; if (!nw || o[0] > e1) e1 = o[0]; if (!nw || o[5] > x1) x1 = o[5];
+      for (int q = 0; q < 5; ++q) ph[q].push_back((o[q + 1] - o[q]) / 100.0);
+      ++nw;
+    }
+    if (!nw) continue;
+    fprintf(f, "%2d %3d | %8.2f %8.2f |", k, nw, (e0 - t0) / 100.0, (e1 - t0) / 100.0);
+    for (int q = 0; q < 5; ++q) { std::sort(ph[q].begin(), ph[q].end()); fprintf(f, " %6.2f", ph[q][ph[q].size() / 2]); }
+    fprintf(f, " | %8.2f\n", (x1 - t0) / 100.0);
+  }
+  fclose(f);
+  return 0;
+}
+
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
   CHK(decode_v2_init(c));
   CHK(v3_aepre_table(c, w, B));
   hipStream_t sb = c->s_bulk;
-  const bool gr = c->use_graph != 0;
+  // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch; 2 = the chain piece too.  Every
+  // piece only waits at its start and records at its end, so the host issues 2 graph launches + 4 event operations per frame.
+  const bool gr = c->use_graph != 0, gr_chain = c->use_graph == 2;
+  auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
+    if (j >= 0) CHK(v3_chain_dec(c, w, B, j, s));
+    if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
+    return v3_final_mel(c, w, B, T, s);
+  };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" +
+                          std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs2(c);
       hipStream_t cs;
       HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       const int prof_keep = c->prof_id; c->prof_id = -1;
-      c->bulk3_g.assign(T, nullptr);
+      c->bulk3_g.assign(T, nullptr); c->chain3_g.assign(T + 1, nullptr);
       int rc = 0;
-      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, f, cs); });
+      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, T, f, cs); });
+      for (int j = -1; gr_chain && j < T && rc == 0; ++j) rc = capture_piece(cs, &c->chain3_g[j + 1], [&]() { return chain_piece(j, cs); });
       c->prof_id = prof_keep;
       HIPCHK(hipStreamDestroy(cs));
       if (rc != 0) { destroy_graphs2(c); return rc; }
@@ -1285,45 +1472,60 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     }
   }
   CHK(v3_vw(c, w, B, N, st));                                              // V . W_top, once per batch
+  CHK(v3_aepre(c, B, 0, st));                                              // row 0's AudioEnc presums (= the biases: every tap reads padding)
   HIPCHK(hipEventRecord(c->ev_fork, st));
   HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
   const int skip = getenv("DCTTS_V3_SKIP") ? atoi(getenv("DCTTS_V3_SKIP")) : 0;   // timing experiments only: 1 = no bulk work, 2 = no chain work
+  const char* tenv = getenv("DCTTS_TRACE");
+  const int tstep = (tenv && !gr_chain) ? atoi(tenv) : -1;
   auto bulk_piece = [&](int f) -> int {
-    if (skip == 1) { HIPCHK(hipEventRecord(c->ev_aepre[f & 3], sb)); HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb)); return 0; }
-    CHK(v3_aepre(c, B, f, sb));
-    HIPCHK(hipEventRecord(c->ev_aepre[f & 3], sb));
-    if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, f, sb));
+    if (skip != 1) { if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, T, f, sb)); }
     HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb));
     return 0;
   };
-  const char* tenv = getenv("DCTTS_TRACE");
-  const int tstep = tenv ? atoi(tenv) : -1;
+  // DCTTS_PIECETIME=<frame>: timing events around 8 consecutive chain / bulk pieces starting there (measurement only)
+  const int pt0 = getenv("DCTTS_PIECETIME") ? atoi(getenv("DCTTS_PIECETIME")) : -1;
+  hipEvent_t pe_c[9][2], pe_b[9][2];
+  if (pt0 >= 0) for (int i = 0; i < 9; ++i) for (int k = 0; k < 2; ++k) { HIPCHK(hipEventCreate(&pe_c[i][k])); HIPCHK(hipEventCreate(&pe_b[i][k])); }
+  auto ptime = [&](int j) { return pt0 >= 0 && j >= pt0 && j < pt0 + 8; };
   const auto host_t0 = std::chrono::steady_clock::now();
   CHK(bulk_piece(0));
-  CHK(v3_chain_enc(c, w, B, N, 0, st, c->ev_aepre[0]));                  // chain piece -1
+  if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[0], st)); else CHK(chain_piece(-1, st));
   HIPCHK(hipEventRecord(c->ev_chain[3], st));
   for (int j = 0; j < T; ++j) {
     if (j + 1 < T) {
       HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));        // bulk piece j+1 needs attnq(j) / C1Q[j]: end of chain piece j-1
+      if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][0], sb));
       CHK(bulk_piece(j + 1));
+      if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][1], sb));
     }
     HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0));
+    if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][0], st));
     if (j == tstep) {
-      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * (8 + 256) * sizeof(long long))); }
-      HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * (8 + 256) * sizeof(long long), st));
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 8 * sizeof(long long))); }
+      HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 64 * 8 * sizeof(long long), st));
       c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
     }
-    if (skip != 2) {
-    CHK(v3_chain_dec(c, w, B, j, st));
-    if (j + 1 < T) CHK(v3_chain_enc(c, w, B, N, j + 1, st, c->ev_aepre[(j + 1) & 3]));
-    else CHK(v3_final_mel(c, w, B, T, st));
-    }
+    if (skip != 2) { if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[j + 1], st)); else CHK(chain_piece(j, st)); }
+    if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][1], st));
     HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
     if (c->trace_on) {
       c->trace_on = false; g_trace_ctx = nullptr;
       HIPCHK(hipStreamSynchronize(st));
-      CHK(write_trace(c, j));
+      CHK(write_trace3(c, j));
     }
+  }
+  if (pt0 >= 0 && pt0 + 8 < T) {
+    HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
+    for (int i = 0; i < 8; ++i) {
+      float dc = 0, db = 0, c2c = 0, b2c = 0, c2b = 0;
+      (void)hipEventElapsedTime(&dc, pe_c[i][0], pe_c[i][1]);
+      if (i > 0) { (void)hipEventElapsedTime(&db, pe_b[i][0], pe_b[i][1]); (void)hipEventElapsedTime(&c2c, pe_c[i - 1][1], pe_c[i][0]);
+                   (void)hipEventElapsedTime(&b2c, pe_b[i][1], pe_c[i][0]); (void)hipEventElapsedTime(&c2b, pe_c[i - 1][0], pe_b[i][0]); }
+      fprintf(stderr, "[dctts] frame %d: chain piece %.1f us, bulk piece %.1f us, prev chain end -> chain start %.1f us, bulk end -> chain start %.1f us, prev chain start -> bulk start %.1f us\n",
+              pt0 + i, dc * 1e3, db * 1e3, c2c * 1e3, b2c * 1e3, c2b * 1e3);
+    }
+    for (int i = 0; i < 9; ++i) for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(pe_c[i][k]); (void)hipEventDestroy(pe_b[i][k]); }
   }
   if (getenv("DCTTS_HOSTTIME")) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
@@ -1342,6 +1544,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   if (const char* e = getenv("DCTTS_BULK_SMALL")) c->bulk_small_rows = atoi(e);
   if (const char* e = getenv("DCTTS_BULK3_SMALL")) c->bulk3_small_rows = atoi(e);
   if (const char* e = getenv("DCTTS_BULK3_FUSED")) c->bulk3_fused = atoi(e);
+  if (const char* e = getenv("DCTTS_HC2_ROWOP")) c->hc2_rowop = atoi(e);
   if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }

@@ -26,6 +26,8 @@
 
 namespace dctts {
 
+__device__ __forceinline__ f32x4 ldv(const float* base, unsigned off) { return *reinterpret_cast<const f32x4*>(base + off); }
+
 enum { MAXWIN = 3 };      // attention_win_size the decode kernels are unrolled for (dctts_create rejects anything larger)
 
 // <= MAXWIN windowed attention weights of one query row held as 4 channels per lane (d == 256).  Returns nk; a[k] = 0 for k >= nk.
@@ -67,6 +69,7 @@ struct RowC1Params {
   const float* bias; const float* g; const float* be;
   int N, d, win; const int* pm_all;
   float* x; long x_bstride; long x_row0; int x_stride; long x_set;   // AudioDec C_1 output rows, parity copy frame & 1
+  float* scal; long s_bstride; long s_row0;                          // per row: (mean, rstd of the pre-norm row, a_0, a_1, a_2, -, -, -) for rowhc2_kernel
 };
 
 __global__ void __launch_bounds__(256) rowc1_kernel(const RowC1Params p) {
@@ -96,6 +99,86 @@ __global__ void __launch_bounds__(256) rowc1_kernel(const RowC1Params p) {
   const float rs = 1.0f / sqrtf(var + 1e-12f);
   const float4 o = make_float4(dv.x * rs * g.x + be.x, dv.y * rs * g.y + be.y, dv.z * rs * g.z + be.z, dv.w * rs * g.w + be.w);
   *reinterpret_cast<float4*>(p.x + (long)(p.frame & 1) * p.x_set + ((long)b * p.x_bstride + p.x_row0 + t) * p.x_stride + c0) = o;
+  if (p.scal && lane == 0) {
+    float* sc = p.scal + ((long)b * p.s_bstride + p.s_row0 + t) * 8;
+    *reinterpret_cast<float4*>(sc) = make_float4(mean, rs, a[0], a[1]);
+    sc[4] = a[2];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- bulk: HC_2 cone rows
+// AudioDec HC_2 (networks.py:175-182, the first highway layer; causal k = 3, dilation 1) over its cone rows, WITHOUT a GEMM.
+// Its input x1[t'] = (pre[t'] - m) r gamma1 + beta1 is affine in C_1's pre-norm row pre[t'] = b1 + sum_k a_k VW[p+k] + C1Q[t'], so with
+// Wt_q = diag(gamma1) W2[q]:
+//     x1[t'] . W2[q] = beta1 . W2[q] + r ( b1 . Wt_q + sum_k a_k (VW[p+k] . Wt_q) + C1Q[t'] . Wt_q - m 1^T Wt_q )
+// where VWW[n][q] = VW[n] . Wt_q is computed once per batch and C1QW[t'][q] = C1Q[t'] . Wt_q once per frame (one new row): the
+// largest GEMM of the cone (82 rows x 768 x 512 per utterance and frame, 45 % of the bulk FLOPs) becomes ~15 vector FMAs per tap.
+// The same wave then finishes the layer: layer-norm of both halves, sigmoid gate, highway mix with x1[t] (modules.py:188-193).
+// Row r of the table is a cone row (offset < 0) or, last, the chain's presum row (offset 0: taps -2 and -1 only, stored un-normalised).
+// grid (ceil(R / 4), B), block 256: one wave per row; lane = channels 4 lane .. 4 lane + 3 of H1 and of H2.
+struct RowHc2Params {
+  int B, R; const int* offs; int frame; int tap_off[3];
+  const float* scal; long s_bstride; long s_row0;                    // rowc1_kernel's per-row scalars
+  const float* VWW; long kv_bstride;                                 // [(b * kv_bstride + n)][3][512]
+  const float* C1QW; long c_bstride; long c_row0;                    // [(b * c_bstride + c_row0 + t)][3][512]
+  const float* consts;                                               // [3 taps][3: beta1.W2, b1.Wt, 1^T Wt][512]
+  const float* bias; const float* g1; const float* b1; const float* g2; const float* b2;   // HC_2's own bias and H1 / H2 layer-norm parameters
+  const float* x1; long x1_bstride; long x1_row0; int x1_stride; long x1_set;   // C_1 output rows (highway residual)
+  float* x2; long x2_bstride; long x2_row0; int x2_stride; long x2_set;        // HC_2 output rows
+  float* presum; long presum_rstride;                                // presum row of utterance b at presum + b * presum_rstride
+  int N, win; const int* pm_all;
+};
+
+__global__ void __launch_bounds__(256) rowhc2_kernel(const RowHc2Params p) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (r >= p.R) return;
+  const int t = p.frame + p.offs[r];
+  if (t < 0) return;
+  const bool pre_row = (r == p.R - 1);
+  const int c0 = lane * 4;
+  const int pm = p.pm_all[(long)p.frame * p.B + b];
+  int nk = p.N - pm; if (nk > p.win) nk = p.win;
+  float4 h1 = ld4(p.bias + c0), h2 = ld4(p.bias + 256 + c0);
+  const long par = p.frame & 1;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int tp = t + p.tap_off[q];
+    if (tp < 0 || (pre_row && q == 2)) continue;                      // causal zero padding / the chain contracts the centre tap
+    const float* sc = p.scal + ((long)b * p.s_bstride + p.s_row0 + tp) * 8;
+    const float4 s4 = ld4(sc); const float a2 = sc[4];
+    const float m = s4.x, rs = s4.y;
+    const float a[3] = {s4.z, s4.w, a2};
+    const float* cq = p.consts + q * 3 * 512;
+    float4 u1 = ld4(cq + 512 + c0), u2 = ld4(cq + 512 + 256 + c0);   // b1 . Wt_q
+    const float4 cs1 = ld4(cq + 1024 + c0), cs2 = ld4(cq + 1024 + 256 + c0);
+    u1.x = fmaf(-m, cs1.x, u1.x); u1.y = fmaf(-m, cs1.y, u1.y); u1.z = fmaf(-m, cs1.z, u1.z); u1.w = fmaf(-m, cs1.w, u1.w);
+    u2.x = fmaf(-m, cs2.x, u2.x); u2.y = fmaf(-m, cs2.y, u2.y); u2.z = fmaf(-m, cs2.z, u2.z); u2.w = fmaf(-m, cs2.w, u2.w);
+    const float* cw = p.C1QW + ((long)b * p.c_bstride + p.c_row0 + tp) * 1536 + q * 512;
+    const float4 w1 = ld4(cw + c0), w2 = ld4(cw + 256 + c0);
+    u1.x += w1.x; u1.y += w1.y; u1.z += w1.z; u1.w += w1.w;
+    u2.x += w2.x; u2.y += w2.y; u2.z += w2.z; u2.w += w2.w;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k < nk) {
+        const float* vw = p.VWW + ((long)b * p.kv_bstride + pm + k) * 1536 + q * 512;
+        const float4 v1 = ld4(vw + c0), v2 = ld4(vw + 256 + c0);
+        u1.x = fmaf(a[k], v1.x, u1.x); u1.y = fmaf(a[k], v1.y, u1.y); u1.z = fmaf(a[k], v1.z, u1.z); u1.w = fmaf(a[k], v1.w, u1.w);
+        u2.x = fmaf(a[k], v2.x, u2.x); u2.y = fmaf(a[k], v2.y, u2.y); u2.z = fmaf(a[k], v2.z, u2.z); u2.w = fmaf(a[k], v2.w, u2.w);
+      }
+    }
+    const float4 e1 = ld4(cq + c0), e2 = ld4(cq + 256 + c0);          // beta1 . W2[q]
+    h1.x += fmaf(rs, u1.x, e1.x); h1.y += fmaf(rs, u1.y, e1.y); h1.z += fmaf(rs, u1.z, e1.z); h1.w += fmaf(rs, u1.w, e1.w);
+    h2.x += fmaf(rs, u2.x, e2.x); h2.y += fmaf(rs, u2.y, e2.y); h2.z += fmaf(rs, u2.z, e2.z); h2.w += fmaf(rs, u2.w, e2.w);
+  }
+  if (pre_row) {
+    float* pr = p.presum + (long)b * p.presum_rstride;
+    *reinterpret_cast<float4*>(pr + c0) = h1; *reinterpret_cast<float4*>(pr + 256 + c0) = h2;
+    return;
+  }
+  RowNorm n; n.g1 = p.g1; n.b1 = p.b1; n.g2 = p.g2; n.b2 = p.b2;
+  const float4 xr = ld4(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + t) * p.x1_stride + c0);
+  const float4 o = norm_hc_regs(n, h1, h2, xr, lane);
+  *reinterpret_cast<float4*>(p.x2 + par * p.x2_set + ((long)b * p.x2_bstride + p.x2_row0 + t) * p.x2_stride + c0) = o;
 }
 
 // ---------------------------------------------------------------------------------------------------------------- chain: attention row j
@@ -132,6 +215,208 @@ __global__ void __launch_bounds__(256) attnq_kernel(const AttnQParams p) {
   }
   *reinterpret_cast<float4*>(p.presum + (long)b * p.d + c0) = y;
   if (lane == 0) p.pm_all[(long)(j + 1) * p.B + b] = pm + am;       // max_attentions[:, j] (synthesize.py:54)
+}
+
+// ---------------------------------------------------------------------------------------------------------------- chain: one layer, newest row
+// chain3_kernel<PRO, HCOUT>: the v3 chain layer over 256 input channels -- out_pre[b][:] = add[b][:] + x[b][:] . W for the newest row of
+// every utterance, x rebuilt from the producing layer's pre-norm row (deferred layer-norm, see decode_kernels.h).  Same arithmetic
+// as hsplit_kernel<16, ., ., 1> (8 rows x one pair of 16-column tiles per workgroup, K = 256 split over 8 waves, 16x16x4 MFMA,
+// fixed-order LDS reduction, partial statistics out), rewritten for the one shape the v3 chain has so that nothing stands between
+// kernel entry and the loads: prologue kind and output kind are template parameters (a run-time `if (ln)` became a branch, and the
+// compiler parked the first loads' s_waitcnt in front of it: one memory round trip before the other 18 loads went out), every
+// address is base + b * stride with the frame offset folded into the base on the host (no offset table, no divisions), the grid is
+// (column groups, row tiles), and the parameter block is small enough for one scalar-load batch.
+struct Chain3Params {
+  int B;
+  const float* P; int p_bs;          // PRO_LN_*: pre-norm row of utterance b at P + b * p_bs;  PRO_RAW: the input row itself
+  const float* stats;                // PRO_LN_*: [b][16][4] per-16-column-group partial statistics of the P rows
+  const float* res; int res_bs;      // PRO_LN_HC: highway residual row at res + b * res_bs
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  int relu;                          // PRO_LN_C: the producing layer ends in a ReLU
+  float* xm; int xm_bs;              // the rebuilt row -> xm + b * xm_bs (written by column group 0); nullptr = not kept
+  const float* wp;                   // [tile][16 k-groups][lane][4]
+  const float* add; int add_bs;      // epilogue addend per (b, column): presum row at add + b * add_bs, or the bias vector when add_bs == 0
+  float* pout; int np_out;           // pre-norm output rows [b][np_out]
+  float* stats_out;                  // [b][16][4]
+  float* raw; int raw_bs;            // the bare contraction -> raw + b * raw_bs (AudioDec C_1 keeps Q[j] . W_bot); nullptr = none
+  int cout;                          // output channels of an LN group (HCOUT: 256 gate + 256 info; else the row width: 256 or 80)
+  const float* xt; int xt_bs;        // TAP2: the previous time step's input row (tap -1 of a dilation-1 layer) at xt + b * xt_bs
+  long long* ts;                     // TS instantiation only (measurement): 8 wall-clock stamps per workgroup
+};
+
+// TAP2: a dilation-1 AudioEnc layer.  Its tap -1 reads the row the chain produced one frame earlier, which no presum computed
+// ahead of the chain piece can contain, so that tap is contracted here as well (K = 512: k-groups 0..15 = tap -1 from the
+// history row, 16..31 = the rebuilt centre row); only the oldest tap arrives through the presum.
+template <int PRO, bool HCOUT, bool TAP2 = false, bool TS = false>
+__global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
+  long long t_in = 0, t_issued = 0, t_landed = 0, t_mfma = 0, t_sync = 0;
+  if constexpr (TS) t_in = wall_clock64();
+  constexpr unsigned NKG = TAP2 ? 32u : 16u, KC = TAP2 ? 16u : 0u;        // k-groups per tile; first k-group of the centre tap
+  __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];       // split-K reduction [wave][tile][j][lane]
+  // the whole parameter block in ONE scalar-load batch (left alone the compiler fetches fields lazily, next to their first use)
+  DCTTS_SGPR(p.B); DCTTS_SGPR(p.P); DCTTS_SGPR(p.p_bs); DCTTS_SGPR(p.stats); DCTTS_SGPR(p.res); DCTTS_SGPR(p.res_bs);
+  DCTTS_SGPR(p.g1); DCTTS_SGPR(p.b1); DCTTS_SGPR(p.g2); DCTTS_SGPR(p.b2); DCTTS_SGPR(p.relu); DCTTS_SGPR(p.xm); DCTTS_SGPR(p.xm_bs);
+  DCTTS_SGPR(p.wp); DCTTS_SGPR(p.add); DCTTS_SGPR(p.add_bs); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.stats_out);
+  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout);
+  if constexpr (TAP2) { DCTTS_SGPR(p.xt); DCTTS_SGPR(p.xt_bs); }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = blockIdx.x, m0 = blockIdx.y * 8;
+  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+  const int b = m0 + arow;
+  const bool valid = arow < 8 && b < p.B;
+  const unsigned bb = valid ? (unsigned)b : 0u;                             // rows that do not exist read utterance 0 and are zeroed
+  // ---- every load of the launch, issued back to back: B fragments of this wave's two k-groups (channels 16 w .. and 128 + 16 w ..)
+  //      for both tiles, then what the prologue needs, then the epilogue addend
+  const float* wb = p.wp + lane * 4;
+  const unsigned w0 = (unsigned)(grp * 2) * NKG * 256u, w1 = w0 + NKG * 256u;
+  f32x4 vb0[2], vb1[2], va[2], vh2[2], vrs[2], vg1[2], vb1_[2], vg2[2], vb2_[2], vst[4];
+  f32x4 vtb0[2], vtb1[2], vta[2];                                           // TAP2: tap -1 weights and history-row fragments
+#pragma unroll
+  for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (KC + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (KC + (unsigned)(wave + 8 * e)) * 256u); }
+  if constexpr (TAP2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u);
+      vta[e] = ldv(p.xt, bb * (unsigned)p.xt_bs + (unsigned)((8 * e + wave) * 16 + c4));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
+    va[e] = ldv(p.P, bb * (unsigned)p.p_bs + ch);
+    if constexpr (PRO != PRO_RAW) { vg1[e] = ldv(p.g1, ch); vb1_[e] = ldv(p.b1, ch); }
+    if constexpr (PRO == PRO_LN_HC) {
+      vh2[e] = ldv(p.P, bb * (unsigned)p.p_bs + 256u + ch);
+      vrs[e] = ldv(p.res, bb * (unsigned)p.res_bs + ch);
+      vg2[e] = ldv(p.g2, ch); vb2_[e] = ldv(p.b2, ch);
+    }
+  }
+  if constexpr (PRO != PRO_RAW) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats, bb * 64u + (unsigned)((aq * 4 + g) * 4));
+  }
+  // epilogue addend of this thread's output element: row (lane >> 4) * 4 + (wave & 3) of the tile, tile wave >> 2, column lane & 15
+  const int erow = aq * 4 + (wave & 3), etile = wave >> 2, ecol = lane & 15;
+  const int eb = m0 + erow;
+  const bool eok_row = erow < 8 && eb < p.B;
+  int pcol; bool ok;
+  if constexpr (HCOUT) { const int c = grp * 16 + ecol; ok = c < p.cout; pcol = etile * p.cout + c; }
+  else                 { pcol = (grp * 2 + etile) * 16 + ecol; ok = pcol < p.cout; }
+  float addv = p.add[(unsigned)(eok_row ? eb * p.add_bs : 0) + (unsigned)(ok ? pcol : 0)];
+  // Pin: ONE asm statement that consumes every loaded vector.  All of them must have been issued before it and nothing that uses
+  // them can start before it, so the launch pays one memory round trip (the addend rides along: waited for later, its s_waitcnt
+  // vmcnt(0) would also wait for the row stores issued in between -- stores count in vmcnt on gfx9).  (Without it the scheduler sinks each load next to its
+  // first use to save registers -- statistics, wait, combine, gamma, wait, ... weights last: ~6 serialised round trips; a
+  // sched_barrier does not help, the arithmetic simply moves above it.)
+  if constexpr (TS) t_issued = wall_clock64();
+#define C3_PIN_BASE "+v"(vb0[0]), "+v"(vb0[1]), "+v"(vb1[0]), "+v"(vb1[1]), "+v"(va[0]), "+v"(va[1]), "+v"(addv)
+#define C3_PIN_LN   "+v"(vg1[0]), "+v"(vg1[1]), "+v"(vb1_[0]), "+v"(vb1_[1]), "+v"(vst[0]), "+v"(vst[1]), "+v"(vst[2]), "+v"(vst[3])
+#define C3_PIN_HC   "+v"(vh2[0]), "+v"(vh2[1]), "+v"(vrs[0]), "+v"(vrs[1]), "+v"(vg2[0]), "+v"(vg2[1]), "+v"(vb2_[0]), "+v"(vb2_[1])
+#define C3_PIN_T2   "+v"(vtb0[0]), "+v"(vtb0[1]), "+v"(vtb1[0]), "+v"(vtb1[1]), "+v"(vta[0]), "+v"(vta[1])
+  if constexpr (PRO == PRO_LN_HC && TAP2) asm volatile("; chain3: all loads in flight" : C3_PIN_BASE, C3_PIN_LN, C3_PIN_HC, C3_PIN_T2);
+  else if constexpr (PRO == PRO_LN_HC)    asm volatile("; chain3: all loads in flight" : C3_PIN_BASE, C3_PIN_LN, C3_PIN_HC);
+  else if constexpr (PRO == PRO_LN_C && TAP2) asm volatile("; chain3: all loads in flight" : C3_PIN_BASE, C3_PIN_LN, C3_PIN_T2);
+  else if constexpr (PRO == PRO_LN_C)     asm volatile("; chain3: all loads in flight" : C3_PIN_BASE, C3_PIN_LN);
+  else { static_assert(PRO != PRO_RAW || !TAP2, "a raw-input layer has no tap -1 form"); asm volatile("; chain3: all loads in flight" : C3_PIN_BASE); }
+#undef C3_PIN_BASE
+#undef C3_PIN_LN
+#undef C3_PIN_HC
+#undef C3_PIN_T2
+  if constexpr (TS) t_landed = wall_clock64();
+  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+  float4 bq0[2], bq1[2], av[2], h2v[2], rsv[2], g1v[2], b1v[2], g2v[2], b2v[2], st[4];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    bq0[e] = f4(vb0[e]); bq1[e] = f4(vb1[e]); av[e] = f4(va[e]);
+    if constexpr (PRO != PRO_RAW) { g1v[e] = f4(vg1[e]); b1v[e] = f4(vb1_[e]); }
+    if constexpr (PRO == PRO_LN_HC) { h2v[e] = f4(vh2[e]); rsv[e] = f4(vrs[e]); g2v[e] = f4(vg2[e]); b2v[e] = f4(vb2_[e]); }
+  }
+  if constexpr (PRO != PRO_RAW) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) st[g] = f4(vst[g]);
+  }
+
+  // ---- rebuild x (LN, + ReLU, or + sigmoid gate + highway mix) in the A-fragment registers
+  if constexpr (PRO != PRO_RAW) {
+    float m1, r1, m2 = 0.f, r2 = 0.f;
+    combine_stats(st, 0, m1, r1);
+    if constexpr (PRO == PRO_LN_HC) combine_stats(st, 1, m2, r2);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      float4 x = av[e];
+      const float4 g1 = g1v[e], b1 = b1v[e];
+      x.x = (x.x - m1) * r1 * g1.x + b1.x; x.y = (x.y - m1) * r1 * g1.y + b1.y;
+      x.z = (x.z - m1) * r1 * g1.z + b1.z; x.w = (x.w - m1) * r1 * g1.w + b1.w;
+      if constexpr (PRO == PRO_LN_HC) {
+        const float4 g2 = g2v[e], b2 = b2v[e], h2 = h2v[e], xr = rsv[e];
+        { const float s_ = sigmoid_fast(x.x); x.x = s_ * ((h2.x - m2) * r2 * g2.x + b2.x) + (1.0f - s_) * xr.x; }
+        { const float s_ = sigmoid_fast(x.y); x.y = s_ * ((h2.y - m2) * r2 * g2.y + b2.y) + (1.0f - s_) * xr.y; }
+        { const float s_ = sigmoid_fast(x.z); x.z = s_ * ((h2.z - m2) * r2 * g2.z + b2.z) + (1.0f - s_) * xr.z; }
+        { const float s_ = sigmoid_fast(x.w); x.w = s_ * ((h2.w - m2) * r2 * g2.w + b2.w) + (1.0f - s_) * xr.w; }
+      } else {
+        if (p.relu) { x.x = fmaxf(x.x, 0.f); x.y = fmaxf(x.y, 0.f); x.z = fmaxf(x.z, 0.f); x.w = fmaxf(x.w, 0.f); }
+      }
+      av[e] = x;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) if (!valid) av[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- 2 k-groups x 4 MFMAs x 2 tiles (TAP2: the previous row's two k-groups first)
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (TAP2) {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      f32x4 a = vta[e];
+      if (!valid) a = f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 b0 = vtb0[e], b1 = vtb1[e];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[i], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[i], acc1, 0, 0, 0); }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float4 a = av[e], b0 = bq0[e], b1 = bq1[e];
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0.x, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1.x, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0.y, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0.z, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1.z, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0.w, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1.w, acc1, 0, 0, 0);
+  }
+  if constexpr (TS) { asm volatile("" : "+v"(acc0), "+v"(acc1)); t_mfma = wall_clock64(); }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+  // the rebuilt row is only needed by later launches (highway residual / history): store it off the path to the barrier
+  if constexpr (PRO != PRO_RAW) {
+    if (p.xm && grp == 0 && valid) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(p.xm + (long)b * p.xm_bs + (8 * e + wave) * 16 + c4) = av[e];
+    }
+  }
+  __syncthreads();
+  if constexpr (TS) t_sync = wall_clock64();
+  // ---- fixed-order reduction over the 8 waves: thread (wave, lane) owns element j = wave & 3 of tile wave >> 2, lane's (row, column)
+  float v_ = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + etile) * 4 + (wave & 3)) * 64 + lane];
+  const bool wr = ok && eok_row;
+  if (p.raw && wr) p.raw[(long)eb * p.raw_bs + pcol] = v_;
+  if (ok) v_ += addv;
+  if (wr) p.pout[(long)eb * p.np_out + pcol] = v_;
+  // partial LN statistics of this 16-column group: a DPP row (16 lanes) holds one output row's 16 columns
+  const float mg = row16_sum(ok ? v_ : 0.f) * (1.0f / 16.0f);
+  const float dv = ok ? v_ - mg : 0.f;
+  const float m2g = row16_sum(dv * dv);
+  if (wr && ecol == 0) {
+    const int G = HCOUT ? grp : grp * 2 + etile;
+    float* so = p.stats_out + ((long)eb * 16 + G) * 4 + (HCOUT ? etile * 2 : 0);
+    so[0] = mg; so[1] = m2g;
+  }
+  if constexpr (TS) {
+    if (p.ts && tid == 0) {
+      long long* o = p.ts + (long)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+      o[0] = t_in; o[1] = t_issued; o[2] = t_landed; o[3] = t_mfma; o[4] = t_sync; o[5] = wall_clock64();
+    }
+  }
 }
 
 }  // namespace dctts

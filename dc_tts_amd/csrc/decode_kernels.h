@@ -123,6 +123,7 @@ struct SplitParams {
   const float* presum; int presum_rstride;                       // 16-row form, R == 1: bias + older taps of row b at presum[b * rstride + col] (replaces bias)
   float* raw_out; long raw_bstride; long raw_row0; int raw_stride;   // 16-row form, R == 1: the bare contraction (no bias / presum) -> raw_out[b][t][col]
   int mask_last;                                                 // hbulk_kernel<12>: row r == R-1 of every utterance is a presum row (centre tap contributes 0)
+  long abs_bstride; long abs_row0; int abs_toff;                 // hbulk: abs_bstride != 0 -> output row index = b * abs_bstride + abs_row0 + t + abs_toff (a time-indexed cache)
   long long* dbg;                                                // optional: 8 wall-clock (100 MHz) stamps of workgroup 0
   long long* dbg_wg;                                             // optional: (entry, end) stamps of every workgroup (<= 128)
 };
@@ -135,8 +136,9 @@ struct SplitParams {
 #define DCTTS_SGPR(x) asm volatile("" ::"s"(x))
 template <int NT>
 __device__ __forceinline__ void prefetch_params(const SplitParams& p) {
-  DCTTS_SGPR(p.M); DCTTS_SGPR(p.R); DCTTS_SGPR(p.b0); DCTTS_SGPR(p.offs); DCTTS_SGPR(p.step); DCTTS_SGPR(p.step_val);
-  DCTTS_SGPR(p.ngroups); DCTTS_SGPR(p.tile_rows); DCTTS_SGPR(p.pro);
+  DCTTS_SGPR(p.M); DCTTS_SGPR(p.b0); DCTTS_SGPR(p.step_val);
+  if constexpr (!(NT == 1 || NT == 2 || NT == 4)) { DCTTS_SGPR(p.R); DCTTS_SGPR(p.offs); DCTTS_SGPR(p.step); DCTTS_SGPR(p.ngroups); }
+  DCTTS_SGPR(p.tile_rows); DCTTS_SGPR(p.pro);
   DCTTS_SGPR(p.nrm.P); DCTTS_SGPR(p.nrm.np); DCTTS_SGPR(p.nrm.g1); DCTTS_SGPR(p.nrm.b1); DCTTS_SGPR(p.nrm.g2); DCTTS_SGPR(p.nrm.b2);
   DCTTS_SGPR(p.nrm.act); DCTTS_SGPR(p.nrm.res); DCTTS_SGPR(p.nrm.res_bstride); DCTTS_SGPR(p.nrm.res_row0);
   DCTTS_SGPR(p.nrm.res_stride); DCTTS_SGPR(p.nrm.res_set); DCTTS_SGPR(p.stats_in);
@@ -145,7 +147,9 @@ __device__ __forceinline__ void prefetch_params(const SplitParams& p) {
   }
   DCTTS_SGPR(p.xmat); DCTTS_SGPR(p.xm_bstride); DCTTS_SGPR(p.xm_row0); DCTTS_SGPR(p.xm_stride); DCTTS_SGPR(p.xm_set);
   DCTTS_SGPR(p.xsrc); DCTTS_SGPR(p.xs_bstride); DCTTS_SGPR(p.xs_row0); DCTTS_SGPR(p.xs_stride); DCTTS_SGPR(p.xs_set);
-  DCTTS_SGPR(p.ntaps); DCTTS_SGPR(p.tap_off[0]); DCTTS_SGPR(p.tap_off[1]); DCTTS_SGPR(p.tap_off[2]); DCTTS_SGPR(p.cin); DCTTS_SGPR(p.cin_p);
+  if constexpr (NT == 1 || NT == 2 || NT == 4) { DCTTS_SGPR(p.tap_off[0]); }
+  else { DCTTS_SGPR(p.ntaps); DCTTS_SGPR(p.tap_off[0]); DCTTS_SGPR(p.tap_off[1]); DCTTS_SGPR(p.tap_off[2]); }
+  DCTTS_SGPR(p.cin); DCTTS_SGPR(p.cin_p);
   DCTTS_SGPR(p.wp); DCTTS_SGPR(p.bias); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.hc); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.stats_out);
   if constexpr (NT == 1) {
     DCTTS_SGPR(p.presum); DCTTS_SGPR(p.presum_rstride); DCTTS_SGPR(p.raw_out); DCTTS_SGPR(p.raw_bstride); DCTTS_SGPR(p.raw_row0); DCTTS_SGPR(p.raw_stride);
@@ -205,13 +209,19 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
   __shared__ long s_prow[MF];                       // output row index per tile row, -1 = skipped
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   prefetch_params<NT>(p);
-  const bool tr = TRACE && p.dbg && blockIdx.x == 0 && tid == 0;
-  if constexpr (TRACE) { if (tr) p.dbg[0] = wall_clock64(); if (p.dbg_wg && tid == 0 && blockIdx.x < 128) p.dbg_wg[2 * blockIdx.x] = wall_clock64(); }
-  const int step = p.step_val + (p.step ? *p.step : 0);
+  const int wgid = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool tr = TRACE && p.dbg && wgid == 0 && tid == 0;
+  if constexpr (TRACE) { if (tr) p.dbg[0] = wall_clock64(); if (p.dbg_wg && tid == 0 && wgid < 128) p.dbg_wg[2 * wgid] = wall_clock64(); }
+  // CHAINROW: the forms only the newest-frame chain uses (one row per utterance, no offset table, frame index by value, grid =
+  // (column groups, row tiles)).  Everything the generic row mapping needs -- a possibly-null offs[] load (its branch made the
+  // wait-count pass put s_waitcnt vmcnt(0) in front of the A loads: one full memory round trip per launch, after the weight
+  // loads), the device step counter, two integer divisions -- is compiled out.
+  constexpr bool CHAINROW = (MF == 16) && (NT == 1 || NT == 2 || NT == 4) && !ONE;
+  const int step = CHAINROW ? p.step_val : p.step_val + (p.step ? *p.step : 0);
   const long par = step & 1;
   const int KG = p.ntaps * p.cin_p / KGS;
-  const int ntile = (p.M + p.tile_rows - 1) / p.tile_rows;
-  const int nitems = ntile * p.ngroups * (ONE ? 2 : 1);
+  const int ntile = CHAINROW ? 1 : (p.M + p.tile_rows - 1) / p.tile_rows;
+  const int nitems = CHAINROW ? 1 : ntile * p.ngroups * (ONE ? 2 : 1);
   const int arow = lane & (MF - 1);
   const int aq = (MF == 32) ? (lane >> 5) : (lane >> 4);
   const int c4 = aq * 4;
@@ -227,9 +237,9 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
 
   // Persistent over work items: the bulk branch launches fewer workgroups than CUs so that the latency-critical
   // chain branch always finds free CUs; the chain itself has exactly one item per workgroup.
-  for (int item = blockIdx.x; item < nitems; item += (MF == 32 ? (int)gridDim.x : nitems)) {
+  for (int item = CHAINROW ? 0 : blockIdx.x; item < nitems; item += (MF == 32 ? (int)gridDim.x : nitems)) {
     const int mytile = ONE ? (item & 1) : 0, rest = ONE ? (item >> 1) : item;
-    const int tile_x = rest / p.ngroups, grp = rest - tile_x * p.ngroups;
+    const int tile_x = CHAINROW ? (int)blockIdx.y : rest / p.ngroups, grp = CHAINROW ? (int)blockIdx.x : rest - tile_x * p.ngroups;
     const int m0 = tile_x * p.tile_rows;
 
     // ---- B fragments: wave w owns k-groups w, w+8, ...; independent of A, so issue first
@@ -252,13 +262,17 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
     {
       const int m = m0 + arow;
       if (arow < p.tile_rows && m < p.M) {
-        int bl = m, r = 0;
-        if (p.R != 1) { bl = m / p.R; r = m - bl * p.R; }
-        b = p.b0 + bl;
-        t = step + (p.offs ? p.offs[r] : 0);
-        prow = (long)b * p.R + r;
-        valid = (t >= 0);
-        cmask = (NT == 3) && p.mask_last && (r == p.R - 1);     // v3 presum row: the chain contracts its centre tap
+        if constexpr (CHAINROW) {
+          b = p.b0 + m; t = step; prow = b; valid = true;
+        } else {
+          int bl = m, r = 0;
+          if (p.R != 1) { bl = m / p.R; r = m - bl * p.R; }
+          b = p.b0 + bl;
+          t = step + (p.offs ? p.offs[r] : 0);
+          prow = (long)b * p.R + r;
+          valid = (t >= 0);
+          cmask = (NT == 3) && p.mask_last && (r == p.R - 1);     // v3 presum row: the chain contracts its centre tap
+        }
       }
       if (wave == 0 && aq == 0) s_prow[arow] = valid ? prow : -1;
     }
@@ -464,7 +478,7 @@ __global__ void __launch_bounds__(512) hsplit_kernel(const SplitParams p) {
         }
       }
     }
-    if constexpr (TRACE) { if (tr) p.dbg[6] = wall_clock64(); if (p.dbg_wg && tid == 0 && blockIdx.x < 128) p.dbg_wg[2 * blockIdx.x + 1] = wall_clock64(); }
+    if constexpr (TRACE) { if (tr) p.dbg[6] = wall_clock64(); if (p.dbg_wg && tid == 0 && wgid < 128) p.dbg_wg[2 * wgid + 1] = wall_clock64(); }
     if (MF == 32 && item + (int)gridDim.x < nitems) __syncthreads();      // s_prow / smem are reused by the next item
   }
 }
@@ -513,6 +527,7 @@ __device__ __forceinline__ void hbulk_body(const PT& p, const int step, const in
       prow = (long)b * p.R + r;
       valid = (t >= 0);
       cmask = p.mask_last && (r == p.R - 1);                   // presum row: the centre tap is contracted by the chain, not here
+      if (p.abs_bstride) prow = (long)b * p.abs_bstride + p.abs_row0 + t + p.abs_toff;
     }
     if (wave == 0 && lane < 32) s_prow[slot][arow] = valid ? prow : -1;
     const unsigned xs_row = valid ? (unsigned)(par * p.xs_set + ((long)b * p.xs_bstride + p.xs_row0 + t) * p.xs_stride) : (unsigned)(p.xs_row0 * p.xs_stride);

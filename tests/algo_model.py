@@ -94,7 +94,7 @@ def incremental_decode(L, W, hp, dtype=np.float32, frozen_R=False):
     return Y, traj
 
 
-def incremental_decode_v3(L, W, hp, dtype=np.float32, stats=None):
+def incremental_decode_v3(L, W, hp, dtype=np.float32, stats=None, hc2_rowop=True):
     """numpy MODEL of the round-2 decode data flow (decode3_kernels.h / dctts_api.hip: decode v3).  Same arithmetic as
     ``incremental_decode`` up to fp32 re-association, organised the way the HIP path computes it:
 
@@ -115,6 +115,14 @@ def incremental_decode_v3(L, W, hp, dtype=np.float32, stats=None):
     W1 = Pd["C_1/conv1d/kernel"][0]                              # (2d, d)
     VW = V @ W1[:d]                                               # (B, N, d)
     b1 = Pd["C_1/conv1d/bias"]
+    g1, be1 = Pd["C_1/normalize/gamma"], Pd["C_1/normalize/beta"]
+    W2 = Pd["HC_2/conv1d/kernel"]                                 # (3, d, 2d)
+    Wt = g1[None, :, None] * W2                                   # diag(gamma1) W2[q]
+    VWW = np.einsum('bnc,qcm->bnqm', VW, Wt)                     # (B, N, 3, 2d), once per batch
+    b1Wt = np.einsum('c,qcm->qm', b1, Wt); cs = Wt.sum(1); betaW = np.einsum('c,qcm->qm', be1, W2)
+    b2v = Pd["HC_2/conv1d/bias"]
+    C1QW = np.zeros((B, PAD + T, 3, 2 * d), dtype)
+    SC = np.zeros((B, PAD + T, 2 + hp.attention_win_size), dtype)   # per C_1 cone row: mean, rstd of the pre-norm row, attention weights
     Ypad = np.zeros((B, PAD + T + 1, hp.n_mels), dtype)
     AE = [np.zeros((B, PAD + T, l.cout), dtype) for l in ae]
     C1Q = np.zeros((B, PAD + T, d), dtype)
@@ -168,7 +176,27 @@ def incremental_decode_v3(L, W, hp, dtype=np.float32, stats=None):
                 n0, n1, lg, a = attn_weights(b, rows)
                 pre = b1 + a @ VW[b, n0:n1, :] + C1Q[b, PAD + np.asarray(rows), :]
                 AD[0][b, PAD + np.asarray(rows), :] = O.normalize(pre, Pd["C_1/normalize/gamma"], Pd["C_1/normalize/beta"])
-        for li in range(1, len(ad)):
+                mrow = pre.mean(-1); vrow = ((pre - mrow[:, None]) ** 2).mean(-1)
+                SC[b, PAD + np.asarray(rows), 0] = mrow; SC[b, PAD + np.asarray(rows), 1] = 1.0 / np.sqrt(vrow + dtype(O.LN_EPS))
+                SC[b, PAD + np.asarray(rows), 2:2 + a.shape[1]] = a
+        # HC_2 over its cone rows is a row operation too: its input x1[t'] = (pre[t'] - m) r gamma1 + beta1 is affine in pre[t'],
+        # and pre[t'] . (diag(gamma1) W2[q]) splits into cached pieces: VWW[n][q] (per batch), C1QW[t'][q] (once per frame)
+        l2 = ad[1]
+        rows2 = [j + o for o in cone[1] if o < 0 and j + o >= 0]
+        if rows2 and hc2_rowop:
+            C1QW[:, PAD + j - 1] = np.einsum('bc,qcn->bqn', C1Q[:, PAD + j - 1, :], Wt)       # the newest cached row (computed at the start of the bulk piece)
+            for b in range(B):
+                n0 = int(p[b]); n1 = min(n0 + hp.attention_win_size, hp.max_N)
+                for t in rows2:
+                    acc = b2v.copy()
+                    for q in range(3):
+                        tp = t - (2 - q) * l2.rate
+                        if tp < 0:
+                            continue
+                        m_, r_, a_ = SC[b, PAD + tp, 0], SC[b, PAD + tp, 1], SC[b, PAD + tp, 2:2 + (n1 - n0)]
+                        acc = acc + betaW[q] + r_ * (b1Wt[q] + a_ @ VWW[b, n0:n1, q, :] + C1QW[b, PAD + tp, q, :] - m_ * cs[q])
+                    AD[1][b, PAD + t, :] = hc_from_pre(l2, Pd, acc, AD[0][b, PAD + t, :])
+        for li in range(1 + (1 if hc2_rowop else 0), len(ad)):
             rows_l = [j + o for o in cone[li] if o < 0 and j + o >= 0]
             if rows_l:
                 AD[li][:, PAD + np.asarray(rows_l), :] = _layer_rows(ad[li], Pd, AD[li - 1], rows_l, dtype)
