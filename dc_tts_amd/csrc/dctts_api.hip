@@ -132,6 +132,10 @@ struct dctts_ctx {
   int* iota_dev = nullptr; int iota_n = 0;
   std::vector<hipGraphExec_t> bulk3_g, chain3_g; std::string graphs3_geom;
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
+  int chain_group = 0;                 // v3: runs of chain highway layers as one persistent launch with in-launch hand-offs (hcgroup_kernel; DCTTS_GROUP=0: one launch per layer)
+  void* group_tab = nullptr; std::string group_geom;   // per-frame HcGroupParams: [T][2] (AudioDec group of frame j, AudioEnc group of frame j)
+  float* group_xch = nullptr;          // exchange buffers, flags, error word (one allocation)
+  int* group_err_host = nullptr;       // pinned copy of the error word, refreshed after every decode
   int hc2_rowop = 1;                   // v3: AudioDec HC_2's cone rows as a row operation on cached products (0: GEMM + LN pass; DCTTS_HC2_ROWOP)
   int bulk3_fused = 0;                 // v3 bulk layers with more rows: 1 = full-row 16-row items with fused LN (hconv16_kernel), 0 = hbulk + ln_rows
   int bulk3_small_rows = 16;           // v3 bulk layers with at most this many rows per utterance (incl. the presum row) use the 16-row kernel form
@@ -363,6 +367,9 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   for (int* p : c->cone3_dev) (void)hipFree(p);
   if (c->iota_dev) (void)hipFree(c->iota_dev);
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
+  if (c->group_tab) (void)hipFree(c->group_tab);
+  if (c->group_xch) (void)hipFree(c->group_xch);
+  if (c->group_err_host) (void)hipHostFree(c->group_err_host);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;
@@ -1342,7 +1349,7 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   const dim3 grid(L.hc ? L.cout / 16 : (L.cout + 31) / 32, (B + 7) / 8);
 #define C3(PRO_, HC_) hipLaunchKernelGGL((chain3_kernel<PRO_, HC_>), grid, dim3(512), 0, st, p)
   if (pro == PRO_LN_HC && L.hc && !L.tap2 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) {   // DCTTS_TRACE: stamped instantiation
-    p.ts = g_trace_ctx->trace_buf + 8 * 64 * g_trace_ctx->trace_n++;
+    p.ts = g_trace_ctx->trace_buf + 32 * 64 * g_trace_ctx->trace_n++;
     hipLaunchKernelGGL((chain3_kernel<PRO_LN_HC, true, false, true>), grid, dim3(512), 0, st, p);
   } else
   if (L.tap2 && pro == PRO_LN_C) hipLaunchKernelGGL((chain3_kernel<PRO_LN_C, true, true>), grid, dim3(512), 0, st, p);
@@ -1358,11 +1365,85 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   return 0;
 }
 
+
+// ---- hcgroup_kernel plumbing: one HcGroupParams per (frame, network) in device memory; exchange buffers + flags + error word
+struct GroupMem { float* xch[2]; float* sch[2]; unsigned* flags[2]; int* err; int bpad; };
+static GroupMem group_mem(dctts_ctx* c, int B) {
+  GroupMem m; const int bpad = (B + 7) / 8 * 8;
+  float* base = c->group_xch;
+  m.bpad = bpad;
+  for (int n = 0; n < 2; ++n) { m.xch[n] = base; base += (size_t)2 * bpad * 512; m.sch[n] = base; base += (size_t)2 * bpad * 64; }
+  for (int n = 0; n < 2; ++n) { m.flags[n] = (unsigned*)base; base += (size_t)(bpad / 8) * 16; }
+  m.err = (int*)base;
+  return m;
+}
+static size_t group_mem_floats(int B) { const int bpad = (B + 7) / 8 * 8; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * (bpad / 8) * 16 + 64; }
+
+static int v3_group_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
+  const std::string g = geom("grp", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p);
+  if (c->group_tab && c->group_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->group_tab) { (void)hipFree(c->group_tab); c->group_tab = nullptr; }
+  if (c->group_xch) { (void)hipFree(c->group_xch); c->group_xch = nullptr; }
+  HIPCHK(hipMalloc((void**)&c->group_xch, group_mem_floats(B) * sizeof(float)));
+  HIPCHK(hipMemset(c->group_xch, 0, group_mem_floats(B) * sizeof(float)));
+  if (!c->group_err_host) { HIPCHK(hipHostMalloc((void**)&c->group_err_host, sizeof(int), 0)); *c->group_err_host = 0; }
+  const GroupMem m = group_mem(c, B);
+  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
+  auto rowp = [](const View& v, long par, int j) { return v.p + par * v.set + (v.row0 + j) * (long)v.stride; };
+  std::vector<HcGroupParams> tab((size_t)2 * T);
+  for (int j = 0; j < T; ++j) {
+    const long par = j & 1;
+    for (int net = 0; net < 2; ++net) {                       // 0 = AudioDec highway layers of frame j, 1 = AudioEnc highway layers of frame j
+      HcGroupParams p; memset(&p, 0, sizeof(p));
+      const std::vector<DevLayer>& Lr = net ? AE : AD;
+      size_t i0 = 0; while (i0 < Lr.size() && !Lr[i0].hc) ++i0;
+      size_t i1 = i0; while (i1 < Lr.size() && Lr[i1].hc) ++i1;
+      const int L = (int)(i1 - i0);
+      if (i0 == 0 || L < 2 || L > 10 || Lr[i0 - 1].cout != 256 || Lr[i0 - 1].act != ACT_NONE) return fail(DCTTS_ERR_STATE, "v3 groups: a run of 2..10 highway layers after a linear 256-channel layer");
+      p.B = B; p.L = L;
+      const std::vector<float*>& P = net ? w.pe : w.pd; const std::vector<float*>& S = net ? w.se : w.sd;
+      const std::vector<View>& H = net ? w.ae : w.ad;
+      p.P0 = P[i0 - 1]; p.p0_bs = 256; p.stats0 = S[i0 - 1]; p.pg1 = Lr[i0 - 1].g1; p.pb1 = Lr[i0 - 1].b1;
+      for (int k = 0; k < L; ++k) {
+        const size_t i = i0 + k; const DevLayer& Ly = Lr[i];
+        if (Ly.cout != 256 || Ly.cin != 256 || !Ly.wp16 || !Ly.wp16c) return fail(DCTTS_ERR_STATE, "v3 groups: 256-channel causal k=3 highway layers only");
+        HcGroupLayer& q = p.lay[k];
+        q.wp = Ly.wp16; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2; q.tap2 = Ly.tap2 ? 1 : 0;
+        if (net) { q.presum = w.pse[i] + par * w.pse_set; q.presum_bs = 512; }
+        else { q.presum = w.pb3[i] + par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 512; q.presum_bs = c->cone_len[i] * 512; }
+        const View& hin = H[i - 1];                             // this layer's input rows
+        const bool keep = net ? true : (k + 1 == L);            // AudioEnc: every row is history; AudioDec: only the residual the next launch (C_8) needs
+        if (keep) { q.xm = rowp(hin, net ? 0 : par, j); q.xm_bs = (int)(hin.bstride * hin.stride); }
+        if (Ly.tap2) { q.xt = rowp(hin, 0, j) - hin.stride; q.xt_bs = (int)(hin.bstride * hin.stride); }
+        else { q.xt = q.wp; q.xt_bs = 0; }
+      }
+      p.pout = P[i1 - 1]; p.stats_out = S[i1 - 1];
+      p.xch = m.xch[net]; p.sch = m.sch[net]; p.xch_set = m.bpad * 512; p.sch_set = m.bpad * 64;
+      p.uses0 = (unsigned)j * (unsigned)(L / 2); p.uses1 = (unsigned)j * (unsigned)((L - 1) / 2); p.err = m.err;   // layers 0 .. L-2 publish: copy 0 ceil((L-1)/2) times, copy 1 floor((L-1)/2)
+      tab[(size_t)2 * j + net] = p;
+    }
+  }
+  HIPCHK(hipMalloc(&c->group_tab, tab.size() * sizeof(HcGroupParams)));
+  HIPCHK(hipMemcpy(c->group_tab, tab.data(), tab.size() * sizeof(HcGroupParams), hipMemcpyHostToDevice));
+  c->group_geom = g;
+  return 0;
+}
+
+static int v3_group_launch(dctts_ctx* c, int B, int j, int net, hipStream_t st) {
+  const HcGroupParams* p = (const HcGroupParams*)c->group_tab + (size_t)2 * j + net;
+  hipLaunchKernelGGL((hcgroup_kernel<0>), dim3(16, (B + 7) / 8), dim3(512), 0, st, p);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // AudioDec HC_2 .. C_11 for frame j (its C_1 ran at the end of the previous chain piece)
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
   const int par = j & 1;
-  for (size_t i = 1; i < AD.size(); ++i) {
+  size_t first = 1;
+  if (c->chain_group) { CHK(v3_group_launch(c, B, j, 0, sm)); while (first < AD.size() && AD[first].hc) ++first; }
+  for (size_t i = first; i < AD.size(); ++i) {
     SplitExtra ex;
     if (AD[i].wp16c) { ex.presum = w.pb3[i] + (long)par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout; ex.presum_rstride = c->cone_len[i] * 2 * AD[i].cout; }
     CHK(run_chain3(c, AD[i], B, j, &AD[i - 1], w.pd[i - 1], w.sd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr, &w.ad[i - 1], nullptr,
@@ -1384,6 +1465,8 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1));
     } else if (i == 0) {
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
+    } else if (c->chain_group && AE[i].hc) {
+      if (!AE[i - 1].hc) CHK(v3_group_launch(c, B, j, 1, sm));      // the whole run of highway layers; the other indices of the run are covered by it
     } else {
       SplitExtra ex;
       if (AE[i].wp16c) { ex.presum = w.pse[i] + (long)(j & 1) * w.pse_set; ex.presum_rstride = 2 * AE[i].cout; }
@@ -1414,28 +1497,35 @@ static int v3_final_mel(dctts_ctx* c, const DecodeWs& w, int B, int T, hipStream
 }
 
 static int write_trace3(dctts_ctx* c, int j) {
-  std::vector<long long> h(64 * 64 * 8);
+  std::vector<long long> h(64 * 64 * 32);
   HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   const char* path = getenv("DCTTS_TRACE_FILE");
   FILE* f = fopen(path ? path : "decode_trace.txt", "w");
   if (!f) return 0;
   long long t0 = 0;
-  for (int k = 0; k < c->trace_n; ++k) for (int wg = 0; wg < 64; ++wg) { const long long e = h[(k * 64 + wg) * 8]; if (e && (!t0 || e < t0)) t0 = e; }
+  for (int k = 0; k < c->trace_n; ++k) for (int wg = 0; wg < 64; ++wg) { const long long e = h[(k * 64 + wg) * 32]; if (e && (!t0 || e < t0)) t0 = e; }
   fprintf(f, "# chain3_kernel<LN_HC, HC> launches of chain piece %d: microseconds (100 MHz wall clock) since the first entry of the piece\n", j);
-  fprintf(f, "# idx wgs | first_entry last_entry | median over workgroups of: entry->loads_issued ->landed ->mfma_done ->barrier ->end | last_end\n");
+  fprintf(f, "# idx wgs | first_entry last_entry | median over workgroups, wave 0: entry->loads_issued ->landed ->mfma_done ->barrier ->end | last_end | median over workgroups of (last wave - first wave): entry, landed, mfma_done\n");
   for (int k = 0; k < c->trace_n; ++k) {
-    std::vector<double> ph[5]; long long e0 = 0, e1 = 0, x1 = 0; int nw = 0;
+    std::vector<double> ph[8]; long long e0 = 0, e1 = 0, x1 = 0; int nw = 0;
     for (int wg = 0; wg < 64; ++wg) {
-      const long long* o = &h[(k * 64 + wg) * 8];
+      const long long* o = &h[(k * 64 + wg) * 32];
       if (!o[0] || !o[5]) continue;
       if (!nw || o[0] < e0) e0 = o[0]; if (!nw || o[0] > e1) e1 = o[0]; if (!nw || o[5] > x1) x1 = o[5];
       for (int q = 0; q < 5; ++q) ph[q].push_back((o[q + 1] - o[q]) / 100.0);
+      for (int q = 0; q < 3; ++q) {
+        long long mn = o[8 + 8 * q], mx = mn;
+        for (int w = 1; w < 8; ++w) { mn = std::min(mn, o[8 + 8 * q + w]); mx = std::max(mx, o[8 + 8 * q + w]); }
+        ph[5 + q].push_back((mx - mn) / 100.0);
+      }
       ++nw;
     }
     if (!nw) continue;
     fprintf(f, "%2d %3d | %8.2f %8.2f |", k, nw, (e0 - t0) / 100.0, (e1 - t0) / 100.0);
     for (int q = 0; q < 5; ++q) { std::sort(ph[q].begin(), ph[q].end()); fprintf(f, " %6.2f", ph[q][ph[q].size() / 2]); }
-    fprintf(f, " | %8.2f\n", (x1 - t0) / 100.0);
+    fprintf(f, " | %8.2f |", (x1 - t0) / 100.0);
+    for (int q = 5; q < 8; ++q) { std::sort(ph[q].begin(), ph[q].end()); fprintf(f, " %6.2f", ph[q][ph[q].size() / 2]); }
+    fprintf(f, "\n");
   }
   fclose(f);
   return 0;
@@ -1444,6 +1534,13 @@ static int write_trace3(dctts_ctx* c, int j) {
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
   CHK(decode_v2_init(c));
   CHK(v3_aepre_table(c, w, B));
+  if (c->chain_group) {
+    if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off of the previous decode timed out (hcgroup_kernel)");
+    CHK(v3_group_table(c, w, B, T));
+    const GroupMem m = group_mem(c, B);
+    HIPCHK(hipMemsetAsync(m.xch[0], 0xFF, (size_t)2 * (2 * m.bpad * 512 + 2 * m.bpad * 64) * sizeof(float), st));   // exchange words: stamp 1 (the first use expects 0)
+    HIPCHK(hipMemsetAsync(m.err, 0, sizeof(int), st));
+  }
   hipStream_t sb = c->s_bulk;
   // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch; 2 = the chain piece too.  Every
   // piece only waits at its start and records at its end, so the host issues 2 graph launches + 4 event operations per frame.
@@ -1454,7 +1551,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     return v3_final_mel(c, w, B, T, s);
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" +
                           std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs2(c);
@@ -1502,8 +1599,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0));
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][0], st));
     if (j == tstep) {
-      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 8 * sizeof(long long))); }
-      HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 64 * 8 * sizeof(long long), st));
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
+      HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long), st));
       c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
     }
     if (skip != 2) { if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[j + 1], st)); else CHK(chain_piece(j, st)); }
@@ -1515,6 +1612,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       CHK(write_trace3(c, j));
     }
   }
+  if (c->chain_group) HIPCHK(hipMemcpyAsync(c->group_err_host, group_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
     for (int i = 0; i < 8; ++i) {
@@ -1545,6 +1643,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   if (const char* e = getenv("DCTTS_BULK3_SMALL")) c->bulk3_small_rows = atoi(e);
   if (const char* e = getenv("DCTTS_BULK3_FUSED")) c->bulk3_fused = atoi(e);
   if (const char* e = getenv("DCTTS_HC2_ROWOP")) c->hc2_rowop = atoi(e);
+  if (const char* e = getenv("DCTTS_GROUP")) c->chain_group = atoi(e);
   if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
   if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
