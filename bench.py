@@ -7,6 +7,15 @@ Multi-GPU: utterances shard embarrassingly, 32 per GPU, no collective on the dat
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+What the JSON line holds besides the contract's fields (everything is measured in this run unless it says otherwise):
+  roofline            the kernel that dominates the step by TIME: chain3_kernel<LN_HC,HC> (newest-row highway layers of the decode),
+                      HIP-event timed on its stream inside the timed region (every 16th frame), both roof fractions
+  kernels             the same figures for the FLOP-dominant kernel (SSRN HC_11/12) and the decode's bulk GEMM (untimed extra passes)
+  phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
+  other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share)
+  cpu_baseline        the oracle (numpy port of the reference loop) on the host cores, bounded sample; + its incremental variant
+  host_transfer / gather     PCIe-inclusive figures (never `value`)
 """
 import argparse
 import json
@@ -21,17 +30,30 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-DOMINANT_KERNEL_ID = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
+PROF_SSRN_HC = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
+PROF_CHAIN_HC = 30000             # include/dctts_hip_debug.h: chain3_kernel<LN_HC, HC>, sampled every 16th frame
+PROF_BULK_GEMM = 30001            # hbulk_kernel<12> (eager decode only)
 
 
-def cpu_baseline(hp, W, seconds_budget=25.0):
-    """The oracle (a port: numpy restatement of the reference, TF being uninstallable here) timed on the host
-    cores, on a bounded sample: a few steps of the reference's full-recompute loop (synthesize.py:47-54, TextEnc
-    recomputed every step as the reference does) for a small batch, plus one SSRN pass, prorated per mel frame."""
+def both_roofs(flop, nbytes, ms):
+    """achieved FLOP/s and B/s of `flop` / `nbytes` of ALGORITHMIC work done in `ms`, as fractions of both roofs."""
+    tf = flop / (ms * 1e-3) / 1e12
+    gb = nbytes / (ms * 1e-3) / 1e9
+    return {"tflops": round(tf, 3), "frac_mfma": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_GBps": round(gb, 1),
+            "frac_hbm": round(gb / PEAK_HBM_GBPS, 4)}
+
+
+def cpu_baseline(hp, W):
+    """The oracle (a port: numpy restatement of the reference, TF being uninstallable here) timed on the host cores, on a
+    bounded sample: a few steps of the reference's full-recompute loop (synthesize.py:47-54, TextEnc recomputed every step as the
+    reference does) for a small batch, plus one SSRN pass, prorated per mel frame.  BASELINE.md section 3 also asks for the
+    oracle's INCREMENTAL variant (oracle/incremental_ref.py: the algorithm the HIP path runs, in numpy), so that the algorithmic
+    and the hardware speed-up can be told apart."""
     from dc_tts_amd.weights import synthetic_text
     from oracle import dctts_ref as O
+    from oracle.incremental_ref import incremental_decode_v3
     Bs, steps = 2, 3
     L = synthetic_text(hp, B=Bs, seed=99)
     Y = np.zeros((Bs, hp.max_T, hp.n_mels), np.float32)
@@ -47,6 +69,11 @@ def cpu_baseline(hp, W, seconds_budget=25.0):
     O.SSRN(Y[:1], W, hp)
     t_ssrn = time.perf_counter() - t0                         # seconds per utterance
     per_frame = t_step / Bs + t_ssrn / hp.max_T               # one loop step yields one mel frame per utterance
+    Ti = 120                                                  # > 85: the full AudioDec cone is re-evaluated in the later steps
+    t0 = time.perf_counter()
+    incremental_decode_v3(L, W, hp.replace(max_T=Ti), np.float32)
+    t_inc = (time.perf_counter() - t0) / (Bs * Ti)            # seconds per mel frame, decode incl. one TextEnc per utterance
+    per_frame_inc = t_inc + t_ssrn / hp.max_T
     try:                                                      # threads numpy's BLAS actually runs on (the matmuls are the work)
         from threadpoolctl import threadpool_info
         cores = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
@@ -56,7 +83,11 @@ def cpu_baseline(hp, W, seconds_budget=25.0):
             "sample": f"{steps} steps of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, "
                       f"B={Bs}, N={hp.max_N}, T={hp.max_T}) + 1 SSRN pass (B=1), numpy fp32 (BLAS threads = cores), "
                       f"prorated per mel frame",
-            "rtf": per_frame / hp.seconds_per_mel_frame}
+            "rtf": per_frame / hp.seconds_per_mel_frame,
+            "incremental_variant": {"value": 1.0 / per_frame_inc, "unit": "mel frames/s", "rtf": per_frame_inc / hp.seconds_per_mel_frame,
+                                    "sample": f"oracle/incremental_ref.incremental_decode_v3 (the HIP path's algorithm in numpy: TextEnc once, "
+                                              f"cached AudioEnc, cone re-evaluation), B={Bs}, T={Ti}, + the same SSRN pass, prorated per mel frame",
+                                    "algorithmic_speedup_over_reference_loop": round(per_frame / per_frame_inc, 1)}}
 
 
 def vocoder_cpu_baseline(hp, mag1):
@@ -107,11 +138,21 @@ def vocoder_section(hp, Z, ms_synth, with_cpu):
     tj = os.path.join(ROOT, "profiles", "r01_vocoder_pmc.json")
     if B == 32 and F == 840 and os.path.exists(tj):           # PMC FETCH_SIZE x2 + WRITE_SIZE per launch, separate rocprofv3 passes
         out["roofline"]["traffic"] = json.load(open(tj))["hbm_bytes_per_launch"]
-        out["roofline"]["traffic_unit"] = "bytes/launch (PMC, separate pass: profiles/r01_vocoder.md)"
+        out["roofline"]["traffic_unit"] = "bytes/launch (PMC, separate pass of round 1: profiles/r01_vocoder.md; kernel unchanged since)"
     if with_cpu:
         out["cpu_baseline"] = vocoder_cpu_baseline(hp, Z[0].cpu().numpy())
     v.close()
     return out
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
 
 
 def main():
@@ -123,9 +164,10 @@ def main():
     ap.add_argument("--max-T", type=int, default=210)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-mode", type=int, default=1, help="0 eager, 1 bulk pieces as hipGraphs (default), 2 chain pieces too")
-    ap.add_argument("--decode-mode", type=int, default=1, help="1 = default (split kernels, two streams), 2 = + fused k=1 row MLP, 0 = fused full-row kernels")
+    ap.add_argument("--decode-mode", type=int, default=3, help="3 = default (round-2 decode: hoisted taps, row-op cone layers), 1 / 2 = round-1 split kernels, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vocoder", action="store_true", help="skip the untimed vocoder-tail section (SURVEY 8f-2)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed per-kernel passes and the other BASELINE configs")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL; the driver's multi-GPU runs) or gloo (plumbing test: ranks may share a GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -140,22 +182,26 @@ def main():
     if args.share_gpu:
         local = 0
     torch.cuda.set_device(local)
+    host_group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            host_group = dist.new_group(backend="gloo")       # the host gather of SURVEY 8e (results meet on rank 0's host, not on a GPU)
         else:
             dist.init_process_group(args.dist_backend)
+            host_group = dist.group.WORLD
 
     from dc_tts_amd.engine import Engine
     from dc_tts_amd.hyperparams import hp as hp0
-    from dc_tts_amd.layers import ssrn_layers
+    from dc_tts_amd.sharding import gather_to_host
     from dc_tts_amd.weights import synthetic_text, synthetic_weights
 
     hp = hp0.replace(max_T=args.max_T)
     B, T = args.batch, hp.max_T
     W = synthetic_weights(hp, seed=1234, perturb=True)
-    eng = Engine(W, hp, device=local, decode_graph=0 if args.no_graph else args.graph_mode)
+    gm = 0 if args.no_graph else args.graph_mode
+    eng = Engine(W, hp, device=local, decode_graph=gm)
     eng.set_decode_mode(args.decode_mode)
     L = torch.from_numpy(synthetic_text(hp, B=B, seed=1234 + rank)).cuda()
 
@@ -168,7 +214,8 @@ def main():
     for _ in range(args.warmup):
         eng.synthesize(L)
     barrier()
-    eng.prof_enable(DOMINANT_KERNEL_ID)
+    chain_prof = args.decode_mode == 3 and gm != 2          # the sampled launches must be eager launches
+    eng.prof_enable(PROF_CHAIN_HC if chain_prof else -1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         Y, Z, mx = eng.synthesize(L)
@@ -178,101 +225,165 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     eng.prof_enable(-1)
-    n_launch, dom_ms = eng.prof_collect()
-    dom_rows = eng.prof_rows()
+    n_chain, chain_ms = eng.prof_collect()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # measurement only: no collective on the data path
         elapsed = float(t.item())
+    eng.decode_status()                                              # raises if an in-launch hand-off timed out (opt-in group kernel)
 
-    # ---- untimed: per-phase breakdown (torch events on the launch stream)
-    def timed(fn, reps=3):
-        fn(); torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record(); torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-    phases = None
-    host_xfer = None
-    if rank == 0:
-        # PCIe-inclusive figure (reported beside `value`, never as it): ids host->device + Z device->pinned host per batch
-        Lh = L.cpu().pin_memory()
-        Zh = torch.empty(Z.shape, dtype=Z.dtype, pin_memory=True)
-        def xfer():
-            L.copy_(Lh, non_blocking=True); Zh.copy_(Z, non_blocking=True)
-        ms_x = timed(xfer)
-        host_xfer = {"h2d_bytes": Lh.numel() * 4, "d2h_bytes": Z.numel() * 4, "ms_per_batch": round(ms_x, 3),
-                     "GBps": round(Z.numel() * 4 / (ms_x * 1e-3) / 1e9, 1)}
-        ms_te = timed(lambda: eng.text_enc(L))
-        ms_t2m = timed(lambda: eng.text2mel(L))
-        ms_ssrn = timed(lambda: eng.ssrn(Y, want_logits=False))
-        phases = {"textenc_ms": round(ms_te, 3), "text2mel_total_ms": round(ms_t2m, 3),
-                  "decode_us_per_step": round((ms_t2m - ms_te) * 1e3 / T, 2), "ssrn_ms": round(ms_ssrn, 3)}
+    # ---- the host gather of SURVEY 8e, timed separately (never part of `value`): every rank's Z -> its pinned host buffer ->
+    #      rank 0's host (gloo); with one rank this is the plain D2H copy
+    Zh = torch.empty(Z.shape, dtype=Z.dtype, pin_memory=True)
+    barrier()
+    tg0 = time.perf_counter()
+    gathered = gather_to_host(Z, Zh, host_group, world, rank)
+    if world > 1:
+        dist.barrier()
+    gather_s = time.perf_counter() - tg0
+    if world > 1:
+        t = torch.tensor([gather_s], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_s = float(t.item())
+    if rank == 0 and world > 1:
+        assert gathered is not None and tuple(gathered.shape) == (world * B, Z.shape[1], Z.shape[2])
 
     if rank == 0:
         frames = world * B * T * args.steps
         value = frames / elapsed
+        ms_step = elapsed / args.steps * 1e3
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
-        # roofline of the dominant kernel: algorithmic FLOPs of one launch = 2 * rows * K * N of the layer
-        C = 2 * hp.c                                             # SSRN HC_11 / HC_12: 1024 -> 2048, k = 3
-        # rows per launch as the library reports them: the layer's B*4T rows minus the row tail that goes to hconv16_kernel
-        rows_per_launch = dom_rows / n_launch if n_launch else B * 4 * T
-        flops_per_launch = 2.0 * rows_per_launch * (3 * C) * (2 * C)
-        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                "traffic": None, "kernel": "hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11/HC_12, 1024ch k=3, fused LN+gate): the largest kernel by FLOPs (27 % of the pipeline); by time the latency-bound decode chain dominates, see phase_rooflines.decode",
-                "launches": n_launch, "avg_launch_ms": None, "flop_per_launch": flops_per_launch,
-                "rows_per_launch": rows_per_launch, "layer_rows": B * 4 * T}
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if B == 32 and T == 210 and os.path.exists(tj):
-            # HBM bytes per launch of this kernel from the PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-            # collected separately with rocprofv3 --pmc (profiles/r01_pmc_traffic.md); bench.py cannot read counters itself
-            roof["traffic"] = json.load(open(tj))["hbm_bytes_per_launch"]
-            roof["traffic_unit"] = "bytes/launch (PMC, separate pass)"
-        if n_launch > 0:
-            avg_ms = dom_ms / n_launch
-            ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roof.update(achieved=round(ach, 2), frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), avg_launch_ms=round(avg_ms, 4))
-        # whole-pipeline algorithmic FLOPs per mel frame: TextEnc/T + AudioEnc + AudioDec cone + attention + SSRN
-        flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6
-        # per-phase fractions of both roofs from SURVEY 8d's algorithmic work (FLOP and fp32 bytes per utterance) and the phase times
-        # above: by TIME the decode dominates and is latency-bound -- `roofline` below is the kernel that dominates by FLOPs
-        def _pr(flop_utt, bytes_utt, ms):
-            tf = B * flop_utt / (ms * 1e-3) / 1e12
-            gb = B * bytes_utt / (ms * 1e-3) / 1e9
-            return {"tflops": round(tf, 2), "frac_mfma": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "algorithmic_GBps": round(gb, 1),
-                    "frac_hbm": round(gb / PEAK_HBM_GBPS, 4)}
-        dec_ms = phases["text2mel_total_ms"] - phases["textenc_ms"]
-        phase_roof = {
-            "textenc": _pr(2 * 3.0789e9, 68.6e6 / B + 0.37e6, phases["textenc_ms"]),
-            "decode": dict(_pr(T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 / B + 125e3), dec_ms),
-                           bound="latency: 25 dependent launches per frame on the critical path (DESIGN.md section 4)"),
-            "ssrn": _pr(T * 187.310e6, 67200 + 3444000 + 113641532.0 / B, phases["ssrn_ms"]),
-        }
+        d = hp.d
+        # ---- roofline: the kernel that dominates the step by time.  Algorithmic work of ONE launch (B rows, 256 -> 2 x 256, fp32):
+        #      weights 256 x 512, presum + pre-norm rows in + out (B x 512 each), partial statistics in + out (B x 64 each), highway
+        #      residual in + rebuilt row out (B x 256 each), LN parameters (4 x 256)
+        c3_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + 2 * B * d + 4 * d)
+        c3_flop = 2.0 * B * d * 2 * d
+        roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "chain3_kernel<LN_HC,HC>: one newest-row highway layer of the decode (AudioEnc HC_5..13 / AudioDec HC_3..7: rebuild "
+                          "the input row from the producer's pre-norm row, 32 x 256 x 512 contraction on 16x16x4 fp32 MFMA, partial LN "
+                          "statistics out); 14 of the 25 dependent launches of a frame, ~35 % of the step time",
+                "launches": n_chain, "sampled": "every 16th frame of the timed region", "avg_launch_ms": None,
+                "algorithmic_bytes_per_launch": c3_bytes, "flop_per_launch": c3_flop,
+                "note": "latency-bound: ~1.45 us of launch boundary + one memory round trip + an 8-wave reduction per 5 us launch; the "
+                        "fraction of either roof is what a 64-workgroup, 25-deep dependent chain leaves (DESIGN.md section 4)"}
+        if n_chain > 0:
+            avg = chain_ms / n_chain
+            roof.update(avg_launch_ms=round(avg, 5), achieved=round(c3_bytes / (avg * 1e-3) / 1e9, 1),
+                        frac=round(c3_bytes / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), frac_mfma=round(c3_flop / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        tj = os.path.join(ROOT, "profiles", "r02_pmc_chain.json")
+        if os.path.exists(tj):
+            roof["traffic"] = json.load(open(tj)).get("hbm_bytes_per_launch")
+            roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: profiles/r02_pmc.md)"
+        flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6      # SURVEY 8d, per mel frame and utterance
         out = {
             "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
             "rtf": rtf, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded character ids, seeded random-init weights)",
             "config": {"workload": f"full Text2Mel autoregressive decode + SSRN, batch={B}/GPU, max_N={hp.max_N}, "
                                    f"max_T={T} mel frames -> ({B},{4 * T},{hp.n_linear}) per GPU; exact-parity incremental decode",
-                       "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_graph_mode": 0 if args.no_graph else args.graph_mode,
+                       "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_mode": args.decode_mode, "decode_graph_mode": gm,
                        "sharding": f"{world} x {B} utterances, no collective"},
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "phases": phases, "phase_rooflines": phase_roof, "roofline": roof, "device_bytes": eng.device_bytes(),
-            "host_transfer": dict(host_xfer, value_incl_transfer=round(world * B * T / ((elapsed / args.steps) + host_xfer["ms_per_batch"] * 1e-3), 1),
-                                  note="serial upper bound on the cost: the copy of batch n can overlap the compute of batch n+1"),
+            "roofline": roof, "device_bytes": eng.device_bytes(),
+            "gather": {"what": "every rank's Z (B,4T,1025) -> its pinned host buffer (D2H) -> rank 0's host over gloo (SURVEY 8e); one rank: the D2H copy",
+                       "bytes_per_rank": Z.numel() * 4, "seconds": round(gather_s, 5),
+                       "value_incl_gather": round(world * B * T / (elapsed / args.steps + gather_s), 1),
+                       "note": "serial upper bound on the cost: the gather of batch n can overlap the compute of batch n+1"},
         }
+        if not args.no_extras:
+            out.update(extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(hp, W)
         if world == 1 and not args.no_vocoder:
-            out["vocoder"] = vocoder_section(hp, Z, elapsed / args.steps * 1e3, not args.no_cpu_baseline)
+            out["vocoder"] = vocoder_section(hp, Z, ms_step, not args.no_cpu_baseline)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
+    """Untimed passes on rank 0 after the timed region: per-phase times, the two other kernels that matter, the other BASELINE
+    configurations that fit one GPU."""
+    from dc_tts_amd.engine import Engine
+    from dc_tts_amd.weights import synthetic_text
+    d, c = hp.d, hp.c
+    res = {}
+    # ---- phases
+    ms_te = timed(lambda: eng.text_enc(L))
+    ms_t2m = timed(lambda: eng.text2mel(L))
+    ms_ssrn = timed(lambda: eng.ssrn(Y, want_logits=False))
+    dec_ms = ms_t2m - ms_te
+    res["phases"] = {"textenc_ms": round(ms_te, 3), "text2mel_total_ms": round(ms_t2m, 3),
+                     "decode_us_per_step": round(dec_ms * 1e3 / T, 2), "ssrn_ms": round(ms_ssrn, 3)}
+    # fractions of BOTH roofs from SURVEY 8d's algorithmic work (FLOP and fp32 bytes per utterance) and the phase times
+    res["phase_rooflines"] = {
+        "textenc": both_roofs(B * 2 * 3.0789e9, 68.6e6 + B * 0.37e6, ms_te),
+        "decode": dict(both_roofs(B * T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 + B * 125e3), dec_ms),
+                       bound="latency: 25 dependent launches per frame on the critical path; the cone work of AudioDec C_1 / HC_2 runs as row "
+                             "operations on cached products, so fewer FLOPs are EXECUTED than the algorithmic count used here (DESIGN.md section 2)"),
+        "ssrn": both_roofs(B * T * 187.310e6, B * (67200 + 3444000) + 113641532.0, ms_ssrn),
+    }
+    res["roofline_frac_decode_phase_mfma"] = res["phase_rooflines"]["decode"]["frac_mfma"]
+    # ---- kernels: event-timed extra passes
+    kern = []
+    eng.prof_enable(PROF_SSRN_HC)
+    for _ in range(2):
+        eng.ssrn(Y, want_logits=False)
+    torch.cuda.synchronize(); eng.prof_enable(-1)
+    n, ms = eng.prof_collect(); rows = eng.prof_rows()
+    if n:
+        C = 2 * c
+        rpl = rows / n
+        kern.append(dict(kernel="hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11 / HC_12: 1024 ch, k=3, fused LN + gate): the largest kernel by FLOPs",
+                         bound="mfma", launches=n, avg_launch_ms=round(ms / n, 4), rows_per_launch=rpl, layer_rows=B * 4 * T,
+                         **both_roofs(2.0 * rpl * 3 * C * 2 * C, 4.0 * (rpl * C * 2 + 3 * C * 2 * C), ms / n)))
+    if args.decode_mode == 3:
+        eng.set_decode_graph(0); eng.text2mel(L); torch.cuda.synchronize()
+        eng.prof_enable(PROF_BULK_GEMM); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
+        n, ms = eng.prof_collect(); rows = eng.prof_rows()
+        eng.set_decode_graph(gm)
+        if n:
+            rpl = rows / n
+            kern.append(dict(kernel="hbulk_kernel<12> (decode bulk stream: AudioDec HC_3 cone rows + presum row, 256 ch, k=3, split-K over 8 waves)",
+                             bound="mfma", launches=n, avg_launch_ms=round(ms / n, 5), rows_per_launch=rpl,
+                             **both_roofs(2.0 * rpl * 3 * d * 2 * d, 4.0 * (rpl * (d + 2 * d) + 3 * d * 2 * d), ms / n),
+                             note="eager decode pass (graph mode 0) so that events can bracket the launches; runs concurrently with the chain"))
+    res["kernels"] = kern
+    # ---- host transfer (PCIe-inclusive figure, reported beside `value`, never as it)
+    Lh = L.cpu().pin_memory()
+    Zh = torch.empty(Z.shape, dtype=Z.dtype, pin_memory=True)
+    def xfer():
+        L.copy_(Lh, non_blocking=True); Zh.copy_(Z, non_blocking=True)
+    ms_x = timed(xfer)
+    res["host_transfer"] = {"h2d_bytes": Lh.numel() * 4, "d2h_bytes": Z.numel() * 4, "ms_per_batch": round(ms_x, 3),
+                            "GBps": round(Z.numel() * 4 / (ms_x * 1e-3) / 1e9, 1),
+                            "value_incl_transfer": round(B * T / ((ms_step + ms_x) * 1e-3), 1)}
+    # ---- the other BASELINE configurations that fit one GPU (configs[3] is this run; [0] is the CPU plumbing case)
+    oc = {}
+    oc["config2_text2mel_decode_b32"] = {"workload": f"TextEnc + {T}-step decode, B={B}", "ms_per_batch": round(ms_t2m, 3),
+                                         "mel_frames_per_s": round(B * T / (ms_t2m * 1e-3), 1), "rtf": ms_t2m * 1e-3 / (B * T * hp.seconds_per_mel_frame)}
+    B3 = 128
+    Y3 = torch.rand(B3, T, hp.n_mels, device=Y.device)
+    ms3 = timed(lambda: eng.ssrn(Y3, want_logits=False), reps=2)
+    oc["config3_ssrn_only_b128"] = dict(workload=f"SSRN only, B={B3}: ({B3},{T},80) -> ({B3},{4 * T},1025)", ms_per_batch=round(ms3, 3),
+                                        mel_frames_per_s=round(B3 * T / (ms3 * 1e-3), 1), rtf=ms3 * 1e-3 / (B3 * T * hp.seconds_per_mel_frame),
+                                        **both_roofs(B3 * T * 187.310e6, B3 * (67200 + 3444000) + 113641532.0, ms3))
+    del Y3
+    T5, B5 = 1000, 8
+    h5 = hp.replace(max_T=T5)
+    e5 = Engine(W, h5, device=eng.device_index, decode_graph=gm)
+    e5.set_decode_mode(args.decode_mode)
+    L5 = torch.from_numpy(synthetic_text(h5, B=B5, seed=77)).cuda()
+    ms5 = timed(lambda: e5.synthesize(L5), reps=2)
+    oc["config5_long_form_t1000_b8"] = {"workload": f"full Text2Mel + SSRN, max_T={T5}, B={B5} (one GPU's share of 64)", "ms_per_batch": round(ms5, 3),
+                                        "mel_frames_per_s": round(B5 * T5 / (ms5 * 1e-3), 1), "rtf": ms5 * 1e-3 / (B5 * T5 * h5.seconds_per_mel_frame)}
+    e5.close()
+    res["other_configs"] = oc
+    return res
 
 
 if __name__ == "__main__":

@@ -41,6 +41,7 @@ SYMBOLS = {
     "dctts_ssrn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dctts_text2mel_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dctts_synthesize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dctts_decode_status": (c_int, [c_void_p]),
     "dctts_set_decode_graph": (c_int, [c_void_p, c_int]),
     "dctts_set_decode_mode": (c_int, [c_void_p, c_int]),
     "dctts_device_bytes": (c_size_t, [c_void_p]),

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/dctts_hip.h"
+#include "../../include/dctts_hip_debug.h"
 #include "api_common.h"
 #include "attn_kernels.h"
 #include "decode_kernels.h"
@@ -158,11 +159,29 @@ struct dctts_ctx {
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
   // profiling
+  // measurement knobs, read ONCE from the environment in dctts_create (tools/README.md); never consulted per call
+  int bulk_prio = 1, ev_sys = 0, v3_skip = 0, trace_frame = -1, piecetime = -1, hosttime = 0;
+  std::string trace_file;
   int prof_id = -1;
+  bool prof_frame = false;             // decode: the current frame is one of the sampled ones (every 16th) for DCTTS_PROF_CHAIN_HC
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  std::vector<int> prof_cnt;           // launches bracketed by each event pair (runs of consecutive chain launches share one pair)
+  hipEvent_t prof_run_e0 = nullptr; int prof_run_n = 0;
 };
 
+// Every entry point runs on the context's device and leaves the caller's current device as it found it.
+struct DevGuard {
+  int prev = -1, dev = -1; bool ok = true;
+  explicit DevGuard(const dctts_ctx* c);
+  ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
 static void destroy_graphs2(dctts_ctx* c);
+DevGuard::DevGuard(const dctts_ctx* c) {
+  if (!c) return;
+  dev = c->device;
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+}
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------------------ weights
@@ -326,6 +345,21 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
   return out;
 }
 
+
+// Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
+static void read_env(dctts_ctx* c) {
+  auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
+  geti("DCTTS_TAIL_SPLIT", &c->tail_split);
+  { int r = c->chain_rows; geti("DCTTS_CHAIN_ROWS", &r); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
+  geti("DCTTS_FUSE_MEL", &c->fuse_mel); geti("DCTTS_BULK_SMALL", &c->bulk_small_rows); geti("DCTTS_BULK_PIPE", &c->bulk_pipelined);
+  geti("DCTTS_CHAIN_ONE", &c->chain_one);
+  { int r = c->bulk_cap; geti("DCTTS_BULK_CAP", &r); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
+  geti("DCTTS_BULK3_SMALL", &c->bulk3_small_rows); geti("DCTTS_BULK3_FUSED", &c->bulk3_fused); geti("DCTTS_HC2_ROWOP", &c->hc2_rowop);
+  geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
+  geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
+  if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI: lifetime
 extern "C" const char* dctts_last_error(void) { return g_err.c_str(); }
 
@@ -335,12 +369,13 @@ extern "C" int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg
   if (cfg->attention_win_size < 1 || cfg->attention_win_size > MAXWIN)
     return fail(DCTTS_ERR_ARG, "attention_win_size must be 1..3: the decode attention kernels are unrolled for a 3-key window (hyperparams.py:32)");
   if (cfg->max_N < 1 || cfg->n_mels < 4 || cfg->n_mels > 128 || (cfg->n_mels & 3)) return fail(DCTTS_ERR_ARG, "unsupported max_N / n_mels");
-  HIPCHK(hipSetDevice(device));
   dctts_ctx* c = new dctts_ctx();
   c->cfg = *cfg; c->device = device;
+  DevGuard dev_guard(c);
+  if (!dev_guard.ok) { delete c; return fail(DCTTS_ERR_HIP, "hipSetDevice: no such device"); }
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
-  if (const char* e = getenv("DCTTS_TAIL_SPLIT")) c->tail_split = atoi(e);
+  read_env(c);
   *out = c;
   return 0;
 }
@@ -353,7 +388,7 @@ static void free_ws(dctts_ctx* c) {
 
 extern "C" int dctts_destroy(dctts_ctx* c) {
   if (!c) return 0;
-  (void)hipSetDevice(c->device);
+  DevGuard dev_guard(c);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
   destroy_graphs2(c);
@@ -388,7 +423,8 @@ extern "C" int dctts_weights_set(dctts_ctx* c, const char* name, const float* da
 extern "C" int dctts_weights_finalize(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   if (c->finalized) return 0;
-  HIPCHK(hipSetDevice(c->device));
+  DevGuard dev_guard(c);
+  if (!dev_guard.ok) return fail(DCTTS_ERR_HIP, "hipSetDevice");
   const dctts_config& g = c->cfg;
   const int d = g.d, cc = g.c, F = g.n_linear, Fp = round_up(F, 32);
   char nm[64];
@@ -589,15 +625,15 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
     if ((tiles32 - full) * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
   }
   HIPCHK(launch_hconv(L.shape, p, st, tiles32));
-  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
+  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
   if (m_tail < p.M) { p.wp = L.wp16r; HIPCHK(launch_hconv16(L.shape16, p, m_tail, st)); }
   return 0;
 }
 
-static int check_ready(dctts_ctx* c) {
+static int check_ready(dctts_ctx* c, const DevGuard& g) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   if (!c->finalized) return fail(DCTTS_ERR_WEIGHTS, "weights not finalized");
-  if (hipSetDevice(c->device) != hipSuccess) return fail(DCTTS_ERR_HIP, "hipSetDevice");
+  if (!g.ok) return fail(DCTTS_ERR_HIP, "hipSetDevice");
   return 0;
 }
 
@@ -638,7 +674,8 @@ static int textenc_into(dctts_ctx* c, const int32_t* L, int B, int N, View* kv_o
 }
 
 extern "C" int dctts_textenc_fwd(dctts_ctx* c, const int32_t* L, int B, int N, float* K, float* V, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!L || !K || !V || B <= 0 || N <= 0) return fail(DCTTS_ERR_ARG, "textenc: bad argument");
   hipStream_t st = (hipStream_t)stream;
   View kv;
@@ -659,7 +696,8 @@ static int t2m_ws(dctts_ctx* c, int B, int T, View* a, View* b) {
 }
 
 extern "C" int dctts_audioenc_fwd(dctts_ctx* c, const float* S, int B, int T, float* Q, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!S || !Q || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audioenc: bad argument");
   hipStream_t st = (hipStream_t)stream;
   View a, b; CHK(t2m_ws(c, B, T, &a, &b));
@@ -676,7 +714,8 @@ extern "C" int dctts_audioenc_fwd(dctts_ctx* c, const float* S, int B, int T, fl
 }
 
 extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, float* logits, float* Y, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!R || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audiodec: bad argument");
   hipStream_t st = (hipStream_t)stream;
   View a, b; CHK(t2m_ws(c, B, T, &a, &b));
@@ -696,7 +735,8 @@ extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, fl
 extern "C" int dctts_attention_fwd(dctts_ctx* c, const float* Q, const float* K, const float* V, int B, int T, int N,
                                    int monotonic, const int32_t* prev_max, float* R, float* alignments,
                                    int64_t* max_attentions, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!Q || !K || !V || !R || B <= 0 || T <= 0 || N <= 0) return fail(DCTTS_ERR_ARG, "attention: bad argument");
   if (monotonic && !prev_max) return fail(DCTTS_ERR_ARG, "attention: monotonic mode needs prev_max_attentions");
   if (monotonic && N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "attention: monotonic mask is built from hp.max_N (networks.py:142); N must equal it");
@@ -712,7 +752,8 @@ extern "C" int dctts_attention_fwd(dctts_ctx* c, const float* Q, const float* K,
 
 // ------------------------------------------------------------------------------------------------ SSRN
 extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const int cc = c->cfg.c, F = c->cfg.n_linear, Fp = round_up(F, 32);
@@ -944,12 +985,16 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
     const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
     const bool plain = (pro == PRO_RAW) && L.cin == L.cin_p && c->bulk_pipelined;   // hbulk_kernel: software-pipelined across items
     if (ex && ex->mask_last && !(kg == 96 && plain)) return fail(DCTTS_ERR_STATE, "split kernel: presum rows need hbulk_kernel<12>");
+    const bool profb = c->prof_id == DCTTS_PROF_BULK_GEMM && kg == 96 && plain;
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (profb) { HIPCHK(hipEventCreate(&pe0)); HIPCHK(hipEventCreate(&pe1)); HIPCHK(hipEventRecord(pe0, st)); }
     if (kg == 96 && plain)      hipLaunchKernelGGL((hbulk_kernel<12>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 64 && plain) hipLaunchKernelGGL((hbulk_kernel<8>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 32 && plain) hipLaunchKernelGGL((hbulk_kernel<4>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 96) hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 64) hipLaunchKernelGGL((hsplit_kernel<32, false, 8>), dim3(nblk), dim3(512), sm, st, p);
-    else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): K must be 512 or 768");
+    else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): K must be 256, 512 or 768");
+    if (profb) { HIPCHK(hipEventRecord(pe1, st)); c->prof_ev.emplace_back(pe0, pe1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -962,12 +1007,11 @@ static int decode_v2_init(dctts_ctx* c) {
     // prefers the latency-critical chain launches (caller's stream) whenever both have workgroups ready
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const char* e = getenv("DCTTS_BULK_PRIO");
-    if (e && atoi(e) == 0) HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
+    if (!c->bulk_prio) HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
     else HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, lo));
   }
   // the two streams hand data to each other through device memory only: device-scope release on the event markers (no system-scope flush)
-  const unsigned evf = (getenv("DCTTS_EV_SYS") ? 0u : (unsigned)hipEventReleaseToDevice) | hipEventDisableTiming;
+  const unsigned evf = (c->ev_sys ? 0u : (unsigned)hipEventReleaseToDevice) | hipEventDisableTiming;
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, evf));
   for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], evf)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], evf)); }
   HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1148,7 +1192,8 @@ static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
 static int write_trace(dctts_ctx* c, int j) {
   std::vector<long long> h(64 * (8 + 256));
   HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  FILE* f = fopen("gpurun_out/decode_trace.txt", "w");
+  if (c->trace_file.empty()) return 0;                      // DCTTS_TRACE_FILE: where the stamps go (no default path)
+  FILE* f = fopen(c->trace_file.c_str(), "w");
   if (!f) return 0;
   long long t0 = 0; for (int k = 0; k < c->trace_n; ++k) if (h[8 * k] && (!t0 || h[8 * k] < t0)) t0 = h[8 * k];
   fprintf(f, "# chain launches (hsplit_kernel<16>) of chain piece %d, workgroup 0 thread 0, microseconds since first entry (100 MHz wall clock)\n", j);
@@ -1318,6 +1363,15 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
 }
 
 
+static int prof_close_run(dctts_ctx* c, hipStream_t st) {
+  if (!c->prof_run_e0) return 0;
+  hipEvent_t e1 = nullptr;
+  HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e1, st));
+  c->prof_ev.emplace_back(c->prof_run_e0, e1); c->prof_cnt.push_back(c->prof_run_n);
+  c->prof_run_e0 = nullptr; c->prof_run_n = 0;
+  return 0;
+}
+
 // One v3 chain layer on chain3_kernel (256 input channels).  `prod` = the layer whose pre-norm rows `P` (+ partial statistics
 // `stats_in`) are this layer's input (nullptr: PRO_RAW, `xin` is the input row view); `res` = highway residual of `prod`;
 // `xmat` = where the rebuilt input row is kept.  The frame offset is folded into every base pointer here.
@@ -1347,6 +1401,12 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   if (ex && ex->raw) { p.raw = row(*ex->raw); p.raw_bs = (int)(ex->raw->bstride * ex->raw->stride); }
   p.pout = pout; p.np_out = L.hc ? 2 * L.cout : L.cout; p.stats_out = stats_out; p.cout = L.cout;
   const dim3 grid(L.hc ? L.cout / 16 : (L.cout + 31) / 32, (B + 7) / 8);
+  // measurement (dctts_hip_debug.h): HIP events on the launch stream around sampled launches of the time-dominant decode kernel
+  // Consecutive launches of the kernel share ONE event pair (a pair around every 5 us launch measures its own marker packets:
+  // 8.5 us instead of 5.3): the first opens the run, the next launch of anything else -- or the end of the piece -- closes it.
+  const bool prof = c->prof_id == DCTTS_PROF_CHAIN_HC && c->prof_frame && pro == PRO_LN_HC && L.hc && !L.tap2;
+  if (prof && !c->prof_run_e0) { HIPCHK(hipEventCreate(&c->prof_run_e0)); HIPCHK(hipEventRecord(c->prof_run_e0, st)); c->prof_run_n = 0; }
+  if (!prof) CHK(prof_close_run(c, st));
 #define C3(PRO_, HC_) hipLaunchKernelGGL((chain3_kernel<PRO_, HC_>), grid, dim3(512), 0, st, p)
   if (pro == PRO_LN_HC && L.hc && !L.tap2 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) {   // DCTTS_TRACE: stamped instantiation
     p.ts = g_trace_ctx->trace_buf + 32 * 64 * g_trace_ctx->trace_n++;
@@ -1362,6 +1422,7 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   else return fail(DCTTS_ERR_STATE, "chain3: unsupported layer form");
 #undef C3
   HIPCHK(hipGetLastError());
+  if (prof) { ++c->prof_run_n; c->prof_rows += B; }
   return 0;
 }
 
@@ -1481,6 +1542,7 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
   a.qhist = w.ae[la].p; a.q_bstride = w.ae[la].bstride; a.q_row0 = w.ae[la].row0; a.q_stride = d;
   a.K = w.kv.p; a.k_stride = 2 * d; a.VW = w.vw; a.vw_stride = d; a.kv_bstride = N;
   a.bias = c->audiodec[0].bias; a.N = N; a.d = d; a.win = c->cfg.attention_win_size; a.pm_all = w.pm_all; a.presum = w.ps0;
+  CHK(prof_close_run(c, sm));
   hipLaunchKernelGGL(attnq_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
   HIPCHK(hipGetLastError());
   SplitExtra ex; ex.presum = w.ps0; ex.presum_rstride = d; ex.raw = &w.c1q;
@@ -1499,8 +1561,8 @@ static int v3_final_mel(dctts_ctx* c, const DecodeWs& w, int B, int T, hipStream
 static int write_trace3(dctts_ctx* c, int j) {
   std::vector<long long> h(64 * 64 * 32);
   HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  const char* path = getenv("DCTTS_TRACE_FILE");
-  FILE* f = fopen(path ? path : "decode_trace.txt", "w");
+  if (c->trace_file.empty()) return 0;
+  FILE* f = fopen(c->trace_file.c_str(), "w");
   if (!f) return 0;
   long long t0 = 0;
   for (int k = 0; k < c->trace_n; ++k) for (int wg = 0; wg < 64; ++wg) { const long long e = h[(k * 64 + wg) * 32]; if (e && (!t0 || e < t0)) t0 = e; }
@@ -1572,16 +1634,15 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   CHK(v3_aepre(c, B, 0, st));                                              // row 0's AudioEnc presums (= the biases: every tap reads padding)
   HIPCHK(hipEventRecord(c->ev_fork, st));
   HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
-  const int skip = getenv("DCTTS_V3_SKIP") ? atoi(getenv("DCTTS_V3_SKIP")) : 0;   // timing experiments only: 1 = no bulk work, 2 = no chain work
-  const char* tenv = getenv("DCTTS_TRACE");
-  const int tstep = (tenv && !gr_chain) ? atoi(tenv) : -1;
+  const int skip = c->v3_skip;                                             // timing experiments only: 1 = no bulk work, 2 = no chain work
+  const int tstep = gr_chain ? -1 : c->trace_frame;
   auto bulk_piece = [&](int f) -> int {
     if (skip != 1) { if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, T, f, sb)); }
     HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb));
     return 0;
   };
   // DCTTS_PIECETIME=<frame>: timing events around 8 consecutive chain / bulk pieces starting there (measurement only)
-  const int pt0 = getenv("DCTTS_PIECETIME") ? atoi(getenv("DCTTS_PIECETIME")) : -1;
+  const int pt0 = c->piecetime;
   hipEvent_t pe_c[9][2], pe_b[9][2];
   if (pt0 >= 0) for (int i = 0; i < 9; ++i) for (int k = 0; k < 2; ++k) { HIPCHK(hipEventCreate(&pe_c[i][k])); HIPCHK(hipEventCreate(&pe_b[i][k])); }
   auto ptime = [&](int j) { return pt0 >= 0 && j >= pt0 && j < pt0 + 8; };
@@ -1603,7 +1664,10 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long), st));
       c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
     }
+    c->prof_frame = (j & 15) == 8;
     if (skip != 2) { if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[j + 1], st)); else CHK(chain_piece(j, st)); }
+    CHK(prof_close_run(c, st));
+    c->prof_frame = false;
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][1], st));
     HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
     if (c->trace_on) {
@@ -1625,7 +1689,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     }
     for (int i = 0; i < 9; ++i) for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(pe_c[i][k]); (void)hipEventDestroy(pe_b[i][k]); }
   }
-  if (getenv("DCTTS_HOSTTIME")) {
+  if (c->hosttime) {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
     fprintf(stderr, "[dctts] decode v3: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
   }
@@ -1637,16 +1701,6 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
   const bool v2 = (c->decode_mode == 1), v3 = (c->decode_mode == 3);
-  if (const char* e = getenv("DCTTS_CHAIN_ROWS")) { const int r = atoi(e); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
-  if (const char* e = getenv("DCTTS_FUSE_MEL")) c->fuse_mel = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("DCTTS_BULK_SMALL")) c->bulk_small_rows = atoi(e);
-  if (const char* e = getenv("DCTTS_BULK3_SMALL")) c->bulk3_small_rows = atoi(e);
-  if (const char* e = getenv("DCTTS_BULK3_FUSED")) c->bulk3_fused = atoi(e);
-  if (const char* e = getenv("DCTTS_HC2_ROWOP")) c->hc2_rowop = atoi(e);
-  if (const char* e = getenv("DCTTS_GROUP")) c->chain_group = atoi(e);
-  if (const char* e = getenv("DCTTS_BULK_PIPE")) c->bulk_pipelined = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("DCTTS_CHAIN_ONE")) c->chain_one = atoi(e) ? 1 : 0;
-  if (const char* e = getenv("DCTTS_BULK_CAP")) { const int r = atoi(e); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   if (v2) CHK(decode_v2_init(c));
   if (!v2 && !v3) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }     // v1 uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
@@ -1682,8 +1736,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
         c->graphs2_geom = g;
       }
     }
-    const char* tenv = getenv("DCTTS_TRACE");
-    const int tstep = (tenv && !gr_chain) ? atoi(tenv) : -1;
+    const int tstep = gr_chain ? -1 : c->trace_frame;
     // the bulk stream joins the caller's stream at the start (TextEnc, resets)
     HIPCHK(hipEventRecord(c->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
@@ -1714,7 +1767,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
         CHK(write_trace(c, j));
       }
     }
-    if (getenv("DCTTS_HOSTTIME")) {
+    if (c->hosttime) {
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
       fprintf(stderr, "[dctts] decode: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
     }
@@ -1752,16 +1805,24 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
 }
 
 extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!L || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "decode: bad argument");
   return decode_impl(c, L, B, N, T, Y, maxatt, (hipStream_t)stream);
 }
 
 extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, float* Z, int64_t* maxatt, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!L || !Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "synthesize: bad argument");
   CHK(decode_impl(c, L, B, N, T, Y, maxatt, (hipStream_t)stream));
   return dctts_ssrn_fwd(c, Y, B, T, nullptr, Z, stream);                  // synthesize.py:57
+}
+
+extern "C" int dctts_decode_status(dctts_ctx* c) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off timed out (hcgroup_kernel); results of that decode are invalid");
+  return 0;
 }
 
 extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
@@ -1782,7 +1843,8 @@ extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
 // Runs ONE device layer of a network on a caller tensor X (B,T,Cin) -> out (B,T',Cout); T' = 2T for a
 // transposed conv (both phases run).  Used by tests/ to compare every kernel shape class with the oracle.
 extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const float* X, int B, int T, float* out, void* stream) {
-  CHK(check_ready(c));
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
   if (!net || !X || !out || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "debug_layer: bad argument");
   hipStream_t st = (hipStream_t)stream;
   const std::string n(net);
@@ -1850,14 +1912,15 @@ extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
 extern "C" int dctts_prof_collect(dctts_ctx* c, int* launches, double* total_ms) {
   if (!c || !launches || !total_ms) return fail(DCTTS_ERR_ARG, "null argument");
   double tot = 0; int n = 0;
-  for (auto& e : c->prof_ev) {
+  for (size_t i = 0; i < c->prof_ev.size(); ++i) {
+    auto& e = c->prof_ev[i];
     HIPCHK(hipEventSynchronize(e.second));
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e.first, e.second));
-    tot += ms; ++n;
+    tot += ms; n += (i < c->prof_cnt.size()) ? c->prof_cnt[i] : 1;
     (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
   }
-  c->prof_ev.clear();
+  c->prof_ev.clear(); c->prof_cnt.clear();
   *launches = n; *total_ms = tot;
   return 0;
 }

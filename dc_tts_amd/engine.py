@@ -82,7 +82,12 @@ class Engine:
         self._ok(self.lib.dctts_set_decode_graph(self._h, int(enable)))
 
     def set_decode_mode(self, mode: int):
+        """3 (default): round-2 decode (hoisted taps, row-op cone layers); 1 / 2: round-1 split kernels; 0: fused full-row kernels."""
         self._ok(self.lib.dctts_set_decode_mode(self._h, int(mode)))
+
+    def decode_status(self):
+        """Raise if a decode on this engine failed on the device (call after synchronising); see dctts_decode_status."""
+        self._ok(self.lib.dctts_decode_status(self._h))
 
     def device_bytes(self) -> int:
         return int(self.lib.dctts_device_bytes(self._h))

@@ -20,25 +20,62 @@ def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + q + (1 if rank < r else 0)
 
 
+def _gather_rows(x: torch.Tensor, counts, group, rank: int, dst: int = 0):
+    """Host gather of per-rank row blocks x (n_r, ...) (CPU tensors, ideally pinned) to rank `dst` with tensor collectives only
+    (no pickling): blocks are padded to the largest count, gathered, and cut back.  Returns the concatenation on dst, else None."""
+    world = len(counts)
+    nmax = max(counts)
+    pad = x
+    if x.shape[0] != nmax:
+        pad = torch.zeros((nmax,) + tuple(x.shape[1:]), dtype=x.dtype)
+        pad[: x.shape[0]] = x
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == dst else None
+    dist.gather(pad.contiguous(), bufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0)
+
+
+def gather_to_host(Z: torch.Tensor, Zh: torch.Tensor, group, world: int, rank: int):
+    """SURVEY 8e's result gather for equal shards: this rank's device tensor Z -> its pinned host buffer Zh (one D2H copy), then
+    rank 0's host over `group` (gloo).  Returns the (world * B, ...) host tensor on rank 0, Zh itself when world == 1, else None."""
+    Zh.copy_(Z, non_blocking=True)
+    torch.cuda.synchronize()
+    if world == 1:
+        return Zh
+    return _gather_rows(Zh, [Z.shape[0]] * world, group, rank)
+
+
 def synthesize_sharded(L: np.ndarray, synth: Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray, np.ndarray]],
                        group: Optional[dist.ProcessGroup] = None):
     """Every rank passes the SAME full character batch L (B, max_N) int32 (host); `synth` maps a host slice of it to
-    host arrays (Y, Z, max_attentions) -- on a GPU rank: upload, Engine.synthesize, download.  Rank 0 returns the
-    full-batch (Y, Z, max_attentions) in the original utterance order; other ranks return None.
-    The only communication is this final host gather (gather_object: slices may be ragged)."""
+    host arrays (Y, Z, max_attentions) -- on a GPU rank: upload, Engine.synthesize, download into pinned memory.  Rank 0
+    returns the full-batch (Y, Z, max_attentions) in the original utterance order; other ranks return None.
+    The only communication is this final host gather: three tensor gathers over `group` (gloo on the GPU ranks too: results
+    meet on the host), shards may be ragged (sizes differ by at most one; an empty shard sends nothing but padding)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    lo, hi = shard_bounds(L.shape[0], world, rank)
+    Bt = L.shape[0]
+    bounds = [shard_bounds(Bt, world, r) for r in range(world)]
+    lo, hi = bounds[rank]
     out = synth(L[lo:hi]) if hi > lo else None
     if world == 1:
         return out
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object((lo, hi, out), gathered, dst=0, group=group)
-    if rank != 0:
-        return None
-    parts = sorted((g for g in gathered if g[2] is not None), key=lambda g: g[0])
-    assert parts and parts[0][0] == 0 and all(a[1] == b[0] for a, b in zip(parts, parts[1:])) and parts[-1][1] == L.shape[0]
-    return tuple(np.concatenate([p[2][k] for p in parts], axis=0) for k in range(3))
+    counts = [b[1] - b[0] for b in bounds]
+    # shapes of one utterance's results are known from any non-empty shard; rank 0 always owns one when Bt >= 1
+    shapes = [None, None, None]
+    if out is not None:
+        shapes = [(tuple(o.shape[1:]), str(o.dtype)) for o in out]
+    meta = [shapes]
+    dist.broadcast_object_list(meta, src=0, group=group)               # a few dozen bytes of shape metadata, not the data
+    shapes = meta[0]
+    res = []
+    for k in range(3):
+        shp, dt = shapes[k]
+        x = torch.from_numpy(np.ascontiguousarray(out[k])) if out is not None else torch.zeros((0,) + shp, dtype=getattr(torch, dt))
+        g = _gather_rows(x, counts, group, rank)
+        res.append(None if g is None else g.numpy())
+    return tuple(res) if rank == 0 else None
 
 
 def gpu_synth(engine) -> Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray, np.ndarray]]:
@@ -46,5 +83,11 @@ def gpu_synth(engine) -> Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray, np
     def run(Ls: np.ndarray):
         Ld = torch.from_numpy(np.ascontiguousarray(Ls, dtype=np.int32)).to(engine.device)
         Y, Z, mx = engine.synthesize(Ld)
-        return Y.cpu().numpy(), Z.cpu().numpy(), mx.cpu().numpy()
+        outs = []
+        for t in (Y, Z, mx):                                           # one D2H copy each, into pinned host memory
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            outs.append(h)
+        torch.cuda.synchronize()
+        return tuple(h.numpy() for h in outs)
     return run

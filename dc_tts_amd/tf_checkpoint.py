@@ -2,8 +2,10 @@
 TensorFlow -- so the reference's trained weights (`synthesize.py:32-40` restores `Text2Mel/*` from `logdir-1` and `SSRN/*`
 from `logdir-2`) can feed `dc_tts_amd.engine.Engine` directly.
 
-Formats implemented from their public specifications (TensorFlow is not installable here, so this reader is exercised
-against bundles produced by the spec-following writer in tests/test_tf_checkpoint.py, not against TF-written files):
+Formats implemented from their public specifications.  UNPINNED: TensorFlow is not installable here and no TF-written bundle is
+reachable (no network), so this reader is exercised only against bundles produced by the spec-following writer in
+tests/test_tf_checkpoint.py.  What it does not implement fails with a named CheckpointError instead of mis-reading: compressed
+(snappy) table blocks, partitioned (sliced) variables, big-endian bundles, missing shard files; multi-shard bundles are read.
   * `.index` is a LevelDB-style sorted string table (tensorflow/core/lib/io/table): 48-byte footer = metaindex BlockHandle,
     index BlockHandle (varint64 offset + size each), zero padding, magic 0xdb4775248b80fb57; every block is followed by a
     5-byte trailer (compression type, masked crc32c); block entries are (shared, non_shared, value_len) varint32 triples with
@@ -122,7 +124,9 @@ def _read_block(data: bytes, offset: int, size: int, verify: bool) -> bytes:
         if mask_crc(crc32c(data[offset:offset + size + 1])) != stored:
             raise CheckpointError("block checksum mismatch")
     if ctype != 0:
-        raise CheckpointError("compressed table blocks are not supported (TF's BundleWriter writes them uncompressed)")
+        kind = {1: "snappy"}.get(ctype, f"type {ctype}")
+        raise CheckpointError(f"{kind}-compressed table block at offset {offset}: only uncompressed index blocks are supported "
+                              "(TF's BundleWriter writes them uncompressed; re-save the checkpoint with a stock tf.train.Saver)")
     return body
 
 
@@ -179,12 +183,19 @@ def read_checkpoint(prefix: str, names: Optional[Iterable[str]] = None, verify: 
         if want is not None and name not in want:
             continue
         if e["sliced"]:
-            raise CheckpointError(f"{name}: partitioned (sliced) variables are not supported")
+            raise CheckpointError(f"{name}: partitioned (sliced) variable -- the bundle stores it as several slices "
+                                  "(BundleEntryProto.slices); the synthesis path's variables are never partitioned, so this is not a dc_tts checkpoint")
         if e["dtype"] not in _DTYPES:
             raise CheckpointError(f"{name}: unsupported dtype enum {e['dtype']}")
         sid = e["shard_id"]
         if sid not in shards:
-            shards[sid] = open("%s.data-%05d-of-%05d" % (prefix, sid, header["num_shards"]), "rb").read()
+            if not 0 <= sid < header["num_shards"]:
+                raise CheckpointError(f"{name}: shard_id {sid} outside the header's num_shards = {header['num_shards']}")
+            shard_path = "%s.data-%05d-of-%05d" % (prefix, sid, header["num_shards"])
+            if not os.path.exists(shard_path):
+                raise CheckpointError(f"{name}: shard file {os.path.basename(shard_path)} is missing (multi-shard bundle: all "
+                                      f"{header['num_shards']} .data-* files must sit next to the .index)")
+            shards[sid] = open(shard_path, "rb").read()
         raw = shards[sid][e["offset"]:e["offset"] + e["size"]]
         dt = np.dtype(_DTYPES[e["dtype"]])
         count = int(np.prod(e["shape"])) if e["shape"] else 1

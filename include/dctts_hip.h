@@ -86,44 +86,28 @@ int dctts_text2mel_decode(dctts_ctx* ctx, const int32_t* L, int B, int N, int T,
 int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y, float* Z,
                      int64_t* max_attentions, void* stream);
 
+/* Status of the decodes issued so far on this context; call after synchronising their stream.  0, or DCTTS_ERR_STATE if the
+ * opt-in persistent highway-group kernel (DCTTS_GROUP=1) gave up waiting for another workgroup's hand-off (every spin is bounded). */
+int dctts_decode_status(dctts_ctx* ctx);
+
 /* Decode launch mode: 0 = every launch eager; 1 (default) = the side-stream (bulk) work of each frame is one hipGraph launch,
- * the latency-critical chain launches stay eager; 2 = chain pieces are per-frame hipGraphs too (decode mode 0: 1 and 2 both
- * mean one graph replay per frame). */
+ * the latency-critical chain launches stay eager; 2 = chain pieces are per-frame hipGraphs too (measured slower: a graph launch per
+ * piece costs more start-up latency than 25 eager launches cost host time). */
 int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
 /* Decode algorithm form (results agree to fp32 re-association; all are the exact-parity incremental decode):
- * 0 = fused full-row kernels on one stream (one workgroup per 32-row block),
- * 1 = (default) column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone run on two streams,
- * 2 = as 1, but the k=1 layers around the mel frame (AudioDec C_8..C_11 + sigmoid, next frame's AudioEnc C_1..C_3) run as one
- *     row-per-workgroup launch (fewer launches, measured slower: bound by the bytes one CU can pull). */
+ * 3 = (default) round-2 form: column-split chain kernels that contract only each layer's centre tap (older taps arrive as presums
+ *     computed on the bulk stream), AudioDec C_1 / HC_2 cone rows as row operations on cached V.W / Q.W products (csrc/decode3_kernels.h),
+ * 1 = round-1 form: column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone on two streams,
+ * 2 = as 1, with the k=1 layers around the mel frame as one row-per-workgroup launch (measured slower),
+ * 0 = fused full-row kernels on one stream (one workgroup per 32-row block; the simplest form, kept as a cross-check). */
 int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
 
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
 size_t dctts_device_bytes(const dctts_ctx* ctx);
 
-/* Test hook: run ONE device layer of a network ("textenc" | "audioenc" | "audiodec" | "ssrn") on a caller
- * tensor X (B,T,Cin) -> out (B,T',Cout) (T' = 2T for a transposed conv, index = its even phase;
- * "textenc" index 0 = embed + C_2 and takes int32 ids).  Layer order = networks.py source order, with
- * each D layer occupying two consecutive indices.  Synchronises (allocates a scratch copy of X). */
-int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X, int B, int T, float* out, void* stream);
-
-/* Measurement aid: create / destroy a stream restricted to CUs [cu_first, cu_first + cu_count) (hipExtStreamCreateWithCUMask);
- * any entry point above accepts it as `stream`. */
-int dctts_debug_stream_create(int cu_first, int cu_count, void** stream);
-int dctts_debug_stream_destroy(void* stream);
-
-/* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
-int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
-
-/* Measurement aid for bench.py's roofline object: HIP events are recorded on the launch stream
- * around every launch of the conv kernel instantiation `kernel_id` = epi*10000 + NT*100 + NW
- * (epi 0 = C, 1 = HC) while enabled.  collect() synchronises those events, returns the number of
- * launches and their summed duration, and clears the list. */
-int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);
-int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
-/* Output rows those launches covered, summed since the last prof_enable (a layer's rows may be split between the
- * 32-row kernel -- the one timed here -- and a 16-row tail launch, see csrc/hconv16_kernel.h). */
-int dctts_prof_rows(dctts_ctx* ctx, long long* rows);
+/* Test / measurement hooks (per-layer test entry, CU-masked streams, calibration copy, kernel timing) are declared in
+ * dctts_hip_debug.h: they are not part of the drop-in surface. */
 
 /* ------------------------------------------------------------------------------------------------
  * Vocoder tail: utils.py:67-114 `spectrogram2wav` / `griffin_lim` / `invert_spectrogram`, which
@@ -161,12 +145,6 @@ int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, int F, floa
  * y (B, hop_length*(F-1)); X_best (B,F,1+n_fft/2,2) interleaved complex64 or NULL = the spectrogram*phase the last
  * iteration produced (needs n_iter >= 1).  n_iter = 0 gives y = istft(spec). */
 int dctts_griffin_lim(dctts_vocoder* v, const float* spec, int B, int F, int n_iter, float* y, float* X_best, void* stream);
-
-/* Measurement aid (bench.py roofline of the vocoder): while enabled, HIP events are recorded on the launch stream around
- * every launch of the Griffin-Lim iteration kernel (gl_iter_wave_kernel); collect() synchronises them, returns the number
- * of launches and their summed duration, and clears the list. */
-int dctts_vocoder_prof_enable(dctts_vocoder* v, int enable);
-int dctts_vocoder_prof_collect(dctts_vocoder* v, int* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

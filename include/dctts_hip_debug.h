@@ -1,0 +1,53 @@
+/* dctts_hip_debug.h -- test and measurement hooks of libdctts_hip.so.  NOT part of the drop-in surface (include/dctts_hip.h):
+ * nothing a consumer of the synthesis path needs lives here.  Used by tests/ (per-layer parity), bench.py (kernel timing for the
+ * roofline objects) and tools/ (PMC calibration, CU-masked streams).
+ * Environment variables the library reads ONCE, in dctts_create (measurement / A-B only; see tools/README.md): DCTTS_*.
+ * DCTTS_TRACE=<frame> + DCTTS_TRACE_FILE=<path> make a decode write in-kernel wall-clock stamps of that frame's chain launches. */
+#ifndef DCTTS_HIP_DEBUG_H
+#define DCTTS_HIP_DEBUG_H
+#include "dctts_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: run ONE device layer of a network ("textenc" | "audioenc" | "audiodec" | "ssrn") on a caller
+ * tensor X (B,T,Cin) -> out (B,T',Cout) (T' = 2T for a transposed conv, index = its even phase;
+ * "textenc" index 0 = embed + C_2 and takes int32 ids).  Layer order = networks.py source order, with
+ * each D layer occupying two consecutive indices.  Synchronises (allocates a scratch copy of X). */
+int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X, int B, int T, float* out, void* stream);
+
+/* Measurement aid: create / destroy a stream restricted to CUs [cu_first, cu_first + cu_count) (hipExtStreamCreateWithCUMask);
+ * any entry point above accepts it as `stream`. */
+int dctts_debug_stream_create(int cu_first, int cu_count, void** stream);
+int dctts_debug_stream_destroy(void* stream);
+
+/* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
+int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
+
+/* Measurement aid for bench.py's roofline objects: HIP events are recorded on the launch stream around launches of one
+ * kernel while enabled; collect() synchronises those events, returns the number of launches and their summed duration,
+ * and clears the list.  kernel_id:
+ *   epi*10000 + NT*100 + NW   every launch of hconv_kernel<epi, NT, NW> (epi 0 = C, 1 = HC), e.g. 10808 = SSRN HC_11 / HC_12;
+ *   DCTTS_PROF_CHAIN_HC       the decode's time-dominant kernel, chain3_kernel<LN_HC, HC> (newest-row highway layers), on every
+ *                             16th frame only (events around every 5 us launch would change what they measure); eager chain only;
+ *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (cone GEMMs of the decode's bulk stream); eager decode only (graph mode 0). */
+#define DCTTS_PROF_CHAIN_HC 30000
+#define DCTTS_PROF_BULK_GEMM 30001
+int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);
+int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
+/* Output rows those launches covered, summed since the last prof_enable (a layer's rows may be split between the
+ * 32-row kernel -- the one timed here -- and a 16-row tail launch, see csrc/hconv16_kernel.h; decode kernels: rows = utterances
+ * (chain) or cone rows (bulk) per launch). */
+int dctts_prof_rows(dctts_ctx* ctx, long long* rows);
+
+/* Measurement aid (bench.py roofline of the vocoder): while enabled, HIP events are recorded on the launch stream around
+ * every launch of the Griffin-Lim iteration kernel (gl_iter_wave_kernel); collect() synchronises them, returns the number
+ * of launches and their summed duration, and clears the list. */
+int dctts_vocoder_prof_enable(dctts_vocoder* v, int enable);
+int dctts_vocoder_prof_collect(dctts_vocoder* v, int* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCTTS_HIP_DEBUG_H */

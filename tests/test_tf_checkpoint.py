@@ -41,34 +41,40 @@ def _block(entries, restart_interval=4):
     return bytes(buf)
 
 
-def write_bundle(prefix, tensors, keys_per_block=5, with_crc=True):
-    """Minimal TF tensor-bundle writer: one shard, uncompressed table blocks, masked crc32c everywhere."""
-    data = bytearray(); entries = []
+def write_bundle(prefix, tensors, keys_per_block=5, with_crc=True, num_shards=1, sliced=(), block_ctype=0):
+    """Minimal TF tensor-bundle writer: uncompressed table blocks, masked crc32c everywhere.  num_shards > 1 deals the tensors
+    round-robin over shard files; `sliced` names get a BundleEntryProto.slices field; block_ctype != 0 marks the data blocks as
+    compressed (the bytes stay raw: only the reader's diagnostic is exercised)."""
+    datas = [bytearray() for _ in range(num_shards)]; entries = []
     dt_enum = {np.dtype(np.float32): 1, np.dtype(np.int32): 3, np.dtype(np.int64): 9}
-    for name in sorted(tensors):
+    for i, name in enumerate(sorted(tensors)):
         a = np.ascontiguousarray(tensors[name]); raw = a.tobytes()
+        sid = i % num_shards; data = datas[sid]
         shape = b"".join(_field(2, 2, _vint(len(d)) + d) for d in (_field(1, 0, _vint(s)) for s in a.shape))
-        e = _field(1, 0, _vint(dt_enum[a.dtype])) + _field(2, 2, _vint(len(shape)) + shape) + _field(3, 0, _vint(0)) + \
+        e = _field(1, 0, _vint(dt_enum[a.dtype])) + _field(2, 2, _vint(len(shape)) + shape) + _field(3, 0, _vint(sid)) + \
             _field(4, 0, _vint(len(data))) + _field(5, 0, _vint(len(raw)))
         if with_crc:
             e += _field(6, 5, struct.pack("<I", C.mask_crc(C.crc32c(raw))))
+        if name in sliced:
+            e += _field(7, 2, _vint(0))                     # repeated TensorSliceProto slices = 7 (an empty message is enough)
         entries.append((name.encode(), e)); data += raw
-    header = _field(1, 0, _vint(1)) + _field(2, 0, _vint(0)) + _field(3, 2, _vint(2) + _field(1, 0, _vint(1)))
+    header = _field(1, 0, _vint(num_shards)) + _field(2, 0, _vint(0)) + _field(3, 2, _vint(2) + _field(1, 0, _vint(1)))
     entries = [(b"", header)] + entries
     out = bytearray(); index = []
-    def emit(block):
-        off = len(out); out.extend(block); trailer = b"\x00"
+    def emit(block, ctype=0):
+        off = len(out); out.extend(block); trailer = bytes([ctype])
         out.extend(trailer + struct.pack("<I", C.mask_crc(C.crc32c(block + trailer))))
         return _vint(off) + _vint(len(block))
     for i in range(0, len(entries), keys_per_block):
         chunk = entries[i:i + keys_per_block]
-        index.append((chunk[-1][0] + b"\xff", emit(_block(chunk))))
+        index.append((chunk[-1][0] + b"\xff", emit(_block(chunk), block_ctype)))
     meta = emit(_block([]))
     idx = emit(_block(index, restart_interval=1))
     footer = meta + idx
     out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", C.TABLE_MAGIC)
     open(prefix + ".index", "wb").write(bytes(out))
-    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    for sid, data in enumerate(datas):
+        open("%s.data-%05d-of-%05d" % (prefix, sid, num_shards), "wb").write(bytes(data))
 
 
 def test_crc32c_known_answers():
@@ -119,3 +125,27 @@ def test_load_reference_weights_layout(tmp_path, weights):
     assert set(W) == set(weights)
     for k in weights:
         np.testing.assert_array_equal(W[k], weights[k])
+
+
+def test_unsupported_layouts_fail_with_named_errors(tmp_path):
+    """What a real TF checkpoint may contain beyond the plain single-shard bundle: multi-shard bundles are read; compressed index
+    blocks, partitioned variables and missing shard files raise CheckpointError naming the problem (never a silent mis-read)."""
+    rng = np.random.default_rng(1)
+    T = {f"SSRN/C_{i}/conv1d/bias": rng.standard_normal(8 + i).astype(np.float32) for i in range(1, 8)}
+    p = str(tmp_path / "multi")
+    write_bundle(p, T, num_shards=3)
+    got = C.read_checkpoint(p)
+    for k in T:
+        np.testing.assert_array_equal(got[k], T[k])
+    os.remove(p + ".data-00001-of-00003")
+    with pytest.raises(C.CheckpointError, match="shard file .* is missing"):
+        C.read_checkpoint(p)
+    p = str(tmp_path / "snappy")
+    write_bundle(p, T, block_ctype=1)
+    with pytest.raises(C.CheckpointError, match="snappy-compressed"):
+        C.read_checkpoint(p)
+    p = str(tmp_path / "sliced")
+    write_bundle(p, T, sliced={"SSRN/C_3/conv1d/bias"})
+    with pytest.raises(C.CheckpointError, match="partitioned"):
+        C.read_checkpoint(p)
+    assert set(C.read_checkpoint(p, ["SSRN/C_1/conv1d/bias"])) == {"SSRN/C_1/conv1d/bias"}     # untouched variables still load
