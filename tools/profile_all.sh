@@ -1,30 +1,31 @@
 #!/bin/bash
-# Reproduces everything under profiles/ on a 1x MI355X box (run from the repo root; ~4 minutes of GPU time).
-# Every profiler command is wrapped in `timeout`: a rocprofv3 --pmc run with an unsupported counter set once aborted and hung.
-# --pmc passes are separate runs with --kernel-trace only (gpurun refuses --pmc combined with the sys/hip/hsa trace domains).
+# Reproduces everything under profiles/ (round 2) on a 1x MI355X box (run from the repo root; ~4 minutes of GPU time).
+# Every profiler command is wrapped in `timeout`; --pmc passes are separate runs with --kernel-trace only.
 set -u
 R=$PWD
-OUT=${1:-$R/gpurun_out/profile_all}
+OUT=${1:-$R/gpurun_out/profile_r02}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-# 1. the bench line (metric, roofline, cpu_baseline, vocoder)                       -> profiles/r01_bench_final.json
-timeout 300 python "$R/bench.py" > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
+# 1. the bench line (metric, roofline of the time-dominant kernel, kernels, other configs, cpu_baseline, vocoder)  -> profiles/r02_bench.json
+timeout 600 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
-# 2. per-kernel time of the same command                                             -> profiles/r01_kernel_stats.{csv,md}
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_stats" -- \
-    python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder > "$OUT/kernel_stats.log" 2>&1
-# 3. HBM traffic of the roofline kernel (FETCH_SIZE x2 per the gfx950 correction, calibrated by a 1 GiB copy; WRITE_SIZE exact)
-#                                                                                    -> profiles/r01_pmc_traffic.{json,md}
-timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$R/tools/pmc_ssrn.py" > "$OUT/pmc_fetch.log" 2>&1
-timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$R/tools/pmc_ssrn.py" > "$OUT/pmc_write.log" 2>&1
-# 4. MFMA-busy of the SSRN kernels                                                   -> profiles/r01_pmc_traffic.md (second table)
-timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-    --output-format csv -d "$OUT/pmc_sq" -- python "$R/tools/pmc_ssrn.py" > "$OUT/pmc_sq.log" 2>&1
-# 5. vocoder tail: kernel trace + HBM traffic                                        -> profiles/r01_vocoder*.{csv,md,json}
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/voc_kernel_stats" -- python "$R/tools/vocoder_bench.py" > "$OUT/voc_kernel_stats.log" 2>&1
-VREPS=1 timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/voc_pmc_fetch" -- python "$R/tools/vocoder_bench.py" > "$OUT/voc_pmc_fetch.log" 2>&1
-VREPS=1 timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/voc_pmc_write" -- python "$R/tools/vocoder_bench.py" > "$OUT/voc_pmc_write.log" 2>&1
+# 2. per-kernel time of the same workload                                               -> profiles/r02_kernel_stats.{csv,md}
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_stats" -- \
+    python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-extras > "$OUT/kernel_stats.log" 2>&1
+# 3. HBM traffic of the decode kernels (FETCH_SIZE x2 per the gfx950 correction; WRITE_SIZE exact)   -> profiles/r02_pmc.{md,json}
+DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_fetch.log" 2>&1
+DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_write.log" 2>&1
+# 4. what the waves of the decode kernels wait for
+DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+    --output-format csv -d "$OUT/pmc_sq" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_sq.log" 2>&1
 cd "$R"
-# 6. where a decode chain launch spends its time (in-kernel wall-clock stamps)       -> gpurun_out/decode_trace.txt
-timeout 100 python "$R/tools/decode_trace.py" > "$OUT/decode_trace.log" 2>&1
+python tools/pmc_summary.py "$OUT/pmc_fetch" FETCH_SIZE > "$OUT/pmc_fetch.txt"
+python tools/pmc_summary.py "$OUT/pmc_write" WRITE_SIZE > "$OUT/pmc_write.txt"
+for ctr in SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE; do
+  echo "== $ctr"; python tools/pmc_summary.py "$OUT/pmc_sq" $ctr | head -12; done > "$OUT/pmc_sq.txt"
+# 5. where a chain launch spends its time (in-kernel wall-clock stamps) and how long the two streams' pieces take
+DCTTS_TRACE_FILE="$OUT/decode_trace.txt" timeout 100 python "$R/tools/decode_trace.py" > "$OUT/decode_trace.log" 2>&1
+DCTTS_PIECETIME=100 DM=3 GM=1 timeout 120 python "$R/tools/decode_time.py" > "$OUT/piece_times.txt" 2>&1
+find "$OUT/kernel_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
+rm -rf "$OUT/kernel_stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq"
 echo "done: $OUT"
