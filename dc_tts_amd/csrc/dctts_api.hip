@@ -133,6 +133,9 @@ struct dctts_ctx {
   int* iota_dev = nullptr; int iota_n = 0;
   std::vector<hipGraphExec_t> bulk3_g, chain3_g; std::string graphs3_geom;
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
+  int chain_mlp = 1;                   // v3: the seven k=1 layers around the mel frame as one row-split launch (mlp_rows_kernel; DCTTS_MLP=0: seven column-split launches)
+  void* mlp_tab = nullptr; std::string mlp_geom;
+  int mlp_rows = 2;                    // utterances per mlp_rows_kernel workgroup (2 or 4; DCTTS_MLP_ROWS)
   int chain_group = 0;                 // v3: runs of chain highway layers as one persistent launch with in-launch hand-offs (hcgroup_kernel; DCTTS_GROUP=0: one launch per layer)
   void* group_tab = nullptr; std::string group_geom;   // per-frame HcGroupParams: [T][2] (AudioDec group of frame j, AudioEnc group of frame j)
   float* group_xch = nullptr;          // exchange buffers, flags, error word (one allocation)
@@ -355,7 +358,8 @@ static void read_env(dctts_ctx* c) {
   geti("DCTTS_CHAIN_ONE", &c->chain_one);
   { int r = c->bulk_cap; geti("DCTTS_BULK_CAP", &r); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   geti("DCTTS_BULK3_SMALL", &c->bulk3_small_rows); geti("DCTTS_BULK3_FUSED", &c->bulk3_fused); geti("DCTTS_HC2_ROWOP", &c->hc2_rowop);
-  geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
+  geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_MLP", &c->chain_mlp);
+  { int r = c->mlp_rows; geti("DCTTS_MLP_ROWS", &r); if (r == 2 || r == 4) c->mlp_rows = r; } geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
   geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
 }
@@ -403,6 +407,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->iota_dev) (void)hipFree(c->iota_dev);
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
   if (c->group_tab) (void)hipFree(c->group_tab);
+  if (c->mlp_tab) (void)hipFree(c->mlp_tab);
   if (c->group_xch) (void)hipFree(c->group_xch);
   if (c->group_err_host) (void)hipHostFree(c->group_err_host);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1498,6 +1503,60 @@ static int v3_group_launch(dctts_ctx* c, int B, int j, int net, hipStream_t st) 
   return 0;
 }
 
+
+// ---- mlp_rows_kernel plumbing: one MlpRowsParams per frame in device memory
+static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
+  const std::string g = geom("mlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]);
+  if (c->mlp_tab && c->mlp_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->mlp_tab) { (void)hipFree(c->mlp_tab); c->mlp_tab = nullptr; }
+  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
+  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
+  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
+  const int ntail = (int)(AD.size() - lh - 1), nhead = (int)nh;
+  if (lh < 1 || ntail < 1 || ntail + nhead > 7 || nhead < 1) return fail(DCTTS_ERR_STATE, "v3 mlp: unexpected layer structure");
+  auto fill = [&](const DevLayer& L, MlpLayer* m) -> int {
+    if (!L.wraw || L.hc || L.ntaps != 1 || (L.cin_real & 7) || (L.cout & 3) || L.cin_real > 256 || L.cout > 256) return fail(DCTTS_ERR_STATE, "v3 mlp: unsupported layer shape");
+    m->w = L.wraw; m->bias = L.bias; m->g = L.g1; m->be = L.b1; m->cin = L.cin_real; m->cout = L.cout; m->relu = (L.act == ACT_RELU) ? 1 : 0;
+    return 0;
+  };
+  std::vector<MlpRowsParams> tab((size_t)T);
+  for (int j = 0; j < T; ++j) {
+    MlpRowsParams p; memset(&p, 0, sizeof(p));
+    p.B = B; p.frame = j; p.par = j & 1;
+    p.nrm = make_norm(AD[lh], w.pd[lh], &w.ad[lh - 1]);
+    int n = 0;
+    for (size_t i = lh + 1; i < AD.size(); ++i) CHK(fill(AD[i], &p.L[n++]));
+    p.mel_layer = n - 1;
+    if (j + 1 < T) for (size_t i = 0; i < nh; ++i) CHK(fill(AE[i], &p.L[n++]));     // the last frame has no next frame to encode
+    p.nlayers = n;
+    p.ypad = w.ypad.p; p.y_bstride = w.ypad.bstride; p.y_row = w.ypad.row0 + 1 + j; p.y_stride = w.ypad.stride;
+    p.logits = w.logits.p; p.l_bstride = w.logits.bstride; p.l_row = j; p.l_stride = w.logits.stride;
+    p.pout = w.pe[nh - 1]; p.stats_out = w.se[nh - 1];
+    tab[j] = p;
+  }
+  HIPCHK(hipMalloc(&c->mlp_tab, tab.size() * sizeof(MlpRowsParams)));
+  HIPCHK(hipMemcpy(c->mlp_tab, tab.data(), tab.size() * sizeof(MlpRowsParams), hipMemcpyHostToDevice));
+  c->mlp_geom = g;
+  return 0;
+}
+
+static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
+  CHK(prof_close_run(c, st));
+  const MlpRowsParams* pm = (const MlpRowsParams*)c->mlp_tab + j;
+  const int R = c->mlp_rows;
+  if (g_trace_ctx && g_trace_ctx->trace_on) {                     // DCTTS_TRACE: stamped instantiation, stamps at the end of the trace buffer
+    long long* ts = c->trace_buf + 64 * 64 * 32 - 64;
+    if (R == 4) hipLaunchKernelGGL((mlp_rows_kernel<4, true>), dim3((B + 3) / 4), dim3(512), 0, st, pm, ts);
+    else hipLaunchKernelGGL((mlp_rows_kernel<2, true>), dim3((B + 1) / 2), dim3(512), 0, st, pm, ts);
+  } else {
+    if (R == 4) hipLaunchKernelGGL((mlp_rows_kernel<4, false>), dim3((B + 3) / 4), dim3(512), 0, st, pm, (long long*)nullptr);
+    else hipLaunchKernelGGL((mlp_rows_kernel<2, false>), dim3((B + 1) / 2), dim3(512), 0, st, pm, (long long*)nullptr);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // AudioDec HC_2 .. C_11 for frame j (its C_1 ran at the end of the previous chain piece)
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
@@ -1505,6 +1564,7 @@ static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream
   size_t first = 1;
   if (c->chain_group) { CHK(v3_group_launch(c, B, j, 0, sm)); while (first < AD.size() && AD[first].hc) ++first; }
   for (size_t i = first; i < AD.size(); ++i) {
+    if (c->chain_mlp && !AD[i].hc) break;                       // C_8 .. C_11 run inside mlp_rows_kernel (launched by the caller)
     SplitExtra ex;
     if (AD[i].wp16c) { ex.presum = w.pb3[i] + (long)par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout; ex.presum_rstride = c->cone_len[i] * 2 * AD[i].cout; }
     CHK(run_chain3(c, AD[i], B, j, &AD[i - 1], w.pd[i - 1], w.sd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr, &w.ad[i - 1], nullptr,
@@ -1519,6 +1579,7 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
   const std::vector<DevLayer>& AE = c->ae_c;
   const std::vector<DevLayer>& AD = c->ad_c;
   for (size_t i = 0; i < AE.size(); ++i) {
+    if (c->chain_mlp && j > 0 && !AE[i].hc) continue;           // C_1 .. C_3 of frame j ran inside frame j-1's mlp_rows_kernel
     if (i == 0 && j > 0) {
       const size_t la = AD.size() - 1;
       RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
@@ -1589,6 +1650,15 @@ static int write_trace3(dctts_ctx* c, int j) {
     for (int q = 5; q < 8; ++q) { std::sort(ph[q].begin(), ph[q].end()); fprintf(f, " %6.2f", ph[q][ph[q].size() / 2]); }
     fprintf(f, "\n");
   }
+  {
+    const long long* o = &h[64 * 64 * 32 - 64];
+    if (o[0]) {
+      fprintf(f, "# mlp_rows_kernel (workgroup 0, thread 0), microseconds since its entry: rows rebuilt | per layer: loads landed, FMAs done, partial sums exchanged, row finished\n");
+      fprintf(f, "  %6.2f |", (o[1] - o[0]) / 100.0);
+      for (int i = 2; i + 3 < 32 && o[i + 3]; i += 4) fprintf(f, "  %6.2f %6.2f %6.2f %6.2f |", (o[i] - o[0]) / 100.0, (o[i + 1] - o[0]) / 100.0, (o[i + 2] - o[0]) / 100.0, (o[i + 3] - o[0]) / 100.0);
+      fprintf(f, "\n");
+    }
+  }
   fclose(f);
   return 0;
 }
@@ -1596,6 +1666,7 @@ static int write_trace3(dctts_ctx* c, int j) {
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
   CHK(decode_v2_init(c));
   CHK(v3_aepre_table(c, w, B));
+  if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));
   if (c->chain_group) {
     if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off of the previous decode timed out (hcgroup_kernel)");
     CHK(v3_group_table(c, w, B, T));
@@ -1609,11 +1680,12 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   const bool gr = c->use_graph != 0, gr_chain = c->use_graph == 2;
   auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
     if (j >= 0) CHK(v3_chain_dec(c, w, B, j, s));
+    if (j >= 0 && c->chain_mlp) CHK(v3_mlp_launch(c, B, j, s));   // AudioDec C_8..C_11, mel frame j, AudioEnc C_1..C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
-    return v3_final_mel(c, w, B, T, s);
+    return c->chain_mlp ? 0 : v3_final_mel(c, w, B, T, s);
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" +
                           std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs2(c);

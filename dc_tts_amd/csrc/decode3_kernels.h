@@ -671,4 +671,196 @@ __global__ void __launch_bounds__(512) hcgroup_kernel(const HcGroupParams* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- chain: the k = 1 layers around the mel frame
+// mlp_rows_kernel: AudioDec C_8 .. C_11 (+ sigmoid = mel frame j, networks.py:192-210) and AudioEnc C_1 .. C_3 of frame j+1
+// (networks.py:82-105) -- seven dependent k = 1 layers -- in ONE launch, split by ROWS: a workgroup owns R (= 2) utterances and every
+// column, so layer-norm is local and nothing is exchanged between workgroups; the price is that each workgroup streams every layer's
+// whole weight matrix (256 KB) through its CU.  That is 1.9-2.1 us per layer (tools/micro/cu_stream.hip: 123-135 GB/s per CU, flat
+// from 1 to 32 workgroups) against 5.3 us for a column-split launch, so 7 launches (36 us per frame) become one of ~18 us.
+// (Round 1's rowmlp_kernel had the same idea and measured 8 us per layer: its loads sat behind uniform branches.)
+// R = rows per workgroup: the FMAs of a layer cost ~0.45 us per row on a SIMD's two waves (packed fp32 FMAs issue at half the rate
+// the peak suggests), the weight stream ~2.1 us whatever R is, so R = 2 (16 workgroups at B = 32) keeps the layer load-bound.
+// Per layer: wave w contracts k in [w cin/8, (w+1) cin/8) for all 4 rows and 4 columns per lane with plain fp32 FMAs (the fp32
+// MFMA rate IS the vector rate, and at 4 rows there is no tile to fill) -- weights in TF layout (Cin, Cout), one coalesced 1 KB
+// row slice per wave load, all of a wave's loads in flight before the first FMA; partial sums meet in LDS in a fixed order; waves
+// 0..3 then finish one row each (bias, two-pass layer-norm over the row, activation) and leave it in LDS as the next layer's input.
+struct MlpLayer { const float* w; const float* bias; const float* g; const float* be; int cin, cout, relu, pad_; };
+struct MlpRowsParams {
+  int B, frame, nlayers, mel_layer;          // mel_layer: index of the layer whose layer-norm output is the mel logits row (-1: none)
+  RowNorm nrm; long par;                     // first input row = gate(LN(P[b])) mixed with the residual row (an HC producer; parity copy `par`)
+  MlpLayer L[7];
+  float* ypad; long y_bstride; long y_row; int y_stride;      // sigmoid(logits) -> ypad[b][y_row] (the +1 shift of train.py:51 folded into y_row)
+  float* logits; long l_bstride; long l_row; int l_stride;
+  float* pout; float* stats_out;             // the LAST layer (when it is not the mel layer): pre-norm rows [b][cout] + per-16-column partial statistics [b][16][4]
+  long long* ts;                             // TS instantiation only (measurement): wall-clock stamps of workgroup 0, wave 0
+};
+
+template <int R, bool TS = false>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) mlp_rows_kernel(const MlpRowsParams* __restrict__ pp, long long* ts) {
+  long long tst[32]; int nts = 0;
+  auto stampt = [&]() { if constexpr (TS) { if (nts < 32) tst[nts++] = wall_clock64(); } };
+  stampt();
+  typedef const __attribute__((address_space(4))) MlpRowsParams CP;
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  CP& p = *(CP*)pp;
+  __shared__ __attribute__((aligned(16))) float xs[R * 256];
+  __shared__ __attribute__((aligned(16))) float red[8 * R * 256];
+  __shared__ int s_desc[7 * 12];             // the layer descriptors, copied once: a scalar load from the (cold, per-frame) parameter
+                                             // block costs a memory round trip, and every layer needed two or three in sequence
+  static_assert(sizeof(MlpLayer) == 48, "MlpLayer is copied to LDS as 12 dwords");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * R, c0 = lane * 4;
+  if (tid < 7 * 12) s_desc[tid] = reinterpret_cast<const int*>(&pp->L[0])[tid];
+  typedef const __attribute__((address_space(1))) float* gptr;   // GLOBAL pointers: rebuilt from integers they would be generic, and the flat loads
+                                                                 // a generic pointer gets also count in lgkmcnt -- the LDS-only barrier then waits for them
+  struct LDesc { gptr w; gptr bias; gptr g; gptr be; int cin, cout, relu; };
+  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto desc = [&](int l) {                   // layer 0 straight from the parameter block (nothing is in LDS yet), the others from LDS
+    LDesc d;
+    if (l == 0) { d.w = (gptr)p.L[0].w; d.bias = (gptr)p.L[0].bias; d.g = (gptr)p.L[0].g; d.be = (gptr)p.L[0].be; d.cin = p.L[0].cin; d.cout = p.L[0].cout; d.relu = p.L[0].relu; return d; }
+    const int* q = &s_desc[l * 12];
+    auto ptr = [&](int i) { return (gptr)(((unsigned long long)(unsigned)rfl(q[2 * i + 1]) << 32) | (unsigned)rfl(q[2 * i])); };
+    d.w = ptr(0); d.bias = ptr(1); d.g = ptr(2); d.be = ptr(3); d.cin = rfl(q[8]); d.cout = rfl(q[9]); d.relu = rfl(q[10]);
+    return d;
+  };
+
+  // A layer's loads: this wave's k slice of the weights (32 row slices of 1 KB, every load unconditional: rows past the slice
+  // re-read an existing row, columns past cout read column 0) + the row-finishing phase's parameters.  They are issued one layer
+  // AHEAD and INTERLEAVED with the current layer's FMAs -- each pair of register slots is refilled right after the FMAs that read
+  // it -- because ISSUING a wave's 35 loads is what takes the time (stamps: eight waves x 35 loads through the CU's one address
+  // path = ~2 us, whatever the rows per workgroup; issued in a burst after the FMAs they delayed the barrier by exactly that).
+  // The pins at the top of the next layer are where they must have landed (see chain3_kernel).
+  f32x8 w8[16]; f32x4 pbias, pg, pbe;
+  struct Slice { gptr wp; int k0, nk, cin, cout; };
+  auto slice_of = [&](const LDesc& d) {
+    Slice sl; sl.cin = d.cin; sl.cout = d.cout;
+    const int kw = (((d.cin >> 3) + 3) >> 2) << 2;                       // k slice per wave, a multiple of 4 (32 for cin 256, 12 for cin 80: aligned LDS reads)
+    sl.k0 = wave * kw;
+    int nk = d.cin - sl.k0; sl.nk = nk < 0 ? 0 : (nk > kw ? kw : nk);
+    sl.wp = d.w + ((c0 < d.cout) ? c0 : 0);
+    return sl;
+  };
+  typedef const __attribute__((address_space(1))) f32x4* gv4;
+  auto load_pair = [&](const Slice& sl, int u) {                         // rows u, u+1 of the slice -> one 8-register slot
+    int ka = sl.k0 + (u < sl.nk ? u : 0), kb = sl.k0 + (u + 1 < sl.nk ? u + 1 : 0);
+    ka = ka < sl.cin ? ka : sl.cin - 1; kb = kb < sl.cin ? kb : sl.cin - 1;
+    const f32x4 a = *(gv4)(sl.wp + (size_t)ka * sl.cout), b = *(gv4)(sl.wp + (size_t)kb * sl.cout);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+  auto load_params = [&](const LDesc& d) {
+    const int cc = (c0 < d.cout) ? c0 : 0;
+    pbias = *(gv4)(d.bias + cc); pg = *(gv4)(d.g + cc); pbe = *(gv4)(d.be + cc);
+  };
+  LDesc cur = desc(0);
+  {
+    const Slice s0 = slice_of(cur);
+#pragma unroll
+    for (int u = 0; u < 32; u += 2) w8[u >> 1] = load_pair(s0, u);
+    load_params(cur);
+  }
+  // ---- first input rows: waves 0..3 rebuild one row each from the highway producer's pre-norm row (full-row statistics: the row is ours)
+  if (wave < R) {
+    const int b = b0 + wave;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (b < p.B) {
+      RowNorm n; n.P = p.nrm.P; n.np = p.nrm.np; n.g1 = p.nrm.g1; n.b1 = p.nrm.b1; n.g2 = p.nrm.g2; n.b2 = p.nrm.b2; n.act = p.nrm.act; n.ngroups = p.nrm.ngroups;
+      n.res = p.nrm.res; n.res_bstride = p.nrm.res_bstride; n.res_row0 = p.nrm.res_row0; n.res_stride = p.nrm.res_stride; n.res_set = p.nrm.res_set;
+      x = norm_row_hc(n, (long)b, b, p.frame, lane, p.par);
+    }
+    *reinterpret_cast<float4*>(&xs[wave * 256 + c0]) = x;
+  }
+  __syncthreads();
+  stampt();
+  const int nlayers = p.nlayers, mel_layer = p.mel_layer;
+  for (int l = 0; l < nlayers; ++l) {
+    const int cin = cur.cin, cout = cur.cout, relu = cur.relu;
+    const int kw = (((cin >> 3) + 3) >> 2) << 2, k0 = wave * kw;
+    int nk = cin - k0; nk = nk < 0 ? 0 : (nk > kw ? kw : nk);          // rows of the slice that exist (cin 80: waves 0..5 have 12, wave 6 has 8, wave 7 none)
+    const bool colok = c0 < cout;
+    const LDesc nxt = desc(l + 1 < nlayers ? l + 1 : l);      // the last layer re-reads itself (harmless)
+    const Slice sn = slice_of(nxt);
+    // Pins in four chunks of eight rows: all of the slice's loads were issued a layer ago (in order), so the first chunk's FMAs can
+    // run while the later rows are still landing.  With ONE pin the last wave to be served waited for its whole slice (the CU's load
+    // path delivers the eight waves' 280 KB over ~2 us) before its first FMA: 4.8 us per layer, stamps.
+    asm volatile("; mlp_rows: parameters + rows 0-7 landed" : "+v"(pbias), "+v"(pg), "+v"(pbe), "+v"(w8[0]), "+v"(w8[1]), "+v"(w8[2]), "+v"(w8[3]) :: "memory");
+    stampt();
+    const f32x4 cbias = pbias, cg = pg, cbe = pbe;
+    f32x4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u4 = 0; u4 < 8; ++u4) {
+      if (u4 == 2) asm volatile("; mlp_rows: rows 8-15 landed" : "+v"(w8[4]), "+v"(w8[5]), "+v"(w8[6]), "+v"(w8[7]) :: "memory");
+      if (u4 == 4) asm volatile("; mlp_rows: rows 16-23 landed" : "+v"(w8[8]), "+v"(w8[9]), "+v"(w8[10]), "+v"(w8[11]) :: "memory");
+      if (u4 == 6) asm volatile("; mlp_rows: rows 24-31 landed" : "+v"(w8[12]), "+v"(w8[13]), "+v"(w8[14]), "+v"(w8[15]) :: "memory");
+      f32x4 xv[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) xv[r] = *reinterpret_cast<const f32x4*>(&xs[r * 256 + (4 * u4 < nk ? k0 + 4 * u4 : 252)]);   // broadcast read, 16-byte aligned; past this wave's slice (cin 80 only): columns 252..255, which are zero then
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        // rows past this wave's slice (cin 80 only) read x from columns that hold exact zeros (a finished row is written as 256
+        // columns, zeros beyond its width) and re-read finite weights, so those products vanish: one address select per four rows
+        // instead of a mask multiply per product (the masks were a third of the VALU work)
+        const int u = 4 * u4 + i;
+        const f32x8 wp8 = w8[u >> 1];
+        const f32x4 wq = (u & 1) ? __builtin_shufflevector(wp8, wp8, 4, 5, 6, 7) : __builtin_shufflevector(wp8, wp8, 0, 1, 2, 3);
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] += xv[r][i] * wq;
+      }
+      // refill the two slots these FMAs just read with the next layer's rows (not earlier: both slices would be live at once)
+      asm volatile("" ::: "memory");
+      w8[2 * u4] = load_pair(sn, 4 * u4); w8[2 * u4 + 1] = load_pair(sn, 4 * u4 + 2);
+    }
+    load_params(nxt);
+    stampt();
+    cur = nxt;
+#pragma unroll
+    for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4*>(&red[(wave * R + r) * 256 + c0]) = acc[r];
+    lds_barrier();             // LDS-only barrier: __syncthreads() would also drain vmcnt, i.e. wait for the next layer's weights (2 us per layer, stamps)
+    stampt();
+    // ---- waves 0..3: one row each -- reduce the 8 partial sums in a fixed order, bias, layer-norm, activation
+    if (wave < R) {
+      const int b = b0 + wave;
+      const bool rowok = b < p.B;
+      f32x4 y = {0.f, 0.f, 0.f, 0.f};
+      if (colok) {
+        y = cbias;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) y += *reinterpret_cast<const f32x4*>(&red[(w * R + wave) * 256 + c0]);
+      }
+      const bool lastl = (l + 1 == nlayers);
+      if (lastl && l != mel_layer) {
+        // hand the pre-norm row + its per-16-column partial statistics to the column-split kernel that follows (chain3_kernel<LN_C>)
+        const float qs = dpp_add<0x4E>(dpp_add<0xB1>(y[0] + y[1] + y[2] + y[3]));       // sum over the 4 lanes of a 16-column group
+        const float mg = qs * (1.0f / 16.0f);
+        const f32x4 dq = {y[0] - mg, y[1] - mg, y[2] - mg, y[3] - mg};
+        const float m2 = dpp_add<0x4E>(dpp_add<0xB1>(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]));
+        if (rowok && colok) {
+          *reinterpret_cast<f32x4*>(p.pout + (long)b * cout + c0) = y;
+          if ((lane & 3) == 0) { float* so = p.stats_out + ((long)b * 16 + (lane >> 2)) * 4; so[0] = mg; so[1] = m2; }
+        }
+      } else {
+        const float invn = 1.0f / (float)cout;
+        const float mean = wave_sum(colok ? y[0] + y[1] + y[2] + y[3] : 0.f) * invn;
+        const f32x4 dv = colok ? f32x4{y[0] - mean, y[1] - mean, y[2] - mean, y[3] - mean} : f32x4{0.f, 0.f, 0.f, 0.f};
+        const float rs = 1.0f / sqrtf(wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * invn + 1e-12f);
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (colok) {
+          o = dv * rs * cg + cbe;
+          if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+          if (l == mel_layer) {                                    // logits of mel frame j (networks.py:202-209); Y[j] = sigmoid (:210)
+            if (rowok) *reinterpret_cast<f32x4*>(p.logits + ((long)b * p.l_bstride + p.l_row) * p.l_stride + c0) = o;
+            o = f32x4{sigmoidf_(o[0]), sigmoidf_(o[1]), sigmoidf_(o[2]), sigmoidf_(o[3])};
+            if (rowok) *reinterpret_cast<f32x4*>(p.ypad + ((long)b * p.y_bstride + p.y_row) * p.y_stride + c0) = o;
+          }
+        }
+        *reinterpret_cast<f32x4*>(&xs[wave * 256 + c0]) = o;      // columns >= cout are zero: never read (the next layer's K is cout)
+      }
+    }
+    lds_barrier();
+    stampt();
+  }
+  if constexpr (TS) { if (ts && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 32; ++i) ts[i] = i < nts ? tst[i] : 0; }
+}
+
 }  // namespace dctts
