@@ -90,7 +90,8 @@ struct DevLayer {
   float* wp16r = nullptr;         // SSRN 4T-resolution layers: packing for hconv16_kernel (row-tail launches)
   ConvShape shape16{0, 0, 0};
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
-  float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for rowmlp_kernel
+  float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for mlp_rows_kernel
+  float* wrc[4] = {nullptr, nullptr, nullptr, nullptr};   // decode layers: 256 x 256 pass matrices packed for rowchain_kernel (k=1: [0]; highway: tap -d gate, info, centre gate, info)
   float* wp16c = nullptr;         // decode causal k=3 layers (v3): centre tap only, 16x16x4 tiles (the chain contracts K = 256)
   float* wpp = nullptr;           // decode causal k=3 layers (v3): the two older taps, 32x32x2 tiles (presum GEMM, K = 512)
   bool tap2 = false;              // v3 chain view of a dilation-1 AudioEnc layer: the chain contracts taps -1 and 0 (K = 512), the presum holds tap -2 only
@@ -135,6 +136,8 @@ struct dctts_ctx {
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
   int chain_mlp = 1;                   // v3: the seven k=1 layers around the mel frame as one row-split launch (mlp_rows_kernel; DCTTS_MLP=0: seven column-split launches)
   void* mlp_tab = nullptr; std::string mlp_geom;
+  int chain_row = 0;                   // decode mode 4: a whole v3 chain piece as ONE row-split launch (rowchain_kernel) instead of 19 column-split launches
+  void* rc_tab = nullptr; void* rc_par = nullptr; std::string rc_geom;
   int mlp_rows = 2;                    // utterances per mlp_rows_kernel workgroup (2 or 4; DCTTS_MLP_ROWS)
   int chain_group = 0;                 // v3: runs of chain highway layers as one persistent launch with in-launch hand-offs (hcgroup_kernel; DCTTS_GROUP=0: one launch per layer)
   void* group_tab = nullptr; std::string group_geom;   // per-frame HcGroupParams: [T][2] (AudioDec group of frame j, AudioEnc group of frame j)
@@ -247,6 +250,17 @@ static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, i
   return pack_bw(W, ntaps, cin_real, cin_p, s.nt * s.nw, cout, hc, 32);
 }
 
+// One 256 x 256 pass matrix of rowchain_kernel (decode3_kernels.h): [wave][i][lane][4] <- W[k = 32 (lane >> 3) + i][col = 32 wave + 4 (lane & 7) + e]
+static std::vector<float> pack_rc(const std::function<float(int, int)>& W) {
+  std::vector<float> out((size_t)256 * 256);
+  for (int wave = 0; wave < 8; ++wave)
+    for (int i = 0; i < 32; ++i)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int e = 0; e < 4; ++e)
+          out[(((size_t)wave * 32 + i) * 64 + lane) * 4 + e] = W(32 * (lane >> 3) + i, 32 * wave + 4 * (lane & 7) + e);
+  return out;
+}
+
 static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L, bool dec = false, bool tail = false) {
   const HostTensor *k, *b, *be, *ga;
   CHK(get_w(c, scope + "/conv1d/kernel", {1, cin_real, cout}, &k));
@@ -261,6 +275,7 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
   CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 31) / 32), cout, false, 16), &L->wp16));
   if (dec) CHK(upload(c, k->v, &L->wraw));
+  if (dec && cin_real <= 256 && cout <= 256) CHK(upload(c, pack_rc([=](int kk, int col) { return (kk < cin_real && col < cout) ? kv[(size_t)kk * cout + col] : 0.f; }), &L->wrc[0]));
   if (tail) {
     L->shape16 = pick_shape16(EPI_C, cout);
     CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, L->shape16.nt * L->shape16.nw, cout, false, 16), &L->wp16r));
@@ -293,6 +308,11 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
     CHK(upload(c, pack_bw(Wc, 1, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16c));
     CHK(upload(c, pack_bw(W, 2, C, L->cin_p, L->shape.nt * L->shape.nw, C, true, 32), &L->wpp));   // taps 0, 1 see x[t-2d], x[t-d]
   }
+  if (dec && k == 3 && causal && C == 256)
+    for (int q = 0; q < 4; ++q) {
+      const int tap = 1 + (q >> 1), half = q & 1;
+      CHK(upload(c, pack_rc([=](int kk, int col) { return kv[((size_t)tap * C + kk) * (2 * C) + half * C + col]; }), &L->wrc[q]));
+    }
   if (tail) {
     L->shape16 = pick_shape16(EPI_HC, C);
     CHK(upload(c, pack_bw(W, k, C, L->cin_p, L->shape16.nt * L->shape16.nw, C, true, 16), &L->wp16r));
@@ -358,7 +378,7 @@ static void read_env(dctts_ctx* c) {
   geti("DCTTS_CHAIN_ONE", &c->chain_one);
   { int r = c->bulk_cap; geti("DCTTS_BULK_CAP", &r); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
   geti("DCTTS_BULK3_SMALL", &c->bulk3_small_rows); geti("DCTTS_BULK3_FUSED", &c->bulk3_fused); geti("DCTTS_HC2_ROWOP", &c->hc2_rowop);
-  geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_MLP", &c->chain_mlp);
+  geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_MLP", &c->chain_mlp); 
   { int r = c->mlp_rows; geti("DCTTS_MLP_ROWS", &r); if (r == 2 || r == 4) c->mlp_rows = r; } geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
   geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
@@ -408,6 +428,8 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
   if (c->group_tab) (void)hipFree(c->group_tab);
   if (c->mlp_tab) (void)hipFree(c->mlp_tab);
+  if (c->rc_tab) (void)hipFree(c->rc_tab);
+  if (c->rc_par) (void)hipFree(c->rc_par);
   if (c->group_xch) (void)hipFree(c->group_xch);
   if (c->group_err_host) (void)hipHostFree(c->group_err_host);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -508,6 +530,8 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     auto Wbot = [=](int, int cc, int col) { return kv[(size_t)(d + cc) * d + col]; };        // rows that multiply Q
     c->ad_c1q = c->audiodec[0]; c->ad_c1q.cin = c->ad_c1q.cin_p = c->ad_c1q.cin_real = d; c->ad_c1q.wp = nullptr; c->ad_c1q.wraw = nullptr;
     CHK(upload(c, pack_bw(Wbot, 1, d, d, 2 * ((d + 31) / 32), d, false, 16), &c->ad_c1q.wp16));
+    for (float*& q : c->ad_c1q.wrc) q = nullptr;
+    if (d == 256) CHK(upload(c, pack_rc([=](int kk, int col) { return kv[(size_t)(d + kk) * d + col]; }), &c->ad_c1q.wrc[0]));   // rows d .. 2d - 1: the rows that multiply Q
     c->ad_vw = c->ad_c1q; c->ad_vw.wp16 = nullptr;
     CHK(upload(c, pack_bw(Wtop, 1, d, d, (d + 31) / 32, d, false, 32), &c->ad_vw.wp));
     CHK(upload(c, std::vector<float>(d, 0.f), &c->ad_vw.bias));
@@ -847,7 +871,7 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
   }
   CHK(ws_get(c, "dec.pm", (size_t)(T + 2) * B * sizeof(int), &p)); w->pm_all = (int*)p;
   CHK(ws_get(c, "dec.step", 256, &p)); w->step = (int*)p;
-  if (c->decode_mode == 3) {
+  if (c->decode_mode == 3 || c->decode_mode == 4) {
     CHK(ws_get(c, "dec.vw", (size_t)B * N * d * sizeof(float), &p)); w->vw = (float*)p;
     CHK(ws_view(c, "dec.c1q", B, rows, PAD, d, &w->c1q));
     CHK(ws_get(c, "dec.ps0", (size_t)B * d * sizeof(float), &p)); w->ps0 = (float*)p;
@@ -1557,6 +1581,101 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
   return 0;
 }
 
+// ---- rowchain_kernel plumbing: per chain piece (j = -1 .. T-1) one RowChainParams + its pass table, in device memory
+static constexpr int RC_MAXP = 48;
+static int v3_rowchain_table(dctts_ctx* c, const DecodeWs& w, int B, int N, int T) {
+  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
+  const size_t la = AE.size() - 1;
+  const std::string g = geom("rowchain", B, T, N) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.pse[la]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" +
+                        std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" +
+                        std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.logits.p);
+  if (c->rc_tab && c->rc_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->rc_tab) { (void)hipFree(c->rc_tab); c->rc_tab = nullptr; }
+  if (c->rc_par) { (void)hipFree(c->rc_par); c->rc_par = nullptr; }
+  const int d = c->cfg.d;
+  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
+  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
+  if (d != 256 || lh < 1 || nh < 1 || !c->ad_c1q.wrc[0]) return fail(DCTTS_ERR_STATE, "rowchain: unexpected layer structure");
+  auto rowp = [](const View& v, int j) { return v.p + (long)(j & 1) * v.set + (v.row0 + j) * (long)v.stride; };
+  auto bs = [](const View& v) { return (int)(v.bstride * v.stride); };
+  HIPCHK(hipMalloc(&c->rc_tab, (size_t)(T + 1) * RC_MAXP * sizeof(RowPass)));
+  HIPCHK(hipMalloc(&c->rc_par, (size_t)(T + 1) * sizeof(RowChainParams)));
+  std::vector<RowPass> tab((size_t)(T + 1) * RC_MAXP);
+  std::vector<RowChainParams> par((size_t)(T + 1));
+  for (int j = -1; j < T; ++j) {
+    RowPass* P = &tab[(size_t)(j + 1) * RC_MAXP]; int n = 0;
+    RowChainParams q; memset(&q, 0, sizeof(q));
+    int nxt = 0;                                                            // dilation-1 layers seen so far (each owns one xp slot)
+    auto c_layer = [&](const DevLayer& L, float* xm, int xm_bs, int flags) -> int {
+      if (!L.wrc[0] || L.hc || L.ntaps != 1 || n >= RC_MAXP) return fail(DCTTS_ERR_STATE, "rowchain: unsupported k=1 layer");
+      RowPass r; memset(&r, 0, sizeof(r));
+      r.w = L.wrc[0]; r.add = L.bias; r.g = L.g1; r.be = L.b1; r.xm = xm; r.xm_bs = xm_bs; r.cin = L.cin_real; r.ncols = L.cout;
+      r.fresh = 1; r.fin = FIN_C; r.relu = (L.act == ACT_RELU) ? 1 : 0; r.flags = flags;
+      P[n++] = r; return 0;
+    };
+    auto hc_layer = [&](const DevLayer& L, const float* presum, int presum_bs, const float* xt, int xt_bs, float* xm, int xm_bs, int flags) -> int {
+      if (!L.wrc[3] || !L.hc || L.cout != 256 || L.cin != 256 || !presum || n + 4 > RC_MAXP) return fail(DCTTS_ERR_STATE, "rowchain: unsupported highway layer");
+      int slot = 0;
+      if (L.tap2) { if (nxt >= 2) return fail(DCTTS_ERR_STATE, "rowchain: more than two dilation-1 layers"); q.xt[nxt] = xt; q.xt_bs[nxt] = xt_bs; slot = ++nxt; }
+      for (int pass = (L.tap2 ? 0 : 2); pass < 4; ++pass) {               // [tap -1: gate, info,] centre tap: gate, info
+        RowPass r; memset(&r, 0, sizeof(r));
+        const int half = pass & 1, centre = pass >> 1;
+        r.w = L.wrc[pass]; r.cin = 256; r.ncols = 256;
+        r.add = presum + half * 256; r.add_bs = presum_bs; r.g = half ? L.g2 : L.g1; r.be = half ? L.b2 : L.b1;
+        r.src = centre ? 0 : slot; r.accsel = half; r.fresh = (centre && L.tap2) ? 0 : 1;
+        if (pass == 3) { r.fin = FIN_HC; r.xm = xm; r.xm_bs = xm_bs; r.flags = flags; }
+        P[n++] = r;
+      }
+      return 0;
+    };
+    if (j >= 0) {
+      for (size_t i = 1; i <= lh; ++i) {
+        if (!AD[i].wp16c) return fail(DCTTS_ERR_STATE, "rowchain: AudioDec highway layers are k = 3");
+        const float* ps = w.pb3[i] + (long)(j & 1) * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout;
+        CHK(hc_layer(AD[i], ps, c->cone_len[i] * 2 * AD[i].cout, nullptr, 0, i < lh ? rowp(w.ad[i], j) : nullptr, i < lh ? bs(w.ad[i]) : 0, 0));
+      }
+      for (size_t i = lh + 1; i < AD.size(); ++i) CHK(c_layer(AD[i], nullptr, 0, i + 1 == AD.size() ? RP_MEL : 0));
+    }
+    const int j1 = j + 1;
+    if (j1 < T) {
+      for (size_t i = 0; i < nh; ++i) CHK(c_layer(AE[i], rowp(w.ae[i], j1), bs(w.ae[i]), 0));
+      for (size_t i = nh; i <= la; ++i) {
+        if (!AE[i].wp16c && !AE[i].tap2) return fail(DCTTS_ERR_STATE, "rowchain: AudioEnc highway layers are k = 3");
+        CHK(hc_layer(AE[i], w.pse[i] + (long)(j1 & 1) * w.pse_set, 2 * AE[i].cout, rowp(w.ae[i - 1], j1) - w.ae[i - 1].stride, bs(w.ae[i - 1]),
+                     rowp(w.ae[i], j1), bs(w.ae[i]), i == la ? RP_ATTN : 0));
+      }
+      RowPass r; memset(&r, 0, sizeof(r));                                // AudioDec C_1 of frame j+1: presum from the attention step + Q . W_bot
+      const DevLayer& L = c->ad_c1q;
+      r.w = L.wrc[0]; r.add = L.bias; r.g = L.g1; r.be = L.b1; r.cin = 256; r.ncols = 256; r.fresh = 1; r.fin = FIN_C1;
+      r.xm = rowp(w.ad[0], j1); r.xm_bs = bs(w.ad[0]); r.raw = rowp(w.c1q, j1); r.raw_bs = bs(w.c1q);
+      if (n >= RC_MAXP) return fail(DCTTS_ERR_STATE, "rowchain: pass table overflow");
+      P[n++] = r;
+    }
+    q.B = B; q.frame = j; q.first = 0; q.npass = n; q.init = (j < 0) ? 1 : 0;
+    q.tab = (const RowPass*)c->rc_tab + (size_t)(j + 1) * RC_MAXP;
+    if (j >= 0) { q.x1 = rowp(w.ad[0], j); q.x1_bs = bs(w.ad[0]); }
+    q.K = w.kv.p; q.k_stride = 2 * d; q.VW = w.vw; q.vw_stride = d; q.kv_bstride = N; q.N = N; q.win = c->cfg.attention_win_size;
+    q.pm_all = w.pm_all; q.c1_bias = c->audiodec[0].bias;
+    q.ypad = w.ypad.p; q.y_bstride = w.ypad.bstride; q.y_row = w.ypad.row0 + 1 + j; q.y_stride = w.ypad.stride;
+    q.logits = w.logits.p; q.l_bstride = w.logits.bstride; q.l_row = j; q.l_stride = w.logits.stride;
+    par[(size_t)(j + 1)] = q;
+  }
+  HIPCHK(hipMemcpy(c->rc_tab, tab.data(), tab.size() * sizeof(RowPass), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(c->rc_par, par.data(), par.size() * sizeof(RowChainParams), hipMemcpyHostToDevice));
+  c->rc_geom = g;
+  return 0;
+}
+
+static int v3_rowchain_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
+  CHK(prof_close_run(c, st));
+  const RowChainParams* q = (const RowChainParams*)c->rc_par + (j + 1);
+  if (g_trace_ctx && g_trace_ctx->trace_on) hipLaunchKernelGGL((rowchain_kernel<2, true>), dim3((B + 1) / 2), dim3(512), 0, st, q, c->trace_buf);   // DCTTS_TRACE: stamped instantiation
+  else hipLaunchKernelGGL((rowchain_kernel<2, false>), dim3((B + 1) / 2), dim3(512), 0, st, q, (long long*)nullptr);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // AudioDec HC_2 .. C_11 for frame j (its C_1 ran at the end of the previous chain piece)
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
@@ -1625,6 +1744,15 @@ static int write_trace3(dctts_ctx* c, int j) {
   if (c->trace_file.empty()) return 0;
   FILE* f = fopen(c->trace_file.c_str(), "w");
   if (!f) return 0;
+  if (c->chain_row) {
+    double tot = 0; for (int q = 1; q <= 7; ++q) tot += (double)h[q];
+    fprintf(f, "# rowchain_kernel, chain piece %d, workgroup 0 / wave 0: %.2f us (100 MHz wall clock), %lld passes, %.0f shader clocks (%.0f MHz); share per section\n", j, h[0] / 100.0, h[8], tot, tot / (h[0] / 100.0));
+    const char* nm[7] = {"launch prologue", "waiting for a pass's first rows", "FMA loop + later waits + issuing the next pass", "fold, reduce-scatter, wave statistics", "barrier 1 (all waves done with the pass)",
+                         "combine, normalise, gate, stores", "barrier 2 (new rows visible) + attention step"};
+    for (int q = 0; q < 7; ++q) fprintf(f, "%5.1f%%  %6.2f us  %s\n", 100.0 * h[q + 1] / tot, h[q + 1] / tot * h[0] / 100.0, nm[q]);
+    fclose(f);
+    return 0;
+  }
   long long t0 = 0;
   for (int k = 0; k < c->trace_n; ++k) for (int wg = 0; wg < 64; ++wg) { const long long e = h[(k * 64 + wg) * 32]; if (e && (!t0 || e < t0)) t0 = e; }
   fprintf(f, "# chain3_kernel<LN_HC, HC> launches of chain piece %d: microseconds (100 MHz wall clock) since the first entry of the piece\n", j);
@@ -1666,8 +1794,9 @@ static int write_trace3(dctts_ctx* c, int j) {
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
   CHK(decode_v2_init(c));
   CHK(v3_aepre_table(c, w, B));
-  if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));
-  if (c->chain_group) {
+  if (c->chain_row) CHK(v3_rowchain_table(c, w, B, N, T));
+  else if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));
+  if (c->chain_group && !c->chain_row) {
     if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off of the previous decode timed out (hcgroup_kernel)");
     CHK(v3_group_table(c, w, B, T));
     const GroupMem m = group_mem(c, B);
@@ -1679,13 +1808,14 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   // piece only waits at its start and records at its end, so the host issues 2 graph launches + 4 event operations per frame.
   const bool gr = c->use_graph != 0, gr_chain = c->use_graph == 2;
   auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
+    if (c->chain_row) return v3_rowchain_launch(c, B, j, s);
     if (j >= 0) CHK(v3_chain_dec(c, w, B, j, s));
     if (j >= 0 && c->chain_mlp) CHK(v3_mlp_launch(c, B, j, s));   // AudioDec C_8..C_11, mel frame j, AudioEnc C_1..C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
     return c->chain_mlp ? 0 : v3_final_mel(c, w, B, T, s);
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string(c->chain_row) + ":" + std::to_string((size_t)c->rc_par) + ":" +
                           std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs2(c);
@@ -1748,7 +1878,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       CHK(write_trace3(c, j));
     }
   }
-  if (c->chain_group) HIPCHK(hipMemcpyAsync(c->group_err_host, group_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (c->chain_group && !c->chain_row) HIPCHK(hipMemcpyAsync(c->group_err_host, group_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
     for (int i = 0; i < 8; ++i) {
@@ -1772,7 +1902,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
-  const bool v2 = (c->decode_mode == 1), v3 = (c->decode_mode == 3);
+  const bool v2 = (c->decode_mode == 1), v3 = (c->decode_mode == 3 || c->decode_mode == 4);
   if (v2) CHK(decode_v2_init(c));
   if (!v2 && !v3) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }     // v1 uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
@@ -1904,8 +2034,9 @@ extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
 }
 
 extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 3) return fail(DCTTS_ERR_ARG, "decode mode must be 0, 1, 2 or 3");
-  c->decode_mode = (mode == 3) ? 3 : (mode ? 1 : 0);
+  if (!c || mode < 0 || mode > 4) return fail(DCTTS_ERR_ARG, "decode mode must be 0 .. 4");
+  c->decode_mode = (mode >= 3) ? mode : (mode ? 1 : 0);
+  c->chain_row = (mode == 4) ? 1 : 0;
   c->fuse_mlp = (mode == 2) ? 1 : 0;
   return 0;
 }

@@ -82,7 +82,8 @@ class Engine:
         self._ok(self.lib.dctts_set_decode_graph(self._h, int(enable)))
 
     def set_decode_mode(self, mode: int):
-        """3 (default): round-2 decode (hoisted taps, row-op cone layers); 1 / 2: round-1 split kernels; 0: fused full-row kernels."""
+        """3 (default): round-2 decode (hoisted taps, row-op cone layers); 4: as 3 with one row-split launch per chain piece;
+        1 / 2: round-1 split kernels; 0: fused full-row kernels."""
         self._ok(self.lib.dctts_set_decode_mode(self._h, int(mode)))
 
     def decode_status(self):

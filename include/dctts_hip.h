@@ -98,6 +98,9 @@ int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 /* Decode algorithm form (results agree to fp32 re-association; all are the exact-parity incremental decode):
  * 3 = (default) round-2 form: column-split chain kernels that contract only each layer's centre tap (older taps arrive as presums
  *     computed on the bulk stream), AudioDec C_1 / HC_2 cone rows as row operations on cached V.W / Q.W products (csrc/decode3_kernels.h),
+ * 4 = as 3, with each chain piece (the newest row of 27 layers + the attention row) as ONE row-split launch: 2 utterances per
+ *     workgroup stream every layer's weights through one CU (rowchain_kernel).  Bound by what a CU can pull (~100 GB/s): 140 us
+ *     per piece against ~125 us for 19 column-split launches, so it is not the default; kept as a measured alternative,
  * 1 = round-1 form: column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone on two streams,
  * 2 = as 1, with the k=1 layers around the mel frame as one row-per-workgroup launch (measured slower),
  * 0 = fused full-row kernels on one stream (one workgroup per 32-row block; the simplest form, kept as a cross-check). */

@@ -306,7 +306,7 @@ def _oracle_decode(weights, T, B, seed):
     return _oracle_cache[key]
 
 
-@pytest.mark.parametrize("mode", [3, 1, 2, 0])
+@pytest.mark.parametrize("mode", [3, 1, 2, 0, 4])
 @pytest.mark.parametrize("graph", [0, 1, 2])
 def test_decode_vs_oracle_loop(weights, graph, mode):
     """Incremental exact decode == restated synthesize.py loop: integer-exact attention trajectory, Y within 1e-3.
@@ -334,7 +334,7 @@ def short_text(h, B, seed):
     return L
 
 
-@pytest.mark.parametrize("mode", [3, 1, 0])
+@pytest.mark.parametrize("mode", [3, 1, 0, 4])
 def test_decode_end_of_text_window(weights, mode):
     """networks.py:142-147 at the end of the text: once prev_max >= max_N - 2 the window is clipped to 2, then 1 key.  A 10-character
     text saturates within ~40 frames; the decode must follow the restated loop through the 3 -> 2 -> 1 key regimes (the
