@@ -152,6 +152,11 @@ struct dctts_ctx {
   uint32_t* ctr_chain = nullptr; uint32_t* ctr_bulk = nullptr;   // signal memory: chain pieces done + 1, bulk pieces done
   int sig_inkernel = 1;                // the chain's counter is written by the first launch of the NEXT piece instead of a write-value packet (DCTTS_SIG_INKERNEL=0)
   unsigned sig_next = 0;               // value the next run_chain3 launch writes (0 = none)
+  int sync_gate = 0;                   // v3, opt-in (DCTTS_GATE=1): no stream operation between pieces at all: the first launch of every piece publishes and waits in-kernel
+                                       // (piece_gate).  Measured 145 us/frame against 138 with stream memory operations: the agent-scope acquire after the wait costs more than the wait launch it replaces.
+  unsigned* gate_ctr = nullptr;        // device memory: [0] chain pieces complete + 1, [32] bulk pieces complete, [64] error word
+  int* gate_err_host = nullptr;        // pinned copy of the error word, refreshed after every decode
+  PieceGate gate_next = {nullptr, 0u, nullptr, 0u, nullptr};   // consumed by the next v3_aepre / run_chain3 launch
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // v1: one step, replayed T times
   std::vector<hipGraphExec_t> chain_g, bulk_g; hipGraphExec_t pro_g = nullptr;   // v2: one small linear graph per frame and stream,
   std::string graphs2_geom;                                                      //     frame index baked into every launch
@@ -384,7 +389,7 @@ static void read_env(dctts_ctx* c) {
   geti("DCTTS_BULK3_SMALL", &c->bulk3_small_rows); geti("DCTTS_BULK3_FUSED", &c->bulk3_fused); geti("DCTTS_HC2_ROWOP", &c->hc2_rowop);
   geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_MLP", &c->chain_mlp); 
   { int r = c->mlp_rows; geti("DCTTS_MLP_ROWS", &r); if (r == 2 || r == 4) c->mlp_rows = r; } geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
-  geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_SIG_INKERNEL", &c->sig_inkernel); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
+  geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_SIG_INKERNEL", &c->sig_inkernel); geti("DCTTS_GATE", &c->sync_gate); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
 }
 
@@ -424,6 +429,8 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->s_bulk) (void)hipStreamDestroy(c->s_bulk);
   if (c->ctr_chain) (void)hipFree(c->ctr_chain);
   if (c->ctr_bulk) (void)hipFree(c->ctr_bulk);
+  if (c->gate_ctr) (void)hipFree(c->gate_ctr);
+  if (c->gate_err_host) (void)hipHostFree(c->gate_err_host);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   free_ws(c);
@@ -1305,7 +1312,8 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
 static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st) {
   const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
   const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * c->aepre_layers;
-  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f);
+  const PieceGate gate = c->gate_next; c->gate_next = PieceGate{nullptr, 0u, nullptr, 0u, nullptr};
+  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f, gate);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1436,6 +1444,7 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   if (ex && ex->raw) { p.raw = row(*ex->raw); p.raw_bs = (int)(ex->raw->bstride * ex->raw->stride); }
   p.pout = pout; p.np_out = L.hc ? 2 * L.cout : L.cout; p.stats_out = stats_out; p.cout = L.cout;
   if (c->sig_next) { p.sig = c->ctr_chain; p.sig_val = c->sig_next; c->sig_next = 0; }
+  if (c->gate_next.sig || c->gate_next.wait) { p.sig = c->gate_next.sig; p.sig_val = c->gate_next.sig_val; p.wait = c->gate_next.wait; p.wait_val = c->gate_next.wait_val; p.gate_err = c->gate_next.err; c->gate_next = PieceGate{nullptr, 0u, nullptr, 0u, nullptr}; }
   const dim3 grid(L.hc ? L.cout / 16 : (L.cout + 31) / 32, (B + 7) / 8);
   // measurement (dctts_hip_debug.h): HIP events on the launch stream around sampled launches of the time-dominant decode kernel
   // Consecutive launches of the kernel share ONE event pair (a pair around every 5 us launch measures its own marker packets:
@@ -1590,12 +1599,12 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
 
 // ---- rowchain_kernel plumbing: per chain piece (j = -1 .. T-1) one RowChainParams + its pass table, in device memory
 static constexpr int RC_MAXP = 48;
-static int v3_rowchain_table(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, bool insig) {
+static int v3_rowchain_table(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, bool insig, bool gate) {
   const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
   const size_t la = AE.size() - 1;
   const std::string g = geom("rowchain", B, T, N) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.pse[la]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" +
                         std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" +
-                        std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.logits.p) + ":" + std::to_string((int)insig);
+                        std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.logits.p) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)gate);
   if (c->rc_tab && c->rc_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->rc_tab) { (void)hipFree(c->rc_tab); c->rc_tab = nullptr; }
@@ -1667,6 +1676,7 @@ static int v3_rowchain_table(dctts_ctx* c, const DecodeWs& w, int B, int N, int 
     q.ypad = w.ypad.p; q.y_bstride = w.ypad.bstride; q.y_row = w.ypad.row0 + 1 + j; q.y_stride = w.ypad.stride;
     q.logits = w.logits.p; q.l_bstride = w.logits.bstride; q.l_row = j; q.l_stride = w.logits.stride;
     if (insig && j >= 0) { q.sig = c->ctr_chain; q.sig_val = (unsigned)(j + 1); }
+    if (gate && j >= 0) { q.sig = c->gate_ctr; q.sig_val = (unsigned)(j + 1); q.wait = c->gate_ctr + 32; q.wait_val = (unsigned)(j + 1); q.gate_err = (int*)(c->gate_ctr + 64); }
     par[(size_t)(j + 1)] = q;
   }
   HIPCHK(hipMemcpy(c->rc_tab, tab.data(), tab.size() * sizeof(RowPass), hipMemcpyHostToDevice));
@@ -1801,7 +1811,15 @@ static int write_trace3(dctts_ctx* c, int j) {
 
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
   CHK(decode_v2_init(c));
-  const bool vs = c->sync_values != 0;
+  // how the two streams meet: in-kernel gates (default) > stream memory operations > events
+  const bool gate = c->sync_gate && !c->chain_group && c->v3_skip == 0;
+  if (gate && !c->gate_ctr) {
+    HIPCHK(hipMalloc((void**)&c->gate_ctr, 128 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->gate_ctr, 0, 128 * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void**)&c->gate_err_host, sizeof(int), 0)); *c->gate_err_host = 0;
+  }
+  if (gate && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: a piece gate of the previous decode timed out (piece_gate)");
+  const bool vs = c->sync_values != 0 && !gate;
   if (vs && !c->ctr_chain) {
     // Stream memory operations: a write packet after a piece, a compare-and-wait packet before the piece that needs it.  The
     // command processor polls the counter itself: no signal objects, no interrupt, and (measured) ~10 us less per frame on the
@@ -1815,7 +1833,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   // instead of a write-value packet behind the piece: one command-processor round trip less per frame on the critical stream
   const bool insig = vs && c->sig_inkernel && !c->chain_group && c->v3_skip != 2;
   CHK(v3_aepre_table(c, w, B));
-  if (c->chain_row) CHK(v3_rowchain_table(c, w, B, N, T, insig));
+  if (c->chain_row) CHK(v3_rowchain_table(c, w, B, N, T, insig, gate));
   else if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));
   if (c->chain_group && !c->chain_row) {
     if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off of the previous decode timed out (hcgroup_kernel)");
@@ -1831,13 +1849,18 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
     if (c->chain_row) return v3_rowchain_launch(c, B, j, s);
     c->sig_next = (insig && j >= 0) ? (unsigned)(j + 1) : 0u;          // written by the piece's first launch (AudioDec HC_2)
+    if (gate && j >= 0) c->gate_next = PieceGate{c->gate_ctr, (unsigned)(j + 1), c->gate_ctr + 32, (unsigned)(j + 1), (int*)(c->gate_ctr + 64)};   // publish "pieces < j done", wait for bulk piece j
     if (j >= 0) CHK(v3_chain_dec(c, w, B, j, s));
     if (j >= 0 && c->chain_mlp) CHK(v3_mlp_launch(c, B, j, s));   // AudioDec C_8..C_11, mel frame j, AudioEnc C_1..C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
     return c->chain_mlp ? 0 : v3_final_mel(c, w, B, T, s);
   };
+  auto bulk_rest = [&](int f, hipStream_t s) -> int {        // bulk piece f; its first launch (the grouped presum launch) carries the gate
+    if (gate && f >= 1) c->gate_next = PieceGate{c->gate_ctr + 32, (unsigned)f, c->gate_ctr, (unsigned)f, (int*)(c->gate_ctr + 64)};   // publish "bulk pieces < f done", wait for chain pieces <= f-2
+    return v3_bulk_rest(c, w, B, N, T, f, s);
+  };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string(c->chain_row) + ":" + std::to_string((size_t)c->rc_par) + ":" + std::to_string((int)insig) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string(c->chain_row) + ":" + std::to_string((size_t)c->rc_par) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)gate) + ":" +
                           std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs2(c);
@@ -1846,7 +1869,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       const int prof_keep = c->prof_id; c->prof_id = -1;
       c->bulk3_g.assign(T, nullptr); c->chain3_g.assign(T + 1, nullptr);
       int rc = 0;
-      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, T, f, cs); });
+      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return bulk_rest(f, cs); });
       for (int j = -1; gr_chain && j < T && rc == 0; ++j) rc = capture_piece(cs, &c->chain3_g[j + 1], [&]() { return chain_piece(j, cs); });
       c->prof_id = prof_keep;
       HIPCHK(hipStreamDestroy(cs));
@@ -1854,6 +1877,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       c->graphs3_geom = g;
     }
   }
+  if (gate) HIPCHK(hipMemsetAsync(c->gate_ctr, 0, 64 * sizeof(unsigned), st));      // both counters; st is ordered after the previous decode's last piece, and that piece after all bulk work
   if (vs) {
     HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 0u, 0));              // st is ordered after the previous decode's last piece, and that piece after all bulk work
     HIPCHK(hipStreamWriteValue32(st, c->ctr_bulk, 0u, 0));
@@ -1865,7 +1889,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   const int skip = c->v3_skip;                                             // timing experiments only: 1 = no bulk work, 2 = no chain work, 3 = no bulk work and no events between the streams
   const int tstep = gr_chain ? -1 : c->trace_frame;
   auto bulk_piece = [&](int f) -> int {
-    if (skip != 1 && skip != 3) { if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, T, f, sb)); }
+    if (skip != 1 && skip != 3) { if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(bulk_rest(f, sb)); }
+    if (gate) { if (f == T - 1) { hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, sb, c->gate_ctr + 32, (unsigned)T); HIPCHK(hipGetLastError()); } return 0; }
     if (skip != 3) { if (vs) HIPCHK(hipStreamWriteValue32(sb, c->ctr_bulk, (uint32_t)(f + 1), 0)); else HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb)); }
     return 0;
   };
@@ -1877,16 +1902,16 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   const auto host_t0 = std::chrono::steady_clock::now();
   CHK(bulk_piece(0));
   if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[0], st)); else CHK(chain_piece(-1, st));
-  if (vs) { if (!insig) HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 1u, 0)); } else HIPCHK(hipEventRecord(c->ev_chain[3], st));
+  if (gate) {} else if (vs) { if (!insig) HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 1u, 0)); } else HIPCHK(hipEventRecord(c->ev_chain[3], st));
   for (int j = 0; j < T; ++j) {
     if (j + 1 < T) {
       // bulk piece j+1 needs attnq(j) / C1Q[j]: end of chain piece j-1
-      if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(sb, c->ctr_chain, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0)); }
+      if (gate) {} else if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(sb, c->ctr_chain, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0)); }
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][0], sb));
       CHK(bulk_piece(j + 1));
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][1], sb));
     }
-    if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(st, c->ctr_bulk, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0)); }
+    if (gate) {} else if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(st, c->ctr_bulk, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0)); }
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][0], st));
     if (j == tstep) {
       if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
@@ -1898,13 +1923,14 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     CHK(prof_close_run(c, st));
     c->prof_frame = false;
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][1], st));
-    if (skip != 3) { if (vs) { if (!insig) HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, (uint32_t)(j + 2), 0)); } else HIPCHK(hipEventRecord(c->ev_chain[j & 3], st)); }
+    if (gate) {} else if (skip != 3) { if (vs) { if (!insig) HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, (uint32_t)(j + 2), 0)); } else HIPCHK(hipEventRecord(c->ev_chain[j & 3], st)); }
     if (c->trace_on) {
       c->trace_on = false; g_trace_ctx = nullptr;
       HIPCHK(hipStreamSynchronize(st));
       CHK(write_trace3(c, j));
     }
   }
+  if (gate) HIPCHK(hipMemcpyAsync(c->gate_err_host, c->gate_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
   if (c->chain_group && !c->chain_row) HIPCHK(hipMemcpyAsync(c->group_err_host, group_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
@@ -2051,6 +2077,7 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 extern "C" int dctts_decode_status(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off timed out (hcgroup_kernel); results of that decode are invalid");
+  if (c->gate_err_host && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: a piece gate timed out (piece_gate: one stream never saw the other's counter); results of that decode are invalid");
   return 0;
 }
 

@@ -242,7 +242,8 @@ struct Chain3Params {
   int cout;                          // output channels of an LN group (HCOUT: 256 gate + 256 info; else the row width: 256 or 80)
   const float* xt; int xt_bs;        // TAP2: the previous time step's input row (tap -1 of a dilation-1 layer) at xt + b * xt_bs
   long long* ts;                     // TS instantiation only (measurement): 8 wall-clock stamps per workgroup
-  unsigned* sig; unsigned sig_val;   // first launch of a chain piece: *sig = sig_val ("every earlier piece is complete": the bulk stream's compare-and-wait polls it)
+  unsigned* sig; unsigned sig_val;   // first launch of a chain piece: *sig = sig_val ("every earlier piece is complete": the bulk stream waits for it)
+  const unsigned* wait; unsigned wait_val; int* gate_err;   // ... and, when set, wait for *wait >= wait_val before anything is loaded (piece_gate)
 };
 
 // TAP2: a dilation-1 AudioEnc layer.  Its tap -1 reads the row the chain produced one frame earlier, which no presum computed
@@ -258,8 +259,9 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
   DCTTS_SGPR(p.B); DCTTS_SGPR(p.P); DCTTS_SGPR(p.p_bs); DCTTS_SGPR(p.stats); DCTTS_SGPR(p.res); DCTTS_SGPR(p.res_bs);
   DCTTS_SGPR(p.g1); DCTTS_SGPR(p.b1); DCTTS_SGPR(p.g2); DCTTS_SGPR(p.b2); DCTTS_SGPR(p.relu); DCTTS_SGPR(p.xm); DCTTS_SGPR(p.xm_bs);
   DCTTS_SGPR(p.wp); DCTTS_SGPR(p.add); DCTTS_SGPR(p.add_bs); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.stats_out);
-  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.sig); DCTTS_SGPR(p.sig_val);
+  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.sig); DCTTS_SGPR(p.sig_val); DCTTS_SGPR(p.wait);
   if constexpr (TAP2) { DCTTS_SGPR(p.xt); DCTTS_SGPR(p.xt_bs); }
+  if (p.wait) piece_gate(p.sig, p.sig_val, p.wait, p.wait_val, p.gate_err, (blockIdx.x | blockIdx.y) == 0);        // first launch of a chain piece: publish, then wait for the bulk stream's rows of this frame
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x, m0 = blockIdx.y * 8;
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
@@ -334,7 +336,7 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
 #undef C3_PIN_T2
   // This launch runs, so every earlier launch of the stream has completed and released its stores: say so to the other stream.
   // (A stream write-value packet after the previous piece says the same ~6 us of command-processor time later.)
-  if (p.sig && (blockIdx.x | blockIdx.y) == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (p.sig && !p.wait && (blockIdx.x | blockIdx.y) == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if constexpr (TS) t_landed = wall_clock64();
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
   float4 bq0[2], bq1[2], av[2], h2v[2], rsv[2], g1v[2], b1v[2], g2v[2], b2v[2], st[4];
@@ -914,6 +916,7 @@ struct RowChainParams {
   float* ypad; long y_bstride; long y_row; int y_stride;      // RP_MEL: sigmoid(logits) -> ypad[b][y_row]; logits -> logits[b][l_row]
   float* logits; long l_bstride; long l_row; int l_stride;
   unsigned* sig; unsigned sig_val;     // *sig = sig_val at launch ("every earlier piece is complete"); nullptr = none
+  const unsigned* wait; unsigned wait_val; int* gate_err;   // when set: wait for *wait >= wait_val before anything is loaded (piece_gate)
 };
 
 // index of channel c inside a row kept in LDS: k-groups of 32 channels padded to 36 floats, so that the 8 k-groups of a wave read 8 different banks
@@ -956,6 +959,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   typedef __attribute__((address_space(1))) float* gwptr;            // stores through generic pointers are FLAT: they make vmcnt out-of-order and every wait a vmcnt(0)
   typedef __attribute__((address_space(1))) f32x4* gv4w;
   CP& p = *(CP*)pp;
+  if (p.wait) piece_gate(p.sig, p.sig_val, p.wait, p.wait_val, p.gate_err, blockIdx.x == 0);
   constexpr int MAXP = 48;
   __shared__ __attribute__((aligned(16))) float xs[R * RC_XS];                 // the current rows
   __shared__ __attribute__((aligned(16))) float xp[2 * R * RC_XS];             // previous-time-step rows of the dilation-1 layers
@@ -1021,7 +1025,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       *reinterpret_cast<f32x4*>(&ps[wave * 256 + c0]) = *(gv4)((gptr)p.c1_bias + c0);          // the presum starts as AudioDec C_1's bias
     }
   }
-  if (p.sig && blockIdx.x == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (p.sig && !p.wait && blockIdx.x == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();                                                    // s_tab, xs, xp
   tick(0);                                  // [0] launch prologue
   PDesc cur = desc(0);

@@ -619,11 +619,41 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
 // Several independent layers of the same shape in ONE launch (v3: the presums of AudioEnc's ten causal k = 3 layers for the
 // next frame).  tab[layer] is a frame-independent descriptor in device memory; the frame index is a kernel argument.
 // grid = nlayers * items_per_layer, one item per workgroup.
+// ---- the two decode streams meet INSIDE the first launch of each piece (no stream operation between pieces).
+// A launch that runs knows that every earlier launch of its stream has completed and released its stores, so the first launch of
+// piece n publishes "pieces < n of my stream are complete" (*sig = sig_val) and then waits until the OTHER stream has published what
+// piece n needs (*wait >= wait_val), followed by an agent-scope acquire: HSA's release (kernel end) -> atomic store -> atomic
+// load -> acquire chain, the same one a stream write-value / wait-value pair builds out of two extra launches (~4-6 us each on
+// the critical stream).  The wait is bounded: on a time-out the launch raises *err and carries on (the host reports it,
+// dctts_decode_status), it never hangs the queue.
+struct PieceGate { unsigned* sig; unsigned sig_val; const unsigned* wait; unsigned wait_val; int* err; };
+__device__ __forceinline__ void piece_gate(unsigned* sig, unsigned sig_val, const unsigned* wait, unsigned wait_val, int* err, bool first_wg) {
+  if (threadIdx.x == 0) {
+    if (sig && first_wg) __hip_atomic_store(sig, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wait) {
+      bool ok = false;
+      for (int i = 0; i < (1 << 20) && !ok; ++i) {                        // ~1 us per poll: gives up after about a second
+        ok = __hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_val;
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+      }
+      if (!ok && err) atomicOr(err, 1);
+    }
+  }
+  if (wait) {
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
+
+// the last bulk piece has no successor to publish its completion
+__global__ void set_word_kernel(unsigned* p, unsigned v) { if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 typedef const __attribute__((address_space(4))) SplitParams ConstSplitParams;   // constant address space: uniform field reads are scalar loads
 template <int NG>
-__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step) {
+__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step, const PieceGate gate) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ long s_prow[2][32];
+  if (gate.sig || gate.wait) piece_gate(gate.sig, gate.sig_val, gate.wait, gate.wait_val, gate.err, blockIdx.x == 0);     // first launch of a bulk piece
   const int layer = blockIdx.x / items_per_layer, item = blockIdx.x - layer * items_per_layer;
   ConstSplitParams& p = *((ConstSplitParams*)tab + layer);
   hbulk_body<NG, ConstSplitParams>(p, step, item, items_per_layer, items_per_layer, smem, s_prow);

@@ -327,6 +327,30 @@ def test_decode_vs_oracle_loop(weights, graph, mode):
     assert trajr.max() > 10
 
 
+@pytest.mark.parametrize("knob", ["DCTTS_GATE=1", "DCTTS_SYNC_VALUES=0", "DCTTS_SIG_INKERNEL=0"])
+def test_decode_stream_meeting_variants(weights, knob):
+    """The chain and bulk streams of the decode can meet three ways (events, stream memory operations, in-kernel gates); the
+    knobs are read when a context is created.  Every variant must reproduce the oracle loop: trajectory integer-exact."""
+    from dc_tts_amd.engine import Engine
+    T = 100
+    name, val = knob.split("=")
+    old = os.environ.get(name)
+    os.environ[name] = val
+    try:
+        eng = Engine(weights, hp.replace(max_T=T))
+    finally:
+        if old is None: del os.environ[name]
+        else: os.environ[name] = old
+    L, Yr, trajr, gap = _oracle_decode(weights, T, 3, 21)
+    for mode in (3, 4):
+        eng.set_decode_mode(mode)
+        Y, mx = eng.text2mel(dev(L))
+        torch.cuda.synchronize(); eng.decode_status()
+        np.testing.assert_array_equal(mx.cpu().numpy(), trajr)
+        assert maxabs(Y.cpu().numpy(), Yr) < TOL
+    eng.close()
+
+
 def short_text(h, B, seed):
     rng = np.random.default_rng(seed)
     L = rng.integers(2, len(h.vocab), (B, h.max_N)).astype(np.int32)
