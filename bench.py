@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--max-T", type=int, default=210)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-mode", type=int, default=1, help="0 eager, 1 bulk pieces as hipGraphs (default), 2 chain pieces too")
-    ap.add_argument("--decode-mode", type=int, default=3, help="3 = default (round-2 decode: hoisted taps, row-op cone layers), 1 / 2 = round-1 split kernels, 0 = fused full-row kernels")
+    ap.add_argument("--decode-mode", type=int, default=3, help="3 = default (round-2 decode: hoisted taps, row-op cone layers), 4 = as 3 with one row-split launch per chain piece, 1 / 2 = round-1 split kernels, 0 = fused full-row kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vocoder", action="store_true", help="skip the untimed vocoder-tail section (SURVEY 8f-2)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed per-kernel passes and the other BASELINE configs")
@@ -262,11 +262,11 @@ def main():
         roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "chain3_kernel<LN_HC,HC>: one newest-row highway layer of the decode (AudioEnc HC_5..13 / AudioDec HC_3..7: rebuild "
                           "the input row from the producer's pre-norm row, 32 x 256 x 512 contraction on 16x16x4 fp32 MFMA, partial LN "
-                          "statistics out); 14 of the 25 dependent launches of a frame, ~35 % of the step time",
+                          "statistics out); 14 of the 19 dependent launches of a frame's chain piece, ~35 % of the step time",
                 "launches": n_chain, "sampled": "every 16th frame of the timed region", "avg_launch_ms": None,
                 "algorithmic_bytes_per_launch": c3_bytes, "flop_per_launch": c3_flop,
                 "note": "latency-bound: ~1.45 us of launch boundary + one memory round trip + an 8-wave reduction per 5 us launch; the "
-                        "fraction of either roof is what a 64-workgroup, 25-deep dependent chain leaves (DESIGN.md section 4)"}
+                        "fraction of either roof is what a 64-workgroup, 19-deep dependent chain leaves (DESIGN.md section 4)"}
         if n_chain > 0:
             avg = chain_ms / n_chain
             roof.update(avg_launch_ms=round(avg, 5), achieved=round(c3_bytes / (avg * 1e-3) / 1e9, 1),
@@ -323,7 +323,7 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     res["phase_rooflines"] = {
         "textenc": both_roofs(B * 2 * 3.0789e9, 68.6e6 + B * 0.37e6, ms_te),
         "decode": dict(both_roofs(B * T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 + B * 125e3), dec_ms),
-                       bound="latency: 25 dependent launches per frame on the critical path; the cone work of AudioDec C_1 / HC_2 runs as row "
+                       bound="latency: 19 dependent launches per frame on the critical path (+ one stream wait); the cone work of AudioDec C_1 / HC_2 runs as row "
                              "operations on cached products, so fewer FLOPs are EXECUTED than the algorithmic count used here (DESIGN.md section 2)"),
         "ssrn": both_roofs(B * T * 187.310e6, B * (67200 + 3444000) + 113641532.0, ms_ssrn),
     }
