@@ -5,13 +5,13 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRCS = [os.path.join(HERE, "csrc", "dctts_api.hip"), os.path.join(HERE, "csrc", "vocoder_api.hip")]
+SRCS = [os.path.join(HERE, "csrc", "dctts_api.hip"), os.path.join(HERE, "csrc", "vocoder_api.hip"), os.path.join(HERE, "csrc", "train_api.hip")]
 OUT = os.path.join(HERE, "lib", "libdctts_hip.so")
 
 
 def _deps():
     return SRCS + glob.glob(os.path.join(HERE, "csrc", "*.h")) + \
-        [os.path.join(os.path.dirname(HERE), "include", "dctts_hip.h")]
+        glob.glob(os.path.join(os.path.dirname(HERE), "include", "*.h"))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

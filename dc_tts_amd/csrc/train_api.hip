@@ -1,0 +1,186 @@
+// train_api.hip -- C ABI of the first training slice (include/dctts_train.h): backward of the highway-convolution block,
+// the losses of train.py:85-110 with gradients, the clip + Adam update of train.py:119-131.  gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "../../include/dctts_hip.h"
+#include "../../include/dctts_train.h"
+#include "train_kernels.h"
+
+using namespace dctts;
+
+int dctts_set_error(int code, const std::string& msg);       // dctts_api.hip: the library's one error channel (dctts_last_error)
+#define TFAIL(code, msg) return dctts_set_error((code), (msg))
+#define THIP(x)                                                                                      \
+  do {                                                                                               \
+    hipError_t e__ = (x);                                                                            \
+    if (e__ != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e__)); \
+  } while (0)
+
+struct TBuf { void* p = nullptr; size_t bytes = 0; };
+
+struct dctts_train {
+  int device = 0;
+  TBuf xp, Hp, dHp, dxp, part, wpart, lpart;
+};
+
+namespace {
+struct DevScope {                    // restores the caller's current device
+  int old = -1; bool ok = false;
+  explicit DevScope(int dev) { ok = hipGetDevice(&old) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
+  ~DevScope() { if (old >= 0) (void)hipSetDevice(old); }
+};
+int reserve(TBuf* b, size_t bytes) {
+  if (b->bytes >= bytes) return 0;
+  (void)hipDeviceSynchronize();
+  if (b->p) (void)hipFree(b->p);
+  b->p = nullptr; b->bytes = 0;
+  if (hipMalloc(&b->p, bytes) != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "training workspace: hipMalloc failed");
+  b->bytes = bytes;
+  return 0;
+}
+template <bool TA, bool TB>
+int gemm(hipStream_t st, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int beta,
+         int splits = 1, long zstride = 0) {
+  GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, beta, K, zstride};
+  if (splits > 1) p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+  const int nz = (K + p.kchunk - 1) / p.kchunk;
+  hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(256), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "gemm launch failed");
+  return nz;
+}
+}  // namespace
+
+extern "C" int dctts_train_create(dctts_train** out, int device) {
+  if (!out) TFAIL(DCTTS_ERR_ARG, "null argument");
+  dctts_train* t = new dctts_train();
+  t->device = device;
+  DevScope ds(device);
+  if (!ds.ok) { delete t; TFAIL(DCTTS_ERR_HIP, "hipSetDevice: no such device"); }
+  *out = t;
+  return 0;
+}
+
+extern "C" int dctts_train_destroy(dctts_train* t) {
+  if (!t) return 0;
+  DevScope ds(t->device);
+  for (TBuf* b : {&t->xp, &t->Hp, &t->dHp, &t->dxp, &t->part, &t->wpart, &t->lpart}) if (b->p) (void)hipFree(b->p);
+  delete t;
+  return 0;
+}
+
+extern "C" size_t dctts_train_device_bytes(const dctts_train* t) {
+  if (!t) return 0;
+  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes;
+}
+
+extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
+                                       const float* g1, const float* b1, const float* g2, const float* b2,
+                                       int B, int T, int C, int k, int rate, int causal,
+                                       float* dx, float* dkernel, float* dbias, float* dg1, float* db1, float* dg2, float* db2, void* stream) {
+  if (!t || !x || !dy || !kernel || !bias || !g1 || !b1 || !g2 || !b2 || !dx || !dkernel || !dbias || !dg1 || !db1 || !dg2 || !db2)
+    TFAIL(DCTTS_ERR_ARG, "hc_backward: null argument");
+  if (B <= 0 || T <= 0 || (C != 256 && C != 512 && C != 1024) || (k != 1 && k != 3) || rate < 1)
+    TFAIL(DCTTS_ERR_ARG, "hc_backward: C must be 256, 512 or 1024, k 1 or 3, rate >= 1");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  // tf.layers.conv1d tap j reads x[t + j*rate - pl] (modules.py:121-125,173-177): CAUSAL pl = (k-1) rate, SAME pl = total / 2
+  const int total = (k - 1) * rate, pl = causal ? total : total / 2, pr = total - pl;
+  const int Tp = pl + T + pr;
+  const long R = (long)B * Tp, Rv = R - pl - pr;          // rows of the padded buffers; rows every GEMM output covers
+  // x-aligned buffers hold t = 0 at row pl of an utterance, H-aligned ones at row pr: then for every tap j
+  //   H_aligned[r] needs x_aligned[r - pr + j*rate]   and   dx_aligned[r] needs dH_aligned[r + pr - j*rate]   (r a flat row index),
+  // i.e. every shift is a pointer offset, and rows that fall into another utterance's padding read / write zeros.
+  if (reserve(&t->xp, (size_t)R * C * 4) || reserve(&t->Hp, (size_t)R * 2 * C * 4) || reserve(&t->dHp, (size_t)R * 2 * C * 4) ||
+      reserve(&t->dxp, (size_t)R * C * 4)) return DCTTS_ERR_HIP;
+  const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
+  const int splits = 8;
+  if (reserve(&t->part, (size_t)nblk * 6 * C * 4) || reserve(&t->wpart, (size_t)splits * C * 2 * C * 4)) return DCTTS_ERR_HIP;
+  float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
+  const long n4 = R * (C / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), B, T, Tp, pl, C, 0);
+  THIP(hipGetLastError());
+  THIP(hipMemsetAsync(dHp, 0, (size_t)R * 2 * C * 4, st));
+  THIP(hipMemsetAsync(dxp, 0, (size_t)R * C * 4, st));
+  // 1. pre-norm H (without bias) over rows [pr, R - pl) of the H-aligned buffer
+  for (int j = 0; j < k; ++j) {
+    const int rc = gemm<false, false>(st, xp + (long)(j * rate) * C, kernel + (long)j * C * 2 * C, Hp + (long)pr * 2 * C, (int)Rv, 2 * C, C, C, 2 * C, 2 * C, j > 0);
+    if (rc < 0) return rc;
+  }
+  // 2. the row part: dH, the direct part of dx, column sums
+  HcBwdRowsParams q{B, T, Tp, C, pr, pl, Hp, x, dy, bias, g1, b1, g2, b2, dHp, dxp, (float*)t->part.p};
+  if (C == 256) hipLaunchKernelGGL((hc_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
+  else if (C == 512) hipLaunchKernelGGL((hc_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((hc_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
+  THIP(hipGetLastError());
+  float* outs[6] = {dg1, db1, dg2, db2, dbias, dbias + C};
+  for (int j = 0; j < 6; ++j) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)t->part.p + (long)j * C, nblk, (long)6 * C, (long)C, outs[j]);
+    THIP(hipGetLastError());
+  }
+  // 3. dkernel[j] = x_shifted^T . dH (K = every row: split-K partials, fixed-order sum);  dx += dH_shifted . kernel[j]^T
+  for (int j = 0; j < k; ++j) {
+    const int nz = gemm<true, false>(st, xp + (long)(j * rate) * C, dHp + (long)pr * 2 * C, (float*)t->wpart.p, C, 2 * C, (int)Rv, C, 2 * C, 2 * C, 0, splits, (long)C * 2 * C);
+    if (nz < 0) return nz;
+    const long nw = (long)C * 2 * C;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->wpart.p, nz, nw, nw, dkernel + (long)j * nw);
+    THIP(hipGetLastError());
+    const int rc = gemm<false, true>(st, dHp + (long)(pl + pr - j * rate) * 2 * C, kernel + (long)j * C * 2 * C, dxp + (long)pl * C, (int)Rv, C, 2 * C, 2 * C, 2 * C, C, 1);
+    if (rc < 0) return rc;
+  }
+  const long m4 = (long)B * T * (C / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, st, dxp, dx, B, T, Tp, pl, C, 1);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+static int loss_blocks(long n) { return (int)std::min<long>(1024, (n + 2047) / 2048); }
+
+extern "C" int dctts_train_ssrn_losses(dctts_train* t, const float* Z, const float* Z_logits, const float* mags, long long n,
+                                       float* losses, float* dZ, float* dlogits, void* stream) {
+  if (!t || !Z || !Z_logits || !mags || !losses || !dZ || !dlogits || n <= 0) TFAIL(DCTTS_ERR_ARG, "losses: bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = loss_blocks(n);
+  if (reserve(&t->lpart, (size_t)3 * 1024 * 4)) return DCTTS_ERR_HIP;
+  hipLaunchKernelGGL(l1_bd_loss_kernel, dim3(nb), dim3(256), 0, st, Z, Z_logits, mags, (long)n, dZ, dlogits, (float*)t->lpart.p);
+  THIP(hipGetLastError());
+  hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)t->lpart.p, nb, 2, 2, 1.0f / (float)n, losses);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_train_text2mel_losses(dctts_train* t, const float* Y, const float* Y_logits, const float* mels, const float* alignments,
+                                           int B, int T, int n_mels, int N, int max_N, int max_T,
+                                           float* losses, float* dY, float* dlogits, float* dA, void* stream) {
+  if (!t || !alignments || !dA || !losses || B <= 0 || T <= 0 || n_mels <= 0 || N <= 0 || max_N <= 0 || max_T <= 0) TFAIL(DCTTS_ERR_ARG, "text2mel losses: bad argument");
+  int rc = dctts_train_ssrn_losses(t, Y, Y_logits, mels, (long long)B * T * n_mels, losses, dY, dlogits, stream);
+  if (rc) return rc;
+  DevScope ds(t->device);
+  hipStream_t st = (hipStream_t)stream;
+  const long n = (long)B * N * T;
+  const int nb = loss_blocks(n);
+  const double mask_sum = (double)B * std::min(N, max_N) * std::min(T, max_T);      // train.py:94,96: entries of the cropped A that are not padding
+  float* part = (float*)t->lpart.p + 2048;
+  hipLaunchKernelGGL(att_loss_kernel, dim3(nb), dim3(256), 0, st, alignments, B, N, T, max_N, max_T, (float)(1.0 / mask_sum), dA, part);
+  THIP(hipGetLastError());
+  hipLaunchKernelGGL(finish_loss_kernel, dim3(1), dim3(256), 0, st, (const float*)part, nb, 1, 1, (float)(1.0 / mask_sum), losses + 2);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_train_adam_step(dctts_train* t, float* var, const float* grad, float* m, float* v, long long n, int step, float lr, void* stream) {
+  if (!t || !var || !grad || !m || !v || n <= 0 || step < 1) TFAIL(DCTTS_ERR_ARG, "adam: bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow(0.999, step)) / (1.0 - std::pow(0.9, step));
+  hipLaunchKernelGGL(adam_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, var, grad, m, v, (long)n, (float)lr_t);
+  THIP(hipGetLastError());
+  return 0;
+}

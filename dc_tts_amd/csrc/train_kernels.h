@@ -1,0 +1,287 @@
+// train_kernels.h -- kernels of the first TRAINING slice for gfx950: backward of the highway-convolution
+// block (modules.py:143-197), the losses of train.py:85-110, the clip + Adam update of train.py:119-131.
+//
+// Backward of hc, given x and dy (all fp32, channel-last):
+//   1. H = conv(x) is recomputed as k plain GEMMs over the zero-padded input rows (the inference kernels never store the
+//      pre-norm tensor);
+//   2. hc_bwd_rows_kernel: per row, both layer-norms forward and backward, the gate and the highway mix backward, in registers
+//      (one wave per row, 4 x NCH channels per lane, DPP reductions): dH (2C), the direct part of dx, and the per-column sums
+//      that become d(gamma), d(beta), d(bias);
+//   3. dkernel[tap] = x_shifted^T . dH (a GEMM whose K is every row of the batch: split-K partials + a fixed-order sum) and
+//      dx += dH_shifted . kernel[tap]^T.
+// Zero pad rows before / after every utterance make every tap shift a pointer offset, so the GEMMs are plain (row-major,
+// leading dimensions, no im2col): one LDS-tiled fp32 MFMA kernel (64 x 64 x 16 tiles, v_mfma_f32_32x32x2_f32) covers the three
+// operand layouts (NN, NT, TN).  Every reduction is two-stage with a fixed order: results are bitwise reproducible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dctts {
+
+// DPP reductions (as in attn_kernels.h, which defines kernels and therefore cannot be included by a second translation unit)
+template <int CTRL>
+__device__ __forceinline__ float t_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float t_wave_sum(float v) {
+  v = t_dpp_add<0xB1>(v); v = t_dpp_add<0x4E>(v); v = t_dpp_add<0x141>(v); v = t_dpp_add<0x140>(v);     // sum of each 16-lane row in all of its lanes
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
+}
+
+typedef float tf32x16 __attribute__((ext_vector_type(16)));
+typedef float tf32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------- GEMM
+struct GemmParams {
+  const float* A; const float* B; float* C;
+  int M, N, K;               // C is M x N; the contraction runs over K
+  int lda, ldb, ldc;         // floats between consecutive rows of the STORED matrices
+  int beta;                  // 0: C = A'B';  1: C += A'B'
+  int kchunk;                // split-K: workgroup z contracts k in [z * kchunk, min(K, (z + 1) * kchunk)) into C + z * c_zstride
+  long c_zstride;
+};
+
+// A' = TA ? A^T : A (A stored M x K, or K x M when TA);  B' = TB ? B^T : B (B stored K x N, or N x K when TB).
+// The contiguous extent of every stored matrix and all leading dimensions are multiples of 4 floats (16-byte loads).
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
+  constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = blockIdx.z * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l31 = lane & 31, lhi = lane >> 5;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_a = [&](int k0) -> float4 {
+    if (TA) { const int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4; return (k < kend && m < p.M) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m) : z4; }
+    const int m = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+    return (m < p.M && k < kend) ? *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k) : z4;
+  };
+  auto load_b = [&](int k0) -> float4 {
+    if (!TB) { const int k = k0 + (tid >> 4), n = n0 + (tid & 15) * 4; return (k < kend && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n) : z4; }
+    const int n = n0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+    return (n < p.N && k < kend) ? *reinterpret_cast<const float4*>(p.B + (long)n * p.ldb + k) : z4;
+  };
+  auto store_a = [&](int buf, const float4 v) {
+    if (TA) { *reinterpret_cast<float4*>(&As[buf][tid >> 4][(tid & 15) * 4]) = v; return; }
+    const int m = tid >> 2, k = (tid & 3) * 4;
+    As[buf][k][m] = v.x; As[buf][k + 1][m] = v.y; As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
+  };
+  auto store_b = [&](int buf, const float4 v) {
+    if (!TB) { *reinterpret_cast<float4*>(&Bs[buf][tid >> 4][(tid & 15) * 4]) = v; return; }
+    const int n = tid >> 2, k = (tid & 3) * 4;
+    Bs[buf][k][n] = v.x; Bs[buf][k + 1][n] = v.y; Bs[buf][k + 2][n] = v.z; Bs[buf][k + 3][n] = v.w;
+  };
+  tf32x16 acc;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  float4 ra = load_a(kbeg), rb = load_b(kbeg);
+  store_a(0, ra); store_b(0, rb);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool more = k0 + BK < kend;
+    if (more) { ra = load_a(k0 + BK); rb = load_b(k0 + BK); }          // in flight while this tile is contracted
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + lhi][wm + l31], Bs[buf][kk + lhi][wn + l31], acc, 0, 0, 0);
+    if (more) { store_a(buf ^ 1, ra); store_b(buf ^ 1, rb); }
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* C = p.C + (long)blockIdx.z * p.c_zstride;
+  const int col = n0 + wn + l31;
+  if (col < p.N) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int row = m0 + wm + (j & 3) + 8 * (j >> 2) + 4 * lhi;      // accumulator layout of v_mfma_f32_32x32x2_f32
+      if (row < p.M) { float* c = C + (long)row * p.ldc + col; *c = (p.beta ? *c : 0.f) + acc[j]; }
+    }
+  }
+}
+
+// out[i] = sum over z of part[z * zstride + i]  (fixed order)
+__global__ void sum_partials_kernel(const float* __restrict__ part, int nz, long zstride, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int z = 0; z < nz; ++z) s += part[(long)z * zstride + i];
+  out[i] = s;
+}
+
+// dst (B, Tp, C) <- src (B, T, C) at rows [off, off + T), zeros elsewhere;  reverse = 1: src (B, T, C) <- dst rows [off, off + T)
+__global__ void pad_rows_kernel(float* __restrict__ padded, float* __restrict__ flat, int B, int T, int Tp, int off, int C, int reverse) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // one float4 each
+  const int c4 = C / 4;
+  if (reverse) {
+    if (i >= (long)B * T * c4) return;
+    const long row = i / c4; const int c = (int)(i - row * c4);
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    reinterpret_cast<float4*>(flat)[i] = reinterpret_cast<const float4*>(padded)[((long)b * Tp + off + t) * c4 + c];
+    return;
+  }
+  if (i >= (long)B * Tp * c4) return;
+  const long row = i / c4; const int c = (int)(i - row * c4);
+  const int b = (int)(row / Tp), tp = (int)(row - (long)b * Tp), t = tp - off;
+  reinterpret_cast<float4*>(padded)[i] = (t >= 0 && t < T) ? reinterpret_cast<const float4*>(flat)[((long)b * T + t) * c4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- hc backward, row part
+struct HcBwdRowsParams {
+  int B, T, Tp, C;
+  int h_off, x_off;                // row offset of t = 0 inside an utterance of the H-aligned / x-aligned padded buffers
+  const float* Hp;                 // (B, Tp, 2C) pre-norm WITHOUT bias, H-aligned
+  const float* x; const float* dy; // (B, T, C)
+  const float* bias; const float* g1; const float* b1; const float* g2; const float* b2;
+  float* dHp;                      // (B, Tp, 2C) H-aligned; pad rows stay zero
+  float* dxp;                      // (B, Tp, C) x-aligned: receives dy * (1 - gate); the GEMMs accumulate the conv part on top
+  float* part;                     // [gridDim.x][6][C]: per-workgroup column sums of d(g1), d(b1), d(g2), d(b2), d(bias[:C]), d(bias[C:])
+};
+
+__device__ __forceinline__ float t_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// One wave per row, lane = 4 x NCH channels (C = 256 NCH).  modules.py:143-197 backward; layer-norm as modules.py:45-64 (biased
+// two-pass variance, eps 1e-12 inside the root).
+template <int NCH>
+__global__ void __launch_bounds__(256) hc_bwd_rows_kernel(const HcBwdRowsParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4][6][NCH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.C;
+  const float invC = 1.0f / (float)C;
+  tf32x4 acc[6][NCH];
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) acc[j][q] = tf32x4{0.f, 0.f, 0.f, 0.f};
+  auto ld = [](const float* q) { return *reinterpret_cast<const tf32x4*>(q); };
+  auto hsum = [](const tf32x4 v) { return v[0] + v[1] + v[2] + v[3]; };
+  const long rows = (long)p.B * p.T;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / p.T), t = (int)(r - (long)b * p.T);
+    const float* H = p.Hp + ((long)b * p.Tp + p.h_off + t) * 2 * C;
+    tf32x4 h1[NCH], h2[NCH], xv[NCH], dv[NCH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      h1[q] = ld(H + c) + ld(p.bias + c); h2[q] = ld(H + C + c) + ld(p.bias + C + c);
+      xv[q] = ld(p.x + r * C + c); dv[q] = ld(p.dy + r * C + c);
+      s1 += hsum(h1[q]); s2 += hsum(h2[q]);
+    }
+    const float m1 = t_wave_sum(s1) * invC, m2 = t_wave_sum(s2) * invC;
+    float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) { h1[q] -= m1; h2[q] -= m2; v1 += hsum(h1[q] * h1[q]); v2 += hsum(h2[q] * h2[q]); }
+    const float r1 = 1.0f / sqrtf(t_wave_sum(v1) * invC + 1e-12f), r2 = 1.0f / sqrtf(t_wave_sum(v2) * invC + 1e-12f);
+    // forward: n = xhat * gamma + beta; s = sigmoid(n1); y = s n2 + (1 - s) x.   backward: dn2 = dy s; dn1 = dy (n2 - x) s (1 - s)
+    tf32x4 dxh1[NCH], dxh2[NCH];
+    float a1 = 0.f, a2 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      const tf32x4 g1 = ld(p.g1 + c), be1 = ld(p.b1 + c), g2 = ld(p.g2 + c), be2 = ld(p.b2 + c);
+      h1[q] *= r1; h2[q] *= r2;                                          // xhat
+      const tf32x4 n1 = h1[q] * g1 + be1, n2 = h2[q] * g2 + be2;
+      tf32x4 s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] = t_sigmoid(n1[e]);
+      const tf32x4 dn2 = dv[q] * s, dn1 = dv[q] * (n2 - xv[q]) * s * (1.0f - s);
+      *reinterpret_cast<tf32x4*>(p.dxp + ((long)b * p.Tp + p.x_off + t) * C + c) = dv[q] * (1.0f - s);
+      acc[0][q] += dn1 * h1[q]; acc[1][q] += dn1; acc[2][q] += dn2 * h2[q]; acc[3][q] += dn2;
+      dxh1[q] = dn1 * g1; dxh2[q] = dn2 * g2;
+      a1 += hsum(dxh1[q]); a2 += hsum(dxh2[q]); c1 += hsum(dxh1[q] * h1[q]); c2 += hsum(dxh2[q] * h2[q]);
+    }
+    const float ma1 = t_wave_sum(a1) * invC, ma2 = t_wave_sum(a2) * invC, mc1 = t_wave_sum(c1) * invC, mc2 = t_wave_sum(c2) * invC;
+    float* dH = p.dHp + ((long)b * p.Tp + p.h_off + t) * 2 * C;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      const tf32x4 d1 = (dxh1[q] - ma1 - h1[q] * mc1) * r1, d2 = (dxh2[q] - ma2 - h2[q] * mc2) * r2;   // layer-norm backward
+      *reinterpret_cast<tf32x4*>(dH + c) = d1; *reinterpret_cast<tf32x4*>(dH + C + c) = d2;
+      acc[4][q] += d1; acc[5][q] += d2;
+    }
+  }
+  // column sums of this workgroup: 4 waves -> one row of `part`
+#pragma unroll
+  for (int j = 0; j < 6; ++j)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) *reinterpret_cast<tf32x4*>(&red[wave][j][q * 256 + lane * 4]) = acc[j][q];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 6 * C; i += 256) {
+    const int j = i / C, c = i - j * C;
+    p.part[((long)blockIdx.x * 6 + j) * C + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- losses
+// train.py:87,90 (and :104,107): L1 and sigmoid cross-entropy means over n elements, gradients of their sum.
+// part[block][2] = partial sums of |Y - z| and xent(logits, z).
+__global__ void __launch_bounds__(256) l1_bd_loss_kernel(const float* __restrict__ Y, const float* __restrict__ logits, const float* __restrict__ z,
+                                                         long n, float* __restrict__ dY, float* __restrict__ dlog, float* __restrict__ part) {
+  __shared__ float sh[2][4];
+  const float invn = 1.0f / (float)n;
+  float l1 = 0.f, bd = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = Y[i] - z[i], x = logits[i];
+    l1 += fabsf(d);
+    dY[i] = (d > 0.f ? invn : (d < 0.f ? -invn : 0.f));
+    bd += fmaxf(x, 0.f) - x * z[i] + log1pf(expf(-fabsf(x)));           // tf.nn.sigmoid_cross_entropy_with_logits
+    dlog[i] = (t_sigmoid(x) - z[i]) * invn;
+  }
+  l1 = t_wave_sum(l1); bd = t_wave_sum(bd);
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = l1; sh[1][threadIdx.x >> 6] = bd; }
+  __syncthreads();
+  if (threadIdx.x < 2) part[(long)blockIdx.x * 2 + threadIdx.x] = (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
+
+// train.py:93-97 with utils.py:134-140's weights: alignments (B, N, T); part[block] = partial sum of |A W| over the cropped region
+__global__ void __launch_bounds__(256) att_loss_kernel(const float* __restrict__ A, int B, int N, int T, int max_N, int max_T, float inv_mask_sum,
+                                                       float* __restrict__ dA, float* __restrict__ part) {
+  __shared__ float sh[4];
+  const long n = (long)B * N * T;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int t = (int)(i % T), nn = (int)((i / T) % N);
+    float g = 0.f;
+    if (nn < max_N && t < max_T) {
+      const float d = (float)t / (float)max_T - (float)nn / (float)max_N;
+      const float w = 1.0f - expf(-d * d / (2.0f * 0.2f * 0.2f));        // utils.py:138, g = 0.2
+      const float aw = A[i] * w;
+      s += fabsf(aw);
+      g = (aw > 0.f ? w : (aw < 0.f ? -w : 0.f)) * inv_mask_sum;
+    }
+    dA[i] = g;
+  }
+  s = t_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// out[j] = scale * sum over blocks of part[block * stride + j], j < nout (one workgroup, fixed order)
+__global__ void __launch_bounds__(256) finish_loss_kernel(const float* __restrict__ part, int nblk, int stride, int nout, float scale, float* __restrict__ out) {
+  __shared__ float sh[4];
+  for (int j = 0; j < nout; ++j) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) s += part[(long)b * stride + j];
+    s = t_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) * scale;
+    __syncthreads();
+  }
+}
+
+// train.py:119-131: clip_by_value(grad, -1, 1) then tf.train.AdamOptimizer (beta1 0.9, beta2 0.999, eps 1e-8)
+__global__ void adam_step_kernel(float* __restrict__ var, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v, long n, float lr_t) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g = fminf(fmaxf(grad[i], -1.0f), 1.0f);
+  const float mi = 0.9f * m[i] + (1.0f - 0.9f) * g, vi = 0.999f * v[i] + (1.0f - 0.999f) * g * g;
+  m[i] = mi; v[i] = vi;
+  var[i] -= lr_t * mi / (sqrtf(vi) + 1e-8f);
+}
+
+}  // namespace dctts

@@ -1,0 +1,117 @@
+"""First slice of the TRAINING path on the MI355X: what `train.py` obtains from TensorFlow's autodiff and
+optimizer for ONE building block, as calls into libdctts_hip.so (include/dctts_train.h).
+
+  reference                                            here
+  modules.py:143-197  hc(...) under tf.gradients       TrainOps.hc_backward
+  train.py:87,90,93-97  loss_mels, loss_bd1, loss_att  TrainOps.text2mel_losses
+  train.py:104,107      loss_mags, loss_bd2            TrainOps.ssrn_losses
+  train.py:119-131      clip_by_value + Adam           TrainOps.adam_step  (+ learning_rate_decay = utils.py:142-145)
+
+There is no CPU or PyTorch fallback: without a GPU and the built library the constructor raises.  The rest of the training graph
+(the other blocks' backward passes, attention backward, the input pipeline) is not built yet.
+"""
+import ctypes
+from typing import Dict, Tuple
+
+import torch
+
+from . import _lib
+from .engine import DcttsError, _check, _ptr
+
+
+def learning_rate_decay(init_lr: float, global_step: int, warmup_steps: float = 4000.0) -> float:
+    """utils.py:142-145 (Noam scheme): init_lr * warmup^0.5 * min(step * warmup^-1.5, step^-0.5), step = global_step + 1."""
+    step = float(global_step + 1)
+    return init_lr * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+
+
+class TrainOps:
+    """Device workspaces + the training-slice entry points for one GPU."""
+
+    def __init__(self, device: int = None):
+        if not torch.cuda.is_available():
+            raise DcttsError("dc_tts_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = _lib.load()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        h = ctypes.c_void_p()
+        self._ok(self.lib.dctts_train_create(ctypes.byref(h), self.device_index))
+        self._h = h
+
+    def _ok(self, rc: int):
+        if rc != 0:
+            raise DcttsError(f"libdctts_hip error {rc}: {_lib.last_error()}")
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dctts_train_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_bytes(self) -> int:
+        return int(self.lib.dctts_train_device_bytes(self._h))
+
+    def hc_backward(self, x: torch.Tensor, dy: torch.Tensor, params: Dict[str, torch.Tensor], rate: int = 1,
+                    padding: str = "SAME") -> Dict[str, torch.Tensor]:
+        """Gradients of y = hc(x) (modules.py:143-197).  params: kernel (k, C, 2C), bias (2C), g1, b1, g2, b2 (C) -- the TF
+        variables conv1d/kernel, conv1d/bias, H1/gamma, H1/beta, H2/gamma, H2/beta.  Returns dx and one gradient per parameter."""
+        _check(x, "x", torch.float32, 3, self.device); _check(dy, "dy", torch.float32, 3, self.device)
+        B, T, C = x.shape
+        if tuple(dy.shape) != (B, T, C):
+            raise ValueError(f"dy {tuple(dy.shape)} != x {tuple(x.shape)}")
+        k = params["kernel"].shape[0]
+        want = {"kernel": (k, C, 2 * C), "bias": (2 * C,), "g1": (C,), "b1": (C,), "g2": (C,), "b2": (C,)}
+        for n, shp in want.items():
+            _check(params[n], n, torch.float32, len(shp), self.device)
+            if tuple(params[n].shape) != shp:
+                raise ValueError(f"{n}: shape {tuple(params[n].shape)} != {shp}")
+        if padding.lower() not in ("same", "causal"):
+            raise ValueError(padding)
+        out = {"dx": torch.empty_like(x)}
+        for n in want:
+            out[n] = torch.empty_like(params[n])
+        self._ok(self.lib.dctts_train_hc_backward(
+            self._h, _ptr(x), _ptr(dy), _ptr(params["kernel"]), _ptr(params["bias"]), _ptr(params["g1"]), _ptr(params["b1"]),
+            _ptr(params["g2"]), _ptr(params["b2"]), B, T, C, k, int(rate), 1 if padding.lower() == "causal" else 0,
+            _ptr(out["dx"]), _ptr(out["kernel"]), _ptr(out["bias"]), _ptr(out["g1"]), _ptr(out["b1"]), _ptr(out["g2"]), _ptr(out["b2"]),
+            self._stream()))
+        return out
+
+    def text2mel_losses(self, Y, Y_logits, mels, alignments, max_N: int, max_T: int):
+        """train.py:85-100: returns (losses (3,) = loss_mels, loss_bd1, loss_att; dY, dY_logits, dalignments)."""
+        for t, n in ((Y, "Y"), (Y_logits, "Y_logits"), (mels, "mels"), (alignments, "alignments")):
+            _check(t, n, torch.float32, 3, self.device)
+        B, T, M = Y.shape
+        if tuple(Y_logits.shape) != (B, T, M) or tuple(mels.shape) != (B, T, M) or alignments.shape[0] != B or alignments.shape[2] != T:
+            raise ValueError("text2mel_losses: shapes do not agree")
+        N = alignments.shape[1]
+        losses = torch.empty(3, dtype=torch.float32, device=self.device)
+        dY, dlog, dA = torch.empty_like(Y), torch.empty_like(Y_logits), torch.empty_like(alignments)
+        self._ok(self.lib.dctts_train_text2mel_losses(self._h, _ptr(Y), _ptr(Y_logits), _ptr(mels), _ptr(alignments), B, T, M, N,
+                                                      int(max_N), int(max_T), _ptr(losses), _ptr(dY), _ptr(dlog), _ptr(dA), self._stream()))
+        return losses, dY, dlog, dA
+
+    def ssrn_losses(self, Z, Z_logits, mags):
+        """train.py:102-110: returns (losses (2,) = loss_mags, loss_bd2; dZ, dZ_logits)."""
+        for t, n in ((Z, "Z"), (Z_logits, "Z_logits"), (mags, "mags")):
+            _check(t, n, torch.float32, Z.dim(), self.device)
+        if Z_logits.shape != Z.shape or mags.shape != Z.shape:
+            raise ValueError("ssrn_losses: shapes do not agree")
+        losses = torch.empty(2, dtype=torch.float32, device=self.device)
+        dZ, dlog = torch.empty_like(Z), torch.empty_like(Z_logits)
+        self._ok(self.lib.dctts_train_ssrn_losses(self._h, _ptr(Z), _ptr(Z_logits), _ptr(mags), Z.numel(), _ptr(losses), _ptr(dZ), _ptr(dlog), self._stream()))
+        return losses, dZ, dlog
+
+    def adam_step(self, var, grad, m, v, step: int, lr: float):
+        """train.py:119-131 in place on var / m / v: clip_by_value(grad, -1, 1), then tf.train.AdamOptimizer's update; step is 1-based."""
+        for t, n in ((var, "var"), (grad, "grad"), (m, "m"), (v, "v")):
+            _check(t, n, torch.float32, var.dim(), self.device)
+        self._ok(self.lib.dctts_train_adam_step(self._h, _ptr(var), _ptr(grad), _ptr(m), _ptr(v), var.numel(), int(step), float(lr), self._stream()))

@@ -1,0 +1,66 @@
+/* dctts_train.h -- C ABI of the first slice of the TRAINING path, MI355X (gfx950).
+ *
+ * What is here (and nothing else of train.py yet): the backward pass of one highway-convolution block, the losses of
+ * train.py:85-110 with their gradients, and the clip + Adam update of train.py:119-131.  A trainer written against the
+ * reference would call these where TensorFlow's autodiff / optimizer ran:
+ *
+ *   reference                                              this library
+ *   modules.py:143-197  hc(...) under tf.gradients         dctts_train_hc_backward
+ *   train.py:87,90,93-97  loss_mels, loss_bd1, loss_att    dctts_train_text2mel_losses
+ *   train.py:104,107      loss_mags, loss_bd2              dctts_train_ssrn_losses
+ *   train.py:119-131      clip_by_value(-1, 1) + Adam      dctts_train_adam_step   (lr from utils.py:142-145, host side)
+ *
+ * Conventions are those of dctts_hip.h: extern "C", raw DEVICE pointers (fp32, channel-last (B, time, C)), sizes, a
+ * hipStream_t as void*, integer status (0 = ok), dctts_last_error() for the message.  Nothing throws; no torch types.
+ * All arithmetic is fp32 (contractions on v_mfma_f32_32x32x2_f32); reductions are two-stage and deterministic (no atomics).
+ */
+#ifndef DCTTS_TRAIN_H_
+#define DCTTS_TRAIN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dctts_train dctts_train;
+
+/* Workspaces are owned by the handle and grow with the largest shape seen. */
+int dctts_train_create(dctts_train** out, int device);
+int dctts_train_destroy(dctts_train* t);
+size_t dctts_train_device_bytes(const dctts_train* t);
+
+/* Backward of y = hc(x) (modules.py:143-197: conv1d(k, dilation `rate`, SAME or CAUSAL padding) to 2C channels -> split ->
+ * layer-norm(H1), layer-norm(H2) -> sigmoid(H1) * H2 + (1 - sigmoid(H1)) * x, training=False dropout i.e. none).
+ *   x, dy, dx            (B, T, C)          C a multiple of 256, k in {1, 3}
+ *   kernel, dkernel      (k, C, 2C)         TF variable layout (conv1d/kernel)
+ *   bias, dbias          (2C)
+ *   g1, b1, g2, b2 and their gradients (C)  H1/gamma, H1/beta, H2/gamma, H2/beta
+ * The forward pre-norm tensor is recomputed here (the inference kernels never store it). */
+int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
+                            const float* g1, const float* b1, const float* g2, const float* b2,
+                            int B, int T, int C, int k, int rate, int causal,
+                            float* dx, float* dkernel, float* dbias, float* dg1, float* db1, float* dg2, float* db2, void* stream);
+
+/* train.py:85-100.  Y, Y_logits, mels (B, T, n_mels); alignments (B, N, T) as networks.py:153 returns them (N <= max_N,
+ * T <= max_T: the reference pads them to (max_N, max_T) with -1 and masks the padding).  losses[3] (device) receives
+ * loss_mels, loss_bd1, loss_att; dY / dlogits / dA the gradients of their sum with respect to Y (L1 term), Y_logits
+ * (divergence term) and alignments (guided-attention term, weights of utils.py:134-140 with g = 0.2). */
+int dctts_train_text2mel_losses(dctts_train* t, const float* Y, const float* Y_logits, const float* mels, const float* alignments,
+                                int B, int T, int n_mels, int N, int max_N, int max_T,
+                                float* losses, float* dY, float* dlogits, float* dA, void* stream);
+
+/* train.py:102-110.  Z, Z_logits, mags (rows, F) flattened; losses[2] = loss_mags, loss_bd2. */
+int dctts_train_ssrn_losses(dctts_train* t, const float* Z, const float* Z_logits, const float* mags, long long n,
+                            float* losses, float* dZ, float* dlogits, void* stream);
+
+/* train.py:119-131 on one variable of n elements: g = clip(grad, -1, 1); Adam moments m, v (updated in place);
+ * var -= lr * sqrt(1 - beta2^step) / (1 - beta1^step) * m / (sqrt(v) + eps), tf.train.AdamOptimizer defaults
+ * beta1 = 0.9, beta2 = 0.999, eps = 1e-8; step is 1-based; lr is utils.py:142-145's schedule, evaluated by the caller. */
+int dctts_train_adam_step(dctts_train* t, float* var, const float* grad, float* m, float* v, long long n, int step, float lr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

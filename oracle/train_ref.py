@@ -1,0 +1,142 @@
+"""CPU ORACLE for the first slice of the TRAINING path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
+
+What it restates, in float64 numpy with every derivative written out by hand:
+  * the backward pass of the highway-convolution block ``hc`` (modules.py:143-197): conv to 2C -> split ->
+    layer-norm(H1), layer-norm(H2) (modules.py:45-64, eps 1e-12) -> sigmoid gate -> highway mix;
+  * the three Text2Mel losses and the two SSRN losses of train.py:85-113 (L1, binary divergence =
+    ``sigmoid_cross_entropy_with_logits``, guided attention with ``utils.py:134-140``'s weight matrix) and their
+    gradients with respect to the network outputs;
+  * the Noam learning-rate schedule (utils.py:142-145) and the clip / Adam step of train.py:119-131.
+
+PARITY UNPINNED, like oracle/dctts_ref.py: TensorFlow is not installable here, so nothing ties these derivatives to
+``tf.gradients``.  They are pinned by mathematics instead: ``tests/test_train_oracle.py`` checks every gradient
+against central finite differences of the float64 forward pass (which IS oracle/dctts_ref.py's forward).
+"""
+import numpy as np
+
+from oracle import dctts_ref as O
+
+LN_EPS = O.LN_EPS
+
+
+# ----------------------------------------------------------------------------- modules.py, backward
+def conv_pads(k, rate, padding):
+    """Left / right zero padding of tf.layers.conv1d as called at modules.py:134,187 (see dctts_ref._conv)."""
+    total = (k - 1) * rate
+    if padding.lower() == "causal":
+        return total, 0
+    pl = total // 2
+    return pl, total - pl
+
+
+def conv_bwd(x, W, dy, rate, padding):
+    """Gradients of y = conv(x, W) + b (dctts_ref._conv):  (dx, dW, db)."""
+    k = W.shape[0]
+    pl, pr = conv_pads(k, rate, padding)
+    T = x.shape[1]
+    xp = np.pad(x, ((0, 0), (pl, pr), (0, 0)))
+    dxp = np.zeros_like(xp)
+    dW = np.zeros_like(W)
+    for j in range(k):
+        xs = xp[:, j * rate: j * rate + T, :]
+        dW[j] = np.einsum("bti,bto->io", xs, dy)
+        dxp[:, j * rate: j * rate + T, :] += dy @ W[j].T
+    return dxp[:, pl: pl + T, :], dW, dy.sum(axis=(0, 1))
+
+
+def normalize_bwd(x, gamma, dy):
+    """Gradients of y = normalize(x, gamma, beta) (modules.py:45-64; biased variance, eps inside the root):  (dx, dgamma, dbeta)."""
+    mean = x.mean(axis=-1, keepdims=True)
+    var = ((x - mean) ** 2).mean(axis=-1, keepdims=True)
+    rstd = 1.0 / np.sqrt(var + LN_EPS)
+    xh = (x - mean) * rstd
+    dxh = dy * gamma
+    dx = rstd * (dxh - dxh.mean(axis=-1, keepdims=True) - xh * (dxh * xh).mean(axis=-1, keepdims=True))
+    red = tuple(range(x.ndim - 1))
+    return dx, (dy * xh).sum(axis=red), dy.sum(axis=red)
+
+
+def hc_fwd(x, p, rate, padding):
+    """modules.py:143-197 with the parameters as a dict: kernel (k, C, 2C), bias, g1, b1, g2, b2."""
+    P = {"s/conv1d/kernel": p["kernel"], "s/conv1d/bias": p["bias"], "s/H1/gamma": p["g1"], "s/H1/beta": p["b1"],
+         "s/H2/gamma": p["g2"], "s/H2/beta": p["b2"]}
+    return O.hc(x, P, "s", rate=rate, padding=padding)
+
+
+def hc_bwd(x, p, dy, rate, padding):
+    """Backward of hc.  Returns dict(dx, kernel, bias, g1, b1, g2, b2) of gradients."""
+    H = O._conv(x, p["kernel"], p["bias"], rate, padding)
+    C = H.shape[-1] // 2
+    H1, H2 = H[..., :C], H[..., C:]
+    n1 = O.normalize(H1, p["g1"], p["b1"])
+    n2 = O.normalize(H2, p["g2"], p["b2"])
+    s = O.sigmoid(n1)
+    # y = s * n2 + (1 - s) * x
+    dn2 = dy * s
+    ds = dy * (n2 - x)
+    dx_direct = dy * (1.0 - s)
+    dn1 = ds * s * (1.0 - s)
+    dH1, dg1, db1 = normalize_bwd(H1, p["g1"], dn1)
+    dH2, dg2, db2 = normalize_bwd(H2, p["g2"], dn2)
+    dH = np.concatenate([dH1, dH2], axis=-1)
+    dx_conv, dW, dbias = conv_bwd(x, p["kernel"], dH, rate, padding)
+    return {"dx": dx_direct + dx_conv, "kernel": dW, "bias": dbias, "g1": dg1, "b1": db1, "g2": dg2, "b2": db2, "dH": dH}
+
+
+# ----------------------------------------------------------------------------- utils.py / train.py
+def guided_attention(max_N, max_T, g=0.2):
+    """utils.py:134-140:  W[n, t] = 1 - exp(-(t / max_T - n / max_N)^2 / (2 g^2))."""
+    n = np.arange(max_N, dtype=np.float64)[:, None] / float(max_N)
+    t = np.arange(max_T, dtype=np.float64)[None, :] / float(max_T)
+    return 1.0 - np.exp(-(t - n) ** 2 / (2.0 * g * g))
+
+
+def learning_rate_decay(init_lr, global_step, warmup_steps=4000.0):
+    """utils.py:142-145 (Noam):  lr = init_lr * warmup^0.5 * min(step * warmup^-1.5, step^-0.5), step = global_step + 1."""
+    step = float(global_step + 1)
+    return init_lr * warmup_steps ** 0.5 * min(step * warmup_steps ** -1.5, step ** -0.5)
+
+
+def sigmoid_xent(logits, labels):
+    """tf.nn.sigmoid_cross_entropy_with_logits:  max(x, 0) - x z + log(1 + exp(-|x|))."""
+    return np.maximum(logits, 0) - logits * labels + np.log1p(np.exp(-np.abs(logits)))
+
+
+def text2mel_losses(Y, Y_logits, mels, alignments, max_N, max_T):
+    """train.py:85-100.  Y, Y_logits, mels (B, T, n_mels); alignments (B, N, T) with N <= max_N, T <= max_T.
+    Returns (loss_mels, loss_bd1, loss_att) and the gradients of their SUM with respect to Y (through the L1 term only),
+    Y_logits (through the divergence term only) and alignments."""
+    loss_mels = np.abs(Y - mels).mean()                                        # :87
+    loss_bd1 = sigmoid_xent(Y_logits, mels).mean()                             # :90
+    B, N, T = alignments.shape
+    A = np.full((B, max_N, max_T), -1.0)                                       # :93  pad with -1 up to (max_N, max_T), then crop
+    A[:, :min(N, max_N), :min(T, max_T)] = alignments[:, :max_N, :max_T]
+    mask = (A != -1.0).astype(np.float64)                                      # :94
+    gts = guided_attention(max_N, max_T)                                       # train.py:30  self.gts
+    mask_sum = mask.sum()                                                      # :96
+    loss_att = (np.abs(A * gts) * mask).sum() / mask_sum                       # :95-97
+    dY = np.sign(Y - mels) / Y.size
+    dlogits = (O.sigmoid(Y_logits) - mels) / Y_logits.size
+    dA = np.zeros_like(alignments)                                             # entries cropped away (:93) get no gradient
+    n_, t_ = min(N, max_N), min(T, max_T)
+    dA[:, :n_, :t_] = (np.sign(A * gts) * gts * mask / mask_sum)[:, :n_, :t_]
+    return (loss_mels, loss_bd1, loss_att), (dY, dlogits, dA)
+
+
+def ssrn_losses(Z, Z_logits, mags):
+    """train.py:102-110.  Returns (loss_mags, loss_bd2) and the gradients of their sum w.r.t. Z and Z_logits."""
+    loss_mags = np.abs(Z - mags).mean()
+    loss_bd2 = sigmoid_xent(Z_logits, mags).mean()
+    return (loss_mags, loss_bd2), (np.sign(Z - mags) / Z.size, (O.sigmoid(Z_logits) - mags) / Z_logits.size)
+
+
+def adam_step(var, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """train.py:119-131: gradients clipped element-wise to [-1, 1], then tf.train.AdamOptimizer's update
+    (lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t);  var -= lr_t * m / (sqrt(v) + eps)), t = step (1-based)."""
+    g = np.clip(grad, -1.0, 1.0)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+    return var - lr_t * m / (np.sqrt(v) + eps), m, v

@@ -1,0 +1,113 @@
+"""GPU parity of the first training slice (include/dctts_train.h) against oracle/train_ref.py (float64 numpy, itself pinned by
+finite differences in tests/test_train_oracle.py).  Tolerances are relative to the largest magnitude of each gradient: the HIP
+path is fp32 (MFMA contractions over up to 7 000 rows), the oracle float64."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_ref as TR
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dc_tts_amd.train import TrainOps
+    o = TrainOps()
+    yield o
+    o.close()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("B,T,C,k,rate,padding", [
+    (2, 37, 256, 3, 1, "causal"),      # AudioEnc / AudioDec HC, dilation 1, ragged T
+    (3, 50, 256, 3, 9, "causal"),      # dilation 9
+    (2, 64, 256, 3, 27, "causal"),     # dilation 27 > T / 3: most taps read padding
+    (2, 41, 512, 3, 3, "same"),        # TextEnc / SSRN HC
+    (2, 33, 512, 1, 1, "same"),        # TextEnc HC_15/16 (k = 1)
+    (1, 24, 1024, 3, 1, "same"),       # SSRN HC_11/12
+])
+def test_hc_backward_vs_oracle(ops, B, T, C, k, rate, padding):
+    rng = np.random.default_rng(100 + C + rate)
+    p = {"kernel": rng.normal(0, (k * C) ** -0.5, (k, C, 2 * C)), "bias": rng.normal(0, 0.1, 2 * C),
+         "g1": 1 + rng.normal(0, 0.1, C), "b1": rng.normal(0, 0.1, C), "g2": 1 + rng.normal(0, 0.1, C), "b2": rng.normal(0, 0.1, C)}
+    p = {n: v.astype(np.float32).astype(np.float64) for n, v in p.items()}
+    x = rng.normal(0, 1, (B, T, C)).astype(np.float32).astype(np.float64)
+    dy = rng.normal(0, 1, (B, T, C)).astype(np.float32).astype(np.float64)
+    ref = TR.hc_bwd(x, p, dy, rate, padding)
+    got = ops.hc_backward(dev(x), dev(dy), {n: dev(v) for n, v in p.items()}, rate=rate, padding=padding)
+    torch.cuda.synchronize()
+    for name in ("dx", "kernel", "bias", "g1", "b1", "g2", "b2"):
+        e = rel(got[name].cpu().numpy().astype(np.float64), ref[name])
+        assert e < 2e-5, f"{name}: relative error {e}"
+
+
+def test_hc_backward_is_reproducible_and_rejects_bad_shapes(ops):
+    rng = np.random.default_rng(3)
+    C = 256
+    p = {"kernel": dev(rng.normal(0, 0.05, (3, C, 2 * C))), "bias": dev(rng.normal(0, 0.1, 2 * C)), "g1": dev(np.ones(C)), "b1": dev(np.zeros(C)),
+         "g2": dev(np.ones(C)), "b2": dev(np.zeros(C))}
+    x, dy = dev(rng.normal(0, 1, (4, 100, C))), dev(rng.normal(0, 1, (4, 100, C)))
+    a = ops.hc_backward(x, dy, p, rate=3, padding="causal")
+    b = ops.hc_backward(x, dy, p, rate=3, padding="causal")
+    torch.cuda.synchronize()
+    for n in a:
+        assert torch.equal(a[n], b[n]), f"{n}: two-stage reductions must be bitwise reproducible"
+    from dc_tts_amd.engine import DcttsError
+    with pytest.raises(ValueError):
+        ops.hc_backward(x, dy[:, :50], p)
+    with pytest.raises(DcttsError):
+        ops.hc_backward(dev(rng.normal(0, 1, (1, 8, 128))), dev(rng.normal(0, 1, (1, 8, 128))),
+                        {"kernel": dev(np.zeros((3, 128, 256))), "bias": dev(np.zeros(256)), "g1": dev(np.ones(128)), "b1": dev(np.zeros(128)),
+                         "g2": dev(np.ones(128)), "b2": dev(np.zeros(128))})
+
+
+def test_losses_vs_oracle(ops):
+    rng = np.random.default_rng(8)
+    B, T, M, N, max_N, max_T = 3, 50, 80, 40, 180, 210
+    logits = rng.normal(0, 2, (B, T, M)).astype(np.float32).astype(np.float64)
+    Y = 1 / (1 + np.exp(-logits))
+    mels = rng.uniform(0, 1, (B, T, M)).astype(np.float32).astype(np.float64)
+    al = rng.uniform(0.0, 1, (B, N, T)); al /= al.sum(axis=1, keepdims=True); al = al.astype(np.float32).astype(np.float64)
+    (l1, l2, l3), (dY, dlog, dA) = TR.text2mel_losses(Y, logits, mels, al, max_N, max_T)
+    losses, gY, glog, gA = ops.text2mel_losses(dev(Y), dev(logits), dev(mels), dev(al), max_N, max_T)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), [l1, l2, l3], rtol=2e-5)
+    assert rel(gY.cpu().numpy(), dY) < 1e-6 and rel(glog.cpu().numpy(), dlog) < 2e-5 and rel(gA.cpu().numpy(), dA) < 2e-5
+    # alignments larger than (max_N, max_T): the reference crops them (train.py:93)
+    (_, _, l3c), (_, _, dAc) = TR.text2mel_losses(Y, logits, mels, al, 30, 45)
+    lossesc, _, _, gAc = ops.text2mel_losses(dev(Y), dev(logits), dev(mels), dev(al), 30, 45)
+    torch.cuda.synchronize()
+    assert abs(float(lossesc[2]) - l3c) < 2e-5 * l3c and rel(gAc.cpu().numpy(), dAc) < 2e-5
+    F = 1025
+    Zl = rng.normal(0, 2, (2, 40, F)).astype(np.float32).astype(np.float64); Z = 1 / (1 + np.exp(-Zl)); mags = rng.uniform(0, 1, (2, 40, F))
+    (m1, m2), (dZ, dZl) = TR.ssrn_losses(Z, Zl, mags.astype(np.float32).astype(np.float64))
+    ls, gZ, gZl = ops.ssrn_losses(dev(Z), dev(Zl), dev(mags))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ls.cpu().numpy(), [m1, m2], rtol=2e-5)
+    assert rel(gZ.cpu().numpy(), dZ) < 1e-6 and rel(gZl.cpu().numpy(), dZl) < 2e-5
+
+
+def test_adam_steps_vs_oracle(ops):
+    from dc_tts_amd.train import learning_rate_decay
+    rng = np.random.default_rng(9)
+    n = 5000
+    var = rng.normal(0, 1, n).astype(np.float32); m = np.zeros(n, np.float32); v = np.zeros(n, np.float32)
+    vr, mr, vvr = var.astype(np.float64), m.astype(np.float64), v.astype(np.float64)
+    dv, dm, dvv = dev(var), dev(m), dev(v)
+    for step in range(1, 6):
+        g = (rng.normal(0, 1.5, n)).astype(np.float32)                 # some |g| > 1: exercises the clip
+        lr = learning_rate_decay(0.001, step - 1)
+        assert abs(lr - TR.learning_rate_decay(0.001, step - 1)) < 1e-18
+        vr, mr, vvr = TR.adam_step(vr, g.astype(np.float64), mr, vvr, step, lr)
+        ops.adam_step(dv, dev(g), dm, dvv, step, lr)
+    torch.cuda.synchronize()
+    # fp32 constants: 1 - 0.999f = 0.00100005 (4.7e-5 off), as in TensorFlow's fp32 Adam kernel; the oracle is float64
+    assert np.abs(dv.cpu().numpy() - vr).max() < 1e-6 and rel(dm.cpu().numpy(), mr) < 1e-5 and rel(dvv.cpu().numpy(), vvr) < 1e-4

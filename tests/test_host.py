@@ -24,10 +24,13 @@ def test_header_symbols_are_exported(built_lib):
     dbg = open(os.path.join(ROOT, "include", "dctts_hip_debug.h")).read()
     surface = set(re.findall(r"\b(dctts_[a-z0-9_]+)\s*\(", hdr))
     assert len(surface) >= 18 and not any("debug" in n or "prof" in n for n in surface)     # measurement hooks live in the debug header
-    declared = surface | set(re.findall(r"\b(dctts_[a-z0-9_]+)\s*\(", dbg))
+    trn = open(os.path.join(ROOT, "include", "dctts_train.h")).read()
+    train_syms = set(re.findall(r"\b(dctts_train_[a-z0-9_]+)\s*\(", trn))
+    assert len(train_syms) == 7                                                              # the first training slice
+    declared = surface | set(re.findall(r"\b(dctts_[a-z0-9_]+)\s*\(", dbg)) | train_syms
     lib = ctypes.CDLL(built_lib)
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} declared in include/dctts_hip.h but not exported by libdctts_hip.so"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported by libdctts_hip.so"
     from dc_tts_amd import _lib
     assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))      # ctypes table in sync with the header
 

@@ -1,0 +1,95 @@
+"""The training-slice oracle (oracle/train_ref.py) pinned by central finite differences of the float64 forward pass.
+CPU only.  The forward pass it differentiates is oracle/dctts_ref.py's (modules.py:143-197)."""
+import numpy as np
+import pytest
+
+from oracle import dctts_ref as O
+from oracle import train_ref as TR
+
+
+def _params(rng, k, C):
+    return {"kernel": rng.normal(0, 0.2, (k, C, 2 * C)), "bias": rng.normal(0, 0.1, 2 * C),
+            "g1": 1 + rng.normal(0, 0.1, C), "b1": rng.normal(0, 0.1, C), "g2": 1 + rng.normal(0, 0.1, C), "b2": rng.normal(0, 0.1, C)}
+
+
+def _fd(f, x, eps=1e-6):
+    g = np.zeros_like(x)
+    it = np.nditer(x, flags=["multi_index"])
+    for _ in it:
+        i = it.multi_index
+        old = x[i]
+        x[i] = old + eps; fp = f()
+        x[i] = old - eps; fm = f()
+        x[i] = old
+        g[i] = (fp - fm) / (2 * eps)
+    return g
+
+
+@pytest.mark.parametrize("k,rate,padding", [(3, 1, "causal"), (3, 3, "causal"), (3, 1, "same"), (3, 3, "same"), (1, 1, "same")])
+def test_hc_backward_matches_finite_differences(k, rate, padding):
+    rng = np.random.default_rng(5)
+    B, T, C = 2, 9, 6
+    p = _params(rng, k, C)
+    x = rng.normal(0, 1, (B, T, C))
+    dy = rng.normal(0, 1, (B, T, C))
+    g = TR.hc_bwd(x, p, dy, rate, padding)
+    loss = lambda: float((TR.hc_fwd(x, p, rate, padding) * dy).sum())
+    np.testing.assert_allclose(g["dx"], _fd(loss, x), rtol=1e-5, atol=1e-7)
+    for name in ("kernel", "bias", "g1", "b1", "g2", "b2"):
+        np.testing.assert_allclose(g[name], _fd(loss, p[name]), rtol=1e-5, atol=1e-7, err_msg=name)
+
+
+def test_normalize_and_conv_backward():
+    rng = np.random.default_rng(6)
+    x = rng.normal(0, 1, (2, 5, 7)); gam = 1 + rng.normal(0, 0.1, 7); bet = rng.normal(0, 0.1, 7); dy = rng.normal(0, 1, (2, 5, 7))
+    dx, dg, db = TR.normalize_bwd(x, gam, dy)
+    f = lambda: float((O.normalize(x, gam, bet) * dy).sum())
+    np.testing.assert_allclose(dx, _fd(f, x), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dg, _fd(f, gam), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(db, _fd(f, bet), rtol=1e-5, atol=1e-7)
+    W = rng.normal(0, 0.3, (3, 7, 4)); b = rng.normal(0, 0.1, 4); dz = rng.normal(0, 1, (2, 5, 4))
+    for rate, padding in ((1, "causal"), (2, "same")):
+        dx, dW, dbias = TR.conv_bwd(x, W, dz, rate, padding)
+        f = lambda: float((O._conv(x, W, b, rate, padding) * dz).sum())
+        np.testing.assert_allclose(dx, _fd(f, x), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(dW, _fd(f, W), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(dbias, _fd(f, b), rtol=1e-5, atol=1e-7)
+
+
+def test_losses_and_their_gradients():
+    rng = np.random.default_rng(7)
+    B, T, M, N = 2, 6, 5, 4
+    max_N, max_T = 7, 9
+    logits = rng.normal(0, 2, (B, T, M)); mels = rng.uniform(0, 1, (B, T, M))
+    al = rng.uniform(0.01, 1, (B, N, T)); al /= al.sum(axis=1, keepdims=True)
+    def total(lg, a):
+        (l1, l2, l3), _ = TR.text2mel_losses(O.sigmoid(lg), lg, mels, a, max_N, max_T)
+        return l1, l2, l3
+    (l1, l2, l3), (dY, dlog, dA) = TR.text2mel_losses(O.sigmoid(logits), logits, mels, al, max_N, max_T)
+    # known answers: guided-attention weights (utils.py:134-140) and the cross-entropy identity
+    W = TR.guided_attention(max_N, max_T)
+    assert W[0, 0] == 0 and abs(W[3, 5] - (1 - np.exp(-(5 / 9 - 3 / 7) ** 2 / 0.08))) < 1e-15
+    assert abs(l3 - (al * W[:N, :T]).sum() / (B * N * T)) < 1e-14          # the mask is 1 exactly where alignments exist
+    y = O.sigmoid(logits)
+    assert abs(l2 - (-(mels * np.log(y) + (1 - mels) * np.log(1 - y))).mean()) < 1e-12
+    # gradients: Y enters the L1 term, the logits the divergence term (Y = sigmoid(logits) chains the first into the second)
+    f_l1 = lambda: float(np.abs(O.sigmoid(logits) - mels).mean())
+    np.testing.assert_allclose(dY * y * (1 - y), _fd(f_l1, logits), rtol=1e-5, atol=1e-9)
+    f_bd = lambda: float(TR.sigmoid_xent(logits, mels).mean())
+    np.testing.assert_allclose(dlog, _fd(f_bd, logits), rtol=1e-5, atol=1e-9)
+    f_att = lambda: total(logits, al)[2]
+    np.testing.assert_allclose(dA, _fd(f_att, al), rtol=1e-5, atol=1e-9)
+    (m1, m2), (dZ, dZl) = TR.ssrn_losses(y, logits, mels)
+    assert abs(m1 - l1) < 1e-15 and abs(m2 - l2) < 1e-15 and np.array_equal(dZ, dY) and np.array_equal(dZl, dlog)
+
+
+def test_noam_schedule_and_adam_step():
+    # utils.py:142-145: linear warm-up to init_lr at step 4000, then step^-0.5
+    assert abs(TR.learning_rate_decay(0.001, 3999) - 0.001) < 1e-15
+    assert abs(TR.learning_rate_decay(0.001, 0) - 0.001 * 4000 ** 0.5 * 4000 ** -1.5) < 1e-18
+    assert abs(TR.learning_rate_decay(0.001, 15999) - 0.0005) < 1e-15
+    var = np.array([1.0, -2.0]); g = np.array([5.0, -0.25])
+    v1, m, v = TR.adam_step(var, g, np.zeros(2), np.zeros(2), 1, 0.1)
+    # first Adam step moves every coordinate by lr * sign(clipped gradient) (up to eps)
+    np.testing.assert_allclose(v1, var - 0.1 * np.sign(g), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(m, 0.1 * np.clip(g, -1, 1)); np.testing.assert_allclose(v, 0.001 * np.clip(g, -1, 1) ** 2)

@@ -1,0 +1,31 @@
+"""Time of the first training slice at the shapes training would run it at (B = 32, T = 210, train.py / hyperparams.py:45-46):
+hc backward for the three highway-block widths of the model, the Text2Mel losses, one Adam step; HIP-event timed."""
+import sys, os, torch, numpy as np
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+from dc_tts_amd.train import TrainOps
+ops = TrainOps()
+def timed(f, n=10):
+    f(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+print("| call | shape | ms | GFLOP | TFLOP/s | of the fp32 MFMA peak |\n|---|---|---|---|---|---|")
+for (B, T, C, k, rate, pad, what) in [(32, 210, 256, 3, 3, "causal", "AudioEnc / AudioDec HC"), (32, 180, 512, 3, 3, "same", "TextEnc HC"),
+                                      (32, 210, 512, 3, 1, "same", "SSRN HC (T rows)"), (32, 840, 1024, 3, 1, "same", "SSRN HC_11/12 (4T rows)")]:
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(B, T, C, device="cuda", generator=g); dy = torch.randn(B, T, C, device="cuda", generator=g)
+    p = {"kernel": torch.randn(k, C, 2 * C, device="cuda", generator=g) * (k * C) ** -0.5, "bias": torch.zeros(2 * C, device="cuda"),
+         "g1": torch.ones(C, device="cuda"), "b1": torch.zeros(C, device="cuda"), "g2": torch.ones(C, device="cuda"), "b2": torch.zeros(C, device="cuda")}
+    ms = timed(lambda: ops.hc_backward(x, dy, p, rate=rate, padding=pad))
+    flop = 3 * 2.0 * B * T * k * C * 2 * C            # forward recompute + dgrad + wgrad
+    print(f"| hc_backward ({what}) | B={B} T={T} C={C} k={k} | {ms:.3f} | {flop / 1e9:.1f} | {flop / ms / 1e9:.1f} | {flop / ms / 1e9 / 157.3:.3f} |")
+B, T, M, N = 32, 210, 80, 180
+lg = torch.randn(B, T, M, device="cuda"); Y = torch.sigmoid(lg); mels = torch.rand(B, T, M, device="cuda"); al = torch.softmax(torch.randn(B, N, T, device="cuda"), 1)
+ms = timed(lambda: ops.text2mel_losses(Y, lg, mels, al, 180, 210))
+print(f"| text2mel_losses | B={B} T={T} n_mels={M} N={N} | {ms:.3f} | | | ({(5 * Y.numel() + 2 * al.numel()) * 4 / ms / 1e6:.0f} GB/s of algorithmic bytes) |")
+n = 52_380_671
+var = torch.zeros(n, device="cuda"); grad = torch.randn(n, device="cuda"); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+ms = timed(lambda: ops.adam_step(var, grad, m, v, 1, 1e-3))
+print(f"| adam_step (all {n} parameters as one array) | | {ms:.3f} | | | ({7 * n * 4 / ms / 1e6:.0f} GB/s = {7 * n * 4 / ms / 1e6 / 8000:.2f} of the HBM roof) |")
