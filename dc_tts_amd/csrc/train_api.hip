@@ -49,7 +49,7 @@ int gemm(hipStream_t st, const float* A, const float* B, float* C, int M, int N,
   GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, beta, K, zstride};
   if (splits > 1) p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
   const int nz = (K + p.kchunk - 1) / p.kchunk;
-  hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 63) / 64, (M + 63) / 64, nz), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 127) / 128, (M + 127) / 128, nz), dim3(256), 0, st, p);
   if (hipGetLastError() != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "gemm launch failed");
   return nz;
 }
@@ -99,7 +99,8 @@ extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const flo
   if (reserve(&t->xp, (size_t)R * C * 4) || reserve(&t->Hp, (size_t)R * 2 * C * 4) || reserve(&t->dHp, (size_t)R * 2 * C * 4) ||
       reserve(&t->dxp, (size_t)R * C * 4)) return DCTTS_ERR_HIP;
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
-  const int splits = 8;
+  const int wtiles = ((C + 127) / 128) * ((2 * C + 127) / 128);
+  const int splits = std::max(1, std::min(64, (512 + wtiles - 1) / wtiles));       // the weight gradient has few output tiles: split its K (= every row) to fill the chip
   if (reserve(&t->part, (size_t)nblk * 6 * C * 4) || reserve(&t->wpart, (size_t)splits * C * 2 * C * 4)) return DCTTS_ERR_HIP;
   float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
   const long n4 = R * (C / 4);
@@ -118,11 +119,8 @@ extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const flo
   else if (C == 512) hipLaunchKernelGGL((hc_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
   else hipLaunchKernelGGL((hc_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
   THIP(hipGetLastError());
-  float* outs[6] = {dg1, db1, dg2, db2, dbias, dbias + C};
-  for (int j = 0; j < 6; ++j) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((C + 255) / 256), dim3(256), 0, st, (const float*)t->part.p + (long)j * C, nblk, (long)6 * C, (long)C, outs[j]);
-    THIP(hipGetLastError());
-  }
+  hipLaunchKernelGGL(colsum6_kernel, dim3((6 * C + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, C, dg1, db1, dg2, db2, dbias);
+  THIP(hipGetLastError());
   // 3. dkernel[j] = x_shifted^T . dH (K = every row: split-K partials, fixed-order sum);  dx += dH_shifted . kernel[j]^T
   for (int j = 0; j < k; ++j) {
     const int nz = gemm<true, false>(st, xp + (long)(j * rate) * C, dHp + (long)pr * 2 * C, (float*)t->wpart.p, C, 2 * C, (int)Rv, C, 2 * C, 2 * C, 0, splits, (long)C * 2 * C);

@@ -10,7 +10,7 @@
 //   3. dkernel[tap] = x_shifted^T . dH (a GEMM whose K is every row of the batch: split-K partials + a fixed-order sum) and
 //      dx += dH_shifted . kernel[tap]^T.
 // Zero pad rows before / after every utterance make every tap shift a pointer offset, so the GEMMs are plain (row-major,
-// leading dimensions, no im2col): one LDS-tiled fp32 MFMA kernel (64 x 64 x 16 tiles, v_mfma_f32_32x32x2_f32) covers the three
+// leading dimensions, no im2col): one LDS-tiled fp32 MFMA kernel (128 x 128 x 16 tiles, v_mfma_f32_32x32x2_f32) covers the three
 // operand layouts (NN, NT, TN).  Every reduction is two-stage with a fixed order: results are bitwise reproducible.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -44,60 +44,79 @@ struct GemmParams {
 
 // A' = TA ? A^T : A (A stored M x K, or K x M when TA);  B' = TB ? B^T : B (B stored K x N, or N x K when TB).
 // The contiguous extent of every stored matrix and all leading dimensions are multiples of 4 floats (16-byte loads).
+// 128 x 128 x 16 tiles, 4 waves of 64 x 64 (2 x 2 MFMA tiles: one LDS read per MFMA), register-prefetched double buffer.
 template <bool TA, bool TB>
 __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
-  constexpr int BM = 64, BN = 64, BK = 16, LD = 68;
+  constexpr int BM = 128, BN = 128, BK = 16, LD = 132;
   __shared__ __attribute__((aligned(16))) float As[2][BK][LD];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = blockIdx.z * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
-  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32, l31 = lane & 31, lhi = lane >> 5;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, l31 = lane & 31, lhi = lane >> 5;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_a = [&](int k0) -> float4 {
-    if (TA) { const int k = k0 + (tid >> 4), m = m0 + (tid & 15) * 4; return (k < kend && m < p.M) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m) : z4; }
-    const int m = m0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+  // a tile is 128 x 16 floats = 512 float4: two per thread (i = 0, 1)
+  auto load_a = [&](int k0, int i) -> float4 {
+    const int idx = tid + i * 256;
+    if (TA) { const int k = k0 + (idx >> 5), m = m0 + (idx & 31) * 4; return (k < kend && m < p.M) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m) : z4; }
+    const int m = m0 + (idx >> 2), k = k0 + (idx & 3) * 4;
     return (m < p.M && k < kend) ? *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k) : z4;
   };
-  auto load_b = [&](int k0) -> float4 {
-    if (!TB) { const int k = k0 + (tid >> 4), n = n0 + (tid & 15) * 4; return (k < kend && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n) : z4; }
-    const int n = n0 + (tid >> 2), k = k0 + (tid & 3) * 4;
+  auto load_b = [&](int k0, int i) -> float4 {
+    const int idx = tid + i * 256;
+    if (!TB) { const int k = k0 + (idx >> 5), n = n0 + (idx & 31) * 4; return (k < kend && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n) : z4; }
+    const int n = n0 + (idx >> 2), k = k0 + (idx & 3) * 4;
     return (n < p.N && k < kend) ? *reinterpret_cast<const float4*>(p.B + (long)n * p.ldb + k) : z4;
   };
-  auto store_a = [&](int buf, const float4 v) {
-    if (TA) { *reinterpret_cast<float4*>(&As[buf][tid >> 4][(tid & 15) * 4]) = v; return; }
-    const int m = tid >> 2, k = (tid & 3) * 4;
-    As[buf][k][m] = v.x; As[buf][k + 1][m] = v.y; As[buf][k + 2][m] = v.z; As[buf][k + 3][m] = v.w;
+  auto store_t = [&](float (*S)[LD], bool direct, int i, const float4 v) {     // direct: the stored matrix is k-major already
+    const int idx = tid + i * 256;
+    if (direct) { *reinterpret_cast<float4*>(&S[idx >> 5][(idx & 31) * 4]) = v; return; }
+    const int r = idx >> 2, k = (idx & 3) * 4;
+    S[k][r] = v.x; S[k + 1][r] = v.y; S[k + 2][r] = v.z; S[k + 3][r] = v.w;
   };
-  auto store_b = [&](int buf, const float4 v) {
-    if (!TB) { *reinterpret_cast<float4*>(&Bs[buf][tid >> 4][(tid & 15) * 4]) = v; return; }
-    const int n = tid >> 2, k = (tid & 3) * 4;
-    Bs[buf][k][n] = v.x; Bs[buf][k + 1][n] = v.y; Bs[buf][k + 2][n] = v.z; Bs[buf][k + 3][n] = v.w;
-  };
-  tf32x16 acc;
+  tf32x16 acc[4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  float4 ra = load_a(kbeg), rb = load_b(kbeg);
-  store_a(0, ra); store_b(0, rb);
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[q][j] = 0.f;
+  float4 ra[2], rb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { ra[i] = load_a(kbeg, i); rb[i] = load_b(kbeg, i); }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { store_t(As[0], TA, i, ra[i]); store_t(Bs[0], !TB, i, rb[i]); }
   __syncthreads();
   int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     const bool more = k0 + BK < kend;
-    if (more) { ra = load_a(k0 + BK); rb = load_b(k0 + BK); }          // in flight while this tile is contracted
+    if (more) {                                                          // in flight while this tile is contracted
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][kk + lhi][wm + l31], Bs[buf][kk + lhi][wn + l31], acc, 0, 0, 0);
-    if (more) { store_a(buf ^ 1, ra); store_b(buf ^ 1, rb); }
+      for (int i = 0; i < 2; ++i) { ra[i] = load_a(k0 + BK, i); rb[i] = load_b(k0 + BK, i); }
+    }
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = As[buf][kk + lhi][wm + l31], a1 = As[buf][kk + lhi][wm + 32 + l31];
+      const float b0 = Bs[buf][kk + lhi][wn + l31], b1 = Bs[buf][kk + lhi][wn + 32 + l31];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[3], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { store_t(As[buf ^ 1], TA, i, ra[i]); store_t(Bs[buf ^ 1], !TB, i, rb[i]); }
+    }
     __syncthreads();
     buf ^= 1;
   }
   float* C = p.C + (long)blockIdx.z * p.c_zstride;
-  const int col = n0 + wn + l31;
-  if (col < p.N) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int col = n0 + wn + (q & 1) * 32 + l31;
+    if (col >= p.N) continue;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int row = m0 + wm + (j & 3) + 8 * (j >> 2) + 4 * lhi;      // accumulator layout of v_mfma_f32_32x32x2_f32
-      if (row < p.M) { float* c = C + (long)row * p.ldc + col; *c = (p.beta ? *c : 0.f) + acc[j]; }
+      const int row = m0 + wm + (q >> 1) * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi;      // accumulator layout of v_mfma_f32_32x32x2_f32
+      if (row < p.M) { float* c = C + (long)row * p.ldc + col; *c = (p.beta ? *c : 0.f) + acc[q][j]; }
     }
   }
 }
@@ -109,6 +128,17 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, int nz, long
   float s = 0.f;
   for (int z = 0; z < nz; ++z) s += part[(long)z * zstride + i];
   out[i] = s;
+}
+
+// the six column sums of hc_bwd_rows_kernel's per-workgroup partials [nblk][6][C] -> d(g1), d(b1), d(g2), d(b2), d(bias) (2C), fixed order
+__global__ void colsum6_kernel(const float* __restrict__ part, int nblk, int C, float* dg1, float* db1, float* dg2, float* db2, float* dbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 6 * C) return;
+  float s = 0.f;
+  for (int z = 0; z < nblk; ++z) s += part[(long)z * 6 * C + i];
+  const int j = i / C, c = i - j * C;
+  float* out = j == 0 ? dg1 : (j == 1 ? db1 : (j == 2 ? dg2 : (j == 3 ? db2 : dbias + (j - 4) * C)));
+  out[c] = s;
 }
 
 // dst (B, Tp, C) <- src (B, T, C) at rows [off, off + T), zeros elsewhere;  reverse = 1: src (B, T, C) <- dst rows [off, off + T)
