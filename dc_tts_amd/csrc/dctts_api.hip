@@ -1819,13 +1819,15 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     HIPCHK(hipHostMalloc((void**)&c->gate_err_host, sizeof(int), 0)); *c->gate_err_host = 0;
   }
   if (gate && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: a piece gate of the previous decode timed out (piece_gate)");
+  if (c->sync_values && !gate && !c->ctr_chain) {            // a device without stream memory operations meets through events
+    int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
+    if (!can) c->sync_values = 0;
+  }
   const bool vs = c->sync_values != 0 && !gate;
   if (vs && !c->ctr_chain) {
     // Stream memory operations: a write packet after a piece, a compare-and-wait packet before the piece that needs it.  The
     // command processor polls the counter itself: no signal objects, no interrupt, and (measured) ~10 us less per frame on the
     // chain's stream than hipEventRecord + hipStreamWaitEvent.
-    int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
-    if (!can) return fail(DCTTS_ERR_HIP, "device does not support hipStreamWaitValue32 (set DCTTS_SYNC_VALUES=0)");
     HIPCHK(hipExtMallocWithFlags((void**)&c->ctr_chain, 8, hipMallocSignalMemory));
     HIPCHK(hipExtMallocWithFlags((void**)&c->ctr_bulk, 8, hipMallocSignalMemory));
   }
