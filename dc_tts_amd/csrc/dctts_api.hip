@@ -152,6 +152,9 @@ struct dctts_ctx {
   uint32_t* ctr_chain = nullptr; uint32_t* ctr_bulk = nullptr;   // signal memory: chain pieces done + 1, bulk pieces done
   int sig_inkernel = 1;                // the chain's counter is written by the first launch of the NEXT piece instead of a write-value packet (DCTTS_SIG_INKERNEL=0)
   unsigned sig_next = 0;               // value the next run_chain3 launch writes (0 = none)
+  int chain_wait_inkernel = 1;         // the chain's wait for the bulk's counter happens inside the piece's first launch (sc1 read of the one operand the bulk
+                                       // produced for it) instead of a wait-value operation in front of it (DCTTS_CHAIN_WAIT=0)
+  unsigned wait2_next = 0;             // counter value the next run_chain3 launch waits for (0 = none)
   int sync_gate = 0;                   // v3, opt-in (DCTTS_GATE=1): no stream operation between pieces at all: the first launch of every piece publishes and waits in-kernel
                                        // (piece_gate).  Measured 145 us/frame against 138 with stream memory operations: the agent-scope acquire after the wait costs more than the wait launch it replaces.
   unsigned* gate_ctr = nullptr;        // device memory: [0] chain pieces complete + 1, [32] bulk pieces complete, [64] error word
@@ -389,7 +392,7 @@ static void read_env(dctts_ctx* c) {
   geti("DCTTS_BULK3_SMALL", &c->bulk3_small_rows); geti("DCTTS_BULK3_FUSED", &c->bulk3_fused); geti("DCTTS_HC2_ROWOP", &c->hc2_rowop);
   geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_MLP", &c->chain_mlp); 
   { int r = c->mlp_rows; geti("DCTTS_MLP_ROWS", &r); if (r == 2 || r == 4) c->mlp_rows = r; } geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
-  geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_SIG_INKERNEL", &c->sig_inkernel); geti("DCTTS_GATE", &c->sync_gate); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
+  geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_SIG_INKERNEL", &c->sig_inkernel); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_GATE", &c->sync_gate); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
 }
 
@@ -1444,6 +1447,10 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   if (ex && ex->raw) { p.raw = row(*ex->raw); p.raw_bs = (int)(ex->raw->bstride * ex->raw->stride); }
   p.pout = pout; p.np_out = L.hc ? 2 * L.cout : L.cout; p.stats_out = stats_out; p.cout = L.cout;
   if (c->sig_next) { p.sig = c->ctr_chain; p.sig_val = c->sig_next; c->sig_next = 0; }
+  if (c->wait2_next) {
+    if (!(ex && ex->presum)) return fail(DCTTS_ERR_STATE, "chain3: the in-kernel wait guards a presum addend");
+    p.wait2 = c->gate_ctr + 32; p.wait_val = c->wait2_next; p.gate_err = (int*)(c->gate_ctr + 64); c->wait2_next = 0;
+  }
   if (c->gate_next.sig || c->gate_next.wait) { p.sig = c->gate_next.sig; p.sig_val = c->gate_next.sig_val; p.wait = c->gate_next.wait; p.wait_val = c->gate_next.wait_val; p.gate_err = c->gate_next.err; c->gate_next = PieceGate{nullptr, 0u, nullptr, 0u, nullptr}; }
   const dim3 grid(L.hc ? L.cout / 16 : (L.cout + 31) / 32, (B + 7) / 8);
   // measurement (dctts_hip_debug.h): HIP events on the launch stream around sampled launches of the time-dominant decode kernel
@@ -1834,6 +1841,15 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   // the chain's counter is written by the first launch of the NEXT piece ("I run, so everything before me is complete and released")
   // instead of a write-value packet behind the piece: one command-processor round trip less per frame on the critical stream
   const bool insig = vs && c->sig_inkernel && !c->chain_group && c->v3_skip != 2;
+  // ... and the chain's wait for the bulk's counter sits inside the piece's first launch (chain3_kernel: wait2): the counter then
+  // lives in plain device memory (the bulk's write-value operation writes it, the launch polls it)
+  const bool cwait = insig && c->chain_wait_inkernel && !c->chain_row && c->v3_skip == 0;
+  if (cwait && !c->gate_ctr) {
+    HIPCHK(hipMalloc((void**)&c->gate_ctr, 128 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->gate_ctr, 0, 128 * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void**)&c->gate_err_host, sizeof(int), 0)); *c->gate_err_host = 0;
+  }
+  if (cwait && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: the in-kernel wait of the previous decode timed out (chain3_kernel)");
   CHK(v3_aepre_table(c, w, B));
   if (c->chain_row) CHK(v3_rowchain_table(c, w, B, N, T, insig, gate));
   else if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));
@@ -1851,6 +1867,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
     if (c->chain_row) return v3_rowchain_launch(c, B, j, s);
     c->sig_next = (insig && j >= 0) ? (unsigned)(j + 1) : 0u;          // written by the piece's first launch (AudioDec HC_2)
+    c->wait2_next = (cwait && j >= 0) ? (unsigned)(j + 1) : 0u;        // ... which also waits for bulk piece j
     if (gate && j >= 0) c->gate_next = PieceGate{c->gate_ctr, (unsigned)(j + 1), c->gate_ctr + 32, (unsigned)(j + 1), (int*)(c->gate_ctr + 64)};   // publish "pieces < j done", wait for bulk piece j
     if (j >= 0) CHK(v3_chain_dec(c, w, B, j, s));
     if (j >= 0 && c->chain_mlp) CHK(v3_mlp_launch(c, B, j, s));   // AudioDec C_8..C_11, mel frame j, AudioEnc C_1..C_3 of frame j+1
@@ -1862,7 +1879,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     return v3_bulk_rest(c, w, B, N, T, f, s);
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string(c->chain_row) + ":" + std::to_string((size_t)c->rc_par) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)gate) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string(c->chain_row) + ":" + std::to_string((size_t)c->rc_par) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)gate) + ":" + std::to_string((int)cwait) + ":" +
                           std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs2(c);
@@ -1879,7 +1896,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       c->graphs3_geom = g;
     }
   }
-  if (gate) HIPCHK(hipMemsetAsync(c->gate_ctr, 0, 64 * sizeof(unsigned), st));      // both counters; st is ordered after the previous decode's last piece, and that piece after all bulk work
+  if (gate || cwait) HIPCHK(hipMemsetAsync(c->gate_ctr, 0, 64 * sizeof(unsigned), st));      // both counters; st is ordered after the previous decode's last piece, and that piece after all bulk work
   if (vs) {
     HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 0u, 0));              // st is ordered after the previous decode's last piece, and that piece after all bulk work
     HIPCHK(hipStreamWriteValue32(st, c->ctr_bulk, 0u, 0));
@@ -1893,7 +1910,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   auto bulk_piece = [&](int f) -> int {
     if (skip != 1 && skip != 3) { if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(bulk_rest(f, sb)); }
     if (gate) { if (f == T - 1) { hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, sb, c->gate_ctr + 32, (unsigned)T); HIPCHK(hipGetLastError()); } return 0; }
-    if (skip != 3) { if (vs) HIPCHK(hipStreamWriteValue32(sb, c->ctr_bulk, (uint32_t)(f + 1), 0)); else HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb)); }
+    if (skip != 3) { if (vs) HIPCHK(hipStreamWriteValue32(sb, cwait ? (void*)(c->gate_ctr + 32) : (void*)c->ctr_bulk, (uint32_t)(f + 1), 0)); else HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb)); }
     return 0;
   };
   // DCTTS_PIECETIME=<frame>: timing events around 8 consecutive chain / bulk pieces starting there (measurement only)
@@ -1913,7 +1930,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       CHK(bulk_piece(j + 1));
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][1], sb));
     }
-    if (gate) {} else if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(st, c->ctr_bulk, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0)); }
+    if (gate || cwait) {} else if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(st, c->ctr_bulk, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0)); }
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][0], st));
     if (j == tstep) {
       if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
@@ -1932,7 +1949,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       CHK(write_trace3(c, j));
     }
   }
-  if (gate) HIPCHK(hipMemcpyAsync(c->gate_err_host, c->gate_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (gate || cwait) HIPCHK(hipMemcpyAsync(c->gate_err_host, c->gate_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
   if (c->chain_group && !c->chain_row) HIPCHK(hipMemcpyAsync(c->group_err_host, group_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));

@@ -244,6 +244,9 @@ struct Chain3Params {
   long long* ts;                     // TS instantiation only (measurement): 8 wall-clock stamps per workgroup
   unsigned* sig; unsigned sig_val;   // first launch of a chain piece: *sig = sig_val ("every earlier piece is complete": the bulk stream waits for it)
   const unsigned* wait; unsigned wait_val; int* gate_err;   // ... and, when set, wait for *wait >= wait_val before anything is loaded (piece_gate)
+  const unsigned* wait2;             // light form of the same wait (first launch of a chain piece): only the epilogue addend comes from the other
+                                     // stream, so every other load is issued first, then *wait2 >= wait_val is polled, then the addend is read past
+                                     // the (possibly stale) L2 with an sc1 load: no stream operation and no cache invalidate on the chain's stream
 };
 
 // TAP2: a dilation-1 AudioEnc layer.  Its tap -1 reads the row the chain produced one frame earlier, which no presum computed
@@ -259,7 +262,7 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
   DCTTS_SGPR(p.B); DCTTS_SGPR(p.P); DCTTS_SGPR(p.p_bs); DCTTS_SGPR(p.stats); DCTTS_SGPR(p.res); DCTTS_SGPR(p.res_bs);
   DCTTS_SGPR(p.g1); DCTTS_SGPR(p.b1); DCTTS_SGPR(p.g2); DCTTS_SGPR(p.b2); DCTTS_SGPR(p.relu); DCTTS_SGPR(p.xm); DCTTS_SGPR(p.xm_bs);
   DCTTS_SGPR(p.wp); DCTTS_SGPR(p.add); DCTTS_SGPR(p.add_bs); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.stats_out);
-  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.sig); DCTTS_SGPR(p.sig_val); DCTTS_SGPR(p.wait);
+  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.sig); DCTTS_SGPR(p.sig_val); DCTTS_SGPR(p.wait); DCTTS_SGPR(p.wait2);
   if constexpr (TAP2) { DCTTS_SGPR(p.xt); DCTTS_SGPR(p.xt_bs); }
   if (p.wait) piece_gate(p.sig, p.sig_val, p.wait, p.wait_val, p.gate_err, (blockIdx.x | blockIdx.y) == 0);        // first launch of a chain piece: publish, then wait for the bulk stream's rows of this frame
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -314,7 +317,23 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
   if constexpr (HCOUT) { const int c = grp * 16 + ecol; ok = c < p.cout; pcol = etile * p.cout + c; }
   else                 { pcol = (grp * 2 + etile) * 16 + ecol; ok = pcol < p.cout; }
   float addv = 0.f;
-  if (eok_row && ok) addv = p.add[(unsigned)(eb * p.add_bs) + (unsigned)pcol];
+  if (p.wait2) {
+    // The bulk stream's kernels that wrote this frame's presum rows have completed and released them (their stream wrote the
+    // counter after them); this launch may have started earlier, so its L2 can still hold the lines of two frames ago: sc1 load.
+    if (tid == 0) {
+      bool okw = false;
+      for (int i = 0; i < (1 << 17) && !okw; ++i) {                       // bounded (~0.1 s): a time-out raises the error word, never hangs the queue
+        okw = __hip_atomic_load(p.wait2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+        if (!okw) __builtin_amdgcn_s_sleep(4);
+      }
+      if (!okw && p.gate_err) atomicOr(p.gate_err, 1);
+    }
+    __syncthreads();
+    if (eok_row && ok) {
+      const float* ap = p.add + (unsigned)(eb * p.add_bs) + (unsigned)pcol;
+      asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(addv) : "v"(ap) : "memory");
+    }
+  } else if (eok_row && ok) addv = p.add[(unsigned)(eb * p.add_bs) + (unsigned)pcol];
   // Pin: ONE asm statement that consumes every loaded vector.  All of them must have been issued before it and nothing that uses
   // them can start before it, so the launch pays one memory round trip (the addend rides along: waited for later, its s_waitcnt
   // vmcnt(0) would also wait for the row stores issued in between -- stores count in vmcnt on gfx9).  (Without it the scheduler sinks each load next to its

@@ -327,7 +327,7 @@ def test_decode_vs_oracle_loop(weights, graph, mode):
     assert trajr.max() > 10
 
 
-@pytest.mark.parametrize("knob", ["DCTTS_GATE=1", "DCTTS_SYNC_VALUES=0", "DCTTS_SIG_INKERNEL=0"])
+@pytest.mark.parametrize("knob", ["DCTTS_GATE=1", "DCTTS_SYNC_VALUES=0", "DCTTS_SIG_INKERNEL=0", "DCTTS_CHAIN_WAIT=0"])
 def test_decode_stream_meeting_variants(weights, knob):
     """The chain and bulk streams of the decode can meet three ways (events, stream memory operations, in-kernel gates); the
     knobs are read when a context is created.  Every variant must reproduce the oracle loop: trajectory integer-exact."""
