@@ -78,6 +78,58 @@ extern "C" size_t dctts_train_device_bytes(const dctts_train* t) {
   return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes;
 }
 
+namespace {
+// Shared scaffolding of the two convolution backward passes.  Cin input channels, Ch pre-norm channels (2C for hc, Cout for conv1d).
+// x-aligned buffers hold t = 0 at row pl of an utterance, H-aligned ones at row pr: then for every tap j
+//   H_aligned[r] needs x_aligned[r - pr + j*rate]   and   dx_aligned[r] needs dH_aligned[r + pr - j*rate]   (r a flat row index),
+// i.e. every shift is a pointer offset, and rows that fall into another utterance's padding read / write zeros.
+struct ConvGeom {
+  int B, T, Cin, Ch, k, rate, pl, pr, Tp; long R, Rv;
+  ConvGeom(int B_, int T_, int Cin_, int Ch_, int k_, int rate_, int causal) : B(B_), T(T_), Cin(Cin_), Ch(Ch_), k(k_), rate(rate_) {
+    // tf.layers.conv1d tap j reads x[t + j*rate - pl] (modules.py:121-125,173-177): CAUSAL pl = (k-1) rate, SAME pl = total / 2
+    const int total = (k - 1) * rate;
+    pl = causal ? total : total / 2; pr = total - pl; Tp = pl + T + pr;
+    R = (long)B * Tp; Rv = R - pl - pr;            // rows of the padded buffers; rows every GEMM output covers
+  }
+  int splits() const { const int wt = ((Cin + 127) / 128) * ((Ch + 127) / 128); return std::max(1, std::min(64, (512 + wt - 1) / wt)); }
+};
+
+// pads x, clears the gradient buffers, recomputes the pre-norm tensor H (without bias) over rows [pr, R - pl) of the H-aligned buffer
+int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* x, const float* kernel) {
+  if (reserve(&t->xp, (size_t)g.R * g.Cin * 4) || reserve(&t->Hp, (size_t)g.R * g.Ch * 4) || reserve(&t->dHp, (size_t)g.R * g.Ch * 4) ||
+      reserve(&t->dxp, (size_t)g.R * g.Cin * 4) || reserve(&t->wpart, (size_t)g.splits() * g.Cin * g.Ch * 4)) return DCTTS_ERR_HIP;
+  float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p;
+  const long n4 = g.R * (g.Cin / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), g.B, g.T, g.Tp, g.pl, g.Cin, 0);
+  THIP(hipGetLastError());
+  THIP(hipMemsetAsync(t->dHp.p, 0, (size_t)g.R * g.Ch * 4, st));
+  THIP(hipMemsetAsync(t->dxp.p, 0, (size_t)g.R * g.Cin * 4, st));
+  for (int j = 0; j < g.k; ++j) {
+    const int rc = gemm<false, false>(st, xp + (long)(j * g.rate) * g.Cin, kernel + (long)j * g.Cin * g.Ch, Hp + (long)g.pr * g.Ch, (int)g.Rv, g.Ch, g.Cin, g.Cin, g.Ch, g.Ch, j > 0);
+    if (rc < 0) return rc;
+  }
+  return 0;
+}
+
+// dkernel[j] = x_shifted^T . dH (K = every row: split-K partials, fixed-order sum);  dx (+)= dH_shifted . kernel[j]^T;  dx out of its padding
+int conv_grads(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* kernel, float* dkernel, float* dx) {
+  float *xp = (float*)t->xp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
+  const long nw = (long)g.Cin * g.Ch;
+  for (int j = 0; j < g.k; ++j) {
+    const int nz = gemm<true, false>(st, xp + (long)(j * g.rate) * g.Cin, dHp + (long)g.pr * g.Ch, (float*)t->wpart.p, g.Cin, g.Ch, (int)g.Rv, g.Cin, g.Ch, g.Ch, 0, g.splits(), nw);
+    if (nz < 0) return nz;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->wpart.p, nz, nw, nw, dkernel + (long)j * nw);
+    THIP(hipGetLastError());
+    const int rc = gemm<false, true>(st, dHp + (long)(g.pl + g.pr - j * g.rate) * g.Ch, kernel + (long)j * nw, dxp + (long)g.pl * g.Cin, (int)g.Rv, g.Cin, g.Ch, g.Ch, g.Ch, g.Cin, 1);
+    if (rc < 0) return rc;
+  }
+  const long m4 = (long)g.B * g.T * (g.Cin / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, st, dxp, dx, g.B, g.T, g.Tp, g.pl, g.Cin, 1);
+  THIP(hipGetLastError());
+  return 0;
+}
+}  // namespace
+
 extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
                                        const float* g1, const float* b1, const float* g2, const float* b2,
                                        int B, int T, int C, int k, int rate, int causal,
@@ -89,52 +141,44 @@ extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const flo
   DevScope ds(t->device);
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
-  // tf.layers.conv1d tap j reads x[t + j*rate - pl] (modules.py:121-125,173-177): CAUSAL pl = (k-1) rate, SAME pl = total / 2
-  const int total = (k - 1) * rate, pl = causal ? total : total / 2, pr = total - pl;
-  const int Tp = pl + T + pr;
-  const long R = (long)B * Tp, Rv = R - pl - pr;          // rows of the padded buffers; rows every GEMM output covers
-  // x-aligned buffers hold t = 0 at row pl of an utterance, H-aligned ones at row pr: then for every tap j
-  //   H_aligned[r] needs x_aligned[r - pr + j*rate]   and   dx_aligned[r] needs dH_aligned[r + pr - j*rate]   (r a flat row index),
-  // i.e. every shift is a pointer offset, and rows that fall into another utterance's padding read / write zeros.
-  if (reserve(&t->xp, (size_t)R * C * 4) || reserve(&t->Hp, (size_t)R * 2 * C * 4) || reserve(&t->dHp, (size_t)R * 2 * C * 4) ||
-      reserve(&t->dxp, (size_t)R * C * 4)) return DCTTS_ERR_HIP;
+  const ConvGeom g(B, T, C, 2 * C, k, rate, causal);
+  int rc = conv_prenorm(t, st, g, x, kernel);
+  if (rc) return rc;
+  // the row part: dH, the direct part of dx, column sums
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
-  const int wtiles = ((C + 127) / 128) * ((2 * C + 127) / 128);
-  const int splits = std::max(1, std::min(64, (512 + wtiles - 1) / wtiles));       // the weight gradient has few output tiles: split its K (= every row) to fill the chip
-  if (reserve(&t->part, (size_t)nblk * 6 * C * 4) || reserve(&t->wpart, (size_t)splits * C * 2 * C * 4)) return DCTTS_ERR_HIP;
-  float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
-  const long n4 = R * (C / 4);
-  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), B, T, Tp, pl, C, 0);
-  THIP(hipGetLastError());
-  THIP(hipMemsetAsync(dHp, 0, (size_t)R * 2 * C * 4, st));
-  THIP(hipMemsetAsync(dxp, 0, (size_t)R * C * 4, st));
-  // 1. pre-norm H (without bias) over rows [pr, R - pl) of the H-aligned buffer
-  for (int j = 0; j < k; ++j) {
-    const int rc = gemm<false, false>(st, xp + (long)(j * rate) * C, kernel + (long)j * C * 2 * C, Hp + (long)pr * 2 * C, (int)Rv, 2 * C, C, C, 2 * C, 2 * C, j > 0);
-    if (rc < 0) return rc;
-  }
-  // 2. the row part: dH, the direct part of dx, column sums
-  HcBwdRowsParams q{B, T, Tp, C, pr, pl, Hp, x, dy, bias, g1, b1, g2, b2, dHp, dxp, (float*)t->part.p};
+  if (reserve(&t->part, (size_t)nblk * 6 * C * 4)) return DCTTS_ERR_HIP;
+  HcBwdRowsParams q{B, T, g.Tp, C, g.pr, g.pl, (const float*)t->Hp.p, x, dy, bias, g1, b1, g2, b2, (float*)t->dHp.p, (float*)t->dxp.p, (float*)t->part.p};
   if (C == 256) hipLaunchKernelGGL((hc_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
   else if (C == 512) hipLaunchKernelGGL((hc_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
   else hipLaunchKernelGGL((hc_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
   THIP(hipGetLastError());
   hipLaunchKernelGGL(colsum6_kernel, dim3((6 * C + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, C, dg1, db1, dg2, db2, dbias);
   THIP(hipGetLastError());
-  // 3. dkernel[j] = x_shifted^T . dH (K = every row: split-K partials, fixed-order sum);  dx += dH_shifted . kernel[j]^T
-  for (int j = 0; j < k; ++j) {
-    const int nz = gemm<true, false>(st, xp + (long)(j * rate) * C, dHp + (long)pr * 2 * C, (float*)t->wpart.p, C, 2 * C, (int)Rv, C, 2 * C, 2 * C, 0, splits, (long)C * 2 * C);
-    if (nz < 0) return nz;
-    const long nw = (long)C * 2 * C;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->wpart.p, nz, nw, nw, dkernel + (long)j * nw);
-    THIP(hipGetLastError());
-    const int rc = gemm<false, true>(st, dHp + (long)(pl + pr - j * rate) * 2 * C, kernel + (long)j * C * 2 * C, dxp + (long)pl * C, (int)Rv, C, 2 * C, 2 * C, 2 * C, C, 1);
-    if (rc < 0) return rc;
-  }
-  const long m4 = (long)B * T * (C / 4);
-  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, st, dxp, dx, B, T, Tp, pl, C, 1);
+  return conv_grads(t, st, g, kernel, dkernel, dx);
+}
+
+extern "C" int dctts_train_conv1d_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
+                                           const float* gamma, const float* beta, int B, int T, int Cin, int Cout, int k, int rate, int causal, int act,
+                                           float* dx, float* dkernel, float* dbias, float* dgamma, float* dbeta, void* stream) {
+  if (!t || !x || !dy || !kernel || !bias || !gamma || !beta || !dx || !dkernel || !dbias || !dgamma || !dbeta) TFAIL(DCTTS_ERR_ARG, "conv1d_backward: null argument");
+  if (B <= 0 || T <= 0 || Cin <= 0 || (Cin & 3) || (Cout != 256 && Cout != 512 && Cout != 1024) || (k != 1 && k != 3) || rate < 1 || act < 0 || act > 2)
+    TFAIL(DCTTS_ERR_ARG, "conv1d_backward: Cin a multiple of 4, Cout 256, 512 or 1024, k 1 or 3, act 0..2");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const ConvGeom g(B, T, Cin, Cout, k, rate, causal);
+  int rc = conv_prenorm(t, st, g, x, kernel);
+  if (rc) return rc;
+  const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
+  if (reserve(&t->part, (size_t)nblk * 6 * Cout * 4)) return DCTTS_ERR_HIP;
+  CBwdRowsParams q{B, T, g.Tp, Cout, g.pr, (const float*)t->Hp.p, dy, bias, gamma, beta, act, (float*)t->dHp.p, (float*)t->part.p};
+  if (Cout == 256) hipLaunchKernelGGL((c_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
+  else if (Cout == 512) hipLaunchKernelGGL((c_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((c_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
   THIP(hipGetLastError());
-  return 0;
+  hipLaunchKernelGGL(colsum3_kernel, dim3((3 * Cout + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, Cout, dgamma, dbeta, dbias);
+  THIP(hipGetLastError());
+  return conv_grads(t, st, g, kernel, dkernel, dx);
 }
 
 static int loss_blocks(long n) { return (int)std::min<long>(1024, (n + 2047) / 2048); }

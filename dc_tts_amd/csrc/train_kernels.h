@@ -245,6 +245,95 @@ __global__ void __launch_bounds__(256) hc_bwd_rows_kernel(const HcBwdRowsParams 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- conv1d backward, row part
+struct CBwdRowsParams {
+  int B, T, Tp, C;                 // C = output channels (a multiple of 256)
+  int h_off;
+  const float* Hp;                 // (B, Tp, C) pre-norm WITHOUT bias, H-aligned
+  const float* dy;                 // (B, T, C)
+  const float* bias; const float* g; const float* b;
+  int act;                         // 0 none, 1 relu, 2 sigmoid (modules.py:136-138)
+  float* dHp;                      // (B, Tp, C) H-aligned; pad rows stay zero
+  float* part;                     // [gridDim.x][3][C]: column sums of d(gamma), d(beta), d(bias)
+};
+
+// modules.py:91-141 backward up to the convolution: y = act(layer_norm(H)).  One wave per row, lane = 4 x NCH channels.
+template <int NCH>
+__global__ void __launch_bounds__(256) c_bwd_rows_kernel(const CBwdRowsParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4][3][NCH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.C;
+  const float invC = 1.0f / (float)C;
+  tf32x4 acc[3][NCH];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) acc[j][q] = tf32x4{0.f, 0.f, 0.f, 0.f};
+  auto ld = [](const float* q) { return *reinterpret_cast<const tf32x4*>(q); };
+  auto hsum = [](const tf32x4 v) { return v[0] + v[1] + v[2] + v[3]; };
+  const long rows = (long)p.B * p.T;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / p.T), t = (int)(r - (long)b * p.T);
+    const float* H = p.Hp + ((long)b * p.Tp + p.h_off + t) * C;
+    tf32x4 h[NCH], dxh[NCH];
+    float s1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) { const int c = q * 256 + lane * 4; h[q] = ld(H + c) + ld(p.bias + c); s1 += hsum(h[q]); }
+    const float m = t_wave_sum(s1) * invC;
+    float v1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) { h[q] -= m; v1 += hsum(h[q] * h[q]); }
+    const float rs = 1.0f / sqrtf(t_wave_sum(v1) * invC + 1e-12f);
+    float a1 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      const tf32x4 g = ld(p.g + c), be = ld(p.b + c), dv = ld(p.dy + r * C + c);
+      h[q] *= rs;                                                        // xhat
+      const tf32x4 n = h[q] * g + be;
+      tf32x4 dn = dv;
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dn[e] = n[e] > 0.f ? dv[e] : 0.f;
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float y = t_sigmoid(n[e]); dn[e] = dv[e] * y * (1.0f - y); }
+      }
+      acc[0][q] += dn * h[q]; acc[1][q] += dn;
+      dxh[q] = dn * g;
+      a1 += hsum(dxh[q]); c1 += hsum(dxh[q] * h[q]);
+    }
+    const float ma = t_wave_sum(a1) * invC, mc = t_wave_sum(c1) * invC;
+    float* dH = p.dHp + ((long)b * p.Tp + p.h_off + t) * C;
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) {
+      const int c = q * 256 + lane * 4;
+      const tf32x4 d = (dxh[q] - ma - h[q] * mc) * rs;
+      *reinterpret_cast<tf32x4*>(dH + c) = d;
+      acc[2][q] += d;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < NCH; ++q) *reinterpret_cast<tf32x4*>(&red[wave][j][q * 256 + lane * 4]) = acc[j][q];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    const int j = i / C, c = i - j * C;
+    p.part[((long)blockIdx.x * 3 + j) * C + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+  }
+}
+
+// the three column sums of c_bwd_rows_kernel's partials [nblk][3][C] -> d(gamma), d(beta), d(bias), fixed order
+__global__ void colsum3_kernel(const float* __restrict__ part, int nblk, int C, float* dg, float* db, float* dbias) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 3 * C) return;
+  float s = 0.f;
+  for (int z = 0; z < nblk; ++z) s += part[(long)z * 3 * C + i];
+  const int j = i / C, c = i - j * C;
+  (j == 0 ? dg : (j == 1 ? db : dbias))[c] = s;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- losses
 // train.py:87,90 (and :104,107): L1 and sigmoid cross-entropy means over n elements, gradients of their sum.
 // part[block][2] = partial sums of |Y - z| and xent(logits, z).

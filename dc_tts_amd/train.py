@@ -3,6 +3,7 @@ optimizer for ONE building block, as calls into libdctts_hip.so (include/dctts_t
 
   reference                                            here
   modules.py:143-197  hc(...) under tf.gradients       TrainOps.hc_backward
+  modules.py:91-141   conv1d(...) under tf.gradients   TrainOps.conv1d_backward
   train.py:87,90,93-97  loss_mels, loss_bd1, loss_att  TrainOps.text2mel_losses
   train.py:104,107      loss_mags, loss_bd2            TrainOps.ssrn_losses
   train.py:119-131      clip_by_value + Adam           TrainOps.adam_step  (+ learning_rate_decay = utils.py:142-145)
@@ -83,6 +84,31 @@ class TrainOps:
             _ptr(params["g2"]), _ptr(params["b2"]), B, T, C, k, int(rate), 1 if padding.lower() == "causal" else 0,
             _ptr(out["dx"]), _ptr(out["kernel"]), _ptr(out["bias"]), _ptr(out["g1"]), _ptr(out["b1"]), _ptr(out["g2"]), _ptr(out["b2"]),
             self._stream()))
+        return out
+
+    def conv1d_backward(self, x: torch.Tensor, dy: torch.Tensor, params: Dict[str, torch.Tensor], rate: int = 1, padding: str = "SAME",
+                        act: str = None) -> Dict[str, torch.Tensor]:
+        """Gradients of y = conv1d(x) (modules.py:91-141).  params: kernel (k, Cin, Cout), bias, gamma, beta (Cout) -- the TF
+        variables conv1d/kernel, conv1d/bias, normalize/gamma, normalize/beta; act in (None, "relu", "sigmoid")."""
+        _check(x, "x", torch.float32, 3, self.device); _check(dy, "dy", torch.float32, 3, self.device)
+        B, T, Cin = x.shape
+        k, _, Cout = params["kernel"].shape
+        if tuple(dy.shape) != (B, T, Cout):
+            raise ValueError(f"dy {tuple(dy.shape)} != {(B, T, Cout)}")
+        want = {"kernel": (k, Cin, Cout), "bias": (Cout,), "gamma": (Cout,), "beta": (Cout,)}
+        for n, shp in want.items():
+            _check(params[n], n, torch.float32, len(shp), self.device)
+            if tuple(params[n].shape) != shp:
+                raise ValueError(f"{n}: shape {tuple(params[n].shape)} != {shp}")
+        if padding.lower() not in ("same", "causal") or act not in (None, "relu", "sigmoid"):
+            raise ValueError((padding, act))
+        out = {"dx": torch.empty_like(x)}
+        for n in want:
+            out[n] = torch.empty_like(params[n])
+        self._ok(self.lib.dctts_train_conv1d_backward(
+            self._h, _ptr(x), _ptr(dy), _ptr(params["kernel"]), _ptr(params["bias"]), _ptr(params["gamma"]), _ptr(params["beta"]),
+            B, T, Cin, Cout, k, int(rate), 1 if padding.lower() == "causal" else 0, {None: 0, "relu": 1, "sigmoid": 2}[act],
+            _ptr(out["dx"]), _ptr(out["kernel"]), _ptr(out["bias"]), _ptr(out["gamma"]), _ptr(out["beta"]), self._stream()))
         return out
 
     def text2mel_losses(self, Y, Y_logits, mels, alignments, max_N: int, max_T: int):

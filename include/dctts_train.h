@@ -1,11 +1,12 @@
 /* dctts_train.h -- C ABI of the first slice of the TRAINING path, MI355X (gfx950).
  *
- * What is here (and nothing else of train.py yet): the backward pass of one highway-convolution block, the losses of
+ * What is here (and nothing else of train.py yet): the backward passes of the highway-convolution block and of conv1d, the losses of
  * train.py:85-110 with their gradients, and the clip + Adam update of train.py:119-131.  A trainer written against the
  * reference would call these where TensorFlow's autodiff / optimizer ran:
  *
  *   reference                                              this library
  *   modules.py:143-197  hc(...) under tf.gradients         dctts_train_hc_backward
+ *   modules.py:91-141   conv1d(...) under tf.gradients     dctts_train_conv1d_backward
  *   train.py:87,90,93-97  loss_mels, loss_bd1, loss_att    dctts_train_text2mel_losses
  *   train.py:104,107      loss_mags, loss_bd2              dctts_train_ssrn_losses
  *   train.py:119-131      clip_by_value(-1, 1) + Adam      dctts_train_adam_step   (lr from utils.py:142-145, host side)
@@ -42,6 +43,13 @@ int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, con
                             const float* g1, const float* b1, const float* g2, const float* b2,
                             int B, int T, int C, int k, int rate, int causal,
                             float* dx, float* dkernel, float* dbias, float* dg1, float* db1, float* dg2, float* db2, void* stream);
+
+/* Backward of y = conv1d(x) (modules.py:91-141: conv1d(k, dilation `rate`, SAME or CAUSAL) Cin -> Cout, layer-norm, activation).
+ *   x, dx (B, T, Cin), Cin a multiple of 4;  dy (B, T, Cout), Cout in {256, 512, 1024};  kernel, dkernel (k, Cin, Cout);
+ *   bias, gamma, beta and their gradients (Cout);  act: 0 none, 1 relu, 2 sigmoid. */
+int dctts_train_conv1d_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
+                                const float* gamma, const float* beta, int B, int T, int Cin, int Cout, int k, int rate, int causal, int act,
+                                float* dx, float* dkernel, float* dbias, float* dgamma, float* dbeta, void* stream);
 
 /* train.py:85-100.  Y, Y_logits, mels (B, T, n_mels); alignments (B, N, T) as networks.py:153 returns them (N <= max_N,
  * T <= max_T: the reference pads them to (max_N, max_T) with -1 and masks the padding).  losses[3] (device) receives

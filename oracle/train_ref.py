@@ -4,7 +4,8 @@ Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 
 What it restates, in float64 numpy with every derivative written out by hand:
   * the backward pass of the highway-convolution block ``hc`` (modules.py:143-197): conv to 2C -> split ->
-    layer-norm(H1), layer-norm(H2) (modules.py:45-64, eps 1e-12) -> sigmoid gate -> highway mix;
+    layer-norm(H1), layer-norm(H2) (modules.py:45-64, eps 1e-12) -> sigmoid gate -> highway mix, and of ``conv1d``
+    (modules.py:91-141): conv -> layer-norm -> activation;
   * the three Text2Mel losses and the two SSRN losses of train.py:85-113 (L1, binary divergence =
     ``sigmoid_cross_entropy_with_logits``, guided attention with ``utils.py:134-140``'s weight matrix) and their
     gradients with respect to the network outputs;
@@ -56,6 +57,28 @@ def normalize_bwd(x, gamma, dy):
     dx = rstd * (dxh - dxh.mean(axis=-1, keepdims=True) - xh * (dxh * xh).mean(axis=-1, keepdims=True))
     red = tuple(range(x.ndim - 1))
     return dx, (dy * xh).sum(axis=red), dy.sum(axis=red)
+
+
+def c_fwd(x, p, rate, padding, act):
+    """modules.py:91-141 with the parameters as a dict: kernel (k, Cin, Cout), bias, gamma, beta; act in (None, "relu", "sigmoid")."""
+    P = {"s/conv1d/kernel": p["kernel"], "s/conv1d/bias": p["bias"], "s/normalize/gamma": p["gamma"], "s/normalize/beta": p["beta"]}
+    return O.conv1d(x, P, "s", rate=rate, padding=padding, act={None: None, "relu": O.relu, "sigmoid": O.sigmoid}[act])
+
+
+def c_bwd(x, p, dy, rate, padding, act):
+    """Backward of conv1d (conv -> layer-norm -> activation).  Returns dict(dx, kernel, bias, gamma, beta)."""
+    H = O._conv(x, p["kernel"], p["bias"], rate, padding)
+    n = O.normalize(H, p["gamma"], p["beta"])
+    if act == "relu":
+        dn = dy * (n > 0)
+    elif act == "sigmoid":
+        y = O.sigmoid(n)
+        dn = dy * y * (1.0 - y)
+    else:
+        dn = dy
+    dH, dg, db = normalize_bwd(H, p["gamma"], dn)
+    dx, dW, dbias = conv_bwd(x, p["kernel"], dH, rate, padding)
+    return {"dx": dx, "kernel": dW, "bias": dbias, "gamma": dg, "beta": db}
 
 
 def hc_fwd(x, p, rate, padding):

@@ -49,6 +49,69 @@ def test_hc_backward_vs_oracle(ops, B, T, C, k, rate, padding):
         assert e < 2e-5, f"{name}: relative error {e}"
 
 
+@pytest.mark.parametrize("B,T,Cin,Cout,k,rate,padding,act", [
+    (2, 37, 80, 256, 1, 1, "causal", "relu"),     # AudioEnc C_1 (mel -> d)
+    (3, 29, 256, 256, 1, 1, "causal", None),      # AudioEnc C_3
+    (2, 45, 128, 512, 1, 1, "same", "relu"),      # TextEnc C_2 (e -> 2d)
+    (2, 31, 512, 1024, 1, 1, "same", None),       # SSRN C_10 (c -> 2c)
+    (2, 33, 256, 256, 3, 2, "causal", "sigmoid"), # not a layer of the model: the generic k = 3 / sigmoid paths
+])
+def test_conv1d_backward_vs_oracle(ops, B, T, Cin, Cout, k, rate, padding, act):
+    rng = np.random.default_rng(200 + Cin + Cout)
+    p = {"kernel": rng.normal(0, (k * Cin) ** -0.5, (k, Cin, Cout)), "bias": rng.normal(0, 0.1, Cout), "gamma": 1 + rng.normal(0, 0.1, Cout), "beta": rng.normal(0, 0.3, Cout)}
+    p = {n: v.astype(np.float32).astype(np.float64) for n, v in p.items()}
+    x = rng.normal(0, 1, (B, T, Cin)).astype(np.float32).astype(np.float64)
+    dy = rng.normal(0, 1, (B, T, Cout)).astype(np.float32).astype(np.float64)
+    ref = TR.c_bwd(x, p, dy, rate, padding, act)
+    got = ops.conv1d_backward(dev(x), dev(dy), {n: dev(v) for n, v in p.items()}, rate=rate, padding=padding, act=act)
+    torch.cuda.synchronize()
+    for name in ("dx", "kernel", "bias", "gamma", "beta"):
+        e = rel(got[name].cpu().numpy().astype(np.float64), ref[name])
+        assert e < 2e-5, f"{name}: relative error {e}"
+
+
+def test_audioenc_backward_end_to_end(ops, weights):
+    """A whole network's backward pass on the GPU: AudioEnc (networks.py:73-124: 3 conv1d + 10 highway blocks, all CAUSAL), layer by
+    layer in reverse with the HIP kernels, against the float64 oracle chain: d(loss)/d(S) and every parameter gradient.  The layer
+    inputs come from the oracle's forward pass, so this test is about the backward pass only."""
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.layers import audioenc_layers
+    rng = np.random.default_rng(31)
+    B, T = 2, 40
+    S = rng.uniform(0, 1, (B, T, hp.n_mels))
+    dQ = rng.normal(0, 1, (B, T, hp.d))
+    pref = "Text2Mel/AudioEnc/"
+    layers = audioenc_layers(hp)                                  # Layer(scope, kind, cin, cout, size, rate, act) in network order
+    W = {n: np.asarray(v, np.float64) for n, v in weights.items() if n.startswith(pref)}
+    def params(L):
+        sc = pref + L.scope
+        if L.kind == "HC":
+            return {"kernel": W[sc + "/conv1d/kernel"], "bias": W[sc + "/conv1d/bias"], "g1": W[sc + "/H1/gamma"], "b1": W[sc + "/H1/beta"],
+                    "g2": W[sc + "/H2/gamma"], "b2": W[sc + "/H2/beta"]}
+        return {"kernel": W[sc + "/conv1d/kernel"], "bias": W[sc + "/conv1d/bias"], "gamma": W[sc + "/normalize/gamma"], "beta": W[sc + "/normalize/beta"]}
+    act_of = lambda L: None if L.act == "none" else L.act
+    xs, x = [], S
+    for L in layers:                                              # forward, keeping every layer's input
+        xs.append(x)
+        x = TR.hc_fwd(x, params(L), L.rate, "causal") if L.kind == "HC" else TR.c_fwd(x, params(L), L.rate, "causal", act_of(L))
+    g_ref, g_gpu = dQ, dev(dQ)
+    worst = 0.0
+    for L, xin in zip(reversed(layers), reversed(xs)):
+        p = params(L)
+        if L.kind == "HC":
+            r = TR.hc_bwd(xin, p, g_ref, L.rate, "causal")
+            o = ops.hc_backward(dev(xin), g_gpu, {n: dev(v) for n, v in p.items()}, rate=L.rate, padding="causal")
+        else:
+            r = TR.c_bwd(xin, p, g_ref, L.rate, "causal", act_of(L))
+            o = ops.conv1d_backward(dev(xin), g_gpu, {n: dev(v) for n, v in p.items()}, rate=L.rate, padding="causal", act=act_of(L))
+        for n in p:
+            worst = max(worst, rel(o[n].cpu().numpy().astype(np.float64), r[n]))
+        g_ref, g_gpu = r["dx"], o["dx"]
+    torch.cuda.synchronize()
+    e = rel(g_gpu.cpu().numpy().astype(np.float64), g_ref)
+    assert e < 1e-4 and worst < 1e-4, (e, worst)                  # 13 layers of fp32 error accumulate on the way down
+
+
 def test_hc_backward_is_reproducible_and_rejects_bad_shapes(ops):
     rng = np.random.default_rng(3)
     C = 256

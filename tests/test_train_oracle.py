@@ -39,6 +39,19 @@ def test_hc_backward_matches_finite_differences(k, rate, padding):
         np.testing.assert_allclose(g[name], _fd(loss, p[name]), rtol=1e-5, atol=1e-7, err_msg=name)
 
 
+@pytest.mark.parametrize("k,rate,padding,act", [(1, 1, "same", "relu"), (1, 1, "same", None), (1, 1, "causal", "sigmoid"), (3, 2, "causal", "relu")])
+def test_conv1d_backward_matches_finite_differences(k, rate, padding, act):
+    rng = np.random.default_rng(15)
+    B, T, Ci, Co = 2, 7, 5, 6
+    p = {"kernel": rng.normal(0, 0.4, (k, Ci, Co)), "bias": rng.normal(0, 0.1, Co), "gamma": 1 + rng.normal(0, 0.1, Co), "beta": rng.normal(0, 0.3, Co)}
+    x = rng.normal(0, 1, (B, T, Ci)); dy = rng.normal(0, 1, (B, T, Co))
+    g = TR.c_bwd(x, p, dy, rate, padding, act)
+    loss = lambda: float((TR.c_fwd(x, p, rate, padding, act) * dy).sum())
+    np.testing.assert_allclose(g["dx"], _fd(loss, x), rtol=1e-5, atol=1e-7)
+    for name in ("kernel", "bias", "gamma", "beta"):
+        np.testing.assert_allclose(g[name], _fd(loss, p[name]), rtol=1e-5, atol=1e-7, err_msg=name)
+
+
 def test_normalize_and_conv_backward():
     rng = np.random.default_rng(6)
     x = rng.normal(0, 1, (2, 5, 7)); gam = 1 + rng.normal(0, 0.1, 7); bet = rng.normal(0, 0.1, 7); dy = rng.normal(0, 1, (2, 5, 7))
