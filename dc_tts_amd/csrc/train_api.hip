@@ -25,7 +25,7 @@ struct TBuf { void* p = nullptr; size_t bytes = 0; };
 
 struct dctts_train {
   int device = 0;
-  TBuf xp, Hp, dHp, dxp, part, wpart, lpart;
+  TBuf xp, Hp, dHp, dxp, part, wpart, lpart, wpad;
 };
 
 namespace {
@@ -68,14 +68,14 @@ extern "C" int dctts_train_create(dctts_train** out, int device) {
 extern "C" int dctts_train_destroy(dctts_train* t) {
   if (!t) return 0;
   DevScope ds(t->device);
-  for (TBuf* b : {&t->xp, &t->Hp, &t->dHp, &t->dxp, &t->part, &t->wpart, &t->lpart}) if (b->p) (void)hipFree(b->p);
+  for (TBuf* b : {&t->xp, &t->Hp, &t->dHp, &t->dxp, &t->part, &t->wpart, &t->lpart, &t->wpad}) if (b->p) (void)hipFree(b->p);
   delete t;
   return 0;
 }
 
 extern "C" size_t dctts_train_device_bytes(const dctts_train* t) {
   if (!t) return 0;
-  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes;
+  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes + t->wpad.bytes;
 }
 
 namespace {
@@ -85,46 +85,66 @@ namespace {
 // i.e. every shift is a pointer offset, and rows that fall into another utterance's padding read / write zeros.
 struct ConvGeom {
   int B, T, Cin, Ch, k, rate, pl, pr, Tp; long R, Rv;
+  int Cinp, Chp;                                   // widths of the padded buffers: multiples of 4 floats (16-byte loads); the extra columns hold zeros
   ConvGeom(int B_, int T_, int Cin_, int Ch_, int k_, int rate_, int causal) : B(B_), T(T_), Cin(Cin_), Ch(Ch_), k(k_), rate(rate_) {
     // tf.layers.conv1d tap j reads x[t + j*rate - pl] (modules.py:121-125,173-177): CAUSAL pl = (k-1) rate, SAME pl = total / 2
     const int total = (k - 1) * rate;
     pl = causal ? total : total / 2; pr = total - pl; Tp = pl + T + pr;
     R = (long)B * Tp; Rv = R - pl - pr;            // rows of the padded buffers; rows every GEMM output covers
+    Cinp = (Cin + 3) / 4 * 4; Chp = (Ch + 3) / 4 * 4;
   }
+  bool padded() const { return Cinp != Cin || Chp != Ch; }
   int splits() const { const int wt = ((Cin + 127) / 128) * ((Ch + 127) / 128); return std::max(1, std::min(64, (512 + wt - 1) / wt)); }
 };
 
-// pads x, clears the gradient buffers, recomputes the pre-norm tensor H (without bias) over rows [pr, R - pl) of the H-aligned buffer
-int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* x, const float* kernel) {
-  if (reserve(&t->xp, (size_t)g.R * g.Cin * 4) || reserve(&t->Hp, (size_t)g.R * g.Ch * 4) || reserve(&t->dHp, (size_t)g.R * g.Ch * 4) ||
-      reserve(&t->dxp, (size_t)g.R * g.Cin * 4) || reserve(&t->wpart, (size_t)g.splits() * g.Cin * g.Ch * 4)) return DCTTS_ERR_HIP;
+// pads x, clears the gradient buffers, recomputes the pre-norm tensor H (without bias) over rows [pr, R - pl) of the H-aligned buffer.
+// *kp = the kernel the GEMMs read: the caller's (k, Cin, Ch) or, when a width is not a multiple of 4, a zero-padded (k, Cinp, Chp) copy.
+int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* x, const float* kernel, const float** kp) {
+  if (reserve(&t->xp, (size_t)g.R * g.Cinp * 4) || reserve(&t->Hp, (size_t)g.R * g.Chp * 4) || reserve(&t->dHp, (size_t)g.R * g.Chp * 4) ||
+      reserve(&t->dxp, (size_t)g.R * g.Cinp * 4) || reserve(&t->wpart, (size_t)g.splits() * g.Cin * g.Ch * 4)) return DCTTS_ERR_HIP;
   float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p;
-  const long n4 = g.R * (g.Cin / 4);
-  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), g.B, g.T, g.Tp, g.pl, g.Cin, 0);
+  *kp = kernel;
+  if (g.padded()) {
+    if (reserve(&t->wpad, (size_t)g.k * g.Cinp * g.Chp * 4)) return DCTTS_ERR_HIP;
+    const long n = (long)g.k * g.Cinp * g.Chp;
+    hipLaunchKernelGGL(pad_matrix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, kernel, (float*)t->wpad.p, g.k, g.Cin, g.Ch, g.Cinp, g.Chp);
+    THIP(hipGetLastError());
+    *kp = (const float*)t->wpad.p;
+    const long ne = g.R * g.Cinp;
+    hipLaunchKernelGGL(pad_rows_generic_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), g.B, g.T, g.Tp, g.pl, g.Cin, g.Cinp, 0);
+  } else {
+    const long n4 = g.R * (g.Cin / 4);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), g.B, g.T, g.Tp, g.pl, g.Cin, 0);
+  }
   THIP(hipGetLastError());
-  THIP(hipMemsetAsync(t->dHp.p, 0, (size_t)g.R * g.Ch * 4, st));
-  THIP(hipMemsetAsync(t->dxp.p, 0, (size_t)g.R * g.Cin * 4, st));
+  THIP(hipMemsetAsync(t->dHp.p, 0, (size_t)g.R * g.Chp * 4, st));
+  THIP(hipMemsetAsync(t->dxp.p, 0, (size_t)g.R * g.Cinp * 4, st));
   for (int j = 0; j < g.k; ++j) {
-    const int rc = gemm<false, false>(st, xp + (long)(j * g.rate) * g.Cin, kernel + (long)j * g.Cin * g.Ch, Hp + (long)g.pr * g.Ch, (int)g.Rv, g.Ch, g.Cin, g.Cin, g.Ch, g.Ch, j > 0);
+    const int rc = gemm<false, false>(st, xp + (long)(j * g.rate) * g.Cinp, *kp + (long)j * g.Cinp * g.Chp, Hp + (long)g.pr * g.Chp, (int)g.Rv, g.Chp, g.Cinp, g.Cinp, g.Chp, g.Chp, j > 0);
     if (rc < 0) return rc;
   }
   return 0;
 }
 
 // dkernel[j] = x_shifted^T . dH (K = every row: split-K partials, fixed-order sum);  dx (+)= dH_shifted . kernel[j]^T;  dx out of its padding
-int conv_grads(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* kernel, float* dkernel, float* dx) {
+int conv_grads(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* kp, float* dkernel, float* dx) {
   float *xp = (float*)t->xp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
   const long nw = (long)g.Cin * g.Ch;
   for (int j = 0; j < g.k; ++j) {
-    const int nz = gemm<true, false>(st, xp + (long)(j * g.rate) * g.Cin, dHp + (long)g.pr * g.Ch, (float*)t->wpart.p, g.Cin, g.Ch, (int)g.Rv, g.Cin, g.Ch, g.Ch, 0, g.splits(), nw);
+    const int nz = gemm<true, false>(st, xp + (long)(j * g.rate) * g.Cinp, dHp + (long)g.pr * g.Chp, (float*)t->wpart.p, g.Cin, g.Ch, (int)g.Rv, g.Cinp, g.Chp, g.Ch, 0, g.splits(), nw);
     if (nz < 0) return nz;
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->wpart.p, nz, nw, nw, dkernel + (long)j * nw);
     THIP(hipGetLastError());
-    const int rc = gemm<false, true>(st, dHp + (long)(g.pl + g.pr - j * g.rate) * g.Ch, kernel + (long)j * nw, dxp + (long)g.pl * g.Cin, (int)g.Rv, g.Cin, g.Ch, g.Ch, g.Ch, g.Cin, 1);
+    const int rc = gemm<false, true>(st, dHp + (long)(g.pl + g.pr - j * g.rate) * g.Chp, kp + (long)j * g.Cinp * g.Chp, dxp + (long)g.pl * g.Cinp, (int)g.Rv, g.Cinp, g.Chp, g.Chp, g.Chp, g.Cinp, 1);
     if (rc < 0) return rc;
   }
-  const long m4 = (long)g.B * g.T * (g.Cin / 4);
-  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, st, dxp, dx, g.B, g.T, g.Tp, g.pl, g.Cin, 1);
+  if (g.padded()) {
+    const long ne = (long)g.B * g.T * g.Cin;
+    hipLaunchKernelGGL(pad_rows_generic_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, dxp, dx, g.B, g.T, g.Tp, g.pl, g.Cin, g.Cinp, 1);
+  } else {
+    const long m4 = (long)g.B * g.T * (g.Cin / 4);
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, st, dxp, dx, g.B, g.T, g.Tp, g.pl, g.Cin, 1);
+  }
   THIP(hipGetLastError());
   return 0;
 }
@@ -142,7 +162,8 @@ extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const flo
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const ConvGeom g(B, T, C, 2 * C, k, rate, causal);
-  int rc = conv_prenorm(t, st, g, x, kernel);
+  const float* kp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
   if (rc) return rc;
   // the row part: dH, the direct part of dx, column sums
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
@@ -154,31 +175,37 @@ extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const flo
   THIP(hipGetLastError());
   hipLaunchKernelGGL(colsum6_kernel, dim3((6 * C + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, C, dg1, db1, dg2, db2, dbias);
   THIP(hipGetLastError());
-  return conv_grads(t, st, g, kernel, dkernel, dx);
+  return conv_grads(t, st, g, kp, dkernel, dx);
 }
 
 extern "C" int dctts_train_conv1d_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
                                            const float* gamma, const float* beta, int B, int T, int Cin, int Cout, int k, int rate, int causal, int act,
                                            float* dx, float* dkernel, float* dbias, float* dgamma, float* dbeta, void* stream) {
   if (!t || !x || !dy || !kernel || !bias || !gamma || !beta || !dx || !dkernel || !dbias || !dgamma || !dbeta) TFAIL(DCTTS_ERR_ARG, "conv1d_backward: null argument");
-  if (B <= 0 || T <= 0 || Cin <= 0 || (Cin & 3) || (Cout != 256 && Cout != 512 && Cout != 1024) || (k != 1 && k != 3) || rate < 1 || act < 0 || act > 2)
-    TFAIL(DCTTS_ERR_ARG, "conv1d_backward: Cin a multiple of 4, Cout 256, 512 or 1024, k 1 or 3, act 0..2");
+  if (B <= 0 || T <= 0 || Cin <= 0 || Cin > 4096 || Cout <= 0 || Cout > 1088 || (k != 1 && k != 3) || rate < 1 || act < 0 || act > 2)
+    TFAIL(DCTTS_ERR_ARG, "conv1d_backward: 1 <= Cout <= 1088, k 1 or 3, act 0..2");
   DevScope ds(t->device);
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const ConvGeom g(B, T, Cin, Cout, k, rate, causal);
-  int rc = conv_prenorm(t, st, g, x, kernel);
+  const float* kp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
   if (rc) return rc;
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
-  if (reserve(&t->part, (size_t)nblk * 6 * Cout * 4)) return DCTTS_ERR_HIP;
+  if (reserve(&t->part, (size_t)nblk * 6 * std::max(Cout, 256) * 4)) return DCTTS_ERR_HIP;
   CBwdRowsParams q{B, T, g.Tp, Cout, g.pr, (const float*)t->Hp.p, dy, bias, gamma, beta, act, (float*)t->dHp.p, (float*)t->part.p};
   if (Cout == 256) hipLaunchKernelGGL((c_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
   else if (Cout == 512) hipLaunchKernelGGL((c_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
-  else hipLaunchKernelGGL((c_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
+  else if (Cout == 1024) hipLaunchKernelGGL((c_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
+  else {                                           // any other width (80 mel bins, 1025 linear bins): scalar lanes
+    const size_t lds = (size_t)4 * 3 * Cout * 4;
+    if (Cout <= 128) hipLaunchKernelGGL((c_bwd_rows_generic_kernel<2>), dim3(nblk), dim3(256), lds, st, q, g.Chp);
+    else hipLaunchKernelGGL((c_bwd_rows_generic_kernel<17>), dim3(nblk), dim3(256), lds, st, q, g.Chp);
+  }
   THIP(hipGetLastError());
   hipLaunchKernelGGL(colsum3_kernel, dim3((3 * Cout + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, Cout, dgamma, dbeta, dbias);
   THIP(hipGetLastError());
-  return conv_grads(t, st, g, kernel, dkernel, dx);
+  return conv_grads(t, st, g, kp, dkernel, dx);
 }
 
 static int loss_blocks(long n) { return (int)std::min<long>(1024, (n + 2047) / 2048); }

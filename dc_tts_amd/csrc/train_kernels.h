@@ -158,6 +158,30 @@ __global__ void pad_rows_kernel(float* __restrict__ padded, float* __restrict__ 
   reinterpret_cast<float4*>(padded)[i] = (t >= 0 && t < T) ? reinterpret_cast<const float4*>(flat)[((long)b * T + t) * c4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// the same for channel counts that are not multiples of 4: padded rows are Cp = round_up(C, 4) floats wide, the extra columns zero
+__global__ void pad_rows_generic_kernel(float* __restrict__ padded, float* __restrict__ flat, int B, int T, int Tp, int off, int C, int Cp, int reverse) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (reverse) {
+    if (i >= (long)B * T * C) return;
+    const long row = i / C; const int c = (int)(i - row * C);
+    const int b = (int)(row / T), t = (int)(row - (long)b * T);
+    flat[i] = padded[((long)b * Tp + off + t) * Cp + c];
+    return;
+  }
+  if (i >= (long)B * Tp * Cp) return;
+  const long row = i / Cp; const int c = (int)(i - row * Cp);
+  const int b = (int)(row / Tp), tp = (int)(row - (long)b * Tp), t = tp - off;
+  padded[i] = (t >= 0 && t < T && c < C) ? flat[((long)b * T + t) * C + c] : 0.f;
+}
+
+// dst (nmat, Rp, Cp) <- src (nmat, R, C), zero padded
+__global__ void pad_matrix_kernel(const float* __restrict__ src, float* __restrict__ dst, int nmat, int R, int C, int Rp, int Cp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)nmat * Rp * Cp) return;
+  const int c = (int)(i % Cp); const long q = i / Cp; const int r = (int)(q % Rp), m = (int)(q / Rp);
+  dst[i] = (r < R && c < C) ? src[((long)m * R + r) * C + c] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- hc backward, row part
 struct HcBwdRowsParams {
   int B, T, Tp, C;
@@ -321,6 +345,67 @@ __global__ void __launch_bounds__(256) c_bwd_rows_kernel(const CBwdRowsParams p)
   for (int i = threadIdx.x; i < 3 * C; i += 256) {
     const int j = i / C, c = i - j * C;
     p.part[((long)blockIdx.x * 3 + j) * C + c] = (red[0][j][c] + red[1][j][c]) + (red[2][j][c] + red[3][j][c]);
+  }
+}
+
+// The same for any width C <= 64 NI (80 mel bins, 1025 linear bins): lane owns channels lane + 64 i; Hp / dHp rows are Cp floats wide.
+template <int NI>
+__global__ void __launch_bounds__(256) c_bwd_rows_generic_kernel(const CBwdRowsParams p, const int Cp) {
+  extern __shared__ float gred[];                  // [4 waves][3][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.C;
+  const float invC = 1.0f / (float)C;
+  float acc[3][NI];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc[j][i] = 0.f;
+  const long rows = (long)p.B * p.T;
+  for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+    const int b = (int)(r / p.T), t = (int)(r - (long)b * p.T);
+    const float* H = p.Hp + ((long)b * p.Tp + p.h_off + t) * Cp;
+    float h[NI], dxh[NI];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int c = lane + 64 * i; h[i] = c < C ? H[c] + p.bias[c] : 0.f; s1 += h[i]; }
+    const float m = t_wave_sum(s1) * invC;
+    float v1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int c = lane + 64 * i; h[i] = c < C ? h[i] - m : 0.f; v1 += h[i] * h[i]; }
+    const float rs = 1.0f / sqrtf(t_wave_sum(v1) * invC + 1e-12f);
+    float a1 = 0.f, c1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      dxh[i] = 0.f;
+      if (c < C) {
+        const float g = p.g[c], dv = p.dy[r * C + c];
+        h[i] *= rs;
+        const float n = h[i] * g + p.b[c];
+        float dn = dv;
+        if (p.act == 1) dn = n > 0.f ? dv : 0.f;
+        else if (p.act == 2) { const float y = t_sigmoid(n); dn = dv * y * (1.0f - y); }
+        acc[0][i] += dn * h[i]; acc[1][i] += dn;
+        dxh[i] = dn * g;
+        a1 += dxh[i]; c1 += dxh[i] * h[i];
+      }
+    }
+    const float ma = t_wave_sum(a1) * invC, mc = t_wave_sum(c1) * invC;
+    float* dH = p.dHp + ((long)b * p.Tp + p.h_off + t) * Cp;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int c = lane + 64 * i;
+      if (c < C) { const float d = (dxh[i] - ma - h[i] * mc) * rs; dH[c] = d; acc[2][i] += d; }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) { const int c = lane + 64 * i; if (c < C) gred[(wave * 3 + j) * C + c] = acc[j][i]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) {
+    const int j = i / C, c = i - j * C;
+    p.part[((long)blockIdx.x * 3 + j) * C + c] = (gred[(0 * 3 + j) * C + c] + gred[(1 * 3 + j) * C + c]) + (gred[(2 * 3 + j) * C + c] + gred[(3 * 3 + j) * C + c]);
   }
 }
 

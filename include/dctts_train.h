@@ -45,7 +45,7 @@ int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, con
                             float* dx, float* dkernel, float* dbias, float* dg1, float* db1, float* dg2, float* db2, void* stream);
 
 /* Backward of y = conv1d(x) (modules.py:91-141: conv1d(k, dilation `rate`, SAME or CAUSAL) Cin -> Cout, layer-norm, activation).
- *   x, dx (B, T, Cin), Cin a multiple of 4;  dy (B, T, Cout), Cout in {256, 512, 1024};  kernel, dkernel (k, Cin, Cout);
+ *   x, dx (B, T, Cin);  dy (B, T, Cout), Cout <= 1088 (256 / 512 / 1024 take the vector path);  kernel, dkernel (k, Cin, Cout);
  *   bias, gamma, beta and their gradients (Cout);  act: 0 none, 1 relu, 2 sigmoid. */
 int dctts_train_conv1d_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
                                 const float* gamma, const float* beta, int B, int T, int Cin, int Cout, int k, int rate, int causal, int act,

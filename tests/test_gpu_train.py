@@ -55,6 +55,9 @@ def test_hc_backward_vs_oracle(ops, B, T, C, k, rate, padding):
     (2, 45, 128, 512, 1, 1, "same", "relu"),      # TextEnc C_2 (e -> 2d)
     (2, 31, 512, 1024, 1, 1, "same", None),       # SSRN C_10 (c -> 2c)
     (2, 33, 256, 256, 3, 2, "causal", "sigmoid"), # not a layer of the model: the generic k = 3 / sigmoid paths
+    (2, 21, 256, 80, 1, 1, "causal", None),       # AudioDec C_11 (d -> n_mels): a width that is not a multiple of 256
+    (1, 12, 1024, 1025, 1, 1, "same", None),      # SSRN C_13 (2c -> 1 + n_fft / 2): not a multiple of 4 either
+    (1, 10, 1025, 1025, 1, 1, "same", "relu"),    # SSRN C_14 / C_15
 ])
 def test_conv1d_backward_vs_oracle(ops, B, T, Cin, Cout, k, rate, padding, act):
     rng = np.random.default_rng(200 + Cin + Cout)
