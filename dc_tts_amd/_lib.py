@@ -65,6 +65,9 @@ SYMBOLS = {
     "dctts_train_device_bytes": (c_size_t, [c_void_p]),
     "dctts_train_hc_backward": (c_int, [c_void_p] + [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 7 + [c_void_p]),
     "dctts_train_conv1d_backward": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int] * 8 + [c_void_p] * 5 + [c_void_p]),
+    "dctts_train_conv1d_transpose_backward": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_void_p]),
+    "dctts_train_attention_backward": (c_int, [c_void_p] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 3 + [c_void_p]),
+    "dctts_train_embed_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "dctts_train_text2mel_losses": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 4 + [c_void_p]),
     "dctts_train_ssrn_losses": (c_int, [c_void_p] + [c_void_p] * 3 + [ctypes.c_longlong] + [c_void_p] * 3 + [c_void_p]),
     "dctts_train_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, ctypes.c_float, c_void_p]),

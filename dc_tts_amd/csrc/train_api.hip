@@ -25,7 +25,7 @@ struct TBuf { void* p = nullptr; size_t bytes = 0; };
 
 struct dctts_train {
   int device = 0;
-  TBuf xp, Hp, dHp, dxp, part, wpart, lpart, wpad;
+  TBuf xp, Hp, dHp, dxp, part, wpart, lpart, wpad, att;
 };
 
 namespace {
@@ -46,12 +46,20 @@ int reserve(TBuf* b, size_t bytes) {
 template <bool TA, bool TB>
 int gemm(hipStream_t st, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int beta,
          int splits = 1, long zstride = 0) {
-  GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, beta, K, zstride};
+  GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, beta, K, zstride, 0, 0, 0};
   if (splits > 1) p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
   const int nz = (K + p.kchunk - 1) / p.kchunk;
   hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 127) / 128, (M + 127) / 128, nz), dim3(256), 0, st, p);
   if (hipGetLastError() != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "gemm launch failed");
   return nz;
+}
+// nb independent GEMMs of the same shape: A + z * a_zs, B + z * b_zs, C + z * c_zs
+template <bool TA, bool TB>
+int gemm_batched(hipStream_t st, int nb, const float* A, long a_zs, const float* B, long b_zs, float* C, long c_zs, int M, int N, int K, int lda, int ldb, int ldc, int beta) {
+  GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, beta, K, c_zs, 1, a_zs, b_zs};
+  hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 127) / 128, (M + 127) / 128, nb), dim3(256), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "gemm launch failed");
+  return 0;
 }
 }  // namespace
 
@@ -68,14 +76,14 @@ extern "C" int dctts_train_create(dctts_train** out, int device) {
 extern "C" int dctts_train_destroy(dctts_train* t) {
   if (!t) return 0;
   DevScope ds(t->device);
-  for (TBuf* b : {&t->xp, &t->Hp, &t->dHp, &t->dxp, &t->part, &t->wpart, &t->lpart, &t->wpad}) if (b->p) (void)hipFree(b->p);
+  for (TBuf* b : {&t->xp, &t->Hp, &t->dHp, &t->dxp, &t->part, &t->wpart, &t->lpart, &t->wpad, &t->att}) if (b->p) (void)hipFree(b->p);
   delete t;
   return 0;
 }
 
 extern "C" size_t dctts_train_device_bytes(const dctts_train* t) {
   if (!t) return 0;
-  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes + t->wpad.bytes;
+  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes + t->wpad.bytes + t->att.bytes;
 }
 
 namespace {
@@ -148,6 +156,21 @@ int conv_grads(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* k
   THIP(hipGetLastError());
   return 0;
 }
+
+// the row part of a conv1d / conv1d_transpose backward: vector lanes for the widths of the hidden layers, scalar lanes otherwise
+int launch_c_rows(dctts_train* t, hipStream_t st, const CBwdRowsParams& q, int Cp, int nblk) {
+  const int C = q.C;
+  if (C == 256 && Cp == C) hipLaunchKernelGGL((c_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
+  else if (C == 512 && Cp == C) hipLaunchKernelGGL((c_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
+  else if (C == 1024 && Cp == C) hipLaunchKernelGGL((c_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
+  else {
+    const size_t lds = (size_t)4 * 3 * C * 4;
+    if (C <= 128) hipLaunchKernelGGL((c_bwd_rows_generic_kernel<2>), dim3(nblk), dim3(256), lds, st, q, Cp);
+    else hipLaunchKernelGGL((c_bwd_rows_generic_kernel<17>), dim3(nblk), dim3(256), lds, st, q, Cp);
+  }
+  THIP(hipGetLastError());
+  return 0;
+}
 }  // namespace
 
 extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
@@ -194,18 +217,104 @@ extern "C" int dctts_train_conv1d_backward(dctts_train* t, const float* x, const
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
   if (reserve(&t->part, (size_t)nblk * 6 * std::max(Cout, 256) * 4)) return DCTTS_ERR_HIP;
   CBwdRowsParams q{B, T, g.Tp, Cout, g.pr, (const float*)t->Hp.p, dy, bias, gamma, beta, act, (float*)t->dHp.p, (float*)t->part.p};
-  if (Cout == 256) hipLaunchKernelGGL((c_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
-  else if (Cout == 512) hipLaunchKernelGGL((c_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
-  else if (Cout == 1024) hipLaunchKernelGGL((c_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
-  else {                                           // any other width (80 mel bins, 1025 linear bins): scalar lanes
-    const size_t lds = (size_t)4 * 3 * Cout * 4;
-    if (Cout <= 128) hipLaunchKernelGGL((c_bwd_rows_generic_kernel<2>), dim3(nblk), dim3(256), lds, st, q, g.Chp);
-    else hipLaunchKernelGGL((c_bwd_rows_generic_kernel<17>), dim3(nblk), dim3(256), lds, st, q, g.Chp);
-  }
-  THIP(hipGetLastError());
+  if ((rc = launch_c_rows(t, st, q, g.Chp, nblk)) != 0) return rc;
   hipLaunchKernelGGL(colsum3_kernel, dim3((3 * Cout + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, Cout, dgamma, dbeta, dbias);
   THIP(hipGetLastError());
   return conv_grads(t, st, g, kp, dkernel, dx);
+}
+
+// modules.py:199-247 backward.  out[2t] = b + x[t] W0^T + x[t-1] W2^T, out[2t+1] = b + x[t] W1^T (W_j = kernel[0][j], Cout x Cin), then layer-norm.
+// x rows get ONE zero row in front of every utterance (flat row r = b (T + 1) + 1 + t); the pre-norm / gradient rows live in a buffer
+// with 2 (T + 1) rows per utterance so that output row 2t + p of an utterance is flat row 2 r + p: every operand of the six GEMMs is a
+// strided view (leading dimension 2 C selects the even or the odd rows).
+extern "C" int dctts_train_conv1d_transpose_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
+                                                     const float* gamma, const float* beta, int B, int T, int Cin, int Cout,
+                                                     float* dx, float* dkernel, float* dbias, float* dgamma, float* dbeta, void* stream) {
+  if (!t || !x || !dy || !kernel || !bias || !gamma || !beta || !dx || !dkernel || !dbias || !dgamma || !dbeta) TFAIL(DCTTS_ERR_ARG, "conv1d_transpose_backward: null argument");
+  if (B <= 0 || T <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || (Cout & 3) || Cout > 1088) TFAIL(DCTTS_ERR_ARG, "conv1d_transpose_backward: Cin, Cout multiples of 4, Cout <= 1088");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const long R = (long)B * (T + 1);
+  const int wt = ((Cin + 127) / 128) * ((Cout + 127) / 128), splits = std::max(1, std::min(64, (512 + wt - 1) / wt));
+  if (reserve(&t->xp, (size_t)R * Cin * 4) || reserve(&t->Hp, (size_t)2 * (R + 1) * Cout * 4) || reserve(&t->dHp, (size_t)2 * (R + 1) * Cout * 4) ||
+      reserve(&t->dxp, (size_t)R * Cin * 4) || reserve(&t->wpart, (size_t)splits * Cin * Cout * 4)) return DCTTS_ERR_HIP;
+  float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
+  const long n4 = R * (Cin / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), B, T, T + 1, 1, Cin, 0);
+  THIP(hipGetLastError());
+  THIP(hipMemsetAsync(dHp, 0, (size_t)2 * (R + 1) * Cout * 4, st));
+  THIP(hipMemsetAsync(dxp, 0, (size_t)R * Cin * 4, st));
+  const long wsz = (long)Cout * Cin;
+  const float *W0 = kernel, *W1 = kernel + wsz, *W2 = kernel + 2 * wsz;
+  const int M = (int)(R - 1);                       // flat rows r = 1 .. R - 1
+  int rc;
+  // pre-norm rows (without bias): even rows 2r, odd rows 2r + 1
+  if ((rc = gemm<false, true>(st, xp + Cin, W0, Hp + 2L * Cout, M, Cout, Cin, Cin, Cin, 2 * Cout, 0)) < 0) return rc;
+  if ((rc = gemm<false, true>(st, xp, W2, Hp + 2L * Cout, M, Cout, Cin, Cin, Cin, 2 * Cout, 1)) < 0) return rc;
+  if ((rc = gemm<false, true>(st, xp + Cin, W1, Hp + 3L * Cout, M, Cout, Cin, Cin, Cin, 2 * Cout, 0)) < 0) return rc;
+  // layer-norm backward over the 2T output rows of every utterance (output row u of utterance b is flat row 2 b (T + 1) + 2 + u)
+  const int nblk = (int)std::min<long>(256, ((long)B * 2 * T + 3) / 4);
+  if (reserve(&t->part, (size_t)nblk * 6 * std::max(Cout, 256) * 4)) return DCTTS_ERR_HIP;
+  CBwdRowsParams q{B, 2 * T, 2 * (T + 1), Cout, 2, Hp, dy, bias, gamma, beta, 0, dHp, (float*)t->part.p};
+  if ((rc = launch_c_rows(t, st, q, Cout, nblk)) != 0) return rc;
+  hipLaunchKernelGGL(colsum3_kernel, dim3((3 * Cout + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, Cout, dgamma, dbeta, dbias);
+  THIP(hipGetLastError());
+  // dW_j (Cout x Cin) = dH_rows^T . x_rows;  dx[r] = dH[2r] W0 + dH[2r+1] W1 + dH[2r+2] W2
+  const float* Aw[3] = {dHp + 2L * Cout, dHp + 3L * Cout, dHp + 2L * Cout};
+  const float* Bw[3] = {xp + Cin, xp + Cin, xp};
+  for (int j = 0; j < 3; ++j) {
+    const int nz = gemm<true, false>(st, Aw[j], Bw[j], (float*)t->wpart.p, Cout, Cin, M, 2 * Cout, Cin, Cin, 0, splits, wsz);
+    if (nz < 0) return nz;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((wsz + 255) / 256)), dim3(256), 0, st, (const float*)t->wpart.p, nz, wsz, wsz, dkernel + (long)j * wsz);
+    THIP(hipGetLastError());
+  }
+  if ((rc = gemm<false, false>(st, dHp + 2L * Cout, W0, dxp + Cin, M, Cin, Cout, 2 * Cout, Cin, Cin, 0)) < 0) return rc;
+  if ((rc = gemm<false, false>(st, dHp + 3L * Cout, W1, dxp + Cin, M, Cin, Cout, 2 * Cout, Cin, Cin, 1)) < 0) return rc;
+  if ((rc = gemm<false, false>(st, dHp + 4L * Cout, W2, dxp + Cin, M, Cin, Cout, 2 * Cout, Cin, Cin, 1)) < 0) return rc;
+  const long m4 = (long)B * T * (Cin / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((m4 + 255) / 256)), dim3(256), 0, st, dxp, dx, B, T, T + 1, 1, Cin, 1);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+// networks.py:126-155 backward, training form (no monotonic mask): A = softmax(Q K^T / sqrt(d)), R = [A V ; Q], alignments = A^T.
+extern "C" int dctts_train_attention_backward(dctts_train* t, const float* Q, const float* K, const float* V, const float* dR, const float* dAl,
+                                              int B, int T, int N, int d, float* dQ, float* dK, float* dV, void* stream) {
+  if (!t || !Q || !K || !V || !dR || !dAl || !dQ || !dK || !dV) TFAIL(DCTTS_ERR_ARG, "attention_backward: null argument");
+  if (B <= 0 || T <= 0 || N <= 0 || (N & 3) || d <= 0 || (d & 3)) TFAIL(DCTTS_ERR_ARG, "attention_backward: N and d multiples of 4");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)B * T;
+  if (reserve(&t->att, (size_t)2 * rows * N * 4)) return DCTTS_ERR_HIP;
+  float* A = (float*)t->att.p; float* dA = A + rows * N;
+  const float scale = 1.0f / std::sqrt((float)d);
+  int rc;
+  // A = softmax(Q K^T * scale)
+  if ((rc = gemm_batched<false, true>(st, B, Q, (long)T * d, K, (long)N * d, A, (long)T * N, T, N, d, d, d, N, 0))) return rc;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, rows, N, N, scale);
+  THIP(hipGetLastError());
+  // dA = dR[:, :, :d] V^T (+ dAl^T in the row kernel);  dV = A^T dR[:, :, :d]
+  if ((rc = gemm_batched<false, true>(st, B, dR, (long)T * 2 * d, V, (long)N * d, dA, (long)T * N, T, N, d, 2 * d, d, N, 0))) return rc;
+  if ((rc = gemm_batched<true, false>(st, B, A, (long)T * N, dR, (long)T * 2 * d, dV, (long)N * d, N, d, T, N, 2 * d, d, 0))) return rc;
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)A, dA, dAl, B, T, N, N, scale);
+  THIP(hipGetLastError());
+  // dQ = dS K + dR[:, :, d:];  dK = dS^T Q      (the 1 / sqrt(d) is folded into dS)
+  hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, dR + d, 2 * d, dQ, rows, d);
+  THIP(hipGetLastError());
+  if ((rc = gemm_batched<false, false>(st, B, dA, (long)T * N, K, (long)N * d, dQ, (long)T * d, T, d, N, N, d, d, 1))) return rc;
+  if ((rc = gemm_batched<true, false>(st, B, dA, (long)T * N, Q, (long)T * d, dK, (long)N * d, N, d, T, N, d, d, 0))) return rc;
+  return 0;
+}
+
+extern "C" int dctts_train_embed_backward(dctts_train* t, const int32_t* ids, const float* dy, long long n, int vocab, int e, float* dtable, void* stream) {
+  if (!t || !ids || !dy || !dtable || n <= 0 || vocab <= 0 || e <= 0) TFAIL(DCTTS_ERR_ARG, "embed_backward: bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(vocab), dim3(256), 0, (hipStream_t)stream, (const int*)ids, dy, (long)n, e, dtable);
+  THIP(hipGetLastError());
+  return 0;
 }
 
 static int loss_blocks(long n) { return (int)std::min<long>(1024, (n + 2047) / 2048); }

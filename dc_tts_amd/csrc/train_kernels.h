@@ -40,6 +40,8 @@ struct GemmParams {
   int beta;                  // 0: C = A'B';  1: C += A'B'
   int kchunk;                // split-K: workgroup z contracts k in [z * kchunk, min(K, (z + 1) * kchunk)) into C + z * c_zstride
   long c_zstride;
+  int batched;               // 1: z is a batch index instead: A + z * a_zs, B + z * b_zs, C + z * c_zstride, the whole K each
+  long a_zs, b_zs;
 };
 
 // A' = TA ? A^T : A (A stored M x K, or K x M when TA);  B' = TB ? B^T : B (B stored K x N, or N x K when TB).
@@ -52,21 +54,23 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = blockIdx.z * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const int kbeg = p.batched ? 0 : blockIdx.z * p.kchunk, kend = p.batched ? p.K : min(p.K, kbeg + p.kchunk);
+  const float* const pA = p.A + (p.batched ? (long)blockIdx.z * p.a_zs : 0L);
+  const float* const pB = p.B + (p.batched ? (long)blockIdx.z * p.b_zs : 0L);
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, l31 = lane & 31, lhi = lane >> 5;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // a tile is 128 x 16 floats = 512 float4: two per thread (i = 0, 1)
   auto load_a = [&](int k0, int i) -> float4 {
     const int idx = tid + i * 256;
-    if (TA) { const int k = k0 + (idx >> 5), m = m0 + (idx & 31) * 4; return (k < kend && m < p.M) ? *reinterpret_cast<const float4*>(p.A + (long)k * p.lda + m) : z4; }
+    if (TA) { const int k = k0 + (idx >> 5), m = m0 + (idx & 31) * 4; return (k < kend && m < p.M) ? *reinterpret_cast<const float4*>(pA + (long)k * p.lda + m) : z4; }
     const int m = m0 + (idx >> 2), k = k0 + (idx & 3) * 4;
-    return (m < p.M && k < kend) ? *reinterpret_cast<const float4*>(p.A + (long)m * p.lda + k) : z4;
+    return (m < p.M && k < kend) ? *reinterpret_cast<const float4*>(pA + (long)m * p.lda + k) : z4;
   };
   auto load_b = [&](int k0, int i) -> float4 {
     const int idx = tid + i * 256;
-    if (!TB) { const int k = k0 + (idx >> 5), n = n0 + (idx & 31) * 4; return (k < kend && n < p.N) ? *reinterpret_cast<const float4*>(p.B + (long)k * p.ldb + n) : z4; }
+    if (!TB) { const int k = k0 + (idx >> 5), n = n0 + (idx & 31) * 4; return (k < kend && n < p.N) ? *reinterpret_cast<const float4*>(pB + (long)k * p.ldb + n) : z4; }
     const int n = n0 + (idx >> 2), k = k0 + (idx & 3) * 4;
-    return (n < p.N && k < kend) ? *reinterpret_cast<const float4*>(p.B + (long)n * p.ldb + k) : z4;
+    return (n < p.N && k < kend) ? *reinterpret_cast<const float4*>(pB + (long)n * p.ldb + k) : z4;
   };
   auto store_t = [&](float (*S)[LD], bool direct, int i, const float4 v) {     // direct: the stored matrix is k-major already
     const int idx = tid + i * 256;
@@ -417,6 +421,57 @@ __global__ void colsum3_kernel(const float* __restrict__ part, int nblk, int C, 
   for (int z = 0; z < nblk; ++z) s += part[(long)z * 3 * C + i];
   const int j = i / C, c = i - j * C;
   (j == 0 ? dg : (j == 1 ? db : dbias))[c] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- attention backward, row parts
+// S (rows, Np) <- softmax over the first N columns of scale * S, in place (networks.py:140,148; training: no mask).  Wave per row.
+__global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, long rows, int N, int Np, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  float* s = S + r * Np;
+  float mx = -INFINITY;
+  for (int n = lane; n < N; n += 64) mx = fmaxf(mx, s[n] * scale);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sum = 0.f;
+  for (int n = lane; n < N; n += 64) { const float e = expf(s[n] * scale - mx); s[n] = e; sum += e; }
+  const float inv = 1.0f / t_wave_sum(sum);
+  for (int n = lane; n < N; n += 64) s[n] *= inv;
+}
+
+// dS = A * (dA + dAl^T - sum_n A (dA + dAl^T)) * scale, in place in dA (rows = B * T; dAl is (B, N, T)).  Wave per row.
+__global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const float* __restrict__ A, float* __restrict__ dA, const float* __restrict__ dAl,
+                                                               int B, int T, int N, int Np, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long)B * T) return;
+  const int b = (int)(r / T), t = (int)(r - (long)b * T);
+  const float* a = A + r * Np; float* d = dA + r * Np;
+  const float* al = dAl + (long)b * N * T + t;
+  float dot = 0.f;
+  for (int n = lane; n < N; n += 64) { const float g = d[n] + al[(long)n * T]; d[n] = g; dot += a[n] * g; }
+  dot = t_wave_sum(dot);
+  for (int n = lane; n < N; n += 64) d[n] = a[n] * (d[n] - dot) * scale;
+}
+
+// dst (rows, C) <- src (rows, C) taken from a wider row (ld floats apart)
+__global__ void copy_cols_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const long r = i / C; const int c = (int)(i - r * C);
+  dst[i] = src[r * ld + c];
+}
+
+// modules.py:13-42 backward: dTable[v] = sum of dy rows whose id is v; row 0 (the zero row of the lookup) receives nothing.
+// One workgroup per vocabulary entry, fixed summation order.
+__global__ void __launch_bounds__(256) embed_bwd_kernel(const int* __restrict__ ids, const float* __restrict__ dy, long n, int e, float* __restrict__ dT) {
+  const int v = blockIdx.x;
+  for (int c = threadIdx.x; c < e; c += 256) {
+    float s = 0.f;
+    if (v != 0) for (long i = 0; i < n; ++i) if (ids[i] == v) s += dy[i * e + c];
+    dT[(long)v * e + c] = s;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- losses

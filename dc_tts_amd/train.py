@@ -4,6 +4,9 @@ optimizer for ONE building block, as calls into libdctts_hip.so (include/dctts_t
   reference                                            here
   modules.py:143-197  hc(...) under tf.gradients       TrainOps.hc_backward
   modules.py:91-141   conv1d(...) under tf.gradients   TrainOps.conv1d_backward
+  modules.py:199-247  conv1d_transpose(...)            TrainOps.conv1d_transpose_backward
+  networks.py:126-155 Attention (training form)        TrainOps.attention_backward
+  modules.py:13-42    embed                            TrainOps.embed_backward
   train.py:87,90,93-97  loss_mels, loss_bd1, loss_att  TrainOps.text2mel_losses
   train.py:104,107      loss_mags, loss_bd2            TrainOps.ssrn_losses
   train.py:119-131      clip_by_value + Adam           TrainOps.adam_step  (+ learning_rate_decay = utils.py:142-145)
@@ -110,6 +113,49 @@ class TrainOps:
             B, T, Cin, Cout, k, int(rate), 1 if padding.lower() == "causal" else 0, {None: 0, "relu": 1, "sigmoid": 2}[act],
             _ptr(out["dx"]), _ptr(out["kernel"]), _ptr(out["bias"]), _ptr(out["gamma"]), _ptr(out["beta"]), self._stream()))
         return out
+
+    def conv1d_transpose_backward(self, x: torch.Tensor, dy: torch.Tensor, params: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Gradients of y = conv1d_transpose(x) (modules.py:199-247).  params: kernel (1, 3, Cout, Cin), bias, gamma, beta (Cout)."""
+        _check(x, "x", torch.float32, 3, self.device); _check(dy, "dy", torch.float32, 3, self.device)
+        B, T, Cin = x.shape
+        Cout = params["kernel"].shape[2]
+        want = {"kernel": (1, 3, Cout, Cin), "bias": (Cout,), "gamma": (Cout,), "beta": (Cout,)}
+        if tuple(dy.shape) != (B, 2 * T, Cout):
+            raise ValueError(f"dy {tuple(dy.shape)} != {(B, 2 * T, Cout)}")
+        for n, shp in want.items():
+            _check(params[n], n, torch.float32, len(shp), self.device)
+            if tuple(params[n].shape) != shp:
+                raise ValueError(f"{n}: shape {tuple(params[n].shape)} != {shp}")
+        out = {"dx": torch.empty_like(x)}
+        for n in want:
+            out[n] = torch.empty_like(params[n])
+        self._ok(self.lib.dctts_train_conv1d_transpose_backward(
+            self._h, _ptr(x), _ptr(dy), _ptr(params["kernel"]), _ptr(params["bias"]), _ptr(params["gamma"]), _ptr(params["beta"]), B, T, Cin, Cout,
+            _ptr(out["dx"]), _ptr(out["kernel"]), _ptr(out["bias"]), _ptr(out["gamma"]), _ptr(out["beta"]), self._stream()))
+        return out
+
+    def attention_backward(self, Q, K, V, dR, dalignments) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Gradients (dQ, dK, dV) of Attention(Q, K, V) in its training form (networks.py:126-155, mononotic_attention=False), given
+        dR (B, T, 2d) and the gradient with respect to the returned alignments (B, N, T)."""
+        for t, n in ((Q, "Q"), (K, "K"), (V, "V"), (dR, "dR"), (dalignments, "dalignments")):
+            _check(t, n, torch.float32, 3, self.device)
+        B, T, d = Q.shape
+        N = K.shape[1]
+        if tuple(K.shape) != (B, N, d) or tuple(V.shape) != (B, N, d) or tuple(dR.shape) != (B, T, 2 * d) or tuple(dalignments.shape) != (B, N, T):
+            raise ValueError("attention_backward: shapes do not agree")
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        self._ok(self.lib.dctts_train_attention_backward(self._h, _ptr(Q), _ptr(K), _ptr(V), _ptr(dR), _ptr(dalignments), B, T, N, d,
+                                                         _ptr(dQ), _ptr(dK), _ptr(dV), self._stream()))
+        return dQ, dK, dV
+
+    def embed_backward(self, ids: torch.Tensor, dy: torch.Tensor, vocab: int) -> torch.Tensor:
+        """Gradient of the lookup table (modules.py:13-42; row 0 receives none).  ids (B, N) int32, dy (B, N, e)."""
+        _check(ids, "ids", torch.int32, 2, self.device); _check(dy, "dy", torch.float32, 3, self.device)
+        if tuple(dy.shape[:2]) != tuple(ids.shape):
+            raise ValueError("embed_backward: shapes do not agree")
+        dT = torch.empty(vocab, dy.shape[2], dtype=torch.float32, device=self.device)
+        self._ok(self.lib.dctts_train_embed_backward(self._h, _ptr(ids), _ptr(dy), ids.numel(), int(vocab), dy.shape[2], _ptr(dT), self._stream()))
+        return dT
 
     def text2mel_losses(self, Y, Y_logits, mels, alignments, max_N: int, max_T: int):
         """train.py:85-100: returns (losses (3,) = loss_mels, loss_bd1, loss_att; dY, dY_logits, dalignments)."""

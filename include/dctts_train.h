@@ -1,12 +1,15 @@
 /* dctts_train.h -- C ABI of the first slice of the TRAINING path, MI355X (gfx950).
  *
- * What is here (and nothing else of train.py yet): the backward passes of the highway-convolution block and of conv1d, the losses of
+ * What is here: the backward pass of every building block of networks.py (hc, conv1d, conv1d_transpose, embed, Attention), the losses of
  * train.py:85-110 with their gradients, and the clip + Adam update of train.py:119-131.  A trainer written against the
  * reference would call these where TensorFlow's autodiff / optimizer ran:
  *
  *   reference                                              this library
  *   modules.py:143-197  hc(...) under tf.gradients         dctts_train_hc_backward
  *   modules.py:91-141   conv1d(...) under tf.gradients     dctts_train_conv1d_backward
+ *   modules.py:199-247  conv1d_transpose(...)              dctts_train_conv1d_transpose_backward
+ *   networks.py:126-155 Attention (training form)          dctts_train_attention_backward
+ *   modules.py:13-42    embed                              dctts_train_embed_backward
  *   train.py:87,90,93-97  loss_mels, loss_bd1, loss_att    dctts_train_text2mel_losses
  *   train.py:104,107      loss_mags, loss_bd2              dctts_train_ssrn_losses
  *   train.py:119-131      clip_by_value(-1, 1) + Adam      dctts_train_adam_step   (lr from utils.py:142-145, host side)
@@ -50,6 +53,21 @@ int dctts_train_hc_backward(dctts_train* t, const float* x, const float* dy, con
 int dctts_train_conv1d_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
                                 const float* gamma, const float* beta, int B, int T, int Cin, int Cout, int k, int rate, int causal, int act,
                                 float* dx, float* dkernel, float* dbias, float* dgamma, float* dbeta, void* stream);
+
+/* Backward of y = conv1d_transpose(x) (modules.py:199-247: tf.layers.conv2d_transpose, kernel (1, 3, Cout, Cin), stride 2, 'same',
+ * then layer-norm): x, dx (B, T, Cin); dy (B, 2T, Cout); kernel, dkernel (1, 3, Cout, Cin); Cin, Cout multiples of 4. */
+int dctts_train_conv1d_transpose_backward(dctts_train* t, const float* x, const float* dy, const float* kernel, const float* bias,
+                                          const float* gamma, const float* beta, int B, int T, int Cin, int Cout,
+                                          float* dx, float* dkernel, float* dbias, float* dgamma, float* dbeta, void* stream);
+
+/* Backward of the training-time Attention (networks.py:126-155, mononotic_attention=False): A = softmax(Q K^T / sqrt(d)),
+ * R = [A V ; Q], alignments = A^T.  Q, dQ (B, T, d); K, V, dK, dV (B, N, d); dR (B, T, 2d); dAl (B, N, T) = gradient with respect to
+ * the returned alignments (the guided-attention loss); N and d multiples of 4.  A is recomputed. */
+int dctts_train_attention_backward(dctts_train* t, const float* Q, const float* K, const float* V, const float* dR, const float* dAl,
+                                   int B, int T, int N, int d, float* dQ, float* dK, float* dV, void* stream);
+
+/* Backward of embed (modules.py:13-42): dtable (vocab, e) = rows of dy (n, e) summed per id; row 0 (zeroed at lookup) receives none. */
+int dctts_train_embed_backward(dctts_train* t, const int32_t* ids, const float* dy, long long n, int vocab, int e, float* dtable, void* stream);
 
 /* train.py:85-100.  Y, Y_logits, mels (B, T, n_mels); alignments (B, N, T) as networks.py:153 returns them (N <= max_N,
  * T <= max_T: the reference pads them to (max_N, max_T) with -1 and masks the padding).  losses[3] (device) receives

@@ -108,6 +108,55 @@ def hc_bwd(x, p, dy, rate, padding):
     return {"dx": dx_direct + dx_conv, "kernel": dW, "bias": dbias, "g1": dg1, "b1": db1, "g2": dg2, "b2": db2, "dH": dH}
 
 
+def d_fwd(x, p):
+    """modules.py:199-247 with the parameters as a dict: kernel (1, 3, Cout, Cin), bias, gamma, beta."""
+    P = {"s/conv2d_transpose/kernel": p["kernel"], "s/conv2d_transpose/bias": p["bias"], "s/normalize/gamma": p["gamma"], "s/normalize/beta": p["beta"]}
+    return O.conv1d_transpose(x, P, "s")
+
+
+def d_bwd(x, p, dy):
+    """Backward of conv1d_transpose (out[2t] = b + x[t] W0^T + x[t-1] W2^T, out[2t+1] = b + x[t] W1^T, then layer-norm).
+    Returns dict(dx, kernel (1, 3, Cout, Cin), bias, gamma, beta)."""
+    W = p["kernel"][0]
+    B, T, _ = x.shape
+    xm1 = np.pad(x, ((0, 0), (1, 0), (0, 0)))[:, :T, :]
+    H = np.zeros((B, 2 * T, W.shape[1]), x.dtype)
+    H[:, 0::2, :] = x @ W[0].T + xm1 @ W[2].T
+    H[:, 1::2, :] = x @ W[1].T
+    H = H + p["bias"]
+    dH, dg, db = normalize_bwd(H, p["gamma"], dy)
+    de, do = dH[:, 0::2, :], dH[:, 1::2, :]
+    dW = np.zeros_like(W)
+    dW[0] = np.einsum("bto,bti->oi", de, x)
+    dW[1] = np.einsum("bto,bti->oi", do, x)
+    dW[2] = np.einsum("bto,bti->oi", de, xm1)
+    dx = de @ W[0] + do @ W[1]
+    dx[:, :-1, :] += de[:, 1:, :] @ W[2]                  # x[t] also feeds out[2(t+1)] through the t-1 tap
+    return {"dx": dx, "kernel": dW[None], "bias": dH.sum(axis=(0, 1)), "gamma": dg, "beta": db}
+
+
+def attention_bwd(Q, K, V, dR, dAl, d):
+    """Backward of the training-time Attention (networks.py:126-155 with mononotic_attention=False): A = softmax(Q K^T / sqrt(d)),
+    R = [A V ; Q], alignments = A^T.  dR (B, T, 2d), dAl (B, N, T) = gradient with respect to the returned alignments.
+    Returns (dQ, dK, dV)."""
+    scale = 1.0 / np.sqrt(float(d))
+    S = (Q @ K.transpose(0, 2, 1)) * scale
+    A = np.exp(S - S.max(axis=-1, keepdims=True)); A /= A.sum(axis=-1, keepdims=True)
+    dRA = dR[..., :d]
+    dA = dRA @ V.transpose(0, 2, 1) + dAl.transpose(0, 2, 1)
+    dV = A.transpose(0, 2, 1) @ dRA
+    dS = A * (dA - (A * dA).sum(axis=-1, keepdims=True)) * scale
+    return dS @ K + dR[..., d:], dS.transpose(0, 2, 1) @ Q, dV
+
+
+def embed_bwd(ids, dy, vocab):
+    """Backward of embed (modules.py:13-42): row 0 of the table is replaced by zeros at lookup time (:36-38), so it receives none."""
+    dT = np.zeros((vocab, dy.shape[-1]), dy.dtype)
+    np.add.at(dT, ids.reshape(-1), dy.reshape(-1, dy.shape[-1]))
+    dT[0] = 0
+    return dT
+
+
 # ----------------------------------------------------------------------------- utils.py / train.py
 def guided_attention(max_N, max_T, g=0.2):
     """utils.py:134-140:  W[n, t] = 1 - exp(-(t / max_T - n / max_N)^2 / (2 g^2))."""

@@ -73,6 +73,36 @@ def test_conv1d_backward_vs_oracle(ops, B, T, Cin, Cout, k, rate, padding, act):
         assert e < 2e-5, f"{name}: relative error {e}"
 
 
+@pytest.mark.parametrize("B,T,C", [(2, 23, 512), (3, 16, 256)])
+def test_conv1d_transpose_backward_vs_oracle(ops, B, T, C):
+    rng = np.random.default_rng(300 + C)
+    p = {"kernel": rng.normal(0, (3 * C) ** -0.5, (1, 3, C, C)), "bias": rng.normal(0, 0.1, C), "gamma": 1 + rng.normal(0, 0.1, C), "beta": rng.normal(0, 0.3, C)}
+    p = {n: v.astype(np.float32).astype(np.float64) for n, v in p.items()}
+    x = rng.normal(0, 1, (B, T, C)).astype(np.float32).astype(np.float64)
+    dy = rng.normal(0, 1, (B, 2 * T, C)).astype(np.float32).astype(np.float64)
+    ref = TR.d_bwd(x, p, dy)
+    got = ops.conv1d_transpose_backward(dev(x), dev(dy), {n: dev(v) for n, v in p.items()})
+    torch.cuda.synchronize()
+    for name in ("dx", "kernel", "bias", "gamma", "beta"):
+        e = rel(got[name].cpu().numpy().astype(np.float64), ref[name])
+        assert e < 2e-5, f"{name}: relative error {e}"
+
+
+def test_attention_and_embed_backward_vs_oracle(ops):
+    rng = np.random.default_rng(41)
+    B, T, N, d = 3, 50, 36, 256
+    f = lambda *s: rng.normal(0, 1, s).astype(np.float32).astype(np.float64)
+    Q, K, V, dR, dAl = f(B, T, d), f(B, N, d), f(B, N, d), f(B, T, 2 * d), f(B, N, T)
+    rQ, rK, rV = TR.attention_bwd(Q, K, V, dR, dAl, d)
+    gQ, gK, gV = ops.attention_backward(dev(Q), dev(K), dev(V), dev(dR), dev(dAl))
+    torch.cuda.synchronize()
+    assert rel(gQ.cpu().numpy(), rQ) < 2e-5 and rel(gK.cpu().numpy(), rK) < 2e-5 and rel(gV.cpu().numpy(), rV) < 2e-5
+    ids = rng.integers(0, 32, (4, 60)).astype(np.int32); dy = f(4, 60, 128)
+    gT = ops.embed_backward(torch.from_numpy(ids).cuda(), dev(dy), 32)
+    torch.cuda.synchronize()
+    assert rel(gT.cpu().numpy(), TR.embed_bwd(ids, dy, 32)) < 1e-5 and float(gT[0].abs().max()) == 0.0
+
+
 def test_audioenc_backward_end_to_end(ops, weights):
     """A whole network's backward pass on the GPU: AudioEnc (networks.py:73-124: 3 conv1d + 10 highway blocks, all CAUSAL), layer by
     layer in reverse with the HIP kernels, against the float64 oracle chain: d(loss)/d(S) and every parameter gradient.  The layer

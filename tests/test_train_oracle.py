@@ -52,6 +52,37 @@ def test_conv1d_backward_matches_finite_differences(k, rate, padding, act):
         np.testing.assert_allclose(g[name], _fd(loss, p[name]), rtol=1e-5, atol=1e-7, err_msg=name)
 
 
+def test_conv1d_transpose_backward_matches_finite_differences():
+    rng = np.random.default_rng(16)
+    B, T, Ci, Co = 2, 5, 4, 6
+    p = {"kernel": rng.normal(0, 0.4, (1, 3, Co, Ci)), "bias": rng.normal(0, 0.1, Co), "gamma": 1 + rng.normal(0, 0.1, Co), "beta": rng.normal(0, 0.3, Co)}
+    x = rng.normal(0, 1, (B, T, Ci)); dy = rng.normal(0, 1, (B, 2 * T, Co))
+    g = TR.d_bwd(x, p, dy)
+    loss = lambda: float((TR.d_fwd(x, p) * dy).sum())
+    np.testing.assert_allclose(g["dx"], _fd(loss, x), rtol=1e-5, atol=1e-7)
+    for name in ("kernel", "bias", "gamma", "beta"):
+        np.testing.assert_allclose(g[name], _fd(loss, p[name]), rtol=1e-5, atol=1e-7, err_msg=name)
+
+
+def test_attention_and_embed_backward_match_finite_differences():
+    from dc_tts_amd.hyperparams import hp
+    rng = np.random.default_rng(17)
+    B, T, N, d = 2, 5, 4, 6
+    h = hp.replace(d=d)
+    Q, K, V = rng.normal(0, 1, (B, T, d)), rng.normal(0, 1, (B, N, d)), rng.normal(0, 1, (B, N, d))
+    dR, dAl = rng.normal(0, 1, (B, T, 2 * d)), rng.normal(0, 1, (B, N, T))
+    def loss():
+        R, al, _ = O.Attention(Q, K, V, h)
+        return float((R * dR).sum() + (al * dAl).sum())
+    dQ, dK, dV = TR.attention_bwd(Q, K, V, dR, dAl, d)
+    np.testing.assert_allclose(dQ, _fd(loss, Q), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dK, _fd(loss, K), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(dV, _fd(loss, V), rtol=1e-5, atol=1e-7)
+    ids = rng.integers(0, 5, (3, 7)); table = rng.normal(0, 1, (5, 4)); dy = rng.normal(0, 1, (3, 7, 4))
+    f = lambda: float((O.embed(ids, table) * dy).sum())
+    np.testing.assert_allclose(TR.embed_bwd(ids, dy, 5), _fd(f, table), rtol=1e-6, atol=1e-8)
+
+
 def test_normalize_and_conv_backward():
     rng = np.random.default_rng(6)
     x = rng.normal(0, 1, (2, 5, 7)); gam = 1 + rng.normal(0, 0.1, 7); bet = rng.normal(0, 0.1, 7); dy = rng.normal(0, 1, (2, 5, 7))
