@@ -157,6 +157,59 @@ def embed_bwd(ids, dy, vocab):
     return dT
 
 
+# ----------------------------------------------------------------------------- networks.py, one network forward / backward
+def _layer_params(W, sc, L):
+    if L.kind == "HC":
+        return {"kernel": W[sc + "/conv1d/kernel"], "bias": W[sc + "/conv1d/bias"], "g1": W[sc + "/H1/gamma"], "b1": W[sc + "/H1/beta"],
+                "g2": W[sc + "/H2/gamma"], "b2": W[sc + "/H2/beta"]}
+    if L.kind == "D":
+        return {"kernel": W[sc + "/conv2d_transpose/kernel"], "bias": W[sc + "/conv2d_transpose/bias"], "gamma": W[sc + "/normalize/gamma"], "beta": W[sc + "/normalize/beta"]}
+    return {"kernel": W[sc + "/conv1d/kernel"], "bias": W[sc + "/conv1d/bias"], "gamma": W[sc + "/normalize/gamma"], "beta": W[sc + "/normalize/beta"]}
+
+
+_NAMES = {"HC": {"kernel": "/conv1d/kernel", "bias": "/conv1d/bias", "g1": "/H1/gamma", "b1": "/H1/beta", "g2": "/H2/gamma", "b2": "/H2/beta"},
+          "C": {"kernel": "/conv1d/kernel", "bias": "/conv1d/bias", "gamma": "/normalize/gamma", "beta": "/normalize/beta"},
+          "D": {"kernel": "/conv2d_transpose/kernel", "bias": "/conv2d_transpose/bias", "gamma": "/normalize/gamma", "beta": "/normalize/beta"}}
+
+
+def network_forward(layers, W, prefix, x, padding):
+    """One network of networks.py as its layer list (dc_tts_amd.layers.*_layers): returns (output, inputs of every layer).
+    x: the first layer's input (character ids when that layer is the embedding)."""
+    xs = []
+    for L in layers:
+        sc = prefix + "/" + L.scope
+        xs.append(x)
+        act = None if L.act == "none" else L.act
+        if L.kind == "E":
+            x = O.embed(x, W[sc + "/lookup_table"])
+        elif L.kind == "HC":
+            x = hc_fwd(x, _layer_params(W, sc, L), L.rate, padding)
+        elif L.kind == "D":
+            x = d_fwd(x, _layer_params(W, sc, L))
+        else:
+            x = c_fwd(x, _layer_params(W, sc, L), L.rate, padding, act)
+    return x, xs
+
+
+def network_backward(layers, W, prefix, xs, dy, padding):
+    """Reverse pass over the same layer list: returns (gradient of the first layer's input or None for an embedding,
+    {TF variable name: gradient})."""
+    grads, g = {}, dy
+    for L, xin in zip(reversed(layers), reversed(xs)):
+        sc = prefix + "/" + L.scope
+        act = None if L.act == "none" else L.act
+        if L.kind == "E":
+            grads[sc + "/lookup_table"] = embed_bwd(xin, g, W[sc + "/lookup_table"].shape[0])
+            g = None
+            continue
+        p = _layer_params(W, sc, L)
+        r = hc_bwd(xin, p, g, L.rate, padding) if L.kind == "HC" else (d_bwd(xin, p, g) if L.kind == "D" else c_bwd(xin, p, g, L.rate, padding, act))
+        for n, suffix in _NAMES[L.kind].items():
+            grads[sc + suffix] = r[n]
+        g = r["dx"]
+    return g, grads
+
+
 # ----------------------------------------------------------------------------- utils.py / train.py
 def guided_attention(max_N, max_T, g=0.2):
     """utils.py:134-140:  W[n, t] = 1 - exp(-(t / max_T - n / max_N)^2 / (2 g^2))."""

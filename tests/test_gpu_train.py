@@ -145,6 +145,92 @@ def test_audioenc_backward_end_to_end(ops, weights):
     assert e < 1e-4 and worst < 1e-4, (e, worst)                  # 13 layers of fp32 error accumulate on the way down
 
 
+def _small_weights(h, seed):
+    """Seeded weights of the whole model at hyper-parameters h, rounded to fp32 and widened (both sides see the same numbers)."""
+    from dc_tts_amd.weights import synthetic_weights
+    return {n: np.asarray(v, np.float32).astype(np.float64) for n, v in synthetic_weights(h, seed=seed, perturb=True).items()}
+
+
+def _compare(grads_gpu, grads_ref, tol):
+    worst, worst_name = 0.0, ""
+    assert set(grads_gpu) == set(grads_ref)
+    for n, r in grads_ref.items():
+        e = rel(grads_gpu[n].cpu().numpy().astype(np.float64), r)
+        if e > worst:
+            worst, worst_name = e, n
+    assert worst < tol, (worst_name, worst)
+    return worst
+
+
+def test_ssrn_training_gradients_end_to_end(ops):
+    """train.py num == 2: SSRN(mels) -> loss_mags + loss_bd2 (train.py:102-110) -> every SSRN parameter gradient, on the GPU (losses
+    + the reverse pass over all 18 layers incl. both transposed convolutions and the 1025-channel output layers) against the float64
+    oracle.  Layer inputs come from the oracle's forward pass."""
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.layers import ssrn_layers
+    from dc_tts_amd.train import network_backward
+    from oracle import dctts_ref as O
+    rng = np.random.default_rng(51)
+    W = _small_weights(hp, 77)
+    B, T = 1, 6
+    mels = rng.uniform(0, 1, (B, T, hp.n_mels)).astype(np.float32).astype(np.float64)
+    mags = rng.uniform(0, 1, (B, 4 * T, hp.n_linear)).astype(np.float32).astype(np.float64)
+    layers = ssrn_layers(hp)
+    logits, xs = TR.network_forward(layers, W, "SSRN", mels, "same")
+    Z = O.sigmoid(logits)
+    (l1, l2), (dZ, dlog) = TR.ssrn_losses(Z, logits, mags)
+    _, gref = TR.network_backward(layers, W, "SSRN", xs, dlog + dZ * Z * (1 - Z), "same")
+    Wd = {n: dev(v) for n, v in W.items() if n.startswith("SSRN/")}
+    losses, gZ, glog = ops.ssrn_losses(dev(Z), dev(logits), dev(mags))
+    Zd = dev(Z)
+    _, ggpu = network_backward(ops, layers, Wd, "SSRN", [dev(x) for x in xs], glog + gZ * Zd * (1 - Zd), "same")
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), [l1, l2], rtol=2e-5)
+    _compare(ggpu, gref, 2e-4)
+
+
+def test_text2mel_training_gradients_end_to_end(ops):
+    """train.py num == 1: TextEnc, AudioEnc, Attention (training form), AudioDec, loss_mels + loss_bd1 + loss_att (train.py:49-100)
+    -> the gradient of every Text2Mel variable (embedding table included), GPU against the float64 oracle."""
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.layers import audiodec_layers, audioenc_layers, textenc_layers
+    from dc_tts_amd.train import network_backward
+    from oracle import dctts_ref as O
+    rng = np.random.default_rng(52)
+    W = _small_weights(hp, 78)
+    B, N, T, d = 2, 12, 10, hp.d
+    ids = rng.integers(1, len(hp.vocab), (B, N)).astype(np.int32); ids[:, -2:] = 0
+    mels = rng.uniform(0, 1, (B, T, hp.n_mels)).astype(np.float32).astype(np.float64)
+    S = np.concatenate((np.zeros_like(mels[:, :1]), mels[:, :-1]), 1)                       # train.py:51
+    te, ae, ad = textenc_layers(hp), audioenc_layers(hp), audiodec_layers(hp)
+    KV, xs_te = TR.network_forward(te, W, "Text2Mel/TextEnc", ids, "same")
+    K, V = KV[..., :d], KV[..., d:]
+    Q, xs_ae = TR.network_forward(ae, W, "Text2Mel/AudioEnc", S, "causal")
+    R, al, _ = O.Attention(Q, K, V, hp)
+    logits, xs_ad = TR.network_forward(ad, W, "Text2Mel/AudioDec", R, "causal")
+    Y = O.sigmoid(logits)
+    (l1, l2, l3), (dY, dlog, dA) = TR.text2mel_losses(Y, logits, mels, al, hp.max_N, hp.max_T)
+    gref = {}
+    dR, g = TR.network_backward(ad, W, "Text2Mel/AudioDec", xs_ad, dlog + dY * Y * (1 - Y), "causal"); gref.update(g)
+    dQ, dK, dV = TR.attention_bwd(Q, K, V, dR, dA, d)
+    _, g = TR.network_backward(ae, W, "Text2Mel/AudioEnc", xs_ae, dQ, "causal"); gref.update(g)
+    _, g = TR.network_backward(te, W, "Text2Mel/TextEnc", xs_te, np.concatenate((dK, dV), -1), "same"); gref.update(g)
+    # the same on the GPU
+    Wd = {n: dev(v) for n, v in W.items() if n.startswith("Text2Mel/")}
+    to = lambda xs: [torch.from_numpy(x).cuda() if x.dtype == np.int32 else dev(x) for x in xs]
+    Yd = dev(Y)
+    losses, gY, glog, gA = ops.text2mel_losses(Yd, dev(logits), dev(mels), dev(al), hp.max_N, hp.max_T)
+    ggpu = {}
+    gR, g = network_backward(ops, ad, Wd, "Text2Mel/AudioDec", to(xs_ad), glog + gY * Yd * (1 - Yd), "causal"); ggpu.update(g)
+    gQ, gK, gV = ops.attention_backward(dev(Q), dev(K), dev(V), gR, gA)
+    _, g = network_backward(ops, ae, Wd, "Text2Mel/AudioEnc", to(xs_ae), gQ, "causal"); ggpu.update(g)
+    _, g = network_backward(ops, te, Wd, "Text2Mel/TextEnc", to(xs_te), torch.cat((gK, gV), -1).contiguous(), "same"); ggpu.update(g)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(losses.cpu().numpy(), [l1, l2, l3], rtol=2e-5)
+    assert len(gref) == len([n for n in W if n.startswith("Text2Mel/")])                   # every Text2Mel variable has a gradient
+    _compare(ggpu, gref, 5e-4)
+
+
 def test_hc_backward_is_reproducible_and_rejects_bad_shapes(ops):
     rng = np.random.default_rng(3)
     C = 256
