@@ -29,3 +29,34 @@ n = 52_380_671
 var = torch.zeros(n, device="cuda"); grad = torch.randn(n, device="cuda"); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
 ms = timed(lambda: ops.adam_step(var, grad, m, v, 1, 1e-3))
 print(f"| adam_step (all {n} parameters as one array) | | {ms:.3f} | | | ({7 * n * 4 / ms / 1e6:.0f} GB/s = {7 * n * 4 / ms / 1e6 / 8000:.2f} of the HBM roof) |")
+
+# ---- whole-network reverse passes at training shapes (B = 32, T = 210, N = 180): activations are random tensors of the right shapes
+from dc_tts_amd.hyperparams import hp
+from dc_tts_amd.layers import audiodec_layers, audioenc_layers, ssrn_layers, textenc_layers
+from dc_tts_amd.train import network_backward
+from dc_tts_amd.weights import synthetic_weights
+Wd = {n: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).cuda() for n, v in synthetic_weights(hp, seed=1).items()}
+def acts(layers, B, T, x0):
+    xs, t = [], T
+    for L in layers:
+        xs.append(x0 if L.kind == "E" else torch.randn(B, t, L.cin, device="cuda"))
+        if L.kind == "D": t *= 2
+    return xs, t
+B, T, N = 32, 210, 180
+ids = torch.randint(1, len(hp.vocab), (B, N), dtype=torch.int32, device="cuda")
+nets = [("SSRN", ssrn_layers(hp), "SSRN", T, None, "same"), ("AudioDec", audiodec_layers(hp), "Text2Mel/AudioDec", T, None, "causal"),
+        ("AudioEnc", audioenc_layers(hp), "Text2Mel/AudioEnc", T, None, "causal"), ("TextEnc", textenc_layers(hp), "Text2Mel/TextEnc", N, ids, "same")]
+total = {}
+for name, layers, prefix, rows, x0, pad in nets:
+    xs, t_out = acts(layers, B, rows, x0)
+    dy = torch.randn(B, t_out, layers[-1].cout, device="cuda")
+    ms = timed(lambda: network_backward(ops, layers, Wd, prefix, xs, dy, pad), n=3)
+    flop = sum(3 * 2.0 * B * (rows * (2 if False else 1)) * L.size * L.cin * L.conv_filters for L in layers if L.kind in ("C", "HC"))
+    total[name] = ms
+    print(f"| reverse pass over {name} ({len(layers)} layers) | B={B} rows={rows} | {ms:.2f} | | | |")
+Q = torch.randn(B, T, hp.d, device="cuda"); K = torch.randn(B, N, hp.d, device="cuda"); V = torch.randn(B, N, hp.d, device="cuda")
+dR = torch.randn(B, T, 2 * hp.d, device="cuda"); dAl = torch.randn(B, N, T, device="cuda")
+ms = timed(lambda: ops.attention_backward(Q, K, V, dR, dAl))
+print(f"| attention_backward | B={B} T={T} N={N} d={hp.d} | {ms:.3f} | | | |")
+print(f"| **Text2Mel gradients** (AudioDec + attention + AudioEnc + TextEnc + losses) | | {total['AudioDec'] + total['AudioEnc'] + total['TextEnc'] + ms + 0.03:.2f} | | | |")
+print(f"| **SSRN gradients** (reverse pass + losses) | | {total['SSRN'] + 0.1:.2f} | | | |")
