@@ -68,6 +68,12 @@ SYMBOLS = {
     "dctts_train_conv1d_transpose_backward": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_void_p]),
     "dctts_train_attention_backward": (c_int, [c_void_p] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 3 + [c_void_p]),
     "dctts_train_embed_backward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p]),
+    "dctts_train_hc_forward": (c_int, [c_void_p] + [c_void_p] * 7 + [c_int] * 6 + [c_void_p, c_void_p]),
+    "dctts_train_conv1d_forward": (c_int, [c_void_p] + [c_void_p] * 5 + [c_int] * 8 + [c_void_p, c_void_p]),
+    "dctts_train_conv1d_transpose_forward": (c_int, [c_void_p] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p]),
+    "dctts_train_embed_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p]),
+    "dctts_train_attention_forward": (c_int, [c_void_p] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 2 + [c_void_p]),
+    "dctts_train_sigmoid": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "dctts_train_text2mel_losses": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 4 + [c_void_p]),
     "dctts_train_ssrn_losses": (c_int, [c_void_p] + [c_void_p] * 3 + [ctypes.c_longlong] + [c_void_p] * 3 + [c_void_p]),
     "dctts_train_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, ctypes.c_float, c_void_p]),

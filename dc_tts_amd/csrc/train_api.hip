@@ -278,6 +278,110 @@ extern "C" int dctts_train_conv1d_transpose_backward(dctts_train* t, const float
   return 0;
 }
 
+// ---- forward passes on the TF-layout variables a trainer holds (the inference context reads MFMA-packed copies made once at upload)
+extern "C" int dctts_train_hc_forward(dctts_train* t, const float* x, const float* kernel, const float* bias, const float* g1, const float* b1,
+                                      const float* g2, const float* b2, int B, int T, int C, int k, int rate, int causal, float* y, void* stream) {
+  if (!t || !x || !kernel || !bias || !g1 || !b1 || !g2 || !b2 || !y) TFAIL(DCTTS_ERR_ARG, "hc_forward: null argument");
+  if (B <= 0 || T <= 0 || (C != 256 && C != 512 && C != 1024) || (k != 1 && k != 3) || rate < 1) TFAIL(DCTTS_ERR_ARG, "hc_forward: C must be 256, 512 or 1024, k 1 or 3, rate >= 1");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const ConvGeom g(B, T, C, 2 * C, k, rate, causal);
+  const float* kp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
+  if (rc) return rc;
+  HcFwdRowsParams q{B, T, g.Tp, C, g.pr, (const float*)t->Hp.p, x, bias, g1, b1, g2, b2, y};
+  const unsigned nb = (unsigned)(((long)B * T + 3) / 4);
+  if (C == 256) hipLaunchKernelGGL((hc_fwd_rows_kernel<1>), dim3(nb), dim3(256), 0, st, q);
+  else if (C == 512) hipLaunchKernelGGL((hc_fwd_rows_kernel<2>), dim3(nb), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL((hc_fwd_rows_kernel<4>), dim3(nb), dim3(256), 0, st, q);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_train_conv1d_forward(dctts_train* t, const float* x, const float* kernel, const float* bias, const float* gamma, const float* beta,
+                                          int B, int T, int Cin, int Cout, int k, int rate, int causal, int act, float* y, void* stream) {
+  if (!t || !x || !kernel || !bias || !gamma || !beta || !y) TFAIL(DCTTS_ERR_ARG, "conv1d_forward: null argument");
+  if (B <= 0 || T <= 0 || Cin <= 0 || Cin > 4096 || Cout <= 0 || Cout > 1088 || (k != 1 && k != 3) || rate < 1 || act < 0 || act > 2) TFAIL(DCTTS_ERR_ARG, "conv1d_forward: 1 <= Cout <= 1088, k 1 or 3, act 0..2");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const ConvGeom g(B, T, Cin, Cout, k, rate, causal);
+  const float* kp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
+  if (rc) return rc;
+  CFwdRowsParams q{B, T, g.Tp, Cout, g.Chp, g.pr, (const float*)t->Hp.p, bias, gamma, beta, act, y};
+  hipLaunchKernelGGL(c_fwd_rows_kernel, dim3((unsigned)(((long)B * T + 3) / 4)), dim3(256), 0, st, q);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_train_conv1d_transpose_forward(dctts_train* t, const float* x, const float* kernel, const float* bias, const float* gamma, const float* beta,
+                                                    int B, int T, int Cin, int Cout, float* y, void* stream) {
+  if (!t || !x || !kernel || !bias || !gamma || !beta || !y) TFAIL(DCTTS_ERR_ARG, "conv1d_transpose_forward: null argument");
+  if (B <= 0 || T <= 0 || Cin <= 0 || (Cin & 3) || Cout <= 0 || (Cout & 3) || Cout > 1088) TFAIL(DCTTS_ERR_ARG, "conv1d_transpose_forward: Cin, Cout multiples of 4, Cout <= 1088");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const long R = (long)B * (T + 1);
+  if (reserve(&t->xp, (size_t)R * Cin * 4) || reserve(&t->Hp, (size_t)2 * (R + 1) * Cout * 4)) return DCTTS_ERR_HIP;
+  float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p;
+  const long n4 = R * (Cin / 4);
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), B, T, T + 1, 1, Cin, 0);
+  THIP(hipGetLastError());
+  const long wsz = (long)Cout * Cin;
+  const int M = (int)(R - 1);
+  int rc;
+  if ((rc = gemm<false, true>(st, xp + Cin, kernel, Hp + 2L * Cout, M, Cout, Cin, Cin, Cin, 2 * Cout, 0)) < 0) return rc;
+  if ((rc = gemm<false, true>(st, xp, kernel + 2 * wsz, Hp + 2L * Cout, M, Cout, Cin, Cin, Cin, 2 * Cout, 1)) < 0) return rc;
+  if ((rc = gemm<false, true>(st, xp + Cin, kernel + wsz, Hp + 3L * Cout, M, Cout, Cin, Cin, Cin, 2 * Cout, 0)) < 0) return rc;
+  CFwdRowsParams q{B, 2 * T, 2 * (T + 1), Cout, Cout, 2, Hp, bias, gamma, beta, 0, y};
+  hipLaunchKernelGGL(c_fwd_rows_kernel, dim3((unsigned)(((long)B * 2 * T + 3) / 4)), dim3(256), 0, st, q);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_train_embed_forward(dctts_train* t, const int32_t* ids, const float* table, long long n, int vocab, int e, float* y, void* stream) {
+  if (!t || !ids || !table || !y || n <= 0 || vocab <= 0 || e <= 0) TFAIL(DCTTS_ERR_ARG, "embed_forward: bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipLaunchKernelGGL(embed_fwd_kernel, dim3((unsigned)((n * e + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const int*)ids, table, (long)n, vocab, e, y);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int dctts_train_sigmoid(dctts_train* t, const float* x, float* y, long long n, void* stream) {
+  if (!t || !x || !y || n <= 0) TFAIL(DCTTS_ERR_ARG, "sigmoid: bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n);
+  THIP(hipGetLastError());
+  return 0;
+}
+
+// networks.py:126-155 forward, training form: R = [softmax(Q K^T / sqrt(d)) V ; Q] (B, T, 2d), alignments (B, N, T)
+extern "C" int dctts_train_attention_forward(dctts_train* t, const float* Q, const float* K, const float* V, int B, int T, int N, int d,
+                                             float* R, float* alignments, void* stream) {
+  if (!t || !Q || !K || !V || !R || !alignments) TFAIL(DCTTS_ERR_ARG, "attention_forward: null argument");
+  if (B <= 0 || T <= 0 || N <= 0 || (N & 3) || d <= 0 || (d & 3)) TFAIL(DCTTS_ERR_ARG, "attention_forward: N and d multiples of 4");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  const long rows = (long)B * T;
+  if (reserve(&t->att, (size_t)2 * rows * N * 4)) return DCTTS_ERR_HIP;
+  float* A = (float*)t->att.p;
+  int rc;
+  if ((rc = gemm_batched<false, true>(st, B, Q, (long)T * d, K, (long)N * d, A, (long)T * N, T, N, d, d, d, N, 0))) return rc;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, rows, N, N, 1.0f / std::sqrt((float)d));
+  THIP(hipGetLastError());
+  if ((rc = gemm_batched<false, false>(st, B, A, (long)T * N, V, (long)N * d, R, (long)T * 2 * d, T, d, N, N, d, 2 * d, 0))) return rc;
+  hipLaunchKernelGGL(scatter_cols_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, Q, R + d, 2 * d, rows, d);
+  THIP(hipGetLastError());
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows * N + 255) / 256)), dim3(256), 0, st, (const float*)A, alignments, B, T, N);
+  THIP(hipGetLastError());
+  return 0;
+}
+
 // networks.py:126-155 backward, training form (no monotonic mask): A = softmax(Q K^T / sqrt(d)), R = [A V ; Q], alignments = A^T.
 extern "C" int dctts_train_attention_backward(dctts_train* t, const float* Q, const float* K, const float* V, const float* dR, const float* dAl,
                                               int B, int T, int N, int d, float* dQ, float* dK, float* dV, void* stream) {

@@ -423,6 +423,99 @@ __global__ void colsum3_kernel(const float* __restrict__ part, int nblk, int C, 
   (j == 0 ? dg : (j == 1 ? db : dbias))[c] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- forward row parts (training keeps TF-layout weights)
+// y = sigmoid(LN(H1)) * LN(H2) + (1 - sigmoid(LN(H1))) * x   (modules.py:189-194), H = Hp + bias.  Wave per row, lane = 4 x NCH channels.
+struct HcFwdRowsParams { int B, T, Tp, C, h_off; const float* Hp; const float* x; const float* bias; const float* g1; const float* b1; const float* g2; const float* b2; float* y; };
+template <int NCH>
+__global__ void __launch_bounds__(256) hc_fwd_rows_kernel(const HcFwdRowsParams p) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long)p.B * p.T) return;
+  const int C = p.C, b = (int)(r / p.T), t = (int)(r - (long)b * p.T);
+  const float invC = 1.0f / (float)C;
+  auto ld = [](const float* q) { return *reinterpret_cast<const tf32x4*>(q); };
+  auto hsum = [](const tf32x4 v) { return v[0] + v[1] + v[2] + v[3]; };
+  const float* H = p.Hp + ((long)b * p.Tp + p.h_off + t) * 2 * C;
+  tf32x4 h1[NCH], h2[NCH];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) { const int c = q * 256 + lane * 4; h1[q] = ld(H + c) + ld(p.bias + c); h2[q] = ld(H + C + c) + ld(p.bias + C + c); s1 += hsum(h1[q]); s2 += hsum(h2[q]); }
+  const float m1 = t_wave_sum(s1) * invC, m2 = t_wave_sum(s2) * invC;
+  float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) { h1[q] -= m1; h2[q] -= m2; v1 += hsum(h1[q] * h1[q]); v2 += hsum(h2[q] * h2[q]); }
+  const float r1 = 1.0f / sqrtf(t_wave_sum(v1) * invC + 1e-12f), r2 = 1.0f / sqrtf(t_wave_sum(v2) * invC + 1e-12f);
+#pragma unroll
+  for (int q = 0; q < NCH; ++q) {
+    const int c = q * 256 + lane * 4;
+    const tf32x4 n1 = h1[q] * r1 * ld(p.g1 + c) + ld(p.b1 + c), n2 = h2[q] * r2 * ld(p.g2 + c) + ld(p.b2 + c), xv = ld(p.x + r * C + c);
+    tf32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float s_ = t_sigmoid(n1[e]); y[e] = s_ * n2[e] + (1.0f - s_) * xv[e]; }
+    *reinterpret_cast<tf32x4*>(p.y + r * C + c) = y;
+  }
+}
+
+// y = act(LN(Hp + bias)) (modules.py:135-138) for any width C <= 1088: lane owns channels lane + 64 i; Hp rows are Cp floats wide.
+struct CFwdRowsParams { int B, T, Tp, C, Cp, h_off; const float* Hp; const float* bias; const float* g; const float* b; int act; float* y; };
+__global__ void __launch_bounds__(256) c_fwd_rows_kernel(const CFwdRowsParams p) {
+  constexpr int NI = 17;
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= (long)p.B * p.T) return;
+  const int C = p.C, b = (int)(r / p.T), t = (int)(r - (long)b * p.T);
+  const float invC = 1.0f / (float)C;
+  const float* H = p.Hp + ((long)b * p.Tp + p.h_off + t) * p.Cp;
+  float h[NI];
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { const int c = lane + 64 * i; h[i] = c < C ? H[c] + p.bias[c] : 0.f; s1 += h[i]; }
+  const float m = t_wave_sum(s1) * invC;
+  float v1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) { const int c = lane + 64 * i; h[i] = c < C ? h[i] - m : 0.f; v1 += h[i] * h[i]; }
+  const float rs = 1.0f / sqrtf(t_wave_sum(v1) * invC + 1e-12f);
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int c = lane + 64 * i;
+    if (c < C) {
+      float n = h[i] * rs * p.g[c] + p.b[c];
+      if (p.act == 1) n = fmaxf(n, 0.f); else if (p.act == 2) n = t_sigmoid(n);
+      p.y[r * C + c] = n;
+    }
+  }
+}
+
+__global__ void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = t_sigmoid(x[i]);
+}
+
+// modules.py:13-42 forward: y[i] = table[ids[i]], row 0 reads as zeros (:36-38); ids outside the table read row 0
+__global__ void embed_fwd_kernel(const int* __restrict__ ids, const float* __restrict__ table, long n, int vocab, int e, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * e) return;
+  const long r = i / e; const int c = (int)(i - r * e);
+  const int id = ids[r];
+  y[i] = (id > 0 && id < vocab) ? table[(long)id * e + c] : 0.f;
+}
+
+// dst (B, C, R) <- src (B, R, C)^T per batch item (alignments = A^T, networks.py:153)
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int R, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * R * C) return;
+  const int r = (int)(i % R); const long q = i / R; const int c = (int)(q % C), b = (int)(q / C);
+  dst[i] = src[((long)b * R + r) * C + c];
+}
+
+// dst rows (ld_dst apart) at column offset <- src rows (C wide)
+__global__ void scatter_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int ld_dst, long rows, int C) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  const long r = i / C; const int c = (int)(i - r * C);
+  dst[r * ld_dst + c] = src[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------------- attention backward, row parts
 // S (rows, Np) <- softmax over the first N columns of scale * S, in place (networks.py:140,148; training: no mask).  Wave per row.
 __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S, long rows, int N, int Np, float scale) {

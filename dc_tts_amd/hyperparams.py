@@ -2,8 +2,8 @@
 
 Mirrors the class attributes of the reference's ``hyperparams.py:7-47`` that the
 synthesis path reads (signal constants, model widths, vocab, max_N / max_T, B).
-Training-only fields (lr, logdir, num_iterations, data paths) are not part of
-the hot path and are omitted.
+Of the training-only fields only ``lr`` (hyperparams.py:43, used by dc_tts_amd/train.py) is kept; logdir,
+num_iterations and the data paths are omitted.
 
 ``max_T`` is overridable (``replace(max_T=1000)``) because the long-form
 configuration of BASELINE.json uses 1000 mel frames; the attention mask is
@@ -36,6 +36,8 @@ class Hyperparams:
     vocab: str = "PE abcdefghijklmnopqrstuvwxyz'.?"
     max_N: int = 180
     max_T: int = 210
+    # training scheme (hyperparams.py:43)
+    lr: float = 0.001
     # batch (hyperparams.py:46)
     B: int = 32
 

@@ -69,6 +69,21 @@ int dctts_train_attention_backward(dctts_train* t, const float* Q, const float* 
 /* Backward of embed (modules.py:13-42): dtable (vocab, e) = rows of dy (n, e) summed per id; row 0 (zeroed at lookup) receives none. */
 int dctts_train_embed_backward(dctts_train* t, const int32_t* ids, const float* dy, long long n, int vocab, int e, float* dtable, void* stream);
 
+/* Forward passes of the same blocks on the TF-layout variables a trainer holds and updates (the inference context of dctts_hip.h
+ * reads MFMA-packed copies made once at upload).  Shapes and arguments as in the matching *_backward; y is the block's output.
+ * conv1d's act: 0 none, 1 relu, 2 sigmoid.  attention_forward is the training form (no monotonic mask): R (B, T, 2d) = [A V ; Q],
+ * alignments (B, N, T) = A^T.  sigmoid: y = 1 / (1 + exp(-x)) elementwise (Y = sigmoid(logits), networks.py:210,290). */
+int dctts_train_hc_forward(dctts_train* t, const float* x, const float* kernel, const float* bias, const float* g1, const float* b1,
+                           const float* g2, const float* b2, int B, int T, int C, int k, int rate, int causal, float* y, void* stream);
+int dctts_train_conv1d_forward(dctts_train* t, const float* x, const float* kernel, const float* bias, const float* gamma, const float* beta,
+                               int B, int T, int Cin, int Cout, int k, int rate, int causal, int act, float* y, void* stream);
+int dctts_train_conv1d_transpose_forward(dctts_train* t, const float* x, const float* kernel, const float* bias, const float* gamma, const float* beta,
+                                         int B, int T, int Cin, int Cout, float* y, void* stream);
+int dctts_train_embed_forward(dctts_train* t, const int32_t* ids, const float* table, long long n, int vocab, int e, float* y, void* stream);
+int dctts_train_attention_forward(dctts_train* t, const float* Q, const float* K, const float* V, int B, int T, int N, int d,
+                                  float* R, float* alignments, void* stream);
+int dctts_train_sigmoid(dctts_train* t, const float* x, float* y, long long n, void* stream);
+
 /* train.py:85-100.  Y, Y_logits, mels (B, T, n_mels); alignments (B, N, T) as networks.py:153 returns them (N <= max_N,
  * T <= max_T: the reference pads them to (max_N, max_T) with -1 and masks the padding).  losses[3] (device) receives
  * loss_mels, loss_bd1, loss_att; dY / dlogits / dA the gradients of their sum with respect to Y (L1 term), Y_logits

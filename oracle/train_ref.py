@@ -265,3 +265,40 @@ def adam_step(var, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
     v = beta2 * v + (1.0 - beta2) * g * g
     lr_t = lr * np.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
     return var - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+# ----------------------------------------------------------------------------- train.py:26-134, one training step
+def train_step(num, W, m, v, global_step, batch, hp):
+    """One `sess.run(g.train_op)` of train.py for Graph(num): forward, losses, gradients of every variable of the network being
+    trained, clip + Adam with the Noam learning rate.  W / m / v: {TF variable name: float64 array}, updated in place.
+    batch: num == 1: (L ids (B, N), mels (B, T, n_mels));  num == 2: (mels (B, T, n_mels), mags (B, 4T, n_linear)).
+    Returns the losses (loss_mels, loss_bd1, loss_att) or (loss_mags, loss_bd2)."""
+    from dc_tts_amd.layers import audiodec_layers, audioenc_layers, ssrn_layers, textenc_layers
+    grads = {}
+    if num == 1:
+        L, mels = batch
+        d = hp.d
+        S = np.concatenate((np.zeros_like(mels[:, :1]), mels[:, :-1]), 1)                    # train.py:51
+        te, ae, ad = textenc_layers(hp), audioenc_layers(hp), audiodec_layers(hp)
+        KV, xs_te = network_forward(te, W, "Text2Mel/TextEnc", L, "same")
+        K, V = KV[..., :d], KV[..., d:]
+        Q, xs_ae = network_forward(ae, W, "Text2Mel/AudioEnc", S, "causal")
+        R, al, _ = O.Attention(Q, K, V, hp)
+        logits, xs_ad = network_forward(ad, W, "Text2Mel/AudioDec", R, "causal")
+        Y = O.sigmoid(logits)
+        losses, (dY, dlog, dA) = text2mel_losses(Y, logits, mels, al, hp.max_N, hp.max_T)
+        dR, g = network_backward(ad, W, "Text2Mel/AudioDec", xs_ad, dlog + dY * Y * (1 - Y), "causal"); grads.update(g)
+        dQ, dK, dV = attention_bwd(Q, K, V, dR, dA, d)
+        _, g = network_backward(ae, W, "Text2Mel/AudioEnc", xs_ae, dQ, "causal"); grads.update(g)
+        _, g = network_backward(te, W, "Text2Mel/TextEnc", xs_te, np.concatenate((dK, dV), -1), "same"); grads.update(g)
+    else:
+        mels, mags = batch
+        layers = ssrn_layers(hp)
+        logits, xs = network_forward(layers, W, "SSRN", mels, "same")
+        Z = O.sigmoid(logits)
+        losses, (dZ, dlog) = ssrn_losses(Z, logits, mags)
+        _, grads = network_backward(layers, W, "SSRN", xs, dlog + dZ * Z * (1 - Z), "same")
+    lr = learning_rate_decay(hp.lr, global_step)                                              # train.py:116
+    for n, g in grads.items():
+        W[n], m[n], v[n] = adam_step(W[n], g, m[n], v[n], global_step + 1, lr)
+    return losses

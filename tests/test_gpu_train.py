@@ -231,6 +231,75 @@ def test_text2mel_training_gradients_end_to_end(ops):
     _compare(ggpu, gref, 5e-4)
 
 
+def test_forward_blocks_vs_oracle(ops):
+    """The trainer's own forward passes (TF-layout variables) against the oracle's forward pass."""
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.layers import audioenc_layers, ssrn_layers
+    from dc_tts_amd.train import network_forward
+    from oracle import dctts_ref as O
+    rng = np.random.default_rng(61)
+    W = _small_weights(hp, 79)
+    Wd = {n: dev(v) for n, v in W.items()}
+    mels = rng.uniform(0, 1, (2, 9, hp.n_mels)).astype(np.float32).astype(np.float64)
+    for layers, prefix, pad in ((audioenc_layers(hp), "Text2Mel/AudioEnc", "causal"), (ssrn_layers(hp), "SSRN", "same")):
+        yr, _ = TR.network_forward(layers, W, prefix, mels, pad)
+        yg, _ = network_forward(ops, layers, Wd, prefix, dev(mels), pad)
+        torch.cuda.synchronize()
+        assert maxabs(yg.cpu().numpy(), yr) < 1e-3, prefix
+    Q, K, V = (rng.normal(0, 1, s).astype(np.float32).astype(np.float64) for s in ((2, 9, 256), (2, 8, 256), (2, 8, 256)))
+    Rr, alr, _ = O.Attention(Q, K, V, hp)
+    Rg, alg = ops.attention_forward(dev(Q), dev(K), dev(V))
+    torch.cuda.synchronize()
+    assert maxabs(Rg.cpu().numpy(), Rr) < 1e-4 and maxabs(alg.cpu().numpy(), alr) < 1e-5
+
+
+def maxabs(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max())
+
+
+def test_train_steps_vs_oracle():
+    """TrainGraph.train_op (dc_tts_amd/train.py) = one sess.run(g.train_op) of train.py: two steps of Text2Mel and one of SSRN on a fixed
+    tiny batch against the float64 restatement (oracle/train_ref.train_step): the losses of every step and every updated variable."""
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.train import TrainGraph
+    rng = np.random.default_rng(71)
+    W0 = _small_weights(hp, 80)
+    GS0 = 3999
+    # ---- Text2Mel, two steps
+    B, N, T = 2, 12, 10
+    ids = rng.integers(1, len(hp.vocab), (B, N)).astype(np.int32)
+    mels = rng.uniform(0, 1, (B, T, hp.n_mels)).astype(np.float32).astype(np.float64)
+    Wr = {n: v.copy() for n, v in W0.items() if n.startswith("Text2Mel/")}
+    mr = {n: np.zeros_like(v) for n, v in Wr.items()}; vr = {n: np.zeros_like(v) for n, v in Wr.items()}
+    g = TrainGraph(1, W0, hp)
+    g.global_step = GS0                       # at the peak of the Noam schedule (lr = 1e-3): the updates are far above fp32 resolution
+    for step in range(GS0, GS0 + 2):
+        lr_ = TR.train_step(1, Wr, mr, vr, step, (ids, mels), hp)
+        lg = g.train_op(torch.from_numpy(ids).cuda(), dev(mels))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(lg.cpu().numpy(), lr_, rtol=2e-4)
+    assert g.global_step == GS0 + 2
+    # every variable moved by ~lr per step in the direction the oracle says (Adam's first steps are sign-like): compare the updates
+    for n in Wr:
+        upd_r = Wr[n] - W0[n]; upd_g = g.W[n].cpu().numpy().astype(np.float64) - W0[n]
+        assert np.abs(upd_g - upd_r).max() < 0.05 * np.abs(upd_r).max() + 2e-7, n
+    # ---- SSRN, one step
+    B, T = 1, 4
+    mels = rng.uniform(0, 1, (B, T, hp.n_mels)).astype(np.float32).astype(np.float64)
+    mags = rng.uniform(0, 1, (B, 4 * T, hp.n_linear)).astype(np.float32).astype(np.float64)
+    Wr = {n: v.copy() for n, v in W0.items() if n.startswith("SSRN/")}
+    mr = {n: np.zeros_like(v) for n, v in Wr.items()}; vr = {n: np.zeros_like(v) for n, v in Wr.items()}
+    g2 = TrainGraph(2, W0, hp)
+    g2.global_step = GS0
+    lr_ = TR.train_step(2, Wr, mr, vr, GS0, (mels, mags), hp)
+    lg = g2.train_op(dev(mels), dev(mags))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(lg.cpu().numpy(), lr_, rtol=5e-5)
+    for n in Wr:
+        upd_r = Wr[n] - W0[n]; upd_g = g2.W[n].cpu().numpy().astype(np.float64) - W0[n]
+        assert np.abs(upd_g - upd_r).max() < 0.05 * np.abs(upd_r).max() + 2e-7, n
+
+
 def test_hc_backward_is_reproducible_and_rejects_bad_shapes(ops):
     rng = np.random.default_rng(3)
     C = 256
