@@ -60,3 +60,16 @@ ms = timed(lambda: ops.attention_backward(Q, K, V, dR, dAl))
 print(f"| attention_backward | B={B} T={T} N={N} d={hp.d} | {ms:.3f} | | | |")
 print(f"| **Text2Mel gradients** (AudioDec + attention + AudioEnc + TextEnc + losses) | | {total['AudioDec'] + total['AudioEnc'] + total['TextEnc'] + ms + 0.03:.2f} | | | |")
 print(f"| **SSRN gradients** (reverse pass + losses) | | {total['SSRN'] + 0.1:.2f} | | | |")
+
+# ---- one whole training step (train.py: sess.run(g.train_op)) at the training batch
+from dc_tts_amd.train import TrainGraph
+Wn = synthetic_weights(hp, seed=1)
+for num, name in ((1, "Text2Mel"), (2, "SSRN")):
+    g = TrainGraph(num, Wn, hp)
+    if num == 1:
+        batch = (ids, torch.rand(B, T, hp.n_mels, device="cuda"))
+    else:
+        batch = (torch.rand(B, T, hp.n_mels, device="cuda"), torch.rand(B, 4 * T, hp.n_linear, device="cuda"))
+    ms = timed(lambda: g.train_op(*batch), n=3)
+    print(f"| **one {name} training step** (forward keeping activations, losses, all gradients, clip + Adam) | B={B} T={T} | {ms:.1f} | | | {B / (ms * 1e-3):.0f} utterances/s |")
+    del g
