@@ -73,6 +73,7 @@ SYMBOLS = {
     "dctts_train_conv1d_transpose_forward": (c_int, [c_void_p] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p, c_void_p]),
     "dctts_train_embed_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, c_void_p]),
     "dctts_train_attention_forward": (c_int, [c_void_p] + [c_void_p] * 3 + [c_int] * 4 + [c_void_p] * 2 + [c_void_p]),
+    "dctts_train_dropout": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, ctypes.c_uint64, ctypes.c_float, c_void_p]),
     "dctts_train_sigmoid": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_void_p]),
     "dctts_train_text2mel_losses": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 4 + [c_void_p]),
     "dctts_train_ssrn_losses": (c_int, [c_void_p] + [c_void_p] * 3 + [ctypes.c_longlong] + [c_void_p] * 3 + [c_void_p]),

@@ -350,6 +350,15 @@ extern "C" int dctts_train_embed_forward(dctts_train* t, const int32_t* ids, con
   return 0;
 }
 
+extern "C" int dctts_train_dropout(dctts_train* t, const float* x, float* y, long long n, uint64_t key, float rate, void* stream) {
+  if (!t || !x || !y || n <= 0 || rate < 0.f || rate >= 1.f) TFAIL(DCTTS_ERR_ARG, "dropout: bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, (unsigned long long)key, rate, 1.0f / (1.0f - rate));
+  THIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int dctts_train_sigmoid(dctts_train* t, const float* x, float* y, long long n, void* stream) {
   if (!t || !x || !y || n <= 0) TFAIL(DCTTS_ERR_ARG, "sigmoid: bad argument");
   DevScope ds(t->device);

@@ -34,11 +34,19 @@ _NAMES = {"HC": {"kernel": "/conv1d/kernel", "bias": "/conv1d/bias", "g1": "/H1/
           "D": {"kernel": "/conv2d_transpose/kernel", "bias": "/conv2d_transpose/bias", "gamma": "/normalize/gamma", "beta": "/normalize/beta"}}
 
 
-def network_forward(ops: "TrainOps", layers, W: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, padding: str):
+def layer_key(seed: int, step: int, prefix: str, index: int) -> int:
+    """Dropout key of layer `index` of the network under scope `prefix` at training step `step`: forward and backward pass of a step
+    derive the same key, different layers / steps / seeds different ones."""
+    h = sum((i + 1) * ord(ch) for i, ch in enumerate(prefix)) % 65521
+    return (int(seed) * 1000003 + int(step)) * 4294967296 + h * 65536 + int(index)
+
+
+def network_forward(ops: "TrainOps", layers, W: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, padding: str, drop=None):
     """One network of networks.py on the trainer's TF-layout variables: returns (output, [input of every layer]) -- the activations
-    network_backward needs.  x: the first layer's input (int32 character ids when that layer is the embedding)."""
+    network_backward needs.  x: the first layer's input (int32 character ids when that layer is the embedding).
+    drop = (rate, seed, step): training=True, i.e. dropout behind every block but the embedding (modules.py:139,195,245)."""
     xs = []
-    for L in layers:
+    for li, L in enumerate(layers):
         sc = prefix + "/" + L.scope
         xs.append(x)
         if L.kind == "E":
@@ -51,18 +59,23 @@ def network_forward(ops: "TrainOps", layers, W: Dict[str, torch.Tensor], prefix:
             x = ops.conv1d_transpose_forward(x, p)
         else:
             x = ops.conv1d_forward(x, p, rate=L.rate, padding=padding, act=None if L.act == "none" else L.act)
+        if drop is not None:
+            x = ops.dropout(x, layer_key(drop[1], drop[2], prefix, li), drop[0])
     return x, xs
 
 
-def network_backward(ops: "TrainOps", layers, W: Dict[str, torch.Tensor], prefix: str, xs, dy: torch.Tensor, padding: str):
+def network_backward(ops: "TrainOps", layers, W: Dict[str, torch.Tensor], prefix: str, xs, dy: torch.Tensor, padding: str, drop=None):
     """Reverse pass over one network of networks.py given as its layer list (dc_tts_amd.layers.textenc_layers / audioenc_layers /
     audiodec_layers / ssrn_layers; prefix = its variable scope, e.g. "Text2Mel/AudioEnc"), W = the TF-named variables as device
     tensors, xs = the input of every layer (kept by the forward pass; character ids for the embedding), dy = gradient of the network's
     output.  Returns (gradient of the network's input, or None when the first layer is the embedding; {TF variable name: gradient}),
     i.e. what tf.gradients(loss, tf.trainable_variables(scope)) gives the optimizer at train.py:125."""
     grads, g = {}, dy
-    for L, xin in zip(reversed(list(layers)), reversed(list(xs))):
+    layers = list(layers)
+    for li, L, xin in zip(reversed(range(len(layers))), reversed(layers), reversed(list(xs))):
         sc = prefix + "/" + L.scope
+        if drop is not None and L.kind != "E":
+            g = ops.dropout(g, layer_key(drop[1], drop[2], prefix, li), drop[0])          # the mask of the forward pass, regenerated from its key
         if L.kind == "E":
             grads[sc + "/lookup_table"] = ops.embed_backward(xin, g, W[sc + "/lookup_table"].shape[0])
             g = None
@@ -162,6 +175,12 @@ class TrainOps:
         R = torch.empty(B, T, 2 * d, dtype=torch.float32, device=self.device); al = torch.empty(B, N, T, dtype=torch.float32, device=self.device)
         self._ok(self.lib.dctts_train_attention_forward(self._h, _ptr(Q), _ptr(K), _ptr(V), B, T, N, d, _ptr(R), _ptr(al), self._stream()))
         return R, al
+
+    def dropout(self, x, key: int, rate: float) -> torch.Tensor:
+        """tf.layers.dropout(rate, training=True): x * keep / (1 - rate) with the keep bits of `key`; on a gradient, the backward pass."""
+        y = torch.empty_like(x)
+        self._ok(self.lib.dctts_train_dropout(self._h, _ptr(x), _ptr(y), x.numel(), ctypes.c_uint64(int(key) & 0xFFFFFFFFFFFFFFFF), ctypes.c_float(rate), self._stream()))
+        return y
 
     def sigmoid(self, x) -> torch.Tensor:
         y = torch.empty_like(x)
@@ -299,14 +318,16 @@ class TrainGraph:
     """train.py:26-134 for mode == "train", one network at a time as the reference does: num = 1 trains Text2Mel, num = 2 trains SSRN.
     Holds the variables of that network in TF layout on the device, their Adam moments and `global_step`; `train_op(...)` is one
     `sess.run(g.train_op)`: forward (keeping every layer's input), the losses of train.py:85-110, the gradient of every variable,
-    clip_by_value(-1, 1) + Adam with the Noam learning rate (train.py:116-131).  Not here: the input pipeline (data_load.py:33-131),
-    checkpoints, summaries and the Supervisor loop (train.py:137-162)."""
+    clip_by_value(-1, 1) + Adam with the Noam learning rate (train.py:116-131).  training=True applies dropout (hp.dropout_rate behind
+    every block, modules.py:139,195,245) from a counter-based hash of (seed, global_step, layer) -- TensorFlow's random stream cannot be
+    reproduced.  Not here: the input pipeline (data_load.py:33-131), checkpoints, summaries and the Supervisor loop (train.py:137-162)."""
 
-    def __init__(self, num: int, weights, hp, device: int = None):
+    def __init__(self, num: int, weights, hp, device: int = None, training: bool = True, seed: int = 0):
         from .layers import audiodec_layers, audioenc_layers, ssrn_layers, textenc_layers
         if num not in (1, 2):
             raise ValueError("num: 1 = Text2Mel, 2 = SSRN (train.py:141)")
         self.num, self.hp = num, hp
+        self.training, self.seed = bool(training), int(seed)       # training=True: dropout hp.dropout_rate behind every block (train.py:55-72)
         self.ops = TrainOps(device)
         prefix = "Text2Mel/" if num == 1 else "SSRN/"
         import numpy as _np
@@ -321,28 +342,29 @@ class TrainGraph:
         Returns (losses on the device: loss_mels, loss_bd1, loss_att / loss_mags, loss_bd2;  {TF variable name: gradient})."""
         ops, W, hp = self.ops, self.W, self.hp
         grads = {}
+        drop = (hp.dropout_rate, self.seed, self.global_step) if self.training and hp.dropout_rate > 0 else None
         if self.num == 1:
             L, mels = batch
             d = hp.d
             S = torch.cat((torch.zeros_like(mels[:, :1]), mels[:, :-1]), 1).contiguous()              # train.py:51
-            KV, xs_te = network_forward(ops, self._te, W, "Text2Mel/TextEnc", L, "SAME")
+            KV, xs_te = network_forward(ops, self._te, W, "Text2Mel/TextEnc", L, "SAME", drop)
             K, V = KV[..., :d].contiguous(), KV[..., d:].contiguous()                                   # networks.py:69
-            Q, xs_ae = network_forward(ops, self._ae, W, "Text2Mel/AudioEnc", S, "CAUSAL")
+            Q, xs_ae = network_forward(ops, self._ae, W, "Text2Mel/AudioEnc", S, "CAUSAL", drop)
             R, al = ops.attention_forward(Q, K, V)
-            logits, xs_ad = network_forward(ops, self._ad, W, "Text2Mel/AudioDec", R, "CAUSAL")
+            logits, xs_ad = network_forward(ops, self._ad, W, "Text2Mel/AudioDec", R, "CAUSAL", drop)
             Y = ops.sigmoid(logits)
             losses, dY, dlog, dA = ops.text2mel_losses(Y, logits, mels, al, hp.max_N, hp.max_T)
             dlog = dlog + dY * Y * (1.0 - Y)                                                            # Y = sigmoid(Y_logits) (networks.py:210)
-            dR, g = network_backward(ops, self._ad, W, "Text2Mel/AudioDec", xs_ad, dlog, "CAUSAL"); grads.update(g)
+            dR, g = network_backward(ops, self._ad, W, "Text2Mel/AudioDec", xs_ad, dlog, "CAUSAL", drop); grads.update(g)
             dQ, dK, dV = ops.attention_backward(Q, K, V, dR, dA)
-            _, g = network_backward(ops, self._ae, W, "Text2Mel/AudioEnc", xs_ae, dQ, "CAUSAL"); grads.update(g)
-            _, g = network_backward(ops, self._te, W, "Text2Mel/TextEnc", xs_te, torch.cat((dK, dV), -1).contiguous(), "SAME"); grads.update(g)
+            _, g = network_backward(ops, self._ae, W, "Text2Mel/AudioEnc", xs_ae, dQ, "CAUSAL", drop); grads.update(g)
+            _, g = network_backward(ops, self._te, W, "Text2Mel/TextEnc", xs_te, torch.cat((dK, dV), -1).contiguous(), "SAME", drop); grads.update(g)
         else:
             mels, mags = batch
-            logits, xs = network_forward(ops, self._ss, W, "SSRN", mels, "SAME")
+            logits, xs = network_forward(ops, self._ss, W, "SSRN", mels, "SAME", drop)
             Z = ops.sigmoid(logits)
             losses, dZ, dlog = ops.ssrn_losses(Z, logits, mags)
-            _, grads = network_backward(ops, self._ss, W, "SSRN", xs, dlog + dZ * Z * (1.0 - Z), "SAME")
+            _, grads = network_backward(ops, self._ss, W, "SSRN", xs, dlog + dZ * Z * (1.0 - Z), "SAME", drop)
         return losses, grads
 
     def train_op(self, *batch):

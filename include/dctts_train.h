@@ -83,6 +83,9 @@ int dctts_train_embed_forward(dctts_train* t, const int32_t* ids, const float* t
 int dctts_train_attention_forward(dctts_train* t, const float* Q, const float* K, const float* V, int B, int T, int N, int d,
                                   float* R, float* alignments, void* stream);
 int dctts_train_sigmoid(dctts_train* t, const float* x, float* y, long long n, void* stream);
+/* tf.layers.dropout(rate, training=True) (modules.py:139,195,245): y = x * keep / (1 - rate), keep bits from a counter-based hash of
+ * (key, element index); the backward pass is the same call on dy with the same key.  x == y (in place) is allowed. */
+int dctts_train_dropout(dctts_train* t, const float* x, float* y, long long n, uint64_t key, float rate, void* stream);
 
 /* train.py:85-100.  Y, Y_logits, mels (B, T, n_mels); alignments (B, N, T) as networks.py:153 returns them (N <= max_N,
  * T <= max_T: the reference pads them to (max_N, max_T) with -1 and masks the padding).  losses[3] (device) receives

@@ -253,6 +253,19 @@ def test_forward_blocks_vs_oracle(ops):
     assert maxabs(Rg.cpu().numpy(), Rr) < 1e-4 and maxabs(alg.cpu().numpy(), alr) < 1e-5
 
 
+def test_dropout_mask_matches_its_restatement(ops):
+    """tf.layers.dropout's random stream cannot be reproduced; what is checked is that the device draws the mask oracle/train_ref.py
+    restates (so the oracle can follow a training step with dropout), that about `rate` of the elements are dropped, and the scaling."""
+    from dc_tts_amd.train import layer_key
+    x = torch.ones(3, 70, 256, device="cuda")
+    key = layer_key(5, 4000, "Text2Mel/AudioEnc", 7)
+    assert key == TR.layer_key(5, 4000, "Text2Mel/AudioEnc", 7)
+    y = ops.dropout(x, key, 0.05).cpu().numpy()
+    keep = TR.dropout_mask(key, x.numel(), 0.05).reshape(y.shape)
+    assert np.array_equal(y != 0, keep) and abs(float(keep.mean()) - 0.95) < 0.01
+    np.testing.assert_allclose(y[keep], 1.0 / 0.95, rtol=1e-6)
+
+
 def maxabs(a, b):
     return float(np.abs(np.asarray(a, np.float64) - b).max())
 
@@ -271,10 +284,10 @@ def test_train_steps_vs_oracle():
     mels = rng.uniform(0, 1, (B, T, hp.n_mels)).astype(np.float32).astype(np.float64)
     Wr = {n: v.copy() for n, v in W0.items() if n.startswith("Text2Mel/")}
     mr = {n: np.zeros_like(v) for n, v in Wr.items()}; vr = {n: np.zeros_like(v) for n, v in Wr.items()}
-    g = TrainGraph(1, W0, hp)
+    g = TrainGraph(1, W0, hp, training=True, seed=5)
     g.global_step = GS0                       # at the peak of the Noam schedule (lr = 1e-3): the updates are far above fp32 resolution
     for step in range(GS0, GS0 + 2):
-        lr_ = TR.train_step(1, Wr, mr, vr, step, (ids, mels), hp)
+        lr_ = TR.train_step(1, Wr, mr, vr, step, (ids, mels), hp, dropout_seed=5)
         lg = g.train_op(torch.from_numpy(ids).cuda(), dev(mels))
         torch.cuda.synchronize()
         np.testing.assert_allclose(lg.cpu().numpy(), lr_, rtol=2e-4)
@@ -289,7 +302,7 @@ def test_train_steps_vs_oracle():
     mags = rng.uniform(0, 1, (B, 4 * T, hp.n_linear)).astype(np.float32).astype(np.float64)
     Wr = {n: v.copy() for n, v in W0.items() if n.startswith("SSRN/")}
     mr = {n: np.zeros_like(v) for n, v in Wr.items()}; vr = {n: np.zeros_like(v) for n, v in Wr.items()}
-    g2 = TrainGraph(2, W0, hp)
+    g2 = TrainGraph(2, W0, hp, training=False)              # the dropout-free graph
     g2.global_step = GS0
     lr_ = TR.train_step(2, Wr, mr, vr, GS0, (mels, mags), hp)
     lg = g2.train_op(dev(mels), dev(mags))
