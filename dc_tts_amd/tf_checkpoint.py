@@ -1,4 +1,4 @@
-"""Reader for TensorFlow V2 checkpoints ("tensor bundles": `<prefix>.index` + `<prefix>.data-XXXXX-of-YYYYY`), without
+"""Reader (and a minimal writer) for TensorFlow V2 checkpoints ("tensor bundles": `<prefix>.index` + `<prefix>.data-XXXXX-of-YYYYY`), without
 TensorFlow -- so the reference's trained weights (`synthesize.py:32-40` restores `Text2Mel/*` from `logdir-1` and `SSRN/*`
 from `logdir-2`) can feed `dc_tts_amd.engine.Engine` directly.
 
@@ -234,3 +234,96 @@ def load_reference_weights(logdir: str, hp=None) -> Dict[str, np.ndarray]:
     W = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in W.items()}
     check_weights(W, hp)
     return W
+
+
+# ------------------------------------------------------------------------------------------------ writer
+# What `sv.saver.save(sess, logdir + '/model_gs_...')` leaves behind (train.py:158), in the subset of the format the reader above
+# understands: one shard, uncompressed table blocks, masked crc32c on every block and tensor.  UNPINNED like the reader: no TensorFlow
+# here to read these files back; the round trip through read_checkpoint is what tests/test_tf_checkpoint.py checks.
+def _vint(n: int) -> bytes:
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        if n:
+            out.append(b | 0x80)
+        else:
+            out.append(b)
+            return bytes(out)
+
+
+def _pb(num: int, wire: int, payload: bytes) -> bytes:
+    return _vint((num << 3) | wire) + payload
+
+
+def _table_block(entries, restart_interval: int = 16) -> bytes:
+    buf, restarts, prev = bytearray(), [], b""
+    for i, (k, v) in enumerate(entries):
+        shared = 0
+        if i % restart_interval == 0:
+            restarts.append(len(buf))
+        else:
+            while shared < min(len(prev), len(k)) and prev[shared] == k[shared]:
+                shared += 1
+        buf += _vint(shared) + _vint(len(k) - shared) + _vint(len(v)) + k[shared:] + v
+        prev = k
+    if not restarts:
+        restarts = [0]
+    for r in restarts:
+        buf += struct.pack("<I", r)
+    buf += struct.pack("<I", len(restarts))
+    return bytes(buf)
+
+
+def write_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], keys_per_block: int = 64) -> None:
+    """Write `<prefix>.index` and `<prefix>.data-00000-of-00001` holding `tensors` (float32 / float64 / int32 / int64 arrays)."""
+    enum = {np.dtype(np.float32): 1, np.dtype(np.float64): 2, np.dtype(np.int32): 3, np.dtype(np.int64): 9}
+    data, entries = bytearray(), []
+    for name in sorted(tensors):
+        a = np.asarray(tensors[name])
+        if not a.flags.c_contiguous:                      # (np.ascontiguousarray would turn a scalar into shape (1,))
+            a = a.copy()
+        if a.dtype not in enum:
+            raise CheckpointError(f"{name}: dtype {a.dtype} cannot be written")
+        raw = a.tobytes()
+        dims = b"".join(_pb(2, 2, _vint(len(d)) + d) for d in (_pb(1, 0, _vint(s)) for s in a.shape))
+        e = _pb(1, 0, _vint(enum[a.dtype])) + _pb(2, 2, _vint(len(dims)) + dims) + _pb(3, 0, _vint(0)) + _pb(4, 0, _vint(len(data))) + \
+            _pb(5, 0, _vint(len(raw))) + _pb(6, 5, struct.pack("<I", mask_crc(crc32c(raw))))
+        entries.append((name.encode(), e))
+        data += raw
+    header = _pb(1, 0, _vint(1)) + _pb(2, 0, _vint(0)) + _pb(3, 2, _vint(2) + _pb(1, 0, _vint(1)))      # num_shards 1, little endian, version {producer 1}
+    entries = [(b"", header)] + entries
+    out, index = bytearray(), []
+
+    def emit(block: bytes) -> bytes:
+        off = len(out)
+        out.extend(block)
+        out.extend(b"\x00" + struct.pack("<I", mask_crc(crc32c(block + b"\x00"))))
+        return _vint(off) + _vint(len(block))
+
+    for i in range(0, len(entries), keys_per_block):
+        chunk = entries[i:i + keys_per_block]
+        index.append((chunk[-1][0] + b"\xff", emit(_table_block(chunk))))
+    footer = emit(_table_block([])) + emit(_table_block(index, restart_interval=1))
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC)
+    os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
+    with open(prefix + ".index", "wb") as f:
+        f.write(bytes(out))
+    with open(prefix + ".data-00000-of-00001", "wb") as f:
+        f.write(bytes(data))
+
+
+def save_checkpoint(logdir: str, variables: Dict[str, np.ndarray], global_step: int, slots: Optional[Dict[str, Dict[str, np.ndarray]]] = None) -> str:
+    """train.py:158  sv.saver.save(sess, logdir + '/model_gs_{}k'.format(gs // 1000)): the trainable variables, `gs/global_step`
+    (train.py:82) and, when given, the optimizer slots under TensorFlow's names (`<variable>/Adam`, `<variable>/Adam_1`), plus the
+    `checkpoint` state file tf.train.latest_checkpoint reads (synthesize.py:34,40).  Returns the prefix."""
+    prefix = os.path.join(logdir, "model_gs_{}k".format(str(global_step // 1000).zfill(3)))
+    t = {n: np.asarray(v) for n, v in variables.items()}
+    t["gs/global_step"] = np.asarray(global_step, dtype=np.int32)
+    for suffix, d in (slots or {}).items():
+        for n, v in d.items():
+            t[n + "/" + suffix] = np.asarray(v)
+    write_checkpoint(prefix, t)
+    with open(os.path.join(logdir, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "{0}"\nall_model_checkpoint_paths: "{0}"\n'.format(os.path.basename(prefix)))
+    return prefix

@@ -375,3 +375,11 @@ class TrainGraph:
             self.ops.adam_step(self.W[n], g, self.m[n], self.v[n], self.global_step + 1, lr)
         self.global_step += 1
         return losses
+
+    def save(self, logdir: str) -> str:
+        """train.py:158: the network's variables, Adam slots and global_step as a TF V2 checkpoint under `logdir` (the reference uses
+        `<hp.logdir>-1` for Text2Mel and `-2` for SSRN); dc_tts_amd.tf_checkpoint.load_reference_weights reads it back."""
+        from .tf_checkpoint import save_checkpoint
+        torch.cuda.synchronize(self.ops.device)
+        cpu = lambda d: {n: t.cpu().numpy() for n, t in d.items()}
+        return save_checkpoint(logdir, cpu(self.W), self.global_step, {"Adam": cpu(self.m), "Adam_1": cpu(self.v)})

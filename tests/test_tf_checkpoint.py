@@ -149,3 +149,23 @@ def test_unsupported_layouts_fail_with_named_errors(tmp_path):
     with pytest.raises(C.CheckpointError, match="partitioned"):
         C.read_checkpoint(p)
     assert set(C.read_checkpoint(p, ["SSRN/C_1/conv1d/bias"])) == {"SSRN/C_1/conv1d/bias"}     # untouched variables still load
+
+
+def test_product_writer_round_trip_and_training_checkpoints(tmp_path, weights):
+    """dc_tts_amd.tf_checkpoint.write_checkpoint / save_checkpoint (what a training run leaves behind, train.py:158) read back by the
+    reader, incl. the logdir-1 / logdir-2 layout synthesize.py:32-40 restores from."""
+    rng = np.random.default_rng(3)
+    t = {"a/b": rng.normal(size=(3, 5)).astype(np.float32), "a/c": np.arange(7, dtype=np.int64), "z": np.float32(2.5).reshape(()),
+         "m/n/o": rng.normal(size=(2, 3, 4)).astype(np.float64)}
+    C.write_checkpoint(str(tmp_path / "x" / "model"), t, keys_per_block=2)
+    back = C.read_checkpoint(str(tmp_path / "x" / "model"))
+    assert set(back) == set(t) and all(np.array_equal(back[n], t[n]) and back[n].dtype == t[n].dtype for n in t)
+    logdir = str(tmp_path / "logdir" / "LJ01")
+    t2m = {n: v for n, v in weights.items() if n.startswith("Text2Mel/")}
+    ssrn = {n: v for n, v in weights.items() if n.startswith("SSRN/")}
+    p1 = C.save_checkpoint(logdir + "-1", t2m, 12345, {"Adam": {n: np.zeros_like(v) for n, v in t2m.items()}})
+    C.save_checkpoint(logdir + "-2", ssrn, 200000)
+    assert os.path.basename(p1) == "model_gs_012k" and C.latest_checkpoint(logdir + "-1") == p1
+    assert int(C.read_checkpoint(p1, ["gs/global_step"])["gs/global_step"]) == 12345
+    W = C.load_reference_weights(logdir)
+    assert set(W) == set(weights) and all(np.array_equal(W[n], weights[n]) for n in weights)
