@@ -137,3 +137,66 @@ def test_noam_schedule_and_adam_step():
     # first Adam step moves every coordinate by lr * sign(clipped gradient) (up to eps)
     np.testing.assert_allclose(v1, var - 0.1 * np.sign(g), rtol=0, atol=1e-6)
     np.testing.assert_allclose(m, 0.1 * np.clip(g, -1, 1)); np.testing.assert_allclose(v, 0.001 * np.clip(g, -1, 1) ** 2)
+
+
+def test_backward_oracle_against_torch_autograd():
+    """Independent of the finite-difference checks above: the same blocks written with torch.nn.functional (float64, CPU) and
+    differentiated by torch.autograd must give oracle/train_ref.py's hand-written gradients (hc, conv1d, conv1d_transpose, attention)."""
+    import torch
+    import torch.nn.functional as F
+    from dc_tts_amd.hyperparams import hp
+    rng = np.random.default_rng(21)
+    tt = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+
+    def t_conv(x, W, b, rate, padding):                       # x (B, T, Ci), W (k, Ci, Co): tf.layers.conv1d as dctts_ref._conv restates it
+        k = W.shape[0]
+        pl, pr = TR.conv_pads(k, rate, padding)
+        y = F.conv1d(F.pad(x.transpose(1, 2), (pl, pr)), W.permute(2, 1, 0), b, dilation=rate)
+        return y.transpose(1, 2)
+
+    def t_ln(x, g, b):
+        return F.layer_norm(x, (x.shape[-1],), g, b, eps=TR.LN_EPS)
+
+    # hc (CAUSAL, dilation 3) and conv1d (SAME, relu)
+    B, T, C = 2, 11, 6
+    p = _params(rng, 3, C); x = rng.normal(0, 1, (B, T, C)); dy = rng.normal(0, 1, (B, T, C))
+    tx, tp = tt(x), {n: tt(v) for n, v in p.items()}
+    H = t_conv(tx, tp["kernel"], tp["bias"], 3, "causal")
+    s = torch.sigmoid(t_ln(H[..., :C], tp["g1"], tp["b1"]))
+    y = s * t_ln(H[..., C:], tp["g2"], tp["b2"]) + (1 - s) * tx
+    (y * torch.tensor(dy)).sum().backward()
+    g = TR.hc_bwd(x, p, dy, 3, "causal")
+    np.testing.assert_allclose(g["dx"], tx.grad.numpy(), rtol=1e-9, atol=1e-11)
+    for n in p:
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-9, atol=1e-11, err_msg=n)
+    pc = {"kernel": rng.normal(0, 0.4, (1, C, 5)), "bias": rng.normal(0, 0.1, 5), "gamma": 1 + rng.normal(0, 0.1, 5), "beta": rng.normal(0, 0.3, 5)}
+    dyc = rng.normal(0, 1, (B, T, 5))
+    tx, tp = tt(x), {n: tt(v) for n, v in pc.items()}
+    (torch.relu(t_ln(t_conv(tx, tp["kernel"], tp["bias"], 1, "same"), tp["gamma"], tp["beta"])) * torch.tensor(dyc)).sum().backward()
+    g = TR.c_bwd(x, pc, dyc, 1, "same", "relu")
+    np.testing.assert_allclose(g["dx"], tx.grad.numpy(), rtol=1e-9, atol=1e-11)
+    for n in pc:
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-9, atol=1e-11, err_msg=n)
+    # conv1d_transpose: tf.layers.conv2d_transpose(kernel (1, 3, Cout, Cin), strides (1, 2), 'same') == conv_transpose1d(stride 2,
+    # padding 0) cropped to 2T (out[2t] = x[t] W0 + x[t-1] W2, out[2t+1] = x[t] W1: SURVEY B.5)
+    pd = {"kernel": rng.normal(0, 0.4, (1, 3, 5, C)), "bias": rng.normal(0, 0.1, 5), "gamma": 1 + rng.normal(0, 0.1, 5), "beta": rng.normal(0, 0.3, 5)}
+    dyd = rng.normal(0, 1, (B, 2 * T, 5))
+    tx, tp = tt(x), {n: tt(v) for n, v in pd.items()}
+    yd = F.conv_transpose1d(tx.transpose(1, 2), tp["kernel"][0].permute(2, 1, 0), tp["bias"], stride=2)[..., :2 * T].transpose(1, 2)
+    np.testing.assert_allclose(t_ln(yd, tp["gamma"], tp["beta"]).detach().numpy(), TR.d_fwd(x, pd), rtol=1e-10, atol=1e-12)
+    (t_ln(yd, tp["gamma"], tp["beta"]) * torch.tensor(dyd)).sum().backward()
+    g = TR.d_bwd(x, pd, dyd)
+    np.testing.assert_allclose(g["dx"], tx.grad.numpy(), rtol=1e-9, atol=1e-11)
+    for n in pd:
+        np.testing.assert_allclose(g[n], tp[n].grad.numpy(), rtol=1e-9, atol=1e-11, err_msg=n)
+    # attention (training form) with a gradient on both outputs
+    d, N = 6, 5
+    Q, K, V = rng.normal(0, 1, (B, T, d)), rng.normal(0, 1, (B, N, d)), rng.normal(0, 1, (B, N, d))
+    dR, dAl = rng.normal(0, 1, (B, T, 2 * d)), rng.normal(0, 1, (B, N, T))
+    tq, tk, tv = tt(Q), tt(K), tt(V)
+    A = torch.softmax(tq @ tk.transpose(1, 2) / np.sqrt(d), -1)
+    ((torch.cat((A @ tv, tq), -1) * torch.tensor(dR)).sum() + (A.transpose(1, 2) * torch.tensor(dAl)).sum()).backward()
+    dQ, dK, dV = TR.attention_bwd(Q, K, V, dR, dAl, d)
+    np.testing.assert_allclose(dQ, tq.grad.numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dK, tk.grad.numpy(), rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(dV, tv.grad.numpy(), rtol=1e-9, atol=1e-11)
