@@ -13,7 +13,8 @@ What it restates, in float64 numpy with every derivative written out by hand:
 
 PARITY UNPINNED, like oracle/dctts_ref.py: TensorFlow is not installable here, so nothing ties these derivatives to
 ``tf.gradients``.  They are pinned by mathematics instead: ``tests/test_train_oracle.py`` checks every gradient
-against central finite differences of the float64 forward pass (which IS oracle/dctts_ref.py's forward).
+against central finite differences of the float64 forward pass (which IS oracle/dctts_ref.py's forward) and against
+torch.autograd on the same blocks written with torch.nn.functional.
 """
 import numpy as np
 
