@@ -63,6 +63,7 @@ SYMBOLS = {
     "dctts_train_create": (c_int, [ctypes.POINTER(c_void_p), c_int]),
     "dctts_train_destroy": (c_int, [c_void_p]),
     "dctts_train_device_bytes": (c_size_t, [c_void_p]),
+    "dctts_train_tape": (c_int, [c_void_p, c_int]),
     "dctts_train_hc_backward": (c_int, [c_void_p] + [c_void_p] * 8 + [c_int] * 6 + [c_void_p] * 7 + [c_void_p]),
     "dctts_train_conv1d_backward": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int] * 8 + [c_void_p] * 5 + [c_void_p]),
     "dctts_train_conv1d_transpose_backward": (c_int, [c_void_p] + [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 5 + [c_void_p]),

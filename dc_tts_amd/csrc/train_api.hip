@@ -23,9 +23,14 @@ int dctts_set_error(int code, const std::string& msg);       // dctts_api.hip: t
 
 struct TBuf { void* p = nullptr; size_t bytes = 0; };
 
+// One saved pre-norm tensor of a forward pass (dctts_train_tape): identified by the layer's kernel pointer and geometry
+struct TapeEntry { TBuf buf; const float* kernel = nullptr; int B = 0, T = 0, Cin = 0, Ch = 0, k = 0, rate = 0, pl = 0; };
+
 struct dctts_train {
   int device = 0;
   TBuf xp, Hp, dHp, dxp, part, wpart, lpart, wpad, att;
+  bool tape_on = false;               // forward passes keep their pre-norm tensors, backward passes consume them in reverse order
+  std::vector<TapeEntry> tape; size_t tape_n = 0;
 };
 
 namespace {
@@ -73,17 +78,26 @@ extern "C" int dctts_train_create(dctts_train** out, int device) {
   return 0;
 }
 
+extern "C" int dctts_train_tape(dctts_train* t, int enable) {
+  if (!t) TFAIL(DCTTS_ERR_ARG, "null argument");
+  t->tape_on = enable != 0;
+  t->tape_n = 0;
+  return 0;
+}
+
 extern "C" int dctts_train_destroy(dctts_train* t) {
   if (!t) return 0;
   DevScope ds(t->device);
   for (TBuf* b : {&t->xp, &t->Hp, &t->dHp, &t->dxp, &t->part, &t->wpart, &t->lpart, &t->wpad, &t->att}) if (b->p) (void)hipFree(b->p);
+  for (TapeEntry& e : t->tape) if (e.buf.p) (void)hipFree(e.buf.p);
   delete t;
   return 0;
 }
 
 extern "C" size_t dctts_train_device_bytes(const dctts_train* t) {
   if (!t) return 0;
-  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes + t->wpad.bytes + t->att.bytes;
+  return t->xp.bytes + t->Hp.bytes + t->dHp.bytes + t->dxp.bytes + t->part.bytes + t->wpart.bytes + t->lpart.bytes + t->wpad.bytes + t->att.bytes +
+         [&] { size_t n = 0; for (const TapeEntry& e : t->tape) n += e.buf.bytes; return n; }();
 }
 
 namespace {
@@ -107,7 +121,9 @@ struct ConvGeom {
 
 // pads x, clears the gradient buffers, recomputes the pre-norm tensor H (without bias) over rows [pr, R - pl) of the H-aligned buffer.
 // *kp = the kernel the GEMMs read: the caller's (k, Cin, Ch) or, when a width is not a multiple of 4, a zero-padded (k, Cinp, Chp) copy.
-int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* x, const float* kernel, const float** kp) {
+// *hp = where the pre-norm rows are: the scratch buffer, or -- backward pass with the tape on and a matching entry on top -- the tensor
+// the forward pass kept (then the k GEMMs are skipped).  fwd: forward pass (keeps a copy when the tape is on).
+int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* x, const float* kernel, const float** kp, const float** hp, bool fwd) {
   if (reserve(&t->xp, (size_t)g.R * g.Cinp * 4) || reserve(&t->Hp, (size_t)g.R * g.Chp * 4) || reserve(&t->dHp, (size_t)g.R * g.Chp * 4) ||
       reserve(&t->dxp, (size_t)g.R * g.Cinp * 4) || reserve(&t->wpart, (size_t)g.splits() * g.Cin * g.Ch * 4)) return DCTTS_ERR_HIP;
   float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p;
@@ -125,11 +141,31 @@ int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float*
     hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, xp, const_cast<float*>(x), g.B, g.T, g.Tp, g.pl, g.Cin, 0);
   }
   THIP(hipGetLastError());
-  THIP(hipMemsetAsync(t->dHp.p, 0, (size_t)g.R * g.Chp * 4, st));
-  THIP(hipMemsetAsync(t->dxp.p, 0, (size_t)g.R * g.Cinp * 4, st));
+  *hp = Hp;
+  if (!fwd) {
+    THIP(hipMemsetAsync(t->dHp.p, 0, (size_t)g.R * g.Chp * 4, st));
+    THIP(hipMemsetAsync(t->dxp.p, 0, (size_t)g.R * g.Cinp * 4, st));
+    if (t->tape_on && t->tape_n > 0) {
+      const TapeEntry& e = t->tape[t->tape_n - 1];
+      if (e.kernel == kernel && e.B == g.B && e.T == g.T && e.Cin == g.Cin && e.Ch == g.Ch && e.k == g.k && e.rate == g.rate && e.pl == g.pl) {
+        --t->tape_n; *hp = (const float*)e.buf.p;
+        return 0;
+      }
+      t->tape_n = 0;                                   // out of step with the forward pass: recompute from here on
+    }
+  }
   for (int j = 0; j < g.k; ++j) {
     const int rc = gemm<false, false>(st, xp + (long)(j * g.rate) * g.Cinp, *kp + (long)j * g.Cinp * g.Chp, Hp + (long)g.pr * g.Chp, (int)g.Rv, g.Chp, g.Cinp, g.Cinp, g.Chp, g.Chp, j > 0);
     if (rc < 0) return rc;
+  }
+  if (fwd && t->tape_on) {
+    if (t->tape_n == t->tape.size()) t->tape.emplace_back();
+    TapeEntry& e = t->tape[t->tape_n];
+    const size_t bytes = (size_t)g.R * g.Chp * 4;
+    if (reserve(&e.buf, bytes)) return DCTTS_ERR_HIP;
+    THIP(hipMemcpyAsync(e.buf.p, Hp, bytes, hipMemcpyDeviceToDevice, st));
+    e.kernel = kernel; e.B = g.B; e.T = g.T; e.Cin = g.Cin; e.Ch = g.Ch; e.k = g.k; e.rate = g.rate; e.pl = g.pl;
+    ++t->tape_n;
   }
   return 0;
 }
@@ -185,13 +221,13 @@ extern "C" int dctts_train_hc_backward(dctts_train* t, const float* x, const flo
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const ConvGeom g(B, T, C, 2 * C, k, rate, causal);
-  const float* kp = nullptr;
-  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
+  const float *kp = nullptr, *hp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp, &hp, false);
   if (rc) return rc;
   // the row part: dH, the direct part of dx, column sums
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
   if (reserve(&t->part, (size_t)nblk * 6 * C * 4)) return DCTTS_ERR_HIP;
-  HcBwdRowsParams q{B, T, g.Tp, C, g.pr, g.pl, (const float*)t->Hp.p, x, dy, bias, g1, b1, g2, b2, (float*)t->dHp.p, (float*)t->dxp.p, (float*)t->part.p};
+  HcBwdRowsParams q{B, T, g.Tp, C, g.pr, g.pl, hp, x, dy, bias, g1, b1, g2, b2, (float*)t->dHp.p, (float*)t->dxp.p, (float*)t->part.p};
   if (C == 256) hipLaunchKernelGGL((hc_bwd_rows_kernel<1>), dim3(nblk), dim3(256), 0, st, q);
   else if (C == 512) hipLaunchKernelGGL((hc_bwd_rows_kernel<2>), dim3(nblk), dim3(256), 0, st, q);
   else hipLaunchKernelGGL((hc_bwd_rows_kernel<4>), dim3(nblk), dim3(256), 0, st, q);
@@ -211,12 +247,12 @@ extern "C" int dctts_train_conv1d_backward(dctts_train* t, const float* x, const
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const ConvGeom g(B, T, Cin, Cout, k, rate, causal);
-  const float* kp = nullptr;
-  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
+  const float *kp = nullptr, *hp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp, &hp, false);
   if (rc) return rc;
   const int nblk = (int)std::min<long>(256, ((long)B * T + 3) / 4);
   if (reserve(&t->part, (size_t)nblk * 6 * std::max(Cout, 256) * 4)) return DCTTS_ERR_HIP;
-  CBwdRowsParams q{B, T, g.Tp, Cout, g.pr, (const float*)t->Hp.p, dy, bias, gamma, beta, act, (float*)t->dHp.p, (float*)t->part.p};
+  CBwdRowsParams q{B, T, g.Tp, Cout, g.pr, hp, dy, bias, gamma, beta, act, (float*)t->dHp.p, (float*)t->part.p};
   if ((rc = launch_c_rows(t, st, q, g.Chp, nblk)) != 0) return rc;
   hipLaunchKernelGGL(colsum3_kernel, dim3((3 * Cout + 255) / 256), dim3(256), 0, st, (const float*)t->part.p, nblk, Cout, dgamma, dbeta, dbias);
   THIP(hipGetLastError());
@@ -287,10 +323,10 @@ extern "C" int dctts_train_hc_forward(dctts_train* t, const float* x, const floa
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const ConvGeom g(B, T, C, 2 * C, k, rate, causal);
-  const float* kp = nullptr;
-  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
+  const float *kp = nullptr, *hp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp, &hp, true);
   if (rc) return rc;
-  HcFwdRowsParams q{B, T, g.Tp, C, g.pr, (const float*)t->Hp.p, x, bias, g1, b1, g2, b2, y};
+  HcFwdRowsParams q{B, T, g.Tp, C, g.pr, hp, x, bias, g1, b1, g2, b2, y};
   const unsigned nb = (unsigned)(((long)B * T + 3) / 4);
   if (C == 256) hipLaunchKernelGGL((hc_fwd_rows_kernel<1>), dim3(nb), dim3(256), 0, st, q);
   else if (C == 512) hipLaunchKernelGGL((hc_fwd_rows_kernel<2>), dim3(nb), dim3(256), 0, st, q);
@@ -307,10 +343,10 @@ extern "C" int dctts_train_conv1d_forward(dctts_train* t, const float* x, const 
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const ConvGeom g(B, T, Cin, Cout, k, rate, causal);
-  const float* kp = nullptr;
-  int rc = conv_prenorm(t, st, g, x, kernel, &kp);
+  const float *kp = nullptr, *hp = nullptr;
+  int rc = conv_prenorm(t, st, g, x, kernel, &kp, &hp, true);
   if (rc) return rc;
-  CFwdRowsParams q{B, T, g.Tp, Cout, g.Chp, g.pr, (const float*)t->Hp.p, bias, gamma, beta, act, y};
+  CFwdRowsParams q{B, T, g.Tp, Cout, g.Chp, g.pr, hp, bias, gamma, beta, act, y};
   hipLaunchKernelGGL(c_fwd_rows_kernel, dim3((unsigned)(((long)B * T + 3) / 4)), dim3(256), 0, st, q);
   THIP(hipGetLastError());
   return 0;

@@ -127,6 +127,10 @@ class TrainOps:
     def device_bytes(self) -> int:
         return int(self.lib.dctts_train_device_bytes(self._h))
 
+    def tape(self, enable: bool):
+        """Start of a training step: forward passes keep their pre-norm tensors, the reverse pass consumes them (dctts_train_tape)."""
+        self._ok(self.lib.dctts_train_tape(self._h, 1 if enable else 0))
+
     # ------------------------------------------------------------------ forward passes on TF-layout variables
     def hc_forward(self, x, params, rate: int = 1, padding: str = "SAME") -> torch.Tensor:
         """y = hc(x) (modules.py:143-197) with params kernel (k, C, 2C), bias, g1, b1, g2, b2."""
@@ -342,6 +346,7 @@ class TrainGraph:
         Returns (losses on the device: loss_mels, loss_bd1, loss_att / loss_mags, loss_bd2;  {TF variable name: gradient})."""
         ops, W, hp = self.ops, self.W, self.hp
         grads = {}
+        ops.tape(True)                                          # the reverse pass reuses the forward pass's pre-norm tensors
         drop = (hp.dropout_rate, self.seed, self.global_step) if self.training and hp.dropout_rate > 0 else None
         if self.num == 1:
             L, mels = batch

@@ -35,6 +35,12 @@ int dctts_train_create(dctts_train** out, int device);
 int dctts_train_destroy(dctts_train* t);
 size_t dctts_train_device_bytes(const dctts_train* t);
 
+/* enable = 1: from now on the hc / conv1d FORWARD passes keep their pre-norm tensors on a tape inside the handle and the matching
+ * BACKWARD passes, called in reverse order (as a reverse pass over a network does), consume them instead of recomputing (a third of a
+ * backward pass's contraction work).  An entry is matched by the layer's kernel pointer and geometry; out of step, the backward pass
+ * silently recomputes.  Every call (enable 0 or 1) empties the tape: call it at the start of each training step. */
+int dctts_train_tape(dctts_train* t, int enable);
+
 /* Backward of y = hc(x) (modules.py:143-197: conv1d(k, dilation `rate`, SAME or CAUSAL padding) to 2C channels -> split ->
  * layer-norm(H1), layer-norm(H2) -> sigmoid(H1) * H2 + (1 - sigmoid(H1)) * x, training=False dropout i.e. none).
  *   x, dy, dx            (B, T, C)          C a multiple of 256, k in {1, 3}
