@@ -394,6 +394,9 @@ static void read_env(dctts_ctx* c) {
   { int r = c->mlp_rows; geti("DCTTS_MLP_ROWS", &r); if (r == 2 || r == 4) c->mlp_rows = r; } geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
   geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_SIG_INKERNEL", &c->sig_inkernel); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_GATE", &c->sync_gate); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
+  // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
+  // (it only times out, with wrong results).  Under counter collection the two decode streams meet through events instead.
+  if (const char* e = getenv("ROCPROF_COUNTER_COLLECTION")) { if (atoi(e) != 0 && !getenv("DCTTS_SYNC_VALUES")) c->sync_values = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI: lifetime
