@@ -1852,7 +1852,11 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     HIPCHK(hipMemset(c->gate_ctr, 0, 128 * sizeof(unsigned)));
     HIPCHK(hipHostMalloc((void**)&c->gate_err_host, sizeof(int), 0)); *c->gate_err_host = 0;
   }
-  if (cwait && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: the in-kernel wait of the previous decode timed out (chain3_kernel)");
+  if (cwait && *c->gate_err_host) {                        // reported once: this call fails, the next one starts clean
+    *c->gate_err_host = 0;
+    HIPCHK(hipMemset(c->gate_ctr + 64, 0, sizeof(int)));
+    return fail(DCTTS_ERR_STATE, "decode: the in-kernel wait of the previous decode timed out (chain3_kernel): its results were invalid");
+  }
   CHK(v3_aepre_table(c, w, B));
   if (c->chain_row) CHK(v3_rowchain_table(c, w, B, N, T, insig, gate));
   else if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));

@@ -321,8 +321,10 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
     // The bulk stream's kernels that wrote this frame's presum rows have completed and released them (their stream wrote the
     // counter after them); this launch may have started earlier, so its L2 can still hold the lines of two frames ago: sc1 load.
     if (tid == 0) {
-      bool okw = false;
-      for (int i = 0; i < (1 << 17) && !okw; ++i) {                       // bounded (~0.1 s): a time-out raises the error word, never hangs the queue
+      // bounded (~1 s): a time-out raises the error word (dctts_decode_status reports it) instead of hanging the queue, and every
+      // later wait of the same decode gives up at once, so a decode that cannot make progress ends in seconds, not minutes
+      bool okw = p.gate_err && __hip_atomic_load(p.gate_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+      for (int i = 0; i < (1 << 20) && !okw; ++i) {
         okw = __hip_atomic_load(p.wait2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
         if (!okw) __builtin_amdgcn_s_sleep(4);
       }
