@@ -79,6 +79,7 @@ SYMBOLS = {
     "dctts_train_text2mel_losses": (c_int, [c_void_p] + [c_void_p] * 4 + [c_int] * 6 + [c_void_p] * 4 + [c_void_p]),
     "dctts_train_ssrn_losses": (c_int, [c_void_p] + [c_void_p] * 3 + [ctypes.c_longlong] + [c_void_p] * 3 + [c_void_p]),
     "dctts_train_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_longlong, c_int, ctypes.c_float, c_void_p]),
+    "dctts_train_adam_step_multi": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_float, c_void_p]),
 }
 
 _lib = None

@@ -511,3 +511,26 @@ extern "C" int dctts_train_adam_step(dctts_train* t, float* var, const float* gr
   THIP(hipGetLastError());
   return 0;
 }
+
+extern "C" int dctts_train_adam_step_multi(dctts_train* t, int count, float* const* vars, const float* const* grads, float* const* ms, float* const* vs,
+                                           const long long* ns, int step, float lr, void* stream) {
+  if (!t || count <= 0 || !vars || !grads || !ms || !vs || !ns || step < 1) TFAIL(DCTTS_ERR_ARG, "adam (multi): bad argument");
+  DevScope ds(t->device);
+  if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 0; i < count; ++i)
+    if (!vars[i] || !grads[i] || !ms[i] || !vs[i] || ns[i] <= 0) TFAIL(DCTTS_ERR_ARG, "adam (multi): null tensor");
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow(0.999, step)) / (1.0 - std::pow(0.9, step));
+  for (int i0 = 0; i0 < count; i0 += 64) {
+    AdamBatch b;
+    const int nb = std::min(64, count - i0);
+    long nmax = 0;
+    for (int i = 0; i < nb; ++i) {
+      b.it[i] = AdamItem{vars[i0 + i], grads[i0 + i], ms[i0 + i], vs[i0 + i], (long)ns[i0 + i]};
+      nmax = std::max(nmax, (long)ns[i0 + i]);
+    }
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)((nmax + 16383) / 16384), (unsigned)nb), dim3(256), 0, st, b, (float)lr_t);
+  }
+  THIP(hipGetLastError());
+  return 0;
+}

@@ -318,6 +318,23 @@ class TrainOps:
         self._ok(self.lib.dctts_train_adam_step(self._h, _ptr(var), _ptr(grad), _ptr(m), _ptr(v), var.numel(), int(step), float(lr), self._stream()))
 
 
+    def adam_step_multi(self, vars_, grads, ms, vs, step: int, lr: float):
+        """The same update on lists of variables in ONE launch (train.py:131 applies the whole gradient list); same results as a loop of
+        adam_step, without ~200 launches and calls per step."""
+        import ctypes
+        n = len(vars_)
+        if not (n == len(grads) == len(ms) == len(vs)) or n == 0:
+            raise ValueError("adam_step_multi: the four lists must have the same non-zero length")
+        for i in range(n):
+            for t, nm in ((vars_[i], "var"), (grads[i], "grad"), (ms[i], "m"), (vs[i], "v")):
+                _check(t, nm, torch.float32, vars_[i].dim(), self.device)
+                if t.numel() != vars_[i].numel():
+                    raise ValueError("adam_step_multi: %s[%d] has %d elements, its variable %d" % (nm, i, t.numel(), vars_[i].numel()))
+        arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+        ns = (ctypes.c_longlong * n)(*[t.numel() for t in vars_])
+        self._ok(self.lib.dctts_train_adam_step_multi(self._h, n, arr(vars_), arr(grads), arr(ms), arr(vs), ns, int(step), float(lr), self._stream()))
+
+
 class TrainGraph:
     """train.py:26-134 for mode == "train", one network at a time as the reference does: num = 1 trains Text2Mel, num = 2 trains SSRN.
     Holds the variables of that network in TF layout on the device, their Adam moments and `global_step`; `train_op(...)` is one
@@ -376,8 +393,9 @@ class TrainGraph:
         """One training step; returns the losses (device tensor) of the step, evaluated before the update as sess.run does."""
         losses, grads = self.loss_and_grads(*batch)
         lr = learning_rate_decay(self.hp.lr, self.global_step)                                          # train.py:116
-        for n, g in grads.items():
-            self.ops.adam_step(self.W[n], g, self.m[n], self.v[n], self.global_step + 1, lr)
+        names = list(grads)
+        self.ops.adam_step_multi([self.W[n] for n in names], [grads[n] for n in names], [self.m[n] for n in names], [self.v[n] for n in names],
+                                 self.global_step + 1, lr)
         self.global_step += 1
         return losses
 

@@ -109,6 +109,10 @@ int dctts_train_ssrn_losses(dctts_train* t, const float* Z, const float* Z_logit
  * var -= lr * sqrt(1 - beta2^step) / (1 - beta1^step) * m / (sqrt(v) + eps), tf.train.AdamOptimizer defaults
  * beta1 = 0.9, beta2 = 0.999, eps = 1e-8; step is 1-based; lr is utils.py:142-145's schedule, evaluated by the caller. */
 int dctts_train_adam_step(dctts_train* t, float* var, const float* grad, float* m, float* v, long long n, int step, float lr, void* stream);
+/* The same update applied to `count` variables in one launch per 64 variables (train.py:131's apply_gradients over all trainable variables): vars / grads /
+ * ms / vs are HOST arrays of `count` device pointers, ns their element counts.  Results are identical to `count` calls of the above. */
+int dctts_train_adam_step_multi(dctts_train* t, int count, float* const* vars, const float* const* grads, float* const* ms, float* const* vs,
+                                const long long* ns, int step, float lr, void* stream);
 
 #ifdef __cplusplus
 }

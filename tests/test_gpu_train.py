@@ -359,6 +359,26 @@ def test_losses_vs_oracle(ops):
     assert rel(gZ.cpu().numpy(), dZ) < 1e-6 and rel(gZl.cpu().numpy(), dZl) < 2e-5
 
 
+def test_adam_multi_equals_per_variable_updates(ops):
+    """One launch over a list of variables (sizes from 1 element to several 16 K-element chunks) == the per-variable call, bit for bit."""
+    rng = np.random.default_rng(10)
+    sizes = [1, 7, 256, 16384, 16385, 70001, 3 * 17 * 33]
+    mk = lambda n, s: rng.normal(0, s, n).astype(np.float32)
+    host = [(mk(n, 1.0), mk(n, 1.5), mk(n, 0.1), np.abs(mk(n, 0.1))) for n in sizes]
+    a = [[dev(t) for t in h] for h in host]; b = [[dev(t) for t in h] for h in host]
+    b[-1] = [t.view(3, 17, 33) for t in b[-1]]                         # any rank, as the variables of a network have
+    for step in (1, 2, 4000):
+        for var, g, m, v in a:
+            ops.adam_step(var, g, m, v, step, 2e-4)
+        ops.adam_step_multi([t[0] for t in b], [t[1] for t in b], [t[2] for t in b], [t[3] for t in b], step, 2e-4)
+    torch.cuda.synchronize()
+    for ta, tb in zip(a, b):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x.reshape(-1), y.reshape(-1))
+    with pytest.raises(ValueError):
+        ops.adam_step_multi([a[0][0]], [a[1][1]], [a[0][2]], [a[0][3]], 1, 1e-3)
+
+
 def test_adam_steps_vs_oracle(ops):
     from dc_tts_amd.train import learning_rate_decay
     rng = np.random.default_rng(9)
