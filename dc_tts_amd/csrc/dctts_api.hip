@@ -172,6 +172,8 @@ struct dctts_ctx {
   int bulk_pipelined = 1;              // bulk contraction = hbulk_kernel (items software-pipelined); 0 = hsplit_kernel<32> (DCTTS_BULK_PIPE)
   int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
+  int ssrn_split = 2;                  // dctts_ssrn_fwd: the batch as this many independent launch sequences on as many streams (DCTTS_SSRN_SPLIT=1: one sequence; max 4)
+  hipStream_t s_ssrn[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_ssrn[4] = {nullptr, nullptr, nullptr, nullptr};
   int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
   int bulk_cap = 176;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
@@ -384,7 +386,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 // Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
-  geti("DCTTS_TAIL_SPLIT", &c->tail_split);
+  geti("DCTTS_TAIL_SPLIT", &c->tail_split); geti("DCTTS_SSRN_SPLIT", &c->ssrn_split);
   { int r = c->chain_rows; geti("DCTTS_CHAIN_ROWS", &r); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
   geti("DCTTS_FUSE_MEL", &c->fuse_mel); geti("DCTTS_BULK_SMALL", &c->bulk_small_rows); geti("DCTTS_BULK_PIPE", &c->bulk_pipelined);
   geti("DCTTS_CHAIN_ONE", &c->chain_one);
@@ -433,6 +435,8 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   destroy_graphs2(c);
   for (int i = 0; i < 4; ++i) { if (c->ev_chain[i]) (void)hipEventDestroy(c->ev_chain[i]); if (c->ev_bulk[i]) (void)hipEventDestroy(c->ev_bulk[i]); }
   if (c->s_bulk) (void)hipStreamDestroy(c->s_bulk);
+  for (hipStream_t q : c->s_ssrn) if (q) (void)hipStreamDestroy(q);
+  for (hipEvent_t e : c->ev_ssrn) if (e) (void)hipEventDestroy(e);
   if (c->ctr_chain) (void)hipFree(c->ctr_chain);
   if (c->ctr_bulk) (void)hipFree(c->ctr_bulk);
   if (c->gate_ctr) (void)hipFree(c->gate_ctr);
@@ -799,22 +803,17 @@ extern "C" int dctts_attention_fwd(dctts_ctx* c, const float* Q, const float* K,
 }
 
 // ------------------------------------------------------------------------------------------------ SSRN
-extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, void* stream) {
-  DevGuard dev_guard(c);
-  CHK(check_ready(c, dev_guard));
-  if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  const int cc = c->cfg.c, F = c->cfg.n_linear, Fp = round_up(F, 32);
-  const std::string g = geom("ssrn", B, T);
-  if (g != c->ws_geom_ssrn) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "ssrn."); c->ws_geom_ssrn = g; }
-  View s1a, s1b, s2a, s2b, s4a, s4b, w4a, w4b, z4a, z4b;
-  CHK(ws_view(c, "ssrn.s1a", B, PAD + T + PAD, PAD, cc, &s1a)); CHK(ws_view(c, "ssrn.s1b", B, PAD + T + PAD, PAD, cc, &s1b));
-  CHK(ws_view(c, "ssrn.s2a", B, PAD + 2 * T + PAD, PAD, cc, &s2a)); CHK(ws_view(c, "ssrn.s2b", B, PAD + 2 * T + PAD, PAD, cc, &s2b));
-  CHK(ws_view(c, "ssrn.s4a", B, PAD + 4 * T + PAD, PAD, cc, &s4a)); CHK(ws_view(c, "ssrn.s4b", B, PAD + 4 * T + PAD, PAD, cc, &s4b));
-  CHK(ws_view(c, "ssrn.w4a", B, PAD + 4 * T + PAD, PAD, 2 * cc, &w4a)); CHK(ws_view(c, "ssrn.w4b", B, PAD + 4 * T + PAD, PAD, 2 * cc, &w4b));
-  CHK(ws_view(c, "ssrn.z4a", B, 4 * T, 0, Fp, &z4a)); CHK(ws_view(c, "ssrn.z4b", B, 4 * T, 0, Fp, &z4b));
-  const View vin{const_cast<float*>(Y), T, 0, c->cfg.n_mels}, vz{Z, 4L * T, 0, F}, vlog{logits, 4L * T, 0, F};
-  const RowMap r1{B, T, nullptr, nullptr}, r2{B, 2 * T, nullptr, nullptr}, r4{B, 4 * T, nullptr, nullptr};
+static View sub_batch(const View& v, int b0) { View r = v; r.p += (long)b0 * v.bstride * v.stride; return r; }
+
+// The layers of networks.py:214-292 over utterances [b0, b0 + Bs) of a batch whose buffers are `ws` (utterance-major: a sub-batch is a pointer offset).
+static int ssrn_layers(dctts_ctx* c, const View* ws, const View& vin0, const View& vz0, const View* vlog0, int b0, int Bs, int T, hipStream_t st) {
+  const int Fp = round_up(c->cfg.n_linear, 32);
+  View v[10];
+  for (int k = 0; k < 10; ++k) v[k] = sub_batch(ws[k], b0);
+  const View &s1a = v[0], &s1b = v[1], &s2a = v[2], &s2b = v[3], &s4a = v[4], &s4b = v[5], &w4a = v[6], &w4b = v[7], &z4a = v[8], &z4b = v[9];
+  const View vin = sub_batch(vin0, b0), vz = sub_batch(vz0, b0);
+  View vlog; if (vlog0) vlog = sub_batch(*vlog0, b0);
+  const RowMap r1{Bs, T, nullptr, nullptr}, r2{Bs, 2 * T, nullptr, nullptr}, r4{Bs, 4 * T, nullptr, nullptr};
   const std::vector<DevLayer>& S = c->ssrn;
   size_t i = 0;
   CHK(run_conv(c, S[i++], vin, nullptr, s1a, r1, st));            // C_1
@@ -834,8 +833,50 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
   CHK(run_conv(c, S[i++], w4a, nullptr, z4a, r4, st, Fp));        // C_13 (pad columns written as 0)
   CHK(run_conv(c, S[i++], z4a, nullptr, z4b, r4, st, Fp));        // C_14
   CHK(run_conv(c, S[i++], z4b, nullptr, z4a, r4, st, Fp));        // C_15
-  CHK(run_conv(c, S[i++], z4a, nullptr, vz, r4, st, 0, logits ? &vlog : nullptr));   // C_16 + sigmoid
+  CHK(run_conv(c, S[i++], z4a, nullptr, vz, r4, st, 0, vlog0 ? &vlog : nullptr));   // C_16 + sigmoid
   return 0;
+}
+
+extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, void* stream) {
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
+  if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  const int cc = c->cfg.c, F = c->cfg.n_linear, Fp = round_up(F, 32);
+  const std::string g = geom("ssrn", B, T);
+  if (g != c->ws_geom_ssrn) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "ssrn."); c->ws_geom_ssrn = g; }
+  View ws[10];
+  CHK(ws_view(c, "ssrn.s1a", B, PAD + T + PAD, PAD, cc, &ws[0])); CHK(ws_view(c, "ssrn.s1b", B, PAD + T + PAD, PAD, cc, &ws[1]));
+  CHK(ws_view(c, "ssrn.s2a", B, PAD + 2 * T + PAD, PAD, cc, &ws[2])); CHK(ws_view(c, "ssrn.s2b", B, PAD + 2 * T + PAD, PAD, cc, &ws[3]));
+  CHK(ws_view(c, "ssrn.s4a", B, PAD + 4 * T + PAD, PAD, cc, &ws[4])); CHK(ws_view(c, "ssrn.s4b", B, PAD + 4 * T + PAD, PAD, cc, &ws[5]));
+  CHK(ws_view(c, "ssrn.w4a", B, PAD + 4 * T + PAD, PAD, 2 * cc, &ws[6])); CHK(ws_view(c, "ssrn.w4b", B, PAD + 4 * T + PAD, PAD, 2 * cc, &ws[7]));
+  CHK(ws_view(c, "ssrn.z4a", B, 4 * T, 0, Fp, &ws[8])); CHK(ws_view(c, "ssrn.z4b", B, 4 * T, 0, Fp, &ws[9]));
+  const View vin{const_cast<float*>(Y), T, 0, c->cfg.n_mels}, vz{Z, 4L * T, 0, F}, vlog{logits, 4L * T, 0, F};
+  // Utterances are independent (no op crosses the batch axis).  A layer is ONE launch of 32-row items, and 256 CUs take them in rounds:
+  // B = 32 at 4T rows is 840 items = 3.28 rounds, the last one a quarter full, on every layer.  Parts of the batch as independent launch
+  // sequences on their own streams have no common barrier per layer: the items of one part fill the CUs another part's last round leaves idle.
+  int parts = std::min(std::min(c->ssrn_split, 4), B);
+  if ((long)B * 4 * T <= 32L * c->n_cu || c->prof_id >= 0) parts = 1;      // one round of items anyway / a kernel is being timed in isolation
+  const View* lg = logits ? &vlog : nullptr;
+  if (parts <= 1) return ssrn_layers(c, ws, vin, vz, lg, 0, B, T, st);
+  if (!c->ev_ssrn[0])
+    for (hipEvent_t& e : c->ev_ssrn) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  for (int k = 0; k + 1 < parts; ++k)
+    if (!c->s_ssrn[k]) HIPCHK(hipStreamCreateWithFlags(&c->s_ssrn[k], hipStreamNonBlocking));
+  HIPCHK(hipEventRecord(c->ev_ssrn[0], st));
+  int rc = 0;
+  for (int k = 0; k < parts; ++k) {
+    const int b0 = (int)((long)B * k / parts), b1 = (int)((long)B * (k + 1) / parts);
+    hipStream_t q = k == 0 ? st : c->s_ssrn[k - 1];
+    if (k) HIPCHK(hipStreamWaitEvent(q, c->ev_ssrn[0], 0));
+    const int r = ssrn_layers(c, ws, vin, vz, lg, b0, b1 - b0, T, q);
+    if (!rc) rc = r;
+    if (k) {            // joined even after an error: the caller's stream must not run ahead of a side stream
+      HIPCHK(hipEventRecord(c->ev_ssrn[k], q));
+      HIPCHK(hipStreamWaitEvent(st, c->ev_ssrn[k], 0));
+    }
+  }
+  return rc;
 }
 
 // ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)

@@ -255,6 +255,32 @@ def test_ssrn(weights):
     assert maxabs(Z.cpu().numpy(), Zr) < TOL and maxabs(lg.cpu().numpy(), lgr) < 5e-3
 
 
+@pytest.mark.parametrize("parts", [1, 3, 4])
+def test_ssrn_batch_parts_on_streams(weights, parts):
+    """dctts_ssrn_fwd runs a batch of more than one round of row items as independent launch sequences over parts of the batch, each on
+    its own stream (default 2; DCTTS_SSRN_SPLIT, read at create).  Any number of parts gives the default's result (<= 1e-5: rows land on
+    the 32-row or the 16-row kernel depending on the launch), uneven parts included (B = 11), logits too, and the oracle's on one utterance."""
+    from dc_tts_amd.engine import Engine
+    B = 11
+    Yh = np.random.default_rng(77).random((B, hp.max_T, hp.n_mels), dtype=np.float32)
+    lg0, Z0 = engine_for(weights).ssrn(dev(Yh))
+    old = os.environ.get("DCTTS_SSRN_SPLIT")
+    os.environ["DCTTS_SSRN_SPLIT"] = str(parts)
+    try:
+        eng = Engine(weights, hp)
+    finally:
+        if old is None: del os.environ["DCTTS_SSRN_SPLIT"]
+        else: os.environ["DCTTS_SSRN_SPLIT"] = old
+    lg, Z = eng.ssrn(dev(Yh))
+    Zb = eng.ssrn(dev(Yh), want_logits=False)[1]
+    torch.cuda.synchronize()
+    assert torch.equal(Z, Zb)
+    assert float((Z - Z0).abs().max()) < 1e-5 and float((lg - lg0).abs().max()) < 1e-3
+    _, Zr = O.SSRN(Yh[B - 1:], weights, hp)
+    assert maxabs(Z[B - 1:].cpu().numpy(), Zr) < TOL
+    eng.close()
+
+
 def test_ssrn_only_batch128_config3(weights):
     """BASELINE configs[2]: SSRN-only, batch 128, (128, 210, 80) -> (128, 840, 1025).  Determinism, agreement with the same
     utterances run as shards of 32 (rows land on the 32-row or the 16-row MFMA kernel depending on the launch: fp32

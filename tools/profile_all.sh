@@ -6,36 +6,39 @@ R=$PWD
 OUT=${1:-$R/gpurun_out/profile_r02}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+STEPS=${STEPS:-1234567}          # e.g. STEPS=127 bash tools/profile_all.sh: only the bench line, the kernel trace and the layer table
+want() { case "$STEPS" in *$1*) return 0;; *) return 1;; esac; }
 # 1. the bench line (metric, roofline of the time-dominant kernel, kernels, other configs, cpu_baseline, vocoder)  -> profiles/r02_bench.json
-timeout 600 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
+want 1 && timeout 600 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
 # 2. per-kernel time of the same workload                                               -> profiles/r02_kernel_stats.{csv,md}
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_stats" -- \
+want 2 && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_stats" -- \
     python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-extras > "$OUT/kernel_stats.log" 2>&1
 # 3. HBM traffic of the decode kernels (FETCH_SIZE x2 per the gfx950 correction; WRITE_SIZE exact)   -> profiles/r02_pmc.{md,json}
 #    Counter collection serialises dispatches ACROSS queues, so a launch that waits for the other stream's counter (stream memory
 #    operations, in-kernel signals) would wait for ever: the counter passes let the two streams meet through events (DCTTS_SYNC_VALUES=0).
 export DCTTS_SYNC_VALUES=0
-DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_fetch.log" 2>&1
-DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_write.log" 2>&1
+want 3 && DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_fetch.log" 2>&1
+want 3 && DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_write.log" 2>&1
 # 4. what the waves of the decode kernels wait for
-DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
+want 4 && DM=3 GM=0 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
     --output-format csv -d "$OUT/pmc_sq" -- python "$R/tools/decode_only.py" 40 > "$OUT/pmc_sq.log" 2>&1
 unset DCTTS_SYNC_VALUES
 cd "$R"
-python tools/pmc_summary.py "$OUT/pmc_fetch" FETCH_SIZE > "$OUT/pmc_fetch.txt"
-python tools/pmc_summary.py "$OUT/pmc_write" WRITE_SIZE > "$OUT/pmc_write.txt"
-for ctr in SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE; do
+want 3 && python tools/pmc_summary.py "$OUT/pmc_fetch" FETCH_SIZE > "$OUT/pmc_fetch.txt"
+want 3 && python tools/pmc_summary.py "$OUT/pmc_write" WRITE_SIZE > "$OUT/pmc_write.txt"
+want 4 && for ctr in SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE; do
   echo "== $ctr"; python tools/pmc_summary.py "$OUT/pmc_sq" $ctr | head -12; done > "$OUT/pmc_sq.txt"
 # 5. where a chain launch spends its time (in-kernel wall-clock stamps) and how long the two streams' pieces take
-DCTTS_TRACE_FILE="$OUT/decode_trace.txt" timeout 100 python "$R/tools/decode_trace.py" > "$OUT/decode_trace.log" 2>&1
-DCTTS_PIECETIME=100 DM=3 GM=1 timeout 120 python "$R/tools/decode_time.py" > "$OUT/piece_times.txt" 2>&1
+want 5 && DCTTS_TRACE_FILE="$OUT/decode_trace.txt" timeout 100 python "$R/tools/decode_trace.py" > "$OUT/decode_trace.log" 2>&1
+want 5 && DCTTS_PIECETIME=100 DM=3 GM=1 timeout 120 python "$R/tools/decode_time.py" > "$OUT/piece_times.txt" 2>&1
 # 6. decode mode 4 (one row-split launch per chain piece): where rowchain_kernel's time goes, and its frame time
-DM=4 GM=1 DCTTS_TRACE_FILE="$OUT/rowchain_trace.txt" timeout 100 python "$R/tools/decode_trace.py" > "$OUT/rowchain_trace.log" 2>&1
-DM=4 GM=1 timeout 120 python "$R/tools/decode_time.py" 2>&1 | grep text2mel >> "$OUT/rowchain_trace.txt"
+want 6 && DM=4 GM=1 DCTTS_TRACE_FILE="$OUT/rowchain_trace.txt" timeout 100 python "$R/tools/decode_trace.py" > "$OUT/rowchain_trace.log" 2>&1
+want 6 && DM=4 GM=1 timeout 120 python "$R/tools/decode_time.py" 2>&1 | grep text2mel >> "$OUT/rowchain_trace.txt"
 # 7. TextEnc and SSRN launch by launch
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/layers" -- python "$R/tools/layer_trace.py" > "$OUT/layers.log" 2>&1)
-python tools/layer_trace_table.py "$OUT/layers" > "$OUT/layers.txt"
-find "$OUT/kernel_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
+#    (the SSRN batch as ONE launch sequence, DCTTS_SSRN_SPLIT=1, so that a duration is that launch alone on the GPU)
+want 7 && (cd /tmp && DCTTS_SSRN_SPLIT=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/layers" -- python "$R/tools/layer_trace.py" > "$OUT/layers.log" 2>&1)
+want 7 && python tools/layer_trace_table.py "$OUT/layers" > "$OUT/layers.txt"
+want 2 && find "$OUT/kernel_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 rm -rf "$OUT/kernel_stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/layers"
 echo "done: $OUT"
