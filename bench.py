@@ -338,7 +338,7 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     if n:
         C = 2 * c
         rpl = rows / n
-        kern.append(dict(kernel="hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11 / HC_12: 1024 ch, k=3, fused LN + gate): the largest kernel by FLOPs; timed alone, the batch as ONE launch sequence (the timed region runs it as two sequences on two streams, DESIGN.md section 4)",
+        kern.append(dict(kernel="hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11 / HC_12: 1024 ch, k=3, fused LN + gate): the largest kernel by FLOPs",
                          bound="mfma", launches=n, avg_launch_ms=round(ms / n, 4), rows_per_launch=rpl, layer_rows=B * 4 * T,
                          **both_roofs(2.0 * rpl * 3 * C * 2 * C, 4.0 * (rpl * C * 2 + 3 * C * 2 * C), ms / n)))
     if args.decode_mode == 3:

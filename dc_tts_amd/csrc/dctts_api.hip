@@ -172,7 +172,10 @@ struct dctts_ctx {
   int bulk_pipelined = 1;              // bulk contraction = hbulk_kernel (items software-pipelined); 0 = hsplit_kernel<32> (DCTTS_BULK_PIPE)
   int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
-  int ssrn_split = 2;                  // dctts_ssrn_fwd: the batch as this many independent launch sequences on as many streams (DCTTS_SSRN_SPLIT=1: one sequence; max 4)
+  int ssrn_prio = 0;                   // priority of those streams: 0 normal, 1 highest, 2 lowest (DCTTS_SSRN_PRIO)
+  int ssrn_split = 1;                  // dctts_ssrn_fwd: the batch as this many independent launch sequences on as many streams (DCTTS_SSRN_SPLIT, max 4).
+                                       // Default 1 = one sequence: 2 parts take SSRN alone from 12.16 to 11.56 ms, but between decodes the gain is ~0.1 ms and
+                                       // the extra active queue can cost the decode's dependent launches more than that
   hipStream_t s_ssrn[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_ssrn[4] = {nullptr, nullptr, nullptr, nullptr};
   int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
   int bulk_cap = 176;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
@@ -386,7 +389,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 // Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
-  geti("DCTTS_TAIL_SPLIT", &c->tail_split); geti("DCTTS_SSRN_SPLIT", &c->ssrn_split);
+  geti("DCTTS_TAIL_SPLIT", &c->tail_split); geti("DCTTS_SSRN_SPLIT", &c->ssrn_split); geti("DCTTS_SSRN_PRIO", &c->ssrn_prio);
   { int r = c->chain_rows; geti("DCTTS_CHAIN_ROWS", &r); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
   geti("DCTTS_FUSE_MEL", &c->fuse_mel); geti("DCTTS_BULK_SMALL", &c->bulk_small_rows); geti("DCTTS_BULK_PIPE", &c->bulk_pipelined);
   geti("DCTTS_CHAIN_ONE", &c->chain_one);
@@ -862,7 +865,12 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
   if (!c->ev_ssrn[0])
     for (hipEvent_t& e : c->ev_ssrn) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (int k = 0; k + 1 < parts; ++k)
-    if (!c->s_ssrn[k]) HIPCHK(hipStreamCreateWithFlags(&c->s_ssrn[k], hipStreamNonBlocking));
+    if (!c->s_ssrn[k]) {
+      int lo = 0, hi = 0;
+      HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      if (c->ssrn_prio == 0) HIPCHK(hipStreamCreateWithFlags(&c->s_ssrn[k], hipStreamNonBlocking));
+      else HIPCHK(hipStreamCreateWithPriority(&c->s_ssrn[k], hipStreamNonBlocking, c->ssrn_prio == 1 ? hi : lo));
+    }
   HIPCHK(hipEventRecord(c->ev_ssrn[0], st));
   int rc = 0;
   for (int k = 0; k < parts; ++k) {

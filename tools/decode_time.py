@@ -11,6 +11,7 @@ for _ in range(2): eng.text2mel(L)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(3): eng.text2mel(L)
+NREP = int(os.environ.get("NREP", "3"))
+for _ in range(NREP): eng.text2mel(L)
 e1.record(); torch.cuda.synchronize()
-print("text2mel ms", e0.elapsed_time(e1) / 3, "us/frame", (e0.elapsed_time(e1) / 3 - 2.54) * 1e3 / T)
+print("text2mel ms", e0.elapsed_time(e1) / NREP, "us/frame", (e0.elapsed_time(e1) / NREP - 2.54) * 1e3 / T)

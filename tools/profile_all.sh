@@ -36,8 +36,7 @@ want 5 && DCTTS_PIECETIME=100 DM=3 GM=1 timeout 120 python "$R/tools/decode_time
 want 6 && DM=4 GM=1 DCTTS_TRACE_FILE="$OUT/rowchain_trace.txt" timeout 100 python "$R/tools/decode_trace.py" > "$OUT/rowchain_trace.log" 2>&1
 want 6 && DM=4 GM=1 timeout 120 python "$R/tools/decode_time.py" 2>&1 | grep text2mel >> "$OUT/rowchain_trace.txt"
 # 7. TextEnc and SSRN launch by launch
-#    (the SSRN batch as ONE launch sequence, DCTTS_SSRN_SPLIT=1, so that a duration is that launch alone on the GPU)
-want 7 && (cd /tmp && DCTTS_SSRN_SPLIT=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/layers" -- python "$R/tools/layer_trace.py" > "$OUT/layers.log" 2>&1)
+want 7 && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/layers" -- python "$R/tools/layer_trace.py" > "$OUT/layers.log" 2>&1)
 want 7 && python tools/layer_trace_table.py "$OUT/layers" > "$OUT/layers.txt"
 want 2 && find "$OUT/kernel_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 rm -rf "$OUT/kernel_stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/layers"
