@@ -50,11 +50,24 @@ int reserve(TBuf* b, size_t bytes) {
 }
 template <bool TA, bool TB>
 int gemm(hipStream_t st, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc, int beta,
-         int splits = 1, long zstride = 0) {
+         int splits = 1, long zstride = 0, int nseg = 1, long a_ss = 0, long b_ss = 0) {
   GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, beta, K, zstride, 0, 0, 0};
+  p.nseg = nseg; p.a_ss = a_ss; p.b_ss = b_ss;
   if (splits > 1) p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
   const int nz = (K + p.kchunk - 1) / p.kchunk;
   hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 127) / 128, (M + 127) / 128, nz), dim3(256), 0, st, p);
+  if (hipGetLastError() != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "gemm launch failed");
+  return nz;
+}
+// nb GEMMs of the same shape (A + b * a_zs, B + b * b_zs), each split over K: the partial of (b, split) lands at C + (b * nz + split) * zstride; returns nz
+template <bool TA, bool TB>
+int gemm_batched_splitk(hipStream_t st, int nb, const float* A, long a_zs, const float* B, long b_zs, float* C, long zstride,
+                        int M, int N, int K, int lda, int ldb, int ldc, int splits) {
+  GemmParams p{A, B, C, M, N, K, lda, ldb, ldc, 0, K, zstride, 1, a_zs, b_zs};
+  if (splits > 1) p.kchunk = ((K + splits - 1) / splits + 15) / 16 * 16;
+  const int nz = (K + p.kchunk - 1) / p.kchunk;
+  p.nsplit = nz;
+  hipLaunchKernelGGL((gemm_kernel<TA, TB>), dim3((N + 127) / 128, (M + 127) / 128, nb * nz), dim3(256), 0, st, p);
   if (hipGetLastError() != hipSuccess) return dctts_set_error(DCTTS_ERR_HIP, "gemm launch failed");
   return nz;
 }
@@ -125,7 +138,7 @@ struct ConvGeom {
 // the forward pass kept (then the k GEMMs are skipped).  fwd: forward pass (keeps a copy when the tape is on).
 int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* x, const float* kernel, const float** kp, const float** hp, bool fwd) {
   if (reserve(&t->xp, (size_t)g.R * g.Cinp * 4) || reserve(&t->Hp, (size_t)g.R * g.Chp * 4) || reserve(&t->dHp, (size_t)g.R * g.Chp * 4) ||
-      reserve(&t->dxp, (size_t)g.R * g.Cinp * 4) || reserve(&t->wpart, (size_t)g.splits() * g.Cin * g.Ch * 4)) return DCTTS_ERR_HIP;
+      reserve(&t->dxp, (size_t)g.R * g.Cinp * 4) || reserve(&t->wpart, (size_t)g.k * g.splits() * g.Cin * g.Ch * 4)) return DCTTS_ERR_HIP;
   float *xp = (float*)t->xp.p, *Hp = (float*)t->Hp.p;
   *kp = kernel;
   if (g.padded()) {
@@ -154,8 +167,9 @@ int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float*
       t->tape_n = 0;                                   // out of step with the forward pass: recompute from here on
     }
   }
-  for (int j = 0; j < g.k; ++j) {
-    const int rc = gemm<false, false>(st, xp + (long)(j * g.rate) * g.Cinp, *kp + (long)j * g.Cinp * g.Chp, Hp + (long)g.pr * g.Chp, (int)g.Rv, g.Chp, g.Cinp, g.Cinp, g.Chp, g.Chp, j > 0);
+  {   // all taps in one launch: tap j reads x shifted by j * rate rows and kernel[j]
+    const int rc = gemm<false, false>(st, xp, *kp, Hp + (long)g.pr * g.Chp, (int)g.Rv, g.Chp, g.Cinp, g.Cinp, g.Chp, g.Chp, 0,
+                                      1, 0, g.k, (long)g.rate * g.Cinp, (long)g.Cinp * g.Chp);
     if (rc < 0) return rc;
   }
   if (fwd && t->tape_on) {
@@ -174,12 +188,14 @@ int conv_prenorm(dctts_train* t, hipStream_t st, const ConvGeom& g, const float*
 int conv_grads(dctts_train* t, hipStream_t st, const ConvGeom& g, const float* kp, float* dkernel, float* dx) {
   float *xp = (float*)t->xp.p, *dHp = (float*)t->dHp.p, *dxp = (float*)t->dxp.p;
   const long nw = (long)g.Cin * g.Ch;
-  for (int j = 0; j < g.k; ++j) {
-    const int nz = gemm<true, false>(st, xp + (long)(j * g.rate) * g.Cinp, dHp + (long)g.pr * g.Chp, (float*)t->wpart.p, g.Cin, g.Ch, (int)g.Rv, g.Cinp, g.Chp, g.Ch, 0, g.splits(), nw);
+  {   // the taps as ONE batched split-K launch (tap j = x shifted by j * rate rows against the same dH), one fixed-order sum, one dgrad launch
+    const int nz = gemm_batched_splitk<true, false>(st, g.k, xp, (long)g.rate * g.Cinp, dHp + (long)g.pr * g.Chp, 0, (float*)t->wpart.p, nw,
+                                                    g.Cin, g.Ch, (int)g.Rv, g.Cinp, g.Chp, g.Ch, g.splits());
     if (nz < 0) return nz;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, (const float*)t->wpart.p, nz, nw, nw, dkernel + (long)j * nw);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((nw + 255) / 256), g.k), dim3(256), 0, st, (const float*)t->wpart.p, nz, nw, nw, dkernel);
     THIP(hipGetLastError());
-    const int rc = gemm<false, true>(st, dHp + (long)(g.pl + g.pr - j * g.rate) * g.Chp, kp + (long)j * g.Cinp * g.Chp, dxp + (long)g.pl * g.Cinp, (int)g.Rv, g.Cinp, g.Chp, g.Chp, g.Chp, g.Cinp, 1);
+    const int rc = gemm<false, true>(st, dHp + (long)(g.pl + g.pr) * g.Chp, kp, dxp + (long)g.pl * g.Cinp, (int)g.Rv, g.Cinp, g.Chp, g.Chp, g.Chp, g.Cinp, 1,      // += : the row kernel left the direct part of dx there
+                                     1, 0, g.k, -(long)g.rate * g.Chp, (long)g.Cinp * g.Chp);
     if (rc < 0) return rc;
   }
   if (g.padded()) {

@@ -42,6 +42,9 @@ struct GemmParams {
   long c_zstride;
   int batched;               // 1: z is a batch index instead: A + z * a_zs, B + z * b_zs, C + z * c_zstride, the whole K each
   long a_zs, b_zs;
+  int nseg = 1;              // the contraction is the SUM over nseg segments s of (A + s * a_ss)' (B + s * b_ss)', each over the same k range:
+  long a_ss = 0, b_ss = 0;   //   the taps of a convolution in one launch (a tap shift is a row offset), no read-modify-write of C between them
+  int nsplit = 1;            // batched AND split-K: z = batch * nsplit + split (C + z * c_zstride holds that split's partial)
 };
 
 // A' = TA ? A^T : A (A stored M x K, or K x M when TA);  B' = TB ? B^T : B (B stored K x N, or N x K when TB).
@@ -54,9 +57,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int kbeg = p.batched ? 0 : blockIdx.z * p.kchunk, kend = p.batched ? p.K : min(p.K, kbeg + p.kchunk);
-  const float* const pA = p.A + (p.batched ? (long)blockIdx.z * p.a_zs : 0L);
-  const float* const pB = p.B + (p.batched ? (long)blockIdx.z * p.b_zs : 0L);
+  const int zb = p.batched ? (int)blockIdx.z / p.nsplit : 0, zk = p.batched ? (int)blockIdx.z % p.nsplit : (int)blockIdx.z;
+  const int kbeg = zk * p.kchunk, kend = min(p.K, kbeg + p.kchunk);
+  const float* pA = p.A + (long)zb * p.a_zs;
+  const float* pB = p.B + (long)zb * p.b_zs;
   const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64, l31 = lane & 31, lhi = lane >> 5;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // a tile is 128 x 16 floats = 512 float4: two per thread (i = 0, 1)
@@ -89,12 +93,15 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) { store_t(As[0], TA, i, ra[i]); store_t(Bs[0], !TB, i, rb[i]); }
   __syncthreads();
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
+  int buf = 0, seg = 0;
+  for (int k0 = kbeg; k0 < kend || seg + 1 < p.nseg; k0 += BK) {
+    if (k0 >= kend) { k0 = kbeg; ++seg; }                               // the tile in LDS is the first one of the next segment
+    bool more = k0 + BK < kend;
+    int kn = k0 + BK;
+    if (!more && seg + 1 < p.nseg) { more = true; kn = kbeg; pA += p.a_ss; pB += p.b_ss; }     // prefetch across the segment boundary
     if (more) {                                                          // in flight while this tile is contracted
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { ra[i] = load_a(k0 + BK, i); rb[i] = load_b(k0 + BK, i); }
+      for (int i = 0; i < 2; ++i) { ra[i] = load_a(kn, i); rb[i] = load_b(kn, i); }
     }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
@@ -126,9 +133,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(const GemmParams p) {
 }
 
 // out[i] = sum over z of part[z * zstride + i]  (fixed order)
+// blockIdx.y = one of several such sums laid out back to back (part + y * nz * zstride -> out + y * n)
 __global__ void sum_partials_kernel(const float* __restrict__ part, int nz, long zstride, long n, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  part += (long)blockIdx.y * nz * zstride; out += (long)blockIdx.y * n;
   float s = 0.f;
   for (int z = 0; z < nz; ++z) s += part[(long)z * zstride + i];
   out[i] = s;
