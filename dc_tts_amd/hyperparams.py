@@ -2,8 +2,8 @@
 
 Mirrors the class attributes of the reference's ``hyperparams.py:7-47`` that the
 synthesis path reads (signal constants, model widths, vocab, max_N / max_T, B).
-Of the training-only fields only ``lr`` (hyperparams.py:43, used by dc_tts_amd/train.py) is kept; logdir,
-num_iterations and the data paths are omitted.
+The training-side fields (``prepro``, ``data``, ``test_data``, ``lr``, ``logdir``, ``sampledir``, ``num_iterations``:
+hyperparams.py:10,35-47) are read by dc_tts_amd/data_load.py, prepo.py and train.py only.
 
 ``max_T`` is overridable (``replace(max_T=1000)``) because the long-form
 configuration of BASELINE.json uses 1000 mel frames; the attention mask is
@@ -36,10 +36,16 @@ class Hyperparams:
     vocab: str = "PE abcdefghijklmnopqrstuvwxyz'.?"
     max_N: int = 180
     max_T: int = 210
-    # training scheme (hyperparams.py:43)
+    # pipeline / data (hyperparams.py:10,35-37)
+    prepro: bool = True
+    data: str = "/data/private/voice/LJSpeech-1.0"
+    test_data: str = "harvard_sentences.txt"
+    # training scheme (hyperparams.py:43-47)
     lr: float = 0.001
-    # batch (hyperparams.py:46)
+    logdir: str = "logdir/LJ01"
+    sampledir: str = "samples"
     B: int = 32
+    num_iterations: int = 2000000
 
     @property
     def hop_length(self) -> int:  # hyperparams.py:17 (int(22050*0.0125) = 275)

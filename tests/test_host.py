@@ -179,8 +179,8 @@ def test_text_front_end_matches_reference_semantics(tmp_path):
     f = tmp_path / "sent.txt"
     f.write_text("http://header.line\n" + "".join(lines), encoding="utf-8")
     np.testing.assert_array_equal(D.load_data("synthesize", str(f)), L)
-    with pytest.raises(NotImplementedError):
-        D.load_data("train")
+    with pytest.raises(ValueError):
+        D.load_data("validate")
     with pytest.raises(ValueError):
         D.encode_lines(["1. " + "a" * 200])
 
