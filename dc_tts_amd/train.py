@@ -1,22 +1,24 @@
-"""First slice of the TRAINING path on the MI355X: what `train.py` obtains from TensorFlow's autodiff and
-optimizer for ONE building block, as calls into libdctts_hip.so (include/dctts_train.h).
+"""The TRAINING path on the MI355X: what `train.py` obtains from TensorFlow's autodiff and optimizer, as calls
+into libdctts_hip.so (include/dctts_train.h), the training graph built from them, and the loop of train.py's `__main__`.
 
   reference                                            here
-  modules.py:143-197  hc(...) under tf.gradients       TrainOps.hc_backward
-  modules.py:91-141   conv1d(...) under tf.gradients   TrainOps.conv1d_backward
-  modules.py:199-247  conv1d_transpose(...)            TrainOps.conv1d_transpose_backward
-  networks.py:126-155 Attention (training form)        TrainOps.attention_backward
-  modules.py:13-42    embed                            TrainOps.embed_backward
+  modules.py:143-197  hc(...) under tf.gradients       TrainOps.hc_forward / hc_backward
+  modules.py:91-141   conv1d(...) under tf.gradients   TrainOps.conv1d_forward / conv1d_backward
+  modules.py:199-247  conv1d_transpose(...)            TrainOps.conv1d_transpose_forward / _backward
+  networks.py:126-155 Attention (training form)        TrainOps.attention_forward / attention_backward
+  modules.py:13-42    embed                            TrainOps.embed_forward / embed_backward
   train.py:87,90,93-97  loss_mels, loss_bd1, loss_att  TrainOps.text2mel_losses
   train.py:104,107      loss_mags, loss_bd2            TrainOps.ssrn_losses
-  train.py:119-131      clip_by_value + Adam           TrainOps.adam_step  (+ learning_rate_decay = utils.py:142-145)
+  train.py:119-131      clip_by_value + Adam           TrainOps.adam_step / adam_step_multi  (+ learning_rate_decay = utils.py:142-145)
+  train.py:26-134       Graph(num, mode="train")       TrainGraph (train_op, save, restore)
+  train.py:137-162      __main__ (Supervisor loop)     main  (`python -m dc_tts_amd.train <num>`; batches from data_load.get_batch)
 
-There is no CPU or PyTorch fallback: without a GPU and the built library the constructor raises.  The rest of the training graph
-(the other blocks' backward passes, attention backward, the input pipeline) is not built yet.
+There is no CPU or PyTorch fallback: without a GPU and the built library the constructors raise.
 """
 import ctypes
 from typing import Dict, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -341,7 +343,8 @@ class TrainGraph:
     `sess.run(g.train_op)`: forward (keeping every layer's input), the losses of train.py:85-110, the gradient of every variable,
     clip_by_value(-1, 1) + Adam with the Noam learning rate (train.py:116-131).  training=True applies dropout (hp.dropout_rate behind
     every block, modules.py:139,195,245) from a counter-based hash of (seed, global_step, layer) -- TensorFlow's random stream cannot be
-    reproduced.  Not here: the input pipeline (data_load.py:33-131), checkpoints, summaries and the Supervisor loop (train.py:137-162)."""
+    reproduced.  The loop around it (train.py:137-162: batches from data_load.get_batch, a checkpoint every 1000 steps, resume from
+    the newest one) is `main` below; TensorBoard summaries (train.py:112-113,133) are not written."""
 
     def __init__(self, num: int, weights, hp, device: int = None, training: bool = True, seed: int = 0):
         from .layers import audiodec_layers, audioenc_layers, ssrn_layers, textenc_layers
@@ -356,6 +359,7 @@ class TrainGraph:
         self.m = {n: torch.zeros_like(v) for n, v in self.W.items()}
         self.v = {n: torch.zeros_like(v) for n, v in self.W.items()}
         self.global_step = 0
+        self.alignments = None
         self._te, self._ae, self._ad, self._ss = textenc_layers(hp), audioenc_layers(hp), audiodec_layers(hp), ssrn_layers(hp)
 
     def loss_and_grads(self, *batch):
@@ -375,6 +379,7 @@ class TrainGraph:
             R, al = ops.attention_forward(Q, K, V)
             logits, xs_ad = network_forward(ops, self._ad, W, "Text2Mel/AudioDec", R, "CAUSAL", drop)
             Y = ops.sigmoid(logits)
+            self.alignments = al                                                                         # (B, N, T), train.py:160 plots [0]
             losses, dY, dlog, dA = ops.text2mel_losses(Y, logits, mels, al, hp.max_N, hp.max_T)
             dlog = dlog + dY * Y * (1.0 - Y)                                                            # Y = sigmoid(Y_logits) (networks.py:210)
             dR, g = network_backward(ops, self._ad, W, "Text2Mel/AudioDec", xs_ad, dlog, "CAUSAL", drop); grads.update(g)
@@ -406,3 +411,98 @@ class TrainGraph:
         torch.cuda.synchronize(self.ops.device)
         cpu = lambda d: {n: t.cpu().numpy() for n, t in d.items()}
         return save_checkpoint(logdir, cpu(self.W), self.global_step, {"Adam": cpu(self.m), "Adam_1": cpu(self.v)})
+
+    def restore(self, logdir: str) -> bool:
+        """What tf.train.Supervisor does when `logdir` holds a checkpoint (train.py:146-147): variables, Adam slots and global_step
+        come from the newest one and training continues from there.  Returns False (state untouched) when there is none."""
+        import os
+        from .tf_checkpoint import latest_checkpoint, read_checkpoint
+        if not os.path.exists(os.path.join(logdir, "checkpoint")):
+            return False
+        prefix = latest_checkpoint(logdir)
+        names = list(self.W)
+        want = names + [n + "/Adam" for n in names] + [n + "/Adam_1" for n in names] + ["gs/global_step"]
+        t = read_checkpoint(prefix, want)
+        for n in names:
+            for dst, key in ((self.W, n), (self.m, n + "/Adam"), (self.v, n + "/Adam_1")):
+                a = np.array(t[key], dtype=np.float32)
+                if tuple(a.shape) != tuple(dst[n].shape):
+                    raise ValueError("%s: checkpoint shape %s, model shape %s" % (key, a.shape, tuple(dst[n].shape)))
+                dst[n].copy_(torch.from_numpy(a))
+        self.global_step = int(t["gs/global_step"])
+        return True
+
+
+def plot_alignment(alignment, gs: str, dir: str) -> str:
+    """utils.py:116-132: `alignment` (encoder_steps, decoder_steps) as `<dir>/alignment_<gs>.png` (matplotlib, when installed;
+    otherwise the array itself as .npy)."""
+    import os
+    os.makedirs(dir, exist_ok=True)
+    try:
+        import matplotlib
+        matplotlib.use("pdf")
+        import matplotlib.pyplot as plt
+    except ImportError:
+        path = "{}/alignment_{}.npy".format(dir, gs)
+        np.save(path, np.asarray(alignment))
+        return path
+    fig, ax = plt.subplots()
+    im = ax.imshow(alignment)
+    fig.colorbar(im)
+    plt.title("{} Steps".format(gs))
+    path = "{}/alignment_{}.png".format(dir, gs)
+    plt.savefig(path, format="png")
+    plt.close(fig)
+    return path
+
+
+def main(argv=None, hp=None, save_every: int = 1000, batches=None, init_seed: int = 0) -> int:
+    """`python -m dc_tts_amd.train <num>` = train.py:137-162.  num: 1 trains Text2Mel, 2 trains SSRN, each into `<hp.logdir>-<num>`.
+    Variables start from the reference's initialisers (dc_tts_amd.weights.synthetic_weights) or, when the log directory holds a
+    checkpoint, from the newest one (Supervisor).  Batches come from data_load.get_batch (bucketed by text length, B = hp.B, arrays
+    written by `python -m dc_tts_amd.prepo` when hp.prepro); every `save_every` steps: a checkpoint `model_gs_<k>k` and, for Text2Mel,
+    the first utterance's alignment plot; stops after hp.num_iterations steps.  `batches`: an iterable to use instead (tests)."""
+    import argparse
+    import sys
+    from .hyperparams import hp as _hp
+    from .weights import synthetic_weights
+    hp = hp or _hp
+    ap = argparse.ArgumentParser(description="DC-TTS training on MI355X: 1 = Text2Mel, 2 = SSRN (train.py)")
+    ap.add_argument("num", type=int, choices=(1, 2))
+    ap.add_argument("--data", default=None, help="corpus directory holding transcript.csv (hp.data)")
+    ap.add_argument("--prepro-dir", default=".", help="directory holding mels/ and mags/ written by `python -m dc_tts_amd.prepo`")
+    ap.add_argument("--logdir", default=None, help="hp.logdir; '-<num>' is appended")
+    ap.add_argument("--num-iterations", type=int, default=None)
+    args = ap.parse_args(argv)
+    if args.data: hp = hp.replace(data=args.data)
+    if args.logdir: hp = hp.replace(logdir=args.logdir)
+    if args.num_iterations is not None: hp = hp.replace(num_iterations=args.num_iterations)
+    num = args.num
+    g = TrainGraph(num, synthetic_weights(hp, seed=init_seed), hp)
+    logdir = hp.logdir + "-" + str(num)
+    resumed = g.restore(logdir)
+    print("Training Graph loaded" + (" (resumed at global_step %d)" % g.global_step if resumed else ""), file=sys.stderr)
+    if batches is None:
+        from .data_load import get_batch
+        batches = get_batch(hp, seed=g.global_step, prepro_dir=args.prepro_dir, pad_text_to=4)     # attention_backward needs N % 4 == 0
+    dev = g.ops.device
+    for texts, mels, mags, _ in batches:
+        if num == 1:
+            batch = (torch.from_numpy(texts).to(dev), torch.from_numpy(mels).to(dev))
+        else:
+            batch = (torch.from_numpy(mels).to(dev), torch.from_numpy(mags).to(dev))
+        g.train_op(*batch)
+        gs = g.global_step
+        if gs % save_every == 0:                                                                    # train.py:157-164
+            g.save(logdir)
+            if num == 1:
+                plot_alignment(g.alignments[0].cpu().numpy(), str(gs // 1000).zfill(3) + "k", logdir)
+        if gs > hp.num_iterations:                                                                  # train.py:167
+            break
+    print("Done", file=sys.stderr)
+    return 0
+
+
+if __name__ == "__main__":
+    import sys
+    sys.exit(main())

@@ -1,6 +1,8 @@
 """GPU parity of the first training slice (include/dctts_train.h) against oracle/train_ref.py (float64 numpy, itself pinned by
 finite differences in tests/test_train_oracle.py).  Tolerances are relative to the largest magnitude of each gradient: the HIP
 path is fp32 (MFMA contractions over up to 7 000 rows), the oracle float64."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -395,3 +397,66 @@ def test_adam_steps_vs_oracle(ops):
     torch.cuda.synchronize()
     # fp32 constants: 1 - 0.999f = 0.00100005 (4.7e-5 off), as in TensorFlow's fp32 Adam kernel; the oracle is float64
     assert np.abs(dv.cpu().numpy() - vr).max() < 1e-6 and rel(dm.cpu().numpy(), mr) < 1e-5 and rel(dvv.cpu().numpy(), vvr) < 1e-4
+
+
+def _synthetic_batches(n, B=4, N=24, T=16, seed=3):
+    from dc_tts_amd.hyperparams import hp
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        texts = rng.integers(2, len(hp.vocab), (B, N)).astype(np.int32); texts[:, -1] = 1
+        out.append((texts, rng.random((B, T, hp.n_mels), dtype=np.float32), rng.random((B, 4 * T, hp.n_linear), dtype=np.float32), ["x.wav"] * B))
+    return out
+
+
+# The two tests below were written after round 2's GPU minutes were spent: their first attempt timed out in the checkpoint writer's
+# byte-loop crc32c (since vectorised), and they have NOT run on a GPU box yet.  They stay out of the default GPU suite until they have.
+_unverified = pytest.mark.skipif(not os.environ.get("DCTTS_TEST_TRAIN_LOOP"), reason="not yet verified on a GPU box: set DCTTS_TEST_TRAIN_LOOP=1 to run")
+
+
+@_unverified
+@pytest.mark.parametrize("num", [1, 2])
+def test_training_loop_checkpoints_and_resumes(tmp_path, num):
+    """dc_tts_amd.train.main = train.py:137-162: a run of 6 steps, and a run of 4 steps that is stopped and resumed from its checkpoint
+    for 2 more (variables, Adam slots and global_step restored, as the Supervisor does), end in the same checkpoint, bit for bit."""
+    from dc_tts_amd import train as TRN
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.tf_checkpoint import latest_checkpoint, read_checkpoint
+    bt = _synthetic_batches(8)
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    assert TRN.main([str(num), "--logdir", a, "--num-iterations", "5"], save_every=2, batches=iter(bt)) == 0       # steps 1..6, saves at 2, 4, 6
+    assert TRN.main([str(num), "--logdir", b, "--num-iterations", "3"], save_every=2, batches=iter(bt)) == 0       # steps 1..4
+    mid = read_checkpoint(latest_checkpoint(b + f"-{num}"), verify_tensors=False)
+    assert int(mid["gs/global_step"]) == 4
+    assert TRN.main([str(num), "--logdir", b, "--num-iterations", "5"], save_every=2, batches=iter(bt[4:])) == 0   # resumed: steps 5, 6
+    A, Bc = read_checkpoint(latest_checkpoint(a + f"-{num}"), verify_tensors=False), read_checkpoint(latest_checkpoint(b + f"-{num}"))
+    assert int(A["gs/global_step"]) == int(Bc["gs/global_step"]) == 6 and set(A) == set(Bc)
+    prefix = "Text2Mel/" if num == 1 else "SSRN/"
+    names = [n for n in A if n.startswith(prefix)]
+    assert len(names) == 3 * (209 if num == 1 else 80)                       # variables + Adam + Adam_1
+    moved = 0
+    for n in names:
+        np.testing.assert_array_equal(A[n], Bc[n], err_msg=n)
+        if not n.endswith(("Adam", "Adam_1")):
+            moved += int(np.abs(A[n] - mid[n]).max() > 0)
+    assert moved > len(names) // 3 * 0.9                                     # the resumed steps did train
+    assert (num == 2) or os.path.exists(os.path.join(b + "-1", "alignment_000k.png")) or os.path.exists(os.path.join(b + "-1", "alignment_000k.npy"))
+
+
+@_unverified
+def test_training_loop_on_a_wave_corpus(tmp_path):
+    """wave files -> prepo -> bucketed batches -> two Text2Mel steps and two SSRN steps, end to end."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_train_input import _corpus
+    from dc_tts_amd import prepo, train as TRN
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.tf_checkpoint import latest_checkpoint, read_checkpoint
+    root, rows = _corpus(tmp_path, n=12)
+    h = hp.replace(data=root, B=4, logdir=str(tmp_path / "log"))
+    pre = str(tmp_path / "pre")
+    assert prepo.main(["--out", pre], hp=h) == 0
+    for num in (1, 2):
+        assert TRN.main([str(num), "--prepro-dir", pre, "--num-iterations", "1"], hp=h, save_every=2) == 0
+        t = read_checkpoint(latest_checkpoint(h.logdir + f"-{num}"))
+        assert int(t["gs/global_step"]) == 2 and all(np.isfinite(v).all() for v in t.values())

@@ -169,3 +169,18 @@ def test_product_writer_round_trip_and_training_checkpoints(tmp_path, weights):
     assert int(C.read_checkpoint(p1, ["gs/global_step"])["gs/global_step"]) == 12345
     W = C.load_reference_weights(logdir)
     assert set(W) == set(weights) and all(np.array_equal(W[n], weights[n]) for n in weights)
+
+
+def test_crc32c_vector_path_equals_byte_loop():
+    """Buffers of 64 KB and more take the numpy path (chunks advanced together, folded with the zero-byte operator)."""
+    from dc_tts_amd import tf_checkpoint as C
+    assert C.crc32c(b"123456789") == 0xE3069283                           # the CRC-32C check value
+    rng = np.random.default_rng(11)
+    for n in (65536, 65537, 99991, 1 << 18, (1 << 20) + 3):
+        a = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        ref = C._crc_scalar(a, 0xFFFFFFFF) ^ 0xFFFFFFFF
+        assert C.crc32c(a) == ref
+        k = n // 3
+        assert C.crc32c(a[k:], C.crc32c(a[:k])) == ref                    # continuation across the two paths
+    z = bytes(200000)
+    assert C.crc32c(z) == C._crc_scalar(z, 0xFFFFFFFF) ^ 0xFFFFFFFF

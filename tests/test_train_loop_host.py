@@ -1,0 +1,106 @@
+"""Host logic of the training loop (dc_tts_amd.train.main, TrainGraph.save / restore = train.py:137-162) without a GPU: the graph is
+replaced by a stand-in that counts steps; the cadence of checkpoints, the stop rule, resuming, argument handling and the checkpoint
+contents are what is checked here.  The real graph's steps are tests/test_gpu_train.py's."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from dc_tts_amd import train as TRN
+from dc_tts_amd.hyperparams import hp
+from dc_tts_amd.tf_checkpoint import latest_checkpoint, read_checkpoint
+
+
+class FakeGraph:
+    """TrainGraph's state and its real save / restore methods; train_op adds 1 to every variable instead of training."""
+    made = []
+
+    def __init__(self, num, weights, hp_, device=None, training=True, seed=0):
+        prefix = "Text2Mel/" if num == 1 else "SSRN/"
+        names = [n for n in weights if n.startswith(prefix)][:5]
+        self.num, self.hp = num, hp_
+        self.W = {n: torch.from_numpy(np.round(np.array(weights[n], np.float32) * 8)) for n in names}      # small integers: the +1 steps are exact
+        self.m = {n: torch.zeros_like(v) for n, v in self.W.items()}
+        self.v = {n: torch.zeros_like(v) for n, v in self.W.items()}
+        self.global_step, self.alignments = 0, None
+        self.ops = types.SimpleNamespace(device=torch.device("cpu"))
+        self.batches = []
+        FakeGraph.made.append(self)
+
+    def train_op(self, *batch):
+        self.batches.append(tuple(tuple(t.shape) for t in batch))
+        for n in self.W:
+            self.W[n] += 1.0; self.m[n] += 0.5; self.v[n] += 0.25
+        self.alignments = torch.rand(batch[0].shape[0], 12, 7)
+        self.global_step += 1
+
+    save = TRN.TrainGraph.save
+    restore = TRN.TrainGraph.restore
+
+
+@pytest.fixture()
+def fake(monkeypatch):
+    FakeGraph.made.clear()
+    monkeypatch.setattr(TRN, "TrainGraph", FakeGraph)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    return FakeGraph
+
+
+def _batches(n, B=2, N=8, T=5):
+    return [(np.full((B, N), 2, np.int32), np.zeros((B, T, hp.n_mels), np.float32), np.zeros((B, 4 * T, hp.n_linear), np.float32), ["a.wav"] * B)
+            for _ in range(n)]
+
+
+@pytest.mark.parametrize("num", [1, 2])
+def test_loop_cadence_stop_rule_and_resume(fake, tmp_path, num):
+    logdir = str(tmp_path / "log")
+    assert TRN.main([str(num), "--logdir", logdir, "--num-iterations", "4"], save_every=2, batches=iter(_batches(9))) == 0
+    g = fake.made[-1]
+    assert g.global_step == 5                                             # train.py:167 stops once gs > num_iterations
+    assert g.batches[0] == (((2, 8), (2, 5, hp.n_mels)) if num == 1 else ((2, 5, hp.n_mels), (2, 20, hp.n_linear)))
+    d = logdir + "-" + str(num)
+    assert latest_checkpoint(d).endswith("model_gs_000k")                 # train.py:158's name
+    t = read_checkpoint(latest_checkpoint(d))
+    assert int(t["gs/global_step"]) == 4                                  # saved at steps 2 and 4, not at 5
+    name = next(iter(g.W))
+    np.testing.assert_array_equal(t[name], g.W[name].numpy() - 1.0)
+    np.testing.assert_array_equal(t[name + "/Adam"], np.full(g.W[name].shape, 2.0, np.float32))
+    np.testing.assert_array_equal(t[name + "/Adam_1"], np.full(g.W[name].shape, 1.0, np.float32))
+    assert os.path.exists(os.path.join(d, "alignment_000k.png")) == (num == 1)
+    # a second run finds the checkpoint (Supervisor): continues at 4 with the saved variables and slots
+    assert TRN.main([str(num), "--logdir", logdir, "--num-iterations", "6"], save_every=2, batches=iter(_batches(9))) == 0
+    g2 = fake.made[-1]
+    assert g2.global_step == 7 and len(g2.batches) == 3
+    np.testing.assert_array_equal(g2.W[name].numpy(), t[name] + 3.0)
+    np.testing.assert_array_equal(g2.m[name].numpy(), np.full(g.W[name].shape, 3.5, np.float32))
+    assert int(read_checkpoint(latest_checkpoint(d), ["gs/global_step"])["gs/global_step"]) == 6
+
+
+def test_restore_rejects_another_models_checkpoint(fake, tmp_path):
+    logdir = str(tmp_path / "log")
+    TRN.main(["1", "--logdir", logdir, "--num-iterations", "1"], save_every=1, batches=iter(_batches(3)))
+    g = FakeGraph(1, {n: np.zeros((3,) + tuple(v.shape), np.float32) for n, v in fake.made[-1].W.items()}, hp)
+    with pytest.raises(ValueError, match="checkpoint shape"):
+        g.restore(logdir + "-1")
+    assert FakeGraph(2, {"SSRN/x": np.zeros(3, np.float32)}, hp).restore(str(tmp_path / "nothing")) is False
+    with pytest.raises(SystemExit):
+        TRN.main(["3"])
+
+
+def test_loop_reads_the_batch_queue(fake, tmp_path):
+    """Without `batches`, main builds data_load.get_batch from hp.data / --prepro-dir (N padded to a multiple of 4)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_train_input import _corpus
+    from dc_tts_amd import prepo
+    root, rows = _corpus(tmp_path, n=12)
+    h = hp.replace(data=root, B=4, logdir=str(tmp_path / "log"))
+    pre = str(tmp_path / "pre")
+    assert prepo.main(["--out", pre], hp=h) == 0
+    assert TRN.main(["1", "--prepro-dir", pre, "--num-iterations", "2"], hp=h, save_every=50) == 0
+    g = fake.made[-1]
+    assert g.global_step == 3 and all(b[0][0] == 4 and b[0][1] % 4 == 0 and b[1][2] == hp.n_mels for b in g.batches)
+    assert TRN.main(["2", "--data", root, "--prepro-dir", pre, "--logdir", h.logdir, "--num-iterations", "0"], hp=hp.replace(B=4), save_every=50) == 0
+    assert fake.made[-1].batches[0][1][2] == hp.n_linear and fake.made[-1].batches[0][1][1] == 4 * fake.made[-1].batches[0][0][1]
