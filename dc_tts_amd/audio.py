@@ -4,7 +4,8 @@ Host-side numpy, run once per corpus by `dc_tts_amd.prepo` (prepo.py) exactly as
 (`spectrogram2wav`) is the GPU vocoder in `dc_tts_amd.utils`.  The reference delegates to librosa, which is not installed here and not
 vendored in /root/reference (no version pin; 2018, so librosa 0.5 / 0.6): the functions below restate the published algorithms
 with that era's defaults and say which.  PARITY UNPINNED against librosa itself: tests check them against independent restatements
-(the test suite's frame-by-frame STFT and trim), closed forms (a stationary sine) and the vocoder round trip.
+(the test suite's frame-by-frame STFT and trim), closed forms (a stationary sine), the vocoder round trip, and a third-party
+librosa-compatible implementation that is installed here (transformers.audio_utils: mel filters to 1e-9, |STFT| to 1e-7).
 
   librosa.load(fpath, sr=hp.sr)          -> load_wav: PCM / float WAV via scipy.io.wavfile, mono (channel mean), float32 in [-1, 1);
                                             a file at another rate is resampled with a polyphase filter (librosa: resampy kaiser_best -- not

@@ -185,3 +185,26 @@ def test_prepo_and_bucketed_batches(tmp_path):
     assert f2 == seen[:4]
     m1 = np.load(os.path.join(out, "mels", f2[0].replace("wav", "npy")))
     np.testing.assert_array_equal(m2[0, :len(m1)], m1)
+
+
+def test_against_transformers_audio_utils():
+    """A third-party pin: `transformers.audio_utils` (installed here) implements librosa-compatible mel filters (norm="slaney",
+    mel_scale="slaney"), windows and spectrograms independently of this repo.  Filterbank, padded window and |STFT| must agree with it."""
+    AU = pytest.importorskip("transformers.audio_utils")
+    M = A.mel_filterbank(hp.sr, hp.n_fft, hp.n_mels)
+    R = AU.mel_filter_bank(1 + hp.n_fft // 2, hp.n_mels, 0.0, hp.sr / 2.0, hp.sr, norm="slaney", mel_scale="slaney").T
+    assert np.abs(M - R).max() < 1e-7
+    w = AU.window_function(hp.win_length, "hann", periodic=True, frame_length=hp.n_fft, center=True)
+    assert np.abs(w - A.padded_window(hp)).max() < 1e-12
+    y = _voice(seed=8)
+    S = AU.spectrogram(y, w, frame_length=hp.n_fft, hop_length=hp.hop_length, fft_length=hp.n_fft, power=1.0, center=True, pad_mode="reflect")
+    mine = np.abs(A.stft(y, hp))
+    assert S.shape == mine.shape and np.abs(S - mine).max() < 1e-5 * mine.max()
+    # the whole chain of utils.py:41-58 rebuilt from that library's pieces
+    yt, _ = A.trim(y)
+    ye = np.append(yt[0], yt[1:] - np.float32(hp.preemphasis) * yt[:-1])
+    mag = AU.spectrogram(ye, w, frame_length=hp.n_fft, hop_length=hp.hop_length, fft_length=hp.n_fft, power=1.0, center=True, pad_mode="reflect")
+    mel = R.astype(np.float32) @ mag
+    norm = lambda x: np.clip((20 * np.log10(np.maximum(1e-5, x)) - hp.ref_db + hp.max_db) / hp.max_db, 1e-8, 1).T
+    mel_p, mag_p = A.spectrograms_of(y, hp)
+    assert np.abs(norm(mag) - mag_p).max() < 1e-4 and np.abs(norm(mel) - mel_p).max() < 1e-4
