@@ -1,6 +1,6 @@
-/* dctts_train.h -- C ABI of the first slice of the TRAINING path, MI355X (gfx950).
+/* dctts_train.h -- C ABI of the TRAINING path, MI355X (gfx950).
  *
- * What is here: the backward pass of every building block of networks.py (hc, conv1d, conv1d_transpose, embed, Attention), the losses of
+ * What is here: the forward and backward pass of every building block of networks.py (hc, conv1d, conv1d_transpose, embed, Attention), the losses of
  * train.py:85-110 with their gradients, and the clip + Adam update of train.py:119-131.  A trainer written against the
  * reference would call these where TensorFlow's autodiff / optimizer ran:
  *

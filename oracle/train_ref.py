@@ -1,4 +1,4 @@
-"""CPU ORACLE for the first slice of the TRAINING path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
+"""CPU ORACLE for the TRAINING path  --  TEST INFRASTRUCTURE, NOT PRODUCT.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module.
 
