@@ -411,7 +411,7 @@ def _synthetic_batches(n, B=4, N=24, T=16, seed=3):
 
 # The two tests below were written after round 2's GPU minutes were spent: their first attempt timed out in the checkpoint writer's
 # byte-loop crc32c (since vectorised), and they have NOT run on a GPU box yet.  They stay out of the default GPU suite until they have.
-_unverified = pytest.mark.skipif(not os.environ.get("DCTTS_TEST_TRAIN_LOOP"), reason="not yet verified on a GPU box: set DCTTS_TEST_TRAIN_LOOP=1 to run")
+_unverified = pytest.mark.skipif(not os.environ.get("DCTTS_TEST_UNVERIFIED"), reason="not yet verified on a GPU box: set DCTTS_TEST_UNVERIFIED=1 to run")
 
 
 @_unverified
