@@ -48,6 +48,10 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
     HCONV2_CASE(EPI_C, 2, 8)
     HCONV2_CASE(EPI_C, 4, 8)
     HCONV2_CASE(EPI_C, 3, 11)
+    if (s.epi == EPI_HC && s.nt == 8 && s.nw == 8) {
+      hipLaunchKernelGGL((hconv_kernel<EPI_HC, 8, 8, 1, true>), grid, dim3(512), 0, stream, p);
+      return hipGetLastError();
+    }
   }
   HCONV_CASE(EPI_HC, 2, 8)
   HCONV_CASE(EPI_HC, 4, 8)

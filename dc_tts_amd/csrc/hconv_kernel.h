@@ -67,8 +67,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 
 // BPF = how many k-groups (8 k each) ahead of its MFMAs a weight fragment is requested.  1: one group = NT * 4 MFMAs = NT * 256 cycles per wave,
 // which for NT <= 4 is about an L2 round trip (the ISA shows s_waitcnt vmcnt on loads issued 6..12 MFMAs earlier, and a drain at every chunk
-// boundary).  2 (opt-in, DCTTS_HCONV_BPF=2, NT <= 4): a second register set (4 * NT VGPRs), requests pinned at the top of their k-group.
-template <int EPI, int NT, int NW, int BPF = 1>
+// boundary).  2 (opt-in, DCTTS_HCONV_BPF=2, NT <= 4): a second register set (4 * NT VGPRs), requests pinned at the top of their k-group (PIN).
+// NT = 8 has no registers for a second set at two waves per SIMD: its opt-in form is BPF = 1 with PIN (the scheduler otherwise sinks requests to
+// just before their use: s_waitcnt vmcnt(0) in the middle of a chunk).
+template <int EPI, int NT, int NW, int BPF = 1, bool PIN = (BPF == 2)>
 __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   constexpr int LDA = 36;
   constexpr int NH = (EPI == EPI_HC) ? 2 : 1;
@@ -165,7 +167,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
       float4 bnext[NT];
 #pragma unroll
       for (int i = 0; i < NT; ++i) bnext[i] = wq[i][(long)kgn * 64];
-      if (BPF == 2) __builtin_amdgcn_sched_barrier(0);      // the requests go out before this group's MFMAs, not somewhere among them
+      if (PIN) __builtin_amdgcn_sched_barrier(0);           // the requests go out before this group's MFMAs, not somewhere among them
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bcur[i].x, acc[i], 0, 0, 0);
 #pragma unroll
