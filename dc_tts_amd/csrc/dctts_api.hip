@@ -70,9 +70,21 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
     return hipGetLastError();                                                                       \
   }
 
+#define HCONV16V2_CASE(E, NT_, NW_)                                                                       \
+  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                         \
+    hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_, (NT_ <= 8 ? 2 : 1)>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
+    return hipGetLastError();                                                                             \
+  }
+
 hipError_t launch_hconv16(const ConvShape& s, const ConvParams& p, int m_start, hipStream_t stream) {
   if (p.M <= m_start) return hipSuccess;
   const dim3 grid((p.M - m_start + 15) / 16);
+  if (s.bpf == 2) {                      // opt-in (hconv16_kernel.h, V2): the SSRN row-tail shapes
+    HCONV16V2_CASE(EPI_HC, 8, 8)
+    HCONV16V2_CASE(EPI_HC, 16, 8)
+    HCONV16V2_CASE(EPI_C, 8, 8)
+    HCONV16V2_CASE(EPI_C, 6, 11)
+  }
   HCONV16_CASE(EPI_HC, 4, 8)
   HCONV16_CASE(EPI_HC, 8, 8)
   HCONV16_CASE(EPI_HC, 16, 8)
@@ -700,7 +712,7 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   ConvShape shp = L.shape; shp.bpf = c->hconv_bpf == 2 ? 2 : 1;
   HIPCHK(launch_hconv(shp, p, st, tiles32));
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
-  if (m_tail < p.M) { p.wp = L.wp16r; HIPCHK(launch_hconv16(L.shape16, p, m_tail, st)); }
+  if (m_tail < p.M) { p.wp = L.wp16r; ConvShape s16 = L.shape16; s16.bpf = shp.bpf; HIPCHK(launch_hconv16(s16, p, m_tail, st)); }
   return 0;
 }
 
