@@ -1,9 +1,10 @@
-"""SSRN phase time (B utterances, T = 210 -> (B, 840, 1025)), HIP-event timed on the caller's stream; env DCTTS_SSRN_SPLIT etc. apply."""
+"""SSRN phase time (B utterances, T = 210 -> (B, 840, 1025)) and TextEnc (B, 180), HIP-event timed on the caller's stream; env DCTTS_SSRN_SPLIT,
+DCTTS_HCONV_BPF etc. apply."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 from dc_tts_amd.engine import Engine
 from dc_tts_amd.hyperparams import hp
-from dc_tts_amd.weights import synthetic_weights
+from dc_tts_amd.weights import synthetic_text, synthetic_weights
 eng = Engine(synthetic_weights(hp, seed=1), hp)
 for B in [int(a) for a in sys.argv[1:]] or [32]:
     Y = torch.rand(B, 210, hp.n_mels, device="cuda")
@@ -16,3 +17,11 @@ for B in [int(a) for a in sys.argv[1:]] or [32]:
     b.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(b) / n
     print(f"B={B}: SSRN {ms:.3f} ms, {B * 39.34e9 / ms / 1e9:.1f} TFLOP/s = {B * 39.34e9 / ms / 1e9 / 157.3:.3f} of the fp32 MFMA peak")
+    L = torch.from_numpy(synthetic_text(hp, B=B)).cuda()
+    for _ in range(3): eng.text_enc(L)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n): eng.text_enc(L)
+    b.record(); torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / n
+    print(f"B={B}: TextEnc {ms:.3f} ms, {B * 2 * 3.0789e9 / ms / 1e9:.1f} TFLOP/s = {B * 2 * 3.0789e9 / ms / 1e9 / 157.3:.3f} of the fp32 MFMA peak")
