@@ -151,6 +151,11 @@ def test_prepo_and_bucketed_batches(tmp_path):
     h = hp.replace(data=root, B=4)
     assert prepo.main(["--out", out], hp=h) == 0
     assert sorted(os.listdir(os.path.join(out, "mels"))) == sorted(os.listdir(os.path.join(out, "mags"))) == [f"LJ{i:03d}.npy" for i in range(len(rows))]
+    out2 = str(tmp_path / "pre2")                                           # the same over worker processes
+    assert prepo.main(["--out", out2, "--workers", "2", "--data", root], hp=hp.replace(B=4)) == 0
+    for sub in ("mels", "mags"):
+        for f in os.listdir(os.path.join(out, sub)):
+            np.testing.assert_array_equal(np.load(os.path.join(out, sub, f)), np.load(os.path.join(out2, sub, f)))
     q = D.get_batch(h, seed=1, prepro_dir=out, pad_text_to=4)
     assert q.num_batch == len(rows) // 4
     lens = np.array(q.text_lengths)
