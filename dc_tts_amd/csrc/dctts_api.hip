@@ -33,26 +33,9 @@ namespace dctts {
     return hipGetLastError();                                                          \
   }
 
-#define HCONV2_CASE(E, NT_, NW_)                                                          \
-  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                          \
-    hipLaunchKernelGGL((hconv_kernel<E, NT_, NW_, 2>), grid, dim3(NW_ * 64), 0, stream, p); \
-    return hipGetLastError();                                                              \
-  }
-
 hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles) {
   const dim3 grid(tiles >= 0 ? tiles : (p.M + 31) / 32);
   if (p.M <= 0 || grid.x == 0) return hipSuccess;
-  if (s.bpf == 2) {                      // opt-in: weight fragments requested two k-groups ahead (hconv_kernel.h)
-    HCONV2_CASE(EPI_HC, 2, 8)
-    HCONV2_CASE(EPI_HC, 4, 8)
-    HCONV2_CASE(EPI_C, 2, 8)
-    HCONV2_CASE(EPI_C, 4, 8)
-    HCONV2_CASE(EPI_C, 3, 11)
-    if (s.epi == EPI_HC && s.nt == 8 && s.nw == 8) {
-      hipLaunchKernelGGL((hconv_kernel<EPI_HC, 8, 8, 1, true>), grid, dim3(512), 0, stream, p);
-      return hipGetLastError();
-    }
-  }
   HCONV_CASE(EPI_HC, 2, 8)
   HCONV_CASE(EPI_HC, 4, 8)
   HCONV_CASE(EPI_HC, 8, 8)
@@ -70,21 +53,9 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
     return hipGetLastError();                                                                       \
   }
 
-#define HCONV16V2_CASE(E, NT_, NW_)                                                                       \
-  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                         \
-    hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_, (NT_ <= 8 ? 2 : 1)>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
-    return hipGetLastError();                                                                             \
-  }
-
 hipError_t launch_hconv16(const ConvShape& s, const ConvParams& p, int m_start, hipStream_t stream) {
   if (p.M <= m_start) return hipSuccess;
   const dim3 grid((p.M - m_start + 15) / 16);
-  if (s.bpf == 2) {                      // opt-in (hconv16_kernel.h, V2): the SSRN row-tail shapes
-    HCONV16V2_CASE(EPI_HC, 8, 8)
-    HCONV16V2_CASE(EPI_HC, 16, 8)
-    HCONV16V2_CASE(EPI_C, 8, 8)
-    HCONV16V2_CASE(EPI_C, 6, 11)
-  }
   HCONV16_CASE(EPI_HC, 4, 8)
   HCONV16_CASE(EPI_HC, 8, 8)
   HCONV16_CASE(EPI_HC, 16, 8)
@@ -206,7 +177,6 @@ struct dctts_ctx {
                                        // Default 1 = one sequence: 2 parts take SSRN alone from 12.16 to 11.56 ms, but between decodes the gain is ~0.1 ms and
                                        // the extra active queue can cost the decode's dependent launches more than that
   hipStream_t s_ssrn[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_ssrn[4] = {nullptr, nullptr, nullptr, nullptr};
-  int hconv_bpf = 1;                   // run_conv: 2 = hconv_kernel<.., BPF = 2> for the shapes that have it (DCTTS_HCONV_BPF; not measured yet)
   int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
   int bulk_cap = 176;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
@@ -419,7 +389,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 // Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
-  geti("DCTTS_TAIL_SPLIT", &c->tail_split); geti("DCTTS_SSRN_SPLIT", &c->ssrn_split); geti("DCTTS_HCONV_BPF", &c->hconv_bpf); geti("DCTTS_SSRN_PRIO", &c->ssrn_prio);
+  geti("DCTTS_TAIL_SPLIT", &c->tail_split); geti("DCTTS_SSRN_SPLIT", &c->ssrn_split); geti("DCTTS_SSRN_PRIO", &c->ssrn_prio);
   { int r = c->chain_rows; geti("DCTTS_CHAIN_ROWS", &r); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
   geti("DCTTS_FUSE_MEL", &c->fuse_mel); geti("DCTTS_BULK_SMALL", &c->bulk_small_rows); geti("DCTTS_BULK_PIPE", &c->bulk_pipelined);
   geti("DCTTS_CHAIN_ONE", &c->chain_one);
@@ -709,10 +679,9 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
     const int full = (tiles32 / c->n_cu) * c->n_cu;
     if ((tiles32 - full) * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
   }
-  ConvShape shp = L.shape; shp.bpf = c->hconv_bpf == 2 ? 2 : 1;
-  HIPCHK(launch_hconv(shp, p, st, tiles32));
+  HIPCHK(launch_hconv(L.shape, p, st, tiles32));
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
-  if (m_tail < p.M) { p.wp = L.wp16r; ConvShape s16 = L.shape16; s16.bpf = shp.bpf; HIPCHK(launch_hconv16(s16, p, m_tail, st)); }
+  if (m_tail < p.M) { p.wp = L.wp16r; HIPCHK(launch_hconv16(L.shape16, p, m_tail, st)); }
   return 0;
 }
 

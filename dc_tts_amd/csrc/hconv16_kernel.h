@@ -20,12 +20,7 @@ typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 // Same ConvParams as hconv_kernel; wp must be packed for 16-column tiles ([tile][k-group of 16][lane][4]);
 // m_start = first output row of this launch (rows [m_start, M)).
-// V2 (opt-in with DCTTS_HCONV_BPF=2, not measured yet): the default form's ISA drains every load at the top of each 32-channel chunk
-// (s_waitcnt vmcnt(0) behind the join of the conditional A load) while the chunk's first weight fragments were requested ~12 MFMAs = 400 cycles
-// earlier.  V2 loads A branch-free (rows that must read as zero are redirected to a readable address and zeroed when stored to LDS, as
-// hconv_kernel does) and pins the weight-fragment requests at the top of their k-group; V2 = 2 requests them TWO k-groups ahead (a second register
-// set: NT <= 8 only, NT = 16 would spill).  Same arithmetic, same order.
-template <int EPI, int NT, int NW, int V2 = 0>
+template <int EPI, int NT, int NW>
 __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, const int m_start) {
   constexpr int LDA = 36;
   constexpr int NH = (EPI == EPI_HC) ? 2 : 1;
@@ -73,18 +68,10 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
   const int nch = p.ntaps * cpt;
   const int KG = nch * 2;                // k-groups of 16
 
-  const long safe_row = p.gather ? 0 : p.in_row0;
   auto load_chunk = [&](int ch) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     const int tap = ch / cpt;
     const int c = (ch - tap * cpt) * 32 + lc4 * 4;
-    if (V2) {                              // no branch around the load: every thread reads something readable, the select happens on the value
-      const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
-      const bool ok = my_inrow >= 0 && c < p.cin && tap != mask_tap;
-      const long row = my_inrow >= 0 ? my_inrow + toff : safe_row;
-      const float4 w = *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
-      return ok ? w : v;
-    }
     if (tid < 128 && my_inrow >= 0 && c < p.cin && tap != mask_tap) {
       const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
       v = *reinterpret_cast<const float4*>(p.in + (my_inrow + toff) * (long)p.in_stride + c);
@@ -105,29 +92,23 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
 
   float4 areg = load_chunk(0);
   if (tid < 128) *reinterpret_cast<float4*>(&As[0][lrow * LDA + lc4 * 4]) = areg;
-  float4 bcur[NT], bnx[NT];
+  float4 bcur[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) bcur[i] = wq[i][0];
-  if (V2 == 2) {
-#pragma unroll
-    for (int i = 0; i < NT; ++i) bnx[i] = wq[i][64];          // KG >= 2 always
-  }
   __syncthreads();
 
   for (int ch = 0; ch < nch; ++ch) {
     const bool more = (ch + 1 < nch);
-    if (V2) { areg = load_chunk(more ? ch + 1 : ch); __builtin_amdgcn_sched_barrier(0); }      // the last chunk re-reads itself
-    else if (more) areg = load_chunk(ch + 1);
+    if (more) areg = load_chunk(ch + 1);
     const float* Ab = As[ch & 1];
 #pragma unroll
     for (int gq = 0; gq < 2; ++gq) {
       const int kg = ch * 2 + gq;
-      const int kgn = (V2 == 2) ? ((kg + 2 < KG) ? kg + 2 : KG - 1) : ((kg + 1 < KG) ? kg + 1 : kg);
+      const int kgn = (kg + 1 < KG) ? kg + 1 : kg;
       const float4 a = *reinterpret_cast<const float4*>(&Ab[arow * LDA + gq * 16 + aq * 4]);
       float4 bnext[NT];
 #pragma unroll
       for (int i = 0; i < NT; ++i) bnext[i] = wq[i][(long)kgn * 64];
-      if (V2) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bcur[i].x, acc[i], 0, 0, 0);
 #pragma unroll
@@ -137,10 +118,7 @@ __global__ void __launch_bounds__(NW * 64) hconv16_kernel(const ConvParams p, co
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bcur[i].w, acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        if (V2 == 2) { bcur[i] = bnx[i]; bnx[i] = bnext[i]; }
-        else bcur[i] = bnext[i];
-      }
+      for (int i = 0; i < NT; ++i) bcur[i] = bnext[i];
     }
     if (more && tid < 128) *reinterpret_cast<float4*>(&As[(ch + 1) & 1][lrow * LDA + lc4 * 4]) = areg;
     __syncthreads();

@@ -65,12 +65,10 @@ struct ConvParams {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// BPF = how many k-groups (8 k each) ahead of its MFMAs a weight fragment is requested.  1: one group = NT * 4 MFMAs = NT * 256 cycles per wave,
-// which for NT <= 4 is about an L2 round trip (the ISA shows s_waitcnt vmcnt on loads issued 6..12 MFMAs earlier, and a drain at every chunk
-// boundary).  2 (opt-in, DCTTS_HCONV_BPF=2, NT <= 4): a second register set (4 * NT VGPRs), requests pinned at the top of their k-group (PIN).
-// NT = 8 has no registers for a second set at two waves per SIMD: its opt-in form is BPF = 1 with PIN (the scheduler otherwise sinks requests to
-// just before their use: s_waitcnt vmcnt(0) in the middle of a chunk).
-template <int EPI, int NT, int NW, int BPF = 1, bool PIN = (BPF == 2)>
+// A weight fragment is requested one k-group (8 k = NT * 4 MFMAs) ahead of its use.  Requesting it two groups ahead from a second register set,
+// or pinning the requests in front of the group's MFMAs with a sched_barrier, was measured in round 3 and is 27 % SLOWER (SSRN 12.13 -> 15.45 ms,
+// profiles/r03_unverified_pass.txt): the waits the ISA shows are covered by the SIMD's other wave, the pinned issue burst is not.
+template <int EPI, int NT, int NW>
 __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   constexpr int LDA = 36;
   constexpr int NH = (EPI == EPI_HC) ? 2 : 1;
@@ -144,13 +142,9 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) *reinterpret_cast<float4*>(&As[0][lrow * LDA + lc4 * 4]) = areg;
   int ntap = 0, ncit = 0;                  // (tap, chunk in tap) of the chunk being prefetched
-  float4 bcur[NT], bnx[NT];                // fragments of k-group kg, and (BPF == 2) of kg + 1
+  float4 bcur[NT];                         // fragments of k-group kg
 #pragma unroll
   for (int i = 0; i < NT; ++i) bcur[i] = wq[i][0];
-  if (BPF == 2) {
-#pragma unroll
-    for (int i = 0; i < NT; ++i) bnx[i] = wq[i][(long)(KG > 1 ? 1 : 0) * 64];
-  }
   __syncthreads();
 
   for (int ch = 0; ch < nch; ++ch) {
@@ -162,12 +156,11 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int kg = ch * 4 + gq;
-      const int kgn = (kg + BPF < KG) ? kg + BPF : KG - 1;
+      const int kgn = (kg + 1 < KG) ? kg + 1 : KG - 1;
       const float4 a = *reinterpret_cast<const float4*>(&Ab[l31 * LDA + gq * 8 + lhi * 4]);
       float4 bnext[NT];
 #pragma unroll
       for (int i = 0; i < NT; ++i) bnext[i] = wq[i][(long)kgn * 64];
-      if (PIN) __builtin_amdgcn_sched_barrier(0);           // the requests go out before this group's MFMAs, not somewhere among them
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bcur[i].x, acc[i], 0, 0, 0);
 #pragma unroll
@@ -177,10 +170,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bcur[i].w, acc[i], 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) {
-        if (BPF == 2) { bcur[i] = bnx[i]; bnx[i] = bnext[i]; }
-        else bcur[i] = bnext[i];
-      }
+      for (int i = 0; i < NT; ++i) bcur[i] = bnext[i];
     }
     if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
     if (more && tid < 256) *reinterpret_cast<float4*>(&As[(ch + 1) & 1][lrow * LDA + lc4 * 4]) = areg;
@@ -318,7 +308,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 
 // Host-side launch: picks the (NT, NW) instantiation from the layer's tile count.
 // Returns hipSuccess or the launch error.
-struct ConvShape { int epi, nt, nw; int bpf = 1; };
+struct ConvShape { int epi, nt, nw; };
 
 inline ConvShape pick_shape(int epi, int cout) {
   if (epi == EPI_HC) {

@@ -255,32 +255,6 @@ def test_ssrn(weights):
     assert maxabs(Z.cpu().numpy(), Zr) < TOL and maxabs(lg.cpu().numpy(), lgr) < 5e-3
 
 
-@pytest.mark.skipif(not os.environ.get("DCTTS_TEST_UNVERIFIED"), reason="hconv_kernel<.., BPF = 2> was written after round 2's GPU minutes "
-                    "were spent and has not run on a GPU yet: set DCTTS_TEST_UNVERIFIED=1 to run")
-def test_hconv_deeper_weight_prefetch_variant(weights):
-    """DCTTS_HCONV_BPF=2 (read at create) selects hconv_kernel<.., BPF = 2> (NT <= 4), its pinned form (NT = 8) and hconv16_kernel<.., V2>
-    (row tails): same arithmetic in the same order, only the weight fragments are requested earlier, so TextEnc, AudioEnc / AudioDec and SSRN must come out BITWISE equal to the default kernels."""
-    from dc_tts_amd.engine import Engine
-    rng = np.random.default_rng(41)
-    L = torch.from_numpy(short_text(hp, 3, 5)).cuda()
-    Yh = rng.random((3, 37, hp.n_mels), dtype=np.float32)
-    Yb = dev(rng.random((12, hp.max_T, hp.n_mels), dtype=np.float32))     # 315 row items at 4T: one exact round on hconv_kernel + a 16-row tail
-    e0 = engine_for(weights)
-    K0, V0 = e0.text_enc(L); Q0 = e0.audio_enc(dev(Yh)); lg0, Z0 = e0.ssrn(dev(Yh)); Zb0 = e0.ssrn(Yb, want_logits=False)[1]
-    old = os.environ.get("DCTTS_HCONV_BPF")
-    os.environ["DCTTS_HCONV_BPF"] = "2"
-    try:
-        e2 = Engine(weights, hp)
-    finally:
-        if old is None: del os.environ["DCTTS_HCONV_BPF"]
-        else: os.environ["DCTTS_HCONV_BPF"] = old
-    K2, V2 = e2.text_enc(L); Q2 = e2.audio_enc(dev(Yh)); lg2, Z2 = e2.ssrn(dev(Yh)); Zb2 = e2.ssrn(Yb, want_logits=False)[1]
-    torch.cuda.synchronize()
-    for a, b in ((K0, K2), (V0, V2), (Q0, Q2), (lg0, lg2), (Z0, Z2), (Zb0, Zb2)):
-        assert torch.equal(a, b)
-    e2.close()
-
-
 @pytest.mark.parametrize("parts", [2, 3, 4])
 def test_ssrn_batch_parts_on_streams(weights, parts):
     """dctts_ssrn_fwd runs a batch of more than one round of row items as independent launch sequences over parts of the batch, each on

@@ -409,12 +409,7 @@ def _synthetic_batches(n, B=4, N=24, T=16, seed=3):
     return out
 
 
-# The two tests below were written after round 2's GPU minutes were spent: their first attempt timed out in the checkpoint writer's
-# byte-loop crc32c (since vectorised), and they have NOT run on a GPU box yet.  They stay out of the default GPU suite until they have.
-_unverified = pytest.mark.skipif(not os.environ.get("DCTTS_TEST_UNVERIFIED"), reason="not yet verified on a GPU box: set DCTTS_TEST_UNVERIFIED=1 to run")
-
-
-@_unverified
+# First run on a GPU box in round 3 (profiles/r03_unverified_pass.txt): green.
 @pytest.mark.parametrize("num", [1, 2])
 def test_training_loop_checkpoints_and_resumes(tmp_path, num):
     """dc_tts_amd.train.main = train.py:137-162: a run of 6 steps, and a run of 4 steps that is stopped and resumed from its checkpoint
@@ -443,7 +438,6 @@ def test_training_loop_checkpoints_and_resumes(tmp_path, num):
     assert (num == 2) or os.path.exists(os.path.join(b + "-1", "alignment_000k.png")) or os.path.exists(os.path.join(b + "-1", "alignment_000k.npy"))
 
 
-@_unverified
 def test_training_loop_on_a_wave_corpus(tmp_path):
     """wave files -> prepo -> bucketed batches -> two Text2Mel steps and two SSRN steps, end to end."""
     import sys

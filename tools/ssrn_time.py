@@ -1,5 +1,5 @@
 """SSRN phase time (B utterances, T = 210 -> (B, 840, 1025)) and TextEnc (B, 180), HIP-event timed on the caller's stream; env DCTTS_SSRN_SPLIT,
-DCTTS_HCONV_BPF etc. apply."""
+DCTTS_* knobs of tools/README.md apply."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 from dc_tts_amd.engine import Engine
