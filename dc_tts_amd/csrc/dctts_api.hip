@@ -27,23 +27,24 @@ using namespace dctts;
 
 namespace dctts {
 
-#define HCONV_CASE(E, NT_, NW_)                                                        \
-  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                      \
-    hipLaunchKernelGGL((hconv_kernel<E, NT_, NW_>), grid, dim3(NW_ * 64), 0, stream, p); \
-    return hipGetLastError();                                                          \
+// (weight prefetch depth BD, scalar tile bases SB) per shape: what measured best on this MI355X (hconv_kernel.h; profiles/r03_hconv_lab.txt)
+#define HCONV_CASE(E, NT_, NW_, BD_, SB_)                                                        \
+  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                \
+    hipLaunchKernelGGL((hconv_kernel<E, NT_, NW_, BD_, SB_>), grid, dim3(NW_ * 64), 0, stream, p); \
+    return hipGetLastError();                                                                    \
   }
 
 hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles) {
   const dim3 grid(tiles >= 0 ? tiles : (p.M + 31) / 32);
   if (p.M <= 0 || grid.x == 0) return hipSuccess;
-  HCONV_CASE(EPI_HC, 2, 8)
-  HCONV_CASE(EPI_HC, 4, 8)
-  HCONV_CASE(EPI_HC, 8, 8)
-  HCONV_CASE(EPI_C, 1, 4)
-  HCONV_CASE(EPI_C, 1, 8)
-  HCONV_CASE(EPI_C, 2, 8)
-  HCONV_CASE(EPI_C, 4, 8)
-  HCONV_CASE(EPI_C, 3, 11)
+  HCONV_CASE(EPI_HC, 2, 8, 2, 0)
+  HCONV_CASE(EPI_HC, 4, 8, 2, 0)
+  HCONV_CASE(EPI_HC, 8, 8, 1, 1)
+  HCONV_CASE(EPI_C, 1, 4, 1, 0)
+  HCONV_CASE(EPI_C, 1, 8, 1, 0)
+  HCONV_CASE(EPI_C, 2, 8, 2, 0)
+  HCONV_CASE(EPI_C, 4, 8, 1, 1)
+  HCONV_CASE(EPI_C, 3, 11, 2, 1)
   return hipErrorInvalidConfiguration;
 }
 

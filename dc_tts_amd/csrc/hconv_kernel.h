@@ -11,8 +11,8 @@
 //   * a workgroup owns BM = 32 output rows x ALL output columns, so the layer-norm statistics
 //     (per row over C channels, two-pass, eps 1e-12) are reduced inside the workgroup and the
 //     pre-norm tensor never touches HBM.  NW waves split the columns, NT 32-wide tiles each.
-//   * A (activations): 32 rows x 32 channels per chunk, register-staged into a double-buffered,
-//     padded LDS tile (row stride 36 floats -> conflict-free ds_read_b128).
+//   * A (activations): 32 rows x 32 channels per chunk, register-staged into a triple-buffered,
+//     padded LDS tile (row stride 36 floats -> conflict-free ds_read_b128), one mid-chunk barrier.
 //   * B (weights): pre-packed on the host in MFMA fragment order, so one coalesced 1 KiB
 //     global_load_dwordx4 per wave feeds four MFMAs; no LDS round trip for an operand that no
 //     other wave of the workgroup shares.  Prefetched one k-group (8 k) ahead.
@@ -64,23 +64,51 @@ struct ConvParams {
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid on v_exp_f32 / v_rcp_f32 (about 1 ulp each; saturates cleanly: exp -> inf gives 0, exp -> 0 gives 1)
+__device__ __forceinline__ float fast_sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// A weight fragment is requested one k-group (8 k = NT * 4 MFMAs) ahead of its use.  Requesting it two groups ahead from a second register set,
-// or pinning the requests in front of the group's MFMAs with a sched_barrier, was measured in round 3 and is 27 % SLOWER (SSRN 12.13 -> 15.45 ms,
-// profiles/r03_unverified_pass.txt): the waits the ISA shows are covered by the SIMD's other wave, the pinned issue burst is not.
-template <int EPI, int NT, int NW>
+// sum over the 32 lanes that share (lane >> 5): four DPP steps inside each 16-lane row (quad_perm, quad_perm, row_half_mirror, row_mirror), one
+// cross-row exchange
+template <int CTRL>
+__device__ __forceinline__ float hconv_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float half_sum32(float v) {
+  v = hconv_dpp_add<0xB1>(v); v = hconv_dpp_add<0x4E>(v); v = hconv_dpp_add<0x141>(v); v = hconv_dpp_add<0x140>(v);
+  return v + __shfl_xor(v, 16);
+}
+
+// Round 3 (tools/micro/hconv_lab.hip; profiles/r03_hconv_lab.txt: every variant timed in turn with a cache-thrashing pass in front of each launch,
+// because repeating one kernel back to back keeps its weights cache-resident and re-ranks the variants):
+//   * K loop: three LDS buffers and ONE barrier per 32-channel chunk, in the MIDDLE of the chunk, with nothing that depends on it right behind it:
+//       chunk ch:  [k-groups 0, 1 from As[ch % 3]]  barrier  [store chunk ch + 2 into As[(ch + 2) % 3]; request chunk ch + 3]  [k-groups 2, 3]
+//     As[(ch + 2) % 3] was last read in chunk ch - 1, which every wave has left once it passed this chunk's barrier; what is stored now is read
+//     from chunk ch + 2 on, behind the barrier of chunk ch + 1.  The A fragment of the next k-group is requested one group ahead, also across the
+//     chunk boundary.  (On its own this is worth nothing measurable; it is what lets the weight requests run BD groups ahead without a drain.)
+//   * BD = how many k-groups (8 k each = NT * 4 MFMAs) ahead of its use a weight fragment is requested, each depth a register set of 4 NT VGPRs.
+//     BD = 2 is worth 10 % on the 512-channel highway layers (a k-group of NT = 4 is ~0.85 us, less than a miss to HBM); with a scheduling
+//     pin in front of the MFMAs (round 2's unmeasured variant) the same depth was 27 % SLOWER: no pins.
+//   * SB = 1: the tile bases are wave-uniform (readfirstlane), so every weight request is scalar base + one shared vector offset: 15 address
+//     VGPRs less at NT = 8 (what makes the batched epilogue fit in 256 registers there).
+//   * epilogue without load-behind-branch chains: bias is the accumulators' initial value; the layer-norm parameters and the first residual
+//     rows are requested before the statistics passes; rows that do not exist are handled by predicated stores, not `continue`; the next four
+//     rows' residuals are in flight while four rows are finished; sigmoid on v_exp_f32 / v_rcp_f32.  2 % (HC_11/12) to 6 % (512-channel, 1025-column).
+template <int EPI, int NT, int NW, int BD = 1, int SB = 0>
 __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   constexpr int LDA = 36;
   constexpr int NH = (EPI == EPI_HC) ? 2 : 1;
+  constexpr int NP = (EPI == EPI_HC) ? NT / 2 : NT;       // output column tiles per wave
   static_assert(EPI != EPI_HC || (NT % 2 == 0), "HC tiles come in (gate, info) pairs");
-  __shared__ __attribute__((aligned(16))) float As[2][32 * LDA];
+  static_assert(BD == 1 || BD == 2 || BD == 4, "the register ring is rotated by the 4 k-groups of a chunk");
+  __shared__ __attribute__((aligned(16))) float As[3][32 * LDA];
   __shared__ float red[NW * 2 * 32];
-  __shared__ float tot[2 * 32];
+  __shared__ float tot[2][2 * 32];           // [pass][h * 32 + row]: mean, then 1 / sqrt(var + eps)
   __shared__ long s_inrow[32];
   __shared__ long s_outrow[32];
   __shared__ long s_out2row[32];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = SB ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int m0 = blockIdx.x * 32;
   const int t_base = p.step ? *p.step : 0;
@@ -118,95 +146,135 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   // address (row in_row0, column 0) and the value is discarded when it is stored to LDS; threads >= 256 load duplicates.
   const bool row_ok = my_inrow >= 0;
   const long safe_row = p.gather ? 0 : p.in_row0;
-  auto load_chunk = [&](int tap, int cit, bool& ok) -> float4 {          // cit = chunk index inside the tap
-    const int c = cit * 32 + lc4 * 4;
-    const int toff = (tap == 0) ? p.tap_off[0] : ((tap == 1) ? p.tap_off[1] : p.tap_off[2]);
+  int ltap = 0, lcit = 0;                  // (tap, chunk in tap) the loader is at: it walks forward one chunk per call, clamped at the last chunk
+  auto load_next = [&](bool& ok) -> float4 {
+    const int c = lcit * 32 + lc4 * 4;
+    const int toff = (ltap == 0) ? p.tap_off[0] : ((ltap == 1) ? p.tap_off[1] : p.tap_off[2]);
     ok = row_ok && c < p.cin;
     const long row = row_ok ? my_inrow + toff : safe_row;
-    return *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
+    const float4 v = *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
+    if (!(ltap == p.ntaps - 1 && lcit == cpt - 1)) { if (++lcit == cpt) { lcit = 0; ++ltap; } }
+    return v;
   };
 
-  const float4* wq[NT];
+  const float4* wq[NT];                    // SB: wave-uniform bases (scalar registers) + the lane as part of the index
 #pragma unroll
   for (int i = 0; i < NT; ++i)
-    wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wave * NT + i) * KG) * 64 + lane;
+    wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wave * NT + i) * KG) * 64 + (SB ? 0 : lane);
+  const int wl = SB ? lane : 0;
 
-  f32x16 acc[NT];
-#pragma unroll
-  for (int i = 0; i < NT; ++i)
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-
-  bool aok;
-  float4 areg = load_chunk(0, 0, aok);
-  if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid < 256) *reinterpret_cast<float4*>(&As[0][lrow * LDA + lc4 * 4]) = areg;
-  int ntap = 0, ncit = 0;                  // (tap, chunk in tap) of the chunk being prefetched
-  float4 bcur[NT];                         // fragments of k-group kg
-#pragma unroll
-  for (int i = 0; i < NT; ++i) bcur[i] = wq[i][0];
-  __syncthreads();
-
-  for (int ch = 0; ch < nch; ++ch) {
-    const bool more = (ch + 1 < nch);
-    if (more) { if (++ncit == cpt) { ncit = 0; ++ntap; } }       // the last chunk re-reads itself: no branch around the load
-    areg = load_chunk(ntap, ncit, aok);
-    __builtin_amdgcn_sched_barrier(0);     // pin the prefetch here: the scheduler otherwise sinks it to the LDS store at the end
-    const float* Ab = As[ch & 1];
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const int kg = ch * 4 + gq;
-      const int kgn = (kg + 1 < KG) ? kg + 1 : KG - 1;
-      const float4 a = *reinterpret_cast<const float4*>(&Ab[l31 * LDA + gq * 8 + lhi * 4]);
-      float4 bnext[NT];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) bnext[i] = wq[i][(long)kgn * 64];
-#pragma unroll
-      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bcur[i].x, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bcur[i].y, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bcur[i].z, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bcur[i].w, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NT; ++i) bcur[i] = bnext[i];
-    }
-    if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (more && tid < 256) *reinterpret_cast<float4*>(&As[(ch + 1) & 1][lrow * LDA + lc4 * 4]) = areg;
-    __syncthreads();
-  }
-
-  // =====================================================================================
-  // Epilogue.  acc[i][j] = conv output at row (j&3) + 8*(j>>2) + 4*lhi, column of tile i / lane l31.
-  // =====================================================================================
+  // channel of tile i inside its layer-norm group; the bias is the accumulators' initial value (columns beyond C: zero weights, zero bias -> exactly 0)
   const int C = p.cout;
-  int chan[NT];          // channel index inside its LN group
-  bool cval[NT];
+  int chan[NT]; bool cval[NT];
+  f32x16 acc[NT];
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     int ch_, bidx;
-    if (EPI == EPI_HC) {
-      const int pp = wave * (NT / 2) + (i >> 1);
-      ch_ = pp * 32 + l31;
-      bidx = (i & 1) * C + ch_;
-    } else {
-      ch_ = (wave * NT + i) * 32 + l31;
-      bidx = ch_;
-    }
-    chan[i] = ch_;
-    cval[i] = ch_ < C;
-    const float bv = cval[i] ? p.bias[bidx] : 0.f;
+    if (EPI == EPI_HC) { ch_ = (wave * NP + (i >> 1)) * 32 + l31; bidx = (i & 1) * C + ch_; }
+    else { ch_ = (wave * NT + i) * 32 + l31; bidx = ch_; }
+    chan[i] = ch_; cval[i] = ch_ < C;
+    const float bv = p.bias[cval[i] ? bidx : 0];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[i][j] += bv;
+    for (int j = 0; j < 16; ++j) acc[i][j] = cval[i] ? bv : 0.f;
   }
 
-  float mean[NH][16], rstd[NH][16];
+  bool aok, aok1;
+  float4 a0 = load_next(aok);
+  float4 a1 = load_next(aok1);
+  float4 bq[BD][NT];                       // fragments of k-groups kg .. kg + BD - 1
+#pragma unroll
+  for (int d = 0; d < BD; ++d)
+#pragma unroll
+    for (int i = 0; i < NT; ++i) bq[d][i] = wq[i][(d < KG ? d : KG - 1) * 64 + wl];
+  if (!aok) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!aok1) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) {
+    *reinterpret_cast<float4*>(&As[0][lrow * LDA + lc4 * 4]) = a0;
+    *reinterpret_cast<float4*>(&As[1][lrow * LDA + lc4 * 4]) = a1;      // with a single chunk this is a copy of chunk 0 that nothing reads
+  }
+  float4 areg = load_next(aok);            // chunk 2 (or a re-read of the last chunk)
+  __syncthreads();
+  const int aoff = l31 * LDA + lhi * 4;
+  float4 a = *reinterpret_cast<const float4*>(&As[0][aoff]);
+  int cb = 0;                              // ch % 3
+  for (int ch = 0; ch < nch; ++ch) {
+    const float* Ab = As[cb];
+    const int cb1 = (cb == 2) ? 0 : cb + 1, cb2 = (cb1 == 2) ? 0 : cb1 + 1;
+    const float* An = As[cb1];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int kg = ch * 4 + gq;
+      const int kgn = (kg + BD < KG) ? kg + BD : KG - 1;
+      if (gq == 2) {
+        __syncthreads();
+        if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ch + 2 < nch && tid < 256) *reinterpret_cast<float4*>(&As[cb2][lrow * LDA + lc4 * 4]) = areg;
+        areg = load_next(aok);             // chunk ch + 3
+      }
+      const float4 an = (gq < 3) ? *reinterpret_cast<const float4*>(&Ab[aoff + (gq + 1) * 8]) : *reinterpret_cast<const float4*>(&An[aoff]);
+      float4 bnext[NT];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) bnext[i] = wq[i][kgn * 64 + wl];
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[0][i].x, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[0][i].y, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[0][i].z, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[0][i].w, acc[i], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+#pragma unroll
+        for (int d = 0; d + 1 < BD; ++d) bq[d][i] = bq[d + 1][i];
+        bq[BD - 1][i] = bnext[i];
+      }
+      a = an;
+    }
+    cb = cb1;
+  }
+
+  // =====================================================================================
+  // Epilogue.  acc[i][j] = conv output (bias included) at row (j&3) + 8*(j>>2) + 4*lhi, column of tile i / lane l31.
+  // Requests first, then the two statistics passes, then the stores.
+  // =====================================================================================
+  float pg1[NP], pb1[NP], pg2[NP], pb2[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int i = (EPI == EPI_HC) ? 2 * k : k;
+    const int cs = cval[i] ? chan[i] : 0;
+    pg1[k] = p.g1[cs]; pb1[k] = p.b1[cs];
+    if (EPI == EPI_HC) { pg2[k] = p.g2[cs]; pb2[k] = p.b2[cs]; }
+  }
+  // residual rows of the highway mix (modules.py:193), four rows (j) at a time; the first batch is requested here, behind nothing
+  constexpr int JB = 4;
+  float xr[2][(EPI == EPI_HC) ? NP : 1][JB];
+  auto load_res = [&](int jb, int slot) {
+    if (EPI != EPI_HC) return;
+#pragma unroll
+    for (int jj = 0; jj < JB; ++jj) {
+      const int j = jb * JB + jj;
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+      const long ir = s_inrow[row];
+      const float* rp = p.in + (ir >= 0 ? ir : safe_row) * (long)p.in_stride;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) xr[slot][k][jj] = rp[cval[2 * k] ? chan[2 * k] : 0];
+    }
+  };
+  load_res(0, 0);
+
+  // ---- pass 1: mean ; pass 2: biased variance about the mean (tf.nn.moments, two-pass), eps 1e-12 inside the root
   const float invC = 1.0f / (float)C;
-  // ---- pass 1: mean ; pass 2: biased variance about the mean (tf.nn.moments, two-pass)
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
     float s[NH][16];
+    float mean[NH][16];
+    if (pass == 1) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mean[h][j] = tot[0][h * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi];
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
@@ -216,23 +284,14 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
       const int h = (EPI == EPI_HC) ? (i & 1) : 0;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        if (pass == 0) {
-          s[h][j] += acc[i][j];            // padded columns hold exactly 0
-        } else {
-          const float d = cval[i] ? (acc[i][j] - mean[h][j]) : 0.f;
-          s[h][j] += d * d;
-        }
+        if (pass == 0) s[h][j] += acc[i][j];            // padded columns hold exactly 0
+        else { const float d = cval[i] ? (acc[i][j] - mean[h][j]) : 0.f; s[h][j] += d * d; }
       }
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = s[h][j];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16);
-        s[h][j] = v;
-      }
+      for (int j = 0; j < 16; ++j) s[h][j] = half_sum32(s[h][j]);
     if (l31 == 0) {
 #pragma unroll
       for (int h = 0; h < NH; ++h)
@@ -245,61 +304,43 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[(w * 2 + h) * 32 + r];
-      tot[h * 32 + r] = v * invC;
+      v *= invC;
+      tot[pass][h * 32 + r] = (pass == 0) ? v : 1.0f / sqrtf(v + 1e-12f);
     }
     __syncthreads();
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float v = tot[h * 32 + (j & 3) + 8 * (j >> 2) + 4 * lhi];
-        if (pass == 0) mean[h][j] = v; else rstd[h][j] = 1.0f / sqrtf(v + 1e-12f);
-      }
-    __syncthreads();      // red/tot are reused by the next pass
   }
 
-  // ---- normalise, activate / gate, store
-  if (EPI == EPI_HC) {
+  // ---- normalise, gate / activate, store: four rows at a time, the next four rows' residuals in flight
 #pragma unroll
-    for (int k = 0; k < NT / 2; ++k) {
-      const int ch_ = chan[2 * k];
-      if (!cval[2 * k]) continue;
-      const float g1 = p.g1[ch_], b1 = p.b1[ch_], g2 = p.g2[ch_], b2 = p.b2[ch_];
+  for (int jb = 0; jb < 16 / JB; ++jb) {
+    if (jb + 1 < 16 / JB) load_res(jb + 1, (jb + 1) & 1);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
-        const long orow = s_outrow[row];
-        if (orow < 0) continue;
-        const float y1 = (acc[2 * k][j] - mean[0][j]) * rstd[0][j] * g1 + b1;
-        const float y2 = (acc[2 * k + 1][j] - mean[1][j]) * rstd[1][j] * g2 + b2;
-        const float gt = sigmoidf_(y1);
-        const float xr = p.in[s_inrow[row] * (long)p.in_stride + ch_];
-        p.out[orow * (long)p.out_stride + ch_] = gt * y2 + (1.0f - gt) * xr;
-      }
-    }
-  } else {
+    for (int jj = 0; jj < JB; ++jj) {
+      const int j = jb * JB + jj;
+      const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+      const long orow = s_outrow[row];
+      const bool ok = orow >= 0;
+      float* op = p.out + (ok ? orow : 0) * (long)p.out_stride;
+      const float r0 = tot[1][row], r1 = tot[1][32 + row];
+      const float m0_ = tot[0][row], m1_ = tot[0][32 + row];
+      if (EPI == EPI_HC) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-      const int ch_ = chan[i];
-      if (cval[i]) {
-        const float g1 = p.g1[ch_], b1 = p.b1[ch_];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
-          const long orow = s_outrow[row];
-          if (orow < 0) continue;
-          float y = (acc[i][j] - mean[0][j]) * rstd[0][j] * g1 + b1;
-          if (p.out2) p.out2[s_out2row[row] * (long)p.out2_stride + ch_] = y;
-          if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
-          else if (p.act == ACT_SIGMOID) y = sigmoidf_(y);
-          p.out[orow * (long)p.out_stride + ch_] = y;
+        for (int k = 0; k < NP; ++k) {
+          const float y1 = (acc[2 * k][j] - m0_) * r0 * pg1[k] + pb1[k];
+          const float y2 = (acc[2 * k + 1][j] - m1_) * r1 * pg2[k] + pb2[k];
+          const float gt = fast_sigmoidf_(y1);
+          const float o = gt * y2 + (1.0f - gt) * xr[jb & 1][k][jj];
+          if (ok && cval[2 * k]) op[chan[2 * k]] = o;
         }
-      } else if (ch_ < p.out_zero_to) {
+      } else {
+        float* op2 = p.out2 ? p.out2 + (ok ? s_out2row[row] : 0) * (long)p.out2_stride : nullptr;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
-          const long orow = s_outrow[row];
-          if (orow >= 0) p.out[orow * (long)p.out_stride + ch_] = 0.f;
+        for (int k = 0; k < NP; ++k) {
+          float y = (acc[k][j] - m0_) * r0 * pg1[k] + pb1[k];
+          if (op2 && ok && cval[k]) op2[chan[k]] = y;
+          if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
+          else if (p.act == ACT_SIGMOID) y = fast_sigmoidf_(y);
+          if (ok && (cval[k] || chan[k] < p.out_zero_to)) op[chan[k]] = cval[k] ? y : 0.f;
         }
       }
     }
@@ -308,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 
 // Host-side launch: picks the (NT, NW) instantiation from the layer's tile count.
 // Returns hipSuccess or the launch error.
-struct ConvShape { int epi, nt, nw; };
+struct ConvShape { int epi, nt, nw; };     // the (BD, SB) of a shape is fixed in launch_hconv (dctts_api.hip)
 
 inline ConvShape pick_shape(int epi, int cout) {
   if (epi == EPI_HC) {

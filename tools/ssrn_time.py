@@ -2,6 +2,8 @@
 DCTTS_* knobs of tools/README.md apply."""
 import os, sys, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import dc_tts_amd._lib as _L
+if os.environ.get("DCTTS_AB_LIB"): _L.LIB_PATH = os.environ["DCTTS_AB_LIB"]      # A/B of two builds of the library (tools only; the product has no such switch)
 from dc_tts_amd.engine import Engine
 from dc_tts_amd.hyperparams import hp
 from dc_tts_amd.weights import synthetic_text, synthetic_weights
