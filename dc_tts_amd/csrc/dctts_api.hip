@@ -48,20 +48,20 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
   return hipErrorInvalidConfiguration;
 }
 
-#define HCONV16_CASE(E, NT_, NW_)                                                                   \
-  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                   \
-    hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
-    return hipGetLastError();                                                                       \
+#define HCONV16_CASE(E, NT_, NW_, BD_, SB_)                                                                   \
+  if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                             \
+    hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_, BD_, SB_>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
+    return hipGetLastError();                                                                                 \
   }
 
 hipError_t launch_hconv16(const ConvShape& s, const ConvParams& p, int m_start, hipStream_t stream) {
   if (p.M <= m_start) return hipSuccess;
   const dim3 grid((p.M - m_start + 15) / 16);
-  HCONV16_CASE(EPI_HC, 4, 8)
-  HCONV16_CASE(EPI_HC, 8, 8)
-  HCONV16_CASE(EPI_HC, 16, 8)
-  HCONV16_CASE(EPI_C, 8, 8)
-  HCONV16_CASE(EPI_C, 6, 11)
+  HCONV16_CASE(EPI_HC, 4, 8, 2, 0)
+  HCONV16_CASE(EPI_HC, 8, 8, 2, 0)
+  HCONV16_CASE(EPI_HC, 16, 8, 1, 1)
+  HCONV16_CASE(EPI_C, 8, 8, 2, 0)
+  HCONV16_CASE(EPI_C, 6, 11, 2, 1)
   return hipErrorInvalidConfiguration;
 }
 

@@ -2,7 +2,7 @@
 # parity tests of the current build, SSRN / TextEnc phase times of both, per-launch tables of both.
 set -u
 R=$PWD; OUT=$R/gpurun_out/ab; mkdir -p $OUT
-timeout 300 python -m pytest tests/test_gpu_parity.py -q -x -k "layer or textenc or ssrn or audioenc or audiodec or fixture or full_size" > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
+timeout 300 python -m pytest tests/test_gpu_parity.py -q -x  > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
 for rep in 1 2; do
 for lib in base new; do
   if [ $lib = base ]; then export DCTTS_AB_LIB=$R/dc_tts_amd/lib/libdctts_hip_base.so; else unset DCTTS_AB_LIB; fi
