@@ -230,7 +230,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # measurement only: no collective on the data path
         elapsed = float(t.item())
-    eng.decode_status()                                              # raises if an in-launch hand-off timed out (opt-in group kernel)
+    eng.decode_status()                                              # raises if a decode's bounded in-kernel wait for the side stream gave up
 
     # ---- the host gather of SURVEY 8e, timed separately (never part of `value`): every rank's Z -> its pinned host buffer ->
     #      rank 0's host (gloo); with one rank this is the plain D2H copy

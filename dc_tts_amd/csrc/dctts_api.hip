@@ -92,7 +92,6 @@ struct DevLayer {
   ConvShape shape16{0, 0, 0};
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
   float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for mlp_rows_kernel
-  float* wrc[4] = {nullptr, nullptr, nullptr, nullptr};   // decode layers: 256 x 256 pass matrices packed for rowchain_kernel (k=1: [0]; highway: tap -d gate, info, centre gate, info)
   float* wp16c = nullptr;         // decode causal k=3 layers (v3): centre tap only, 16x16x4 tiles (the chain contracts K = 256)
   float* wpp = nullptr;           // decode causal k=3 layers (v3): the two older taps, 32x32x2 tiles (presum GEMM, K = 512)
   bool tap2 = false;              // v3 chain view of a dilation-1 AudioEnc layer: the chain contracts taps -1 and 0 (K = 512), the presum holds tap -2 only
@@ -121,10 +120,10 @@ struct dctts_ctx {
   std::vector<int*> cone_dev; std::vector<int> cone_len;
   std::map<std::string, Buf> ws;       // named workspaces; key includes the geometry
   std::string ws_geom_textenc, ws_geom_t2m, ws_geom_dec, ws_geom_ssrn;
-  int use_graph = 0;
-  int decode_mode = 3;                 // 0 = v1 (fused kernels, one stream), 1 = v2 (split kernels, chain + bulk streams),
-                                       // 3 = v3 (v2 + hoisted taps: the chain contracts only centre taps, AudioDec C_1 is a row op)
-  // ---- decode v3
+  int use_graph = 0;                   // decode: 0 = every launch eager, 1 = the side stream's work as one hipGraph per frame
+  int decode_mode = 3;                 // 3 = two-stream incremental form (the default), 0 = simple form: fused kernels, one stream, a device-side
+                                       //     frame counter (cross-check: a different implementation of the same arithmetic)
+  // ---- decode mode 3
   std::vector<DevLayer> ae_c, ad_c;    // chain view of AudioEnc / AudioDec: k=3 layers reduced to their centre tap (k=1 layers unchanged)
   std::vector<DevLayer> ae_p;          // presum view of AudioEnc's k=3 layers (taps -2d, -d; K = 512); entries of k=1 layers are unused
   DevLayer ad_c1q, ad_vw;              // AudioDec C_1 split by input rows: Q half (chain, 16-row tiles), A.V half (V . W_top precompute)
@@ -133,58 +132,31 @@ struct dctts_ctx {
   float* zeros512 = nullptr;
   std::vector<int*> cone3_dev;         // per AudioDec layer: cone offsets < 0 (descending) followed by 0 (the presum row)
   int* iota_dev = nullptr; int iota_n = 0;
-  std::vector<hipGraphExec_t> bulk3_g, chain3_g; std::string graphs3_geom;
+  std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;   // one small linear graph per frame for the side stream, frame index baked into every launch
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
-  int chain_mlp = 1;                   // v3: the seven k=1 layers around the mel frame as one row-split launch (mlp_rows_kernel; DCTTS_MLP=0: seven column-split launches)
   void* mlp_tab = nullptr; std::string mlp_geom;
-  int chain_row = 0;                   // decode mode 4: a whole v3 chain piece as ONE row-split launch (rowchain_kernel) instead of 19 column-split launches
-  void* rc_tab = nullptr; void* rc_par = nullptr; std::string rc_geom;
-  int mlp_rows = 2;                    // utterances per mlp_rows_kernel workgroup (2 or 4; DCTTS_MLP_ROWS)
-  int chain_group = 0;                 // v3: runs of chain highway layers as one persistent launch with in-launch hand-offs (hcgroup_kernel; DCTTS_GROUP=0: one launch per layer)
-  void* group_tab = nullptr; std::string group_geom;   // per-frame HcGroupParams: [T][2] (AudioDec group of frame j, AudioEnc group of frame j)
-  float* group_xch = nullptr;          // exchange buffers, flags, error word (one allocation)
-  int* group_err_host = nullptr;       // pinned copy of the error word, refreshed after every decode
-  int hc2_rowop = 1;                   // v3: AudioDec HC_2's cone rows as a row operation on cached products (0: GEMM + LN pass; DCTTS_HC2_ROWOP)
-  int bulk3_fused = 0;                 // v3 bulk layers with more rows: 1 = full-row 16-row items with fused LN (hconv16_kernel), 0 = hbulk + ln_rows
-  int bulk3_small_rows = 16;           // v3 bulk layers with at most this many rows per utterance (incl. the presum row) use the 16-row kernel form
   hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr};
-  int sync_values = 1;                 // v3: the two streams meet through stream memory operations (hipStreamWriteValue32 / WaitValue32 on two counters) instead of events (DCTTS_SYNC_VALUES=0)
+  int sync_values = 1;                 // the two streams meet through stream memory operations (hipStreamWriteValue32 / WaitValue32 on two counters) instead of events
+                                       // (DCTTS_SYNC_VALUES=0; rocprofv3 --pmc needs events: read_env)
   uint32_t* ctr_chain = nullptr; uint32_t* ctr_bulk = nullptr;   // signal memory: chain pieces done + 1, bulk pieces done
-  int sig_inkernel = 1;                // the chain's counter is written by the first launch of the NEXT piece instead of a write-value packet (DCTTS_SIG_INKERNEL=0)
-  unsigned sig_next = 0;               // value the next run_chain3 launch writes (0 = none)
+  unsigned sig_next = 0;               // value the next run_chain3 launch writes to the chain's counter (0 = none)
   int chain_wait_inkernel = 1;         // the chain's wait for the bulk's counter happens inside the piece's first launch (sc1 read of the one operand the bulk
                                        // produced for it) instead of a wait-value operation in front of it (DCTTS_CHAIN_WAIT=0)
   unsigned wait2_next = 0;             // counter value the next run_chain3 launch waits for (0 = none)
-  int sync_gate = 0;                   // v3, opt-in (DCTTS_GATE=1): no stream operation between pieces at all: the first launch of every piece publishes and waits in-kernel
-                                       // (piece_gate).  Measured 145 us/frame against 138 with stream memory operations: the agent-scope acquire after the wait costs more than the wait launch it replaces.
-  unsigned* gate_ctr = nullptr;        // device memory: [0] chain pieces complete + 1, [32] bulk pieces complete, [64] error word
-  int* gate_err_host = nullptr;        // pinned copy of the error word, refreshed after every decode
-  PieceGate gate_next = {nullptr, 0u, nullptr, 0u, nullptr};   // consumed by the next v3_aepre / run_chain3 launch
-  hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // v1: one step, replayed T times
-  std::vector<hipGraphExec_t> chain_g, bulk_g; hipGraphExec_t pro_g = nullptr;   // v2: one small linear graph per frame and stream,
-  std::string graphs2_geom;                                                      //     frame index baked into every launch
-  int chain_rows = 8;                  // rows per chain workgroup (16 = full MFMA tile; 8 halves the activation bytes each CU pulls)
-  int fuse_mlp = 0;                    // 1: AudioDec C_8..C_11 + sigmoid + next frame's AudioEnc C_1..C_3 as one rowmlp launch (measured slower:
-                                       //    one CU pulls only ~30 GB/s, so 256 KB of weights per layer per workgroup costs ~8 us)
+  unsigned* wait_ctr = nullptr;        // device memory: [32] bulk pieces complete (written by the bulk's write-value operation, polled in-kernel), [64] error word
+  int* wait_err_host = nullptr;        // pinned copy of the error word, refreshed after every decode (dctts_decode_status)
+  hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
-  int fuse_mel = 1;                    // 1: mel finalisation as the prologue of the next frame's AudioEnc C_1 (DCTTS_FUSE_MEL)
-  int bulk_small_rows = 0;             // bulk layers with at most this many rows use the 16-row kernel form (DCTTS_BULK_SMALL, 0 = never)
-  int bulk_pipelined = 1;              // bulk contraction = hbulk_kernel (items software-pipelined); 0 = hsplit_kernel<32> (DCTTS_BULK_PIPE)
-  int chain_one = 0;                   // 1: chain workgroups own one 16-column tile instead of the gate/info pair (DCTTS_CHAIN_ONE)
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
-  int ssrn_prio = 0;                   // priority of those streams: 0 normal, 1 highest, 2 lowest (DCTTS_SSRN_PRIO)
-  int ssrn_split = 1;                  // dctts_ssrn_fwd: the batch as this many independent launch sequences on as many streams (DCTTS_SSRN_SPLIT, max 4).
-                                       // Default 1 = one sequence: 2 parts take SSRN alone from 12.16 to 11.56 ms, but between decodes the gain is ~0.1 ms and
-                                       // the extra active queue can cost the decode's dependent launches more than that
-  hipStream_t s_ssrn[3] = {nullptr, nullptr, nullptr}; hipEvent_t ev_ssrn[4] = {nullptr, nullptr, nullptr, nullptr};
   int tail_split = 1;                  // run_conv: exact rounds on hconv_kernel + row tail on hconv16_kernel (DCTTS_TAIL_SPLIT=0 disables)
   int bulk_cap = 176;                  // workgroups of a bulk (cone) launch: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
   // profiling
   // measurement knobs, read ONCE from the environment in dctts_create (tools/README.md); never consulted per call
-  int bulk_prio = 1, ev_sys = 0, v3_skip = 0, trace_frame = -1, piecetime = -1, hosttime = 0;
+  int trace_frame = -1, piecetime = -1;
+  std::vector<int> init_pm;            // test hook: prev_max_attentions the NEXT decode starts from (consumed by it)
   std::string trace_file;
   int prof_id = -1;
   bool prof_frame = false;             // decode: the current frame is one of the sampled ones (every 16th) for DCTTS_PROF_CHAIN_HC
@@ -199,7 +171,7 @@ struct DevGuard {
   explicit DevGuard(const dctts_ctx* c);
   ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
-static void destroy_graphs2(dctts_ctx* c);
+static void destroy_graphs(dctts_ctx* c);
 DevGuard::DevGuard(const dctts_ctx* c) {
   if (!c) return;
   dev = c->device;
@@ -268,17 +240,6 @@ static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, i
   return pack_bw(W, ntaps, cin_real, cin_p, s.nt * s.nw, cout, hc, 32);
 }
 
-// One 256 x 256 pass matrix of rowchain_kernel (decode3_kernels.h): [wave][i][lane][4] <- W[k = 32 (lane >> 3) + i][col = 32 wave + 4 (lane & 7) + e]
-static std::vector<float> pack_rc(const std::function<float(int, int)>& W) {
-  std::vector<float> out((size_t)256 * 256);
-  for (int wave = 0; wave < 8; ++wave)
-    for (int i = 0; i < 32; ++i)
-      for (int lane = 0; lane < 64; ++lane)
-        for (int e = 0; e < 4; ++e)
-          out[(((size_t)wave * 32 + i) * 64 + lane) * 4 + e] = W(32 * (lane >> 3) + i, 32 * wave + 4 * (lane & 7) + e);
-  return out;
-}
-
 static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_read, int cout, int act, DevLayer* L, bool dec = false, bool tail = false) {
   const HostTensor *k, *b, *be, *ga;
   CHK(get_w(c, scope + "/conv1d/kernel", {1, cin_real, cout}, &k));
@@ -293,7 +254,6 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
   CHK(upload(c, pack_b(W, 1, cin_real, L->cin_p, L->shape, cout, false), &L->wp));
   if (dec) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 2 * ((cout + 31) / 32), cout, false, 16), &L->wp16));
   if (dec) CHK(upload(c, k->v, &L->wraw));
-  if (dec && cin_real <= 256 && cout <= 256) CHK(upload(c, pack_rc([=](int kk, int col) { return (kk < cin_real && col < cout) ? kv[(size_t)kk * cout + col] : 0.f; }), &L->wrc[0]));
   if (tail) {
     L->shape16 = pick_shape16(EPI_C, cout);
     CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, L->shape16.nt * L->shape16.nw, cout, false, 16), &L->wp16r));
@@ -326,11 +286,6 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
     CHK(upload(c, pack_bw(Wc, 1, C, L->cin_p, 2 * (C / 16), C, true, 16), &L->wp16c));
     CHK(upload(c, pack_bw(W, 2, C, L->cin_p, L->shape.nt * L->shape.nw, C, true, 32), &L->wpp));   // taps 0, 1 see x[t-2d], x[t-d]
   }
-  if (dec && k == 3 && causal && C == 256)
-    for (int q = 0; q < 4; ++q) {
-      const int tap = 1 + (q >> 1), half = q & 1;
-      CHK(upload(c, pack_rc([=](int kk, int col) { return kv[((size_t)tap * C + kk) * (2 * C) + half * C + col]; }), &L->wrc[q]));
-    }
   if (tail) {
     L->shape16 = pick_shape16(EPI_HC, C);
     CHK(upload(c, pack_bw(W, k, C, L->cin_p, L->shape16.nt * L->shape16.nw, C, true, 16), &L->wp16r));
@@ -390,15 +345,10 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 // Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
-  geti("DCTTS_TAIL_SPLIT", &c->tail_split); geti("DCTTS_SSRN_SPLIT", &c->ssrn_split); geti("DCTTS_SSRN_PRIO", &c->ssrn_prio);
-  { int r = c->chain_rows; geti("DCTTS_CHAIN_ROWS", &r); if (r == 4 || r == 8 || r == 16) c->chain_rows = r; }
-  geti("DCTTS_FUSE_MEL", &c->fuse_mel); geti("DCTTS_BULK_SMALL", &c->bulk_small_rows); geti("DCTTS_BULK_PIPE", &c->bulk_pipelined);
-  geti("DCTTS_CHAIN_ONE", &c->chain_one);
+  geti("DCTTS_TAIL_SPLIT", &c->tail_split);
   { int r = c->bulk_cap; geti("DCTTS_BULK_CAP", &r); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
-  geti("DCTTS_BULK3_SMALL", &c->bulk3_small_rows); geti("DCTTS_BULK3_FUSED", &c->bulk3_fused); geti("DCTTS_HC2_ROWOP", &c->hc2_rowop);
-  geti("DCTTS_GROUP", &c->chain_group); geti("DCTTS_MLP", &c->chain_mlp); 
-  { int r = c->mlp_rows; geti("DCTTS_MLP_ROWS", &r); if (r == 2 || r == 4) c->mlp_rows = r; } geti("DCTTS_BULK_PRIO", &c->bulk_prio); geti("DCTTS_EV_SYS", &c->ev_sys);
-  geti("DCTTS_V3_SKIP", &c->v3_skip); geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_SIG_INKERNEL", &c->sig_inkernel); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_GATE", &c->sync_gate); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_HOSTTIME", &c->hosttime);
+  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel);
+  geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
   // (it only times out, with wrong results).  Under counter collection the two decode streams meet through events instead.
@@ -436,15 +386,13 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   DevGuard dev_guard(c);
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
-  destroy_graphs2(c);
+  destroy_graphs(c);
   for (int i = 0; i < 4; ++i) { if (c->ev_chain[i]) (void)hipEventDestroy(c->ev_chain[i]); if (c->ev_bulk[i]) (void)hipEventDestroy(c->ev_bulk[i]); }
   if (c->s_bulk) (void)hipStreamDestroy(c->s_bulk);
-  for (hipStream_t q : c->s_ssrn) if (q) (void)hipStreamDestroy(q);
-  for (hipEvent_t e : c->ev_ssrn) if (e) (void)hipEventDestroy(e);
   if (c->ctr_chain) (void)hipFree(c->ctr_chain);
   if (c->ctr_bulk) (void)hipFree(c->ctr_bulk);
-  if (c->gate_ctr) (void)hipFree(c->gate_ctr);
-  if (c->gate_err_host) (void)hipHostFree(c->gate_err_host);
+  if (c->wait_ctr) (void)hipFree(c->wait_ctr);
+  if (c->wait_err_host) (void)hipHostFree(c->wait_err_host);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   free_ws(c);
@@ -453,12 +401,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   for (int* p : c->cone3_dev) (void)hipFree(p);
   if (c->iota_dev) (void)hipFree(c->iota_dev);
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
-  if (c->group_tab) (void)hipFree(c->group_tab);
   if (c->mlp_tab) (void)hipFree(c->mlp_tab);
-  if (c->rc_tab) (void)hipFree(c->rc_tab);
-  if (c->rc_par) (void)hipFree(c->rc_par);
-  if (c->group_xch) (void)hipFree(c->group_xch);
-  if (c->group_err_host) (void)hipHostFree(c->group_err_host);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;
@@ -557,8 +500,6 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     auto Wbot = [=](int, int cc, int col) { return kv[(size_t)(d + cc) * d + col]; };        // rows that multiply Q
     c->ad_c1q = c->audiodec[0]; c->ad_c1q.cin = c->ad_c1q.cin_p = c->ad_c1q.cin_real = d; c->ad_c1q.wp = nullptr; c->ad_c1q.wraw = nullptr;
     CHK(upload(c, pack_bw(Wbot, 1, d, d, 2 * ((d + 31) / 32), d, false, 16), &c->ad_c1q.wp16));
-    for (float*& q : c->ad_c1q.wrc) q = nullptr;
-    if (d == 256) CHK(upload(c, pack_rc([=](int kk, int col) { return kv[(size_t)(d + kk) * d + col]; }), &c->ad_c1q.wrc[0]));   // rows d .. 2d - 1: the rows that multiply Q
     c->ad_vw = c->ad_c1q; c->ad_vw.wp16 = nullptr;
     CHK(upload(c, pack_bw(Wtop, 1, d, d, (d + 31) / 32, d, false, 32), &c->ad_vw.wp));
     CHK(upload(c, std::vector<float>(d, 0.f), &c->ad_vw.bias));
@@ -856,36 +797,7 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
   CHK(ws_view(c, "ssrn.w4a", B, PAD + 4 * T + PAD, PAD, 2 * cc, &ws[6])); CHK(ws_view(c, "ssrn.w4b", B, PAD + 4 * T + PAD, PAD, 2 * cc, &ws[7]));
   CHK(ws_view(c, "ssrn.z4a", B, 4 * T, 0, Fp, &ws[8])); CHK(ws_view(c, "ssrn.z4b", B, 4 * T, 0, Fp, &ws[9]));
   const View vin{const_cast<float*>(Y), T, 0, c->cfg.n_mels}, vz{Z, 4L * T, 0, F}, vlog{logits, 4L * T, 0, F};
-  // Utterances are independent (no op crosses the batch axis).  A layer is ONE launch of 32-row items, and 256 CUs take them in rounds:
-  // B = 32 at 4T rows is 840 items = 3.28 rounds, the last one a quarter full, on every layer.  Parts of the batch as independent launch
-  // sequences on their own streams have no common barrier per layer: the items of one part fill the CUs another part's last round leaves idle.
-  int parts = std::min(std::min(c->ssrn_split, 4), B);
-  if ((long)B * 4 * T <= 32L * c->n_cu || c->prof_id >= 0) parts = 1;      // one round of items anyway / a kernel is being timed in isolation
-  const View* lg = logits ? &vlog : nullptr;
-  if (parts <= 1) return ssrn_layers(c, ws, vin, vz, lg, 0, B, T, st);
-  if (!c->ev_ssrn[0])
-    for (hipEvent_t& e : c->ev_ssrn) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-  for (int k = 0; k + 1 < parts; ++k)
-    if (!c->s_ssrn[k]) {
-      int lo = 0, hi = 0;
-      HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      if (c->ssrn_prio == 0) HIPCHK(hipStreamCreateWithFlags(&c->s_ssrn[k], hipStreamNonBlocking));
-      else HIPCHK(hipStreamCreateWithPriority(&c->s_ssrn[k], hipStreamNonBlocking, c->ssrn_prio == 1 ? hi : lo));
-    }
-  HIPCHK(hipEventRecord(c->ev_ssrn[0], st));
-  int rc = 0;
-  for (int k = 0; k < parts; ++k) {
-    const int b0 = (int)((long)B * k / parts), b1 = (int)((long)B * (k + 1) / parts);
-    hipStream_t q = k == 0 ? st : c->s_ssrn[k - 1];
-    if (k) HIPCHK(hipStreamWaitEvent(q, c->ev_ssrn[0], 0));
-    const int r = ssrn_layers(c, ws, vin, vz, lg, b0, b1 - b0, T, q);
-    if (!rc) rc = r;
-    if (k) {            // joined even after an error: the caller's stream must not run ahead of a side stream
-      HIPCHK(hipEventRecord(c->ev_ssrn[k], q));
-      HIPCHK(hipStreamWaitEvent(st, c->ev_ssrn[k], 0));
-    }
-  }
-  return rc;
+  return ssrn_layers(c, ws, vin, vz, logits ? &vlog : nullptr, 0, B, T, st);
 }
 
 // ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)
@@ -910,7 +822,7 @@ static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
     (void)hipDeviceSynchronize(); drop_ws_prefix(c, "dec."); c->ws_geom_dec = g;
     if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
     if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
-    destroy_graphs2(c);
+    destroy_graphs(c);
   }
   const int d = c->cfg.d, nm = c->cfg.n_mels;
   const long rows = PAD + T + 2;
@@ -998,8 +910,6 @@ static int decode_step_launch(dctts_ctx* c, const DecodeWs& w, int B, int N, hip
 }
 
 // ------------------------------------------------------------------------------------------------ decode v2: split kernels, two streams
-static dctts_ctx* g_trace_ctx = nullptr;
-
 static size_t hsplit_smem(int MF) {
   return (size_t)8 * 2 * (MF == 32 ? 16 : 4) * 64 * sizeof(float);      // split-K reduction buffer
 }
@@ -1047,10 +957,9 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   if (pro != PRO_RAW && pro != PRO_MEL && (MF != 16 || L.cin_p != 256 || !stats_in))
     return fail(DCTTS_ERR_STATE, "split kernel: LN prologue needs the 16-row form, 256 input channels and producer statistics");
   if (L.ntaps > 1 && L.cin_p != 256) return fail(DCTTS_ERR_STATE, "split kernel: multi-tap layers must have 256 input channels");
-  if (MF == 16 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) { p.dbg_wg = g_trace_ctx->trace_buf + 64 * 8 + 256 * g_trace_ctx->trace_n; p.dbg = g_trace_ctx->trace_buf + 8 * (g_trace_ctx->trace_n++); }
   const int groups = L.hc ? L.cout / MF : (L.cout + 2 * MF - 1) / (2 * MF);
   p.ngroups = groups;
-  p.tile_rows = (MF == 16) ? (tile_rows16 ? tile_rows16 : c->chain_rows) : MF;
+  p.tile_rows = (MF == 16) ? (tile_rows16 ? tile_rows16 : 8) : MF;     // chain: 8 rows per workgroup (half of an MFMA tile: half the activation bytes per CU)
   int nblk = ((p.M + p.tile_rows - 1) / p.tile_rows) * groups;
   if (MF == 32 && nblk > c->bulk_cap) nblk = c->bulk_cap;
   const size_t sm = hsplit_smem(MF);
@@ -1060,28 +969,19 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   else if (MF == 16 && L.ntaps == 1 && L.cin == L.cin_p && L.cin_p == 512) nt = 2;
   else if (MF == 16 && L.ntaps == 1 && L.cin_p <= 128) nt = 4;
   if (ex && (ex->presum || ex->raw) && nt != 1) return fail(DCTTS_ERR_STATE, "split kernel: presum / raw output need the k = 1 x 256-channel chain form");
-  const bool one = (MF == 16) && c->chain_one;
-  if (one) nblk *= 2;
-  // the chain-only forms (NT = 1, 2, 4 without ONE) take a (column groups, row tiles) grid and assume one row per utterance
-  const bool chainrow = (MF == 16) && (nt == 1 || nt == 2 || nt == 4) && !one;
+  // the chain-only forms (NT = 1, 2, 4) take a (column groups, row tiles) grid and assume one row per utterance
+  const bool chainrow = (MF == 16) && (nt == 1 || nt == 2 || nt == 4);
   if (chainrow && (R != 1 || offs)) return fail(DCTTS_ERR_STATE, "split kernel: the chain forms take one row per utterance and no offset table");
   const dim3 grid16 = chainrow ? dim3(groups, (p.M + p.tile_rows - 1) / p.tile_rows) : dim3(nblk);
-#define DCTTS_LAUNCH16(TR, NTV)                                                                                          \
-  do {                                                                                                                   \
-    if (one) hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, true>), grid16, dim3(512), sm, st, p);                    \
-    else     hipLaunchKernelGGL((hsplit_kernel<16, TR, 0, NTV, false>), grid16, dim3(512), sm, st, p);                   \
-  } while (0)
-  if (MF == 16 && p.dbg) {
-    if (nt == 3) DCTTS_LAUNCH16(true, 3); else if (nt == 1) DCTTS_LAUNCH16(true, 1); else if (nt == 2) DCTTS_LAUNCH16(true, 2);
-    else if (nt == 4) DCTTS_LAUNCH16(true, 4); else DCTTS_LAUNCH16(true, 0);
-  } else if (MF == 16) {
-    if (nt == 3) DCTTS_LAUNCH16(false, 3); else if (nt == 1) DCTTS_LAUNCH16(false, 1); else if (nt == 2) DCTTS_LAUNCH16(false, 2);
-    else if (nt == 4) DCTTS_LAUNCH16(false, 4); else DCTTS_LAUNCH16(false, 0);
+#define DCTTS_LAUNCH16(NTV) hipLaunchKernelGGL((hsplit_kernel<16, false, 0, NTV, false>), grid16, dim3(512), sm, st, p)
+  if (MF == 16) {
+    if (nt == 3) DCTTS_LAUNCH16(3); else if (nt == 1) DCTTS_LAUNCH16(1); else if (nt == 2) DCTTS_LAUNCH16(2);
+    else if (nt == 4) DCTTS_LAUNCH16(4); else DCTTS_LAUNCH16(0);
   }
 #undef DCTTS_LAUNCH16
   else {
     const int kg = L.ntaps * L.cin_p / 8;                     // k-groups of 8; the 32-row form is instantiated per K (straight-line K loop)
-    const bool plain = (pro == PRO_RAW) && L.cin == L.cin_p && c->bulk_pipelined;   // hbulk_kernel: software-pipelined across items
+    const bool plain = (pro == PRO_RAW) && L.cin == L.cin_p;   // hbulk_kernel: software-pipelined across items
     if (ex && ex->mask_last && !(kg == 96 && plain)) return fail(DCTTS_ERR_STATE, "split kernel: presum rows need hbulk_kernel<12>");
     const bool profb = c->prof_id == DCTTS_PROF_BULK_GEMM && kg == 96 && plain;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -1089,31 +989,26 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
     if (kg == 96 && plain)      hipLaunchKernelGGL((hbulk_kernel<12>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 64 && plain) hipLaunchKernelGGL((hbulk_kernel<8>), dim3(nblk), dim3(512), sm, st, p);
     else if (kg == 32 && plain) hipLaunchKernelGGL((hbulk_kernel<4>), dim3(nblk), dim3(512), sm, st, p);
-    else if (kg == 96) hipLaunchKernelGGL((hsplit_kernel<32, false, 12>), dim3(nblk), dim3(512), sm, st, p);
-    else if (kg == 64) hipLaunchKernelGGL((hsplit_kernel<32, false, 8>), dim3(nblk), dim3(512), sm, st, p);
-    else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): K must be 256, 512 or 768");
+    else return fail(DCTTS_ERR_STATE, "split kernel (32-row form): raw input rows, K = 256, 512 or 768");
     if (profb) { HIPCHK(hipEventRecord(pe1, st)); c->prof_ev.emplace_back(pe0, pe1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int decode_v2_init(dctts_ctx* c) {
+static int decode_streams_init(dctts_ctx* c) {
   if (c->s_bulk) return 0;
   {
     // the bulk stream is throughput work that only has to finish within a frame period: lowest priority, so the dispatcher
     // prefers the latency-critical chain launches (caller's stream) whenever both have workgroups ready
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    if (!c->bulk_prio) HIPCHK(hipStreamCreateWithFlags(&c->s_bulk, hipStreamNonBlocking));
-    else HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, lo));
   }
   // the two streams hand data to each other through device memory only: device-scope release on the event markers (no system-scope flush)
-  const unsigned evf = (c->ev_sys ? 0u : (unsigned)hipEventReleaseToDevice) | hipEventDisableTiming;
+  const unsigned evf = (unsigned)hipEventReleaseToDevice | hipEventDisableTiming;
   HIPCHK(hipEventCreateWithFlags(&c->ev_fork, evf));
   for (int i = 0; i < 4; ++i) { HIPCHK(hipEventCreateWithFlags(&c->ev_chain[i], evf)); HIPCHK(hipEventCreateWithFlags(&c->ev_bulk[i], evf)); }
-  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)hsplit_kernel<32, false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1121,157 +1016,9 @@ static int decode_v2_init(dctts_ctx* c) {
   return 0;
 }
 
-// rowmlp launch: layers NETA[a0, a1) then NETB[b0_, b1) (either range may be empty) as one per-row MLP for `frame`.
-static int run_rowmlp(dctts_ctx* c, const DecodeWs& w, int B, int frame, bool tail, bool head, hipStream_t st) {
-  const std::vector<DevLayer>& AD = c->audiodec; const std::vector<DevLayer>& AE = c->audioenc;
-  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
-  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
-  RowMlpParams p; memset(&p, 0, sizeof(p));
-  p.B = B; p.b0 = 0; p.frame = frame; p.mel_layer = -1;
-  int n = 0;
-  auto add = [&](const DevLayer& L) {
-    RowMlpLayer& m = p.L[n++];
-    m.w = L.wraw; m.bias = L.bias; m.g = L.g1; m.be = L.b1; m.cin = L.cin_real; m.cout = L.cout; m.act = (L.act == ACT_RELU) ? ACT_RELU : ACT_NONE;
-  };
-  if (tail) {
-    const RowNorm nr = make_norm(AD[lh], w.pd[lh], &w.ad[lh - 1]);
-    p.pro = PRO_LN_HC; p.nrm = nr;
-    for (size_t i = lh + 1; i < AD.size(); ++i) add(AD[i]);
-    p.mel_layer = n - 1;
-    p.ypad = w.ypad.p; p.y_bstride = w.ypad.bstride; p.y_row0 = w.ypad.row0 + 1; p.y_stride = w.ypad.stride;
-    p.logits = w.logits.p; p.l_bstride = w.logits.bstride; p.l_stride = w.logits.stride;
-  } else {
-    p.pro = PRO_RAW; p.xsrc = w.ypad.p; p.xs_bstride = w.ypad.bstride; p.xs_row0 = w.ypad.row0; p.xs_stride = w.ypad.stride; p.cin0 = c->cfg.n_mels;
-  }
-  if (head) {
-    for (size_t i = 0; i < nh; ++i) add(AE[i]);
-    p.xout = w.ae[nh - 1].p; p.xo_bstride = w.ae[nh - 1].bstride; p.xo_row0 = w.ae[nh - 1].row0; p.xo_stride = w.ae[nh - 1].stride;
-    p.xo_frame_add = tail ? 1 : 0;                             // after the tail the head works on frame + 1
-  }
-  p.nlayers = n;
-  if (n < 1 || n > 8) return fail(DCTTS_ERR_STATE, "rowmlp: 1..8 layers");
-  for (int i = 0; i < n; ++i) if (!p.L[i].w || (p.L[i].cin & 7) || (p.L[i].cout & 3) || p.L[i].cin > 256 || p.L[i].cout > 256) return fail(DCTTS_ERR_STATE, "rowmlp: unsupported layer shape");
-  hipLaunchKernelGGL(rowmlp_kernel, dim3(B), dim3(512), 0, st, p);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// AudioEnc highway layers for frame j (the k=1 head has already written its C_3 row), then the newest-frame attention.
-// AudioEnc for frame j (13 dependent 16-row x 16-channel-group launches), then the newest-frame attention:
-// rebuild Q[j], materialise it, 3-key softmax, R[j], arg-max -> the window of frame j+1.
-static int v2_audioenc_attn(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hipStream_t sm, bool head_done = false,
-                            bool mel_pro = false, bool mel_only = false) {
-  const int d = c->cfg.d;
-  const std::vector<DevLayer>& AE = c->audioenc;
-  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;
-  for (size_t i = head_done ? nh : 0; i < AE.size(); ++i) {
-    if (head_done && i == nh) {       // C_3's row was materialised by rowmlp: every tap of HC_4 is a raw history row
-      CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ae[i - 1], w.pe[i], sm, nullptr, w.se[i]));
-    } else if (i == 0 && mel_pro) {
-      // mel frame j-1 = sigmoid(LN(AudioDec C_11 pre-norm)) is rebuilt here, in AudioEnc C_1's prologue (no finalize launch);
-      // column group 0 writes it to S[j] (ypad) and its logits to row j-1
-      const std::vector<DevLayer>& AD = c->audiodec;
-      const size_t la = AD.size() - 1;
-      RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
-      n.act = ACT_SIGMOID;
-      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1));
-      if (mel_only) return 0;     // after the last frame only the mel row is wanted (same arithmetic as every other frame's)
-    } else if (i == 0) {
-      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
-    } else {
-      const RowNorm n = make_norm(AE[i - 1], w.pe[i - 1], (AE[i - 1].hc && i >= 2) ? &w.ae[i - 2] : nullptr);
-      CHK(run_split(c, 16, AE[i], B, 1, nullptr, j, AE[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ae[i - 1], w.ae[i - 1], w.pe[i], sm, w.se[i - 1], w.se[i]));
-    }
-  }
-  AttnRow0Params a; memset(&a, 0, sizeof(a));
-  const size_t la = AE.size() - 1;
-  a.Bg = B; a.b0 = 0; a.B = B; a.step = nullptr; a.step_val = j;
-  a.nrm = make_norm(AE[la], w.pe[la], &w.ae[la - 1]);
-  a.qhist = w.ae[la].p; a.q_bstride = w.ae[la].bstride; a.q_row0 = w.ae[la].row0; a.q_stride = d;
-  a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N; a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
-  a.pm_all = w.pm_all; a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0; a.r_set = w.rbuf.set;
-  hipLaunchKernelGGL(attention_row0_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, a);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// The decode loop runs as two concurrent streams (DESIGN.md "decode pipeline"):
-//   chain stream, piece j : AudioDec chain for frame j -> mel frame j -> AudioEnc chain + attention for frame j+1
-//   bulk  stream, piece f : the cone rows (offsets < 0) of frame f, re-evaluated with frame f's window, written into
-//                           parity copy f&1 of the cone buffers.  Needs attention(f-1) = end of chain piece f-2 and
-//                           must finish before chain piece f: it overlaps chain piece f-1.
-// The frame index is passed by value: no device-side counter, no dependent load at kernel start.
-static int v2_bulk_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int f, hipStream_t sb) {
-  const int d = c->cfg.d;
-  const std::vector<DevLayer>& AD = c->audiodec;
-  AttnWinParams a;
-  a.Qh = w.ae.back().p; a.q_bstride = w.ae.back().bstride; a.q_row0 = w.ae.back().row0; a.q_stride = d;
-  a.K = w.kv.p; a.V = w.kv.p + d; a.kv_stride = 2 * d; a.kv_bstride = N;
-  a.N = N; a.d = d; a.win = c->cfg.attention_win_size;
-  a.step = nullptr; a.step_val = f; a.offs = c->cone_dev[0] + 1; a.R = c->cone_len[0] - 1;
-  a.pm_all = w.pm_all; a.B = B;
-  a.rbuf = w.rbuf.p; a.r_bstride = w.rbuf.bstride; a.r_row0 = w.rbuf.row0; a.r_set = w.rbuf.set;
-  hipLaunchKernelGGL(attention_window_kernel, dim3((a.R + 3) / 4, B), dim3(256), 0, sb, a);
-  HIPCHK(hipGetLastError());
-  for (size_t i = 0; i < AD.size(); ++i) {
-    const int Rb = c->cone_len[i] - 1;
-    if (Rb <= 0) break;
-    const View& src = (i == 0) ? w.rbuf : w.ad[i - 1];
-    // the last cone layers have few rows (14 / 4 / 2 per utterance): as 32-row items they are one latency-bound round of a
-    // handful of workgroups (~13 us); the 16-row chain form spreads them over (rows / 16) x 16 workgroups (~6 us)
-    if (B * Rb <= c->bulk_small_rows && AD[i].ntaps == 3)
-      CHK(run_split(c, 16, AD[i], B, Rb, c->cone_dev[i] + 1, f, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb, nullptr, nullptr, 16));
-    else
-      CHK(run_split(c, 32, AD[i], B, Rb, c->cone_dev[i] + 1, f, PRO_RAW, nullptr, nullptr, src, w.pb[i], sb));
-    LnRowsParams q; memset(&q, 0, sizeof(q));
-    q.M = B * Rb; q.R = Rb; q.b0 = 0; q.offs = c->cone_dev[i] + 1; q.step = nullptr; q.step_val = f; q.hc = AD[i].hc ? 1 : 0;
-    q.nrm = make_norm(AD[i], w.pb[i], AD[i].hc ? &src : nullptr);
-    q.x = w.ad[i].p; q.x_bstride = w.ad[i].bstride; q.x_row0 = w.ad[i].row0; q.x_stride = w.ad[i].stride; q.x_set = w.ad[i].set;
-    hipLaunchKernelGGL(ln_rows_kernel, dim3((q.M + 3) / 4), dim3(256), 0, sb, q);
-    HIPCHK(hipGetLastError());
-  }
-  return 0;
-}
-
-static int v2_chain_piece(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, bool with_next, hipStream_t sm) {
-  const std::vector<DevLayer>& AD = c->audiodec;
-  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;
-  const size_t nsplit = c->fuse_mlp ? lh + 1 : AD.size();
-  for (size_t i = 0; i < nsplit; ++i) {
-    if (i == 0) {
-      CHK(run_split(c, 16, AD[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.rbuf, w.pd[0], sm, nullptr, w.sd[0]));
-    } else {
-      const RowNorm n = make_norm(AD[i - 1], w.pd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr);
-      CHK(run_split(c, 16, AD[i], B, 1, nullptr, j, AD[i - 1].hc ? PRO_LN_HC : PRO_LN_C, &n, &w.ad[i - 1], w.ad[i - 1], w.pd[i], sm, w.sd[i - 1], w.sd[i]));
-    }
-  }
-  if (c->fuse_mlp) {
-    // C_8..C_11 + sigmoid (mel frame j) and, for the next frame, AudioEnc C_1..C_3: one per-row MLP launch
-    CHK(run_rowmlp(c, w, B, j, true, with_next, sm));
-    if (with_next) CHK(v2_audioenc_attn(c, w, B, N, j + 1, sm, true));
-    return 0;
-  }
-  if (c->fuse_mel) return v2_audioenc_attn(c, w, B, N, j + 1, sm, false, true, !with_next);   // finalisation rides in AudioEnc C_1
-  const DevLayer& Ll = AD.back();
-  FinalizeParams f; memset(&f, 0, sizeof(f));
-  f.Bg = B; f.b0 = 0; f.step = nullptr; f.step_val = j; f.P = w.pd[AD.size() - 1]; f.np = Ll.cout; f.g = Ll.g1; f.be = Ll.b1; f.n = Ll.cout;
-  f.ypad = w.ypad.p; f.y_bstride = w.ypad.bstride; f.y_row0 = w.ypad.row0 + 1; f.y_stride = w.ypad.stride;
-  f.logits = w.logits.p; f.l_bstride = w.logits.bstride; f.l_stride = w.logits.stride;
-  hipLaunchKernelGGL(finalize_kernel, dim3((B + 3) / 4), dim3(256), 0, sm, f);
-  HIPCHK(hipGetLastError());
-  if (with_next) CHK(v2_audioenc_attn(c, w, B, N, j + 1, sm));
-  return 0;
-}
-
-static void destroy_graphs2(dctts_ctx* c) {
-  for (hipGraphExec_t g : c->chain_g) if (g) (void)hipGraphExecDestroy(g);
-  for (hipGraphExec_t g : c->bulk_g) if (g) (void)hipGraphExecDestroy(g);
-  if (c->pro_g) (void)hipGraphExecDestroy(c->pro_g);
-  c->pro_g = nullptr;
-  c->chain_g.clear(); c->bulk_g.clear(); c->graphs2_geom.clear();
+static void destroy_graphs(dctts_ctx* c) {
   for (hipGraphExec_t g : c->bulk3_g) if (g) (void)hipGraphExecDestroy(g);
-  for (hipGraphExec_t g : c->chain3_g) if (g) (void)hipGraphExecDestroy(g);
-  c->bulk3_g.clear(); c->chain3_g.clear(); c->graphs3_geom.clear();
+  c->bulk3_g.clear(); c->graphs3_geom.clear();
 }
 
 template <typename F>
@@ -1286,35 +1033,6 @@ static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
   (void)hipGraphDestroy(gr);
   return 0;
 }
-
-static int write_trace(dctts_ctx* c, int j) {
-  std::vector<long long> h(64 * (8 + 256));
-  HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-  if (c->trace_file.empty()) return 0;                      // DCTTS_TRACE_FILE: where the stamps go (no default path)
-  FILE* f = fopen(c->trace_file.c_str(), "w");
-  if (!f) return 0;
-  long long t0 = 0; for (int k = 0; k < c->trace_n; ++k) if (h[8 * k] && (!t0 || h[8 * k] < t0)) t0 = h[8 * k];
-  fprintf(f, "# chain launches (hsplit_kernel<16>) of chain piece %d, workgroup 0 thread 0, microseconds since first entry (100 MHz wall clock)\n", j);
-  fprintf(f, "# idx entry rowinfo loads_issued centre_rebuilt kloop_done reduce_sync end\n");
-  for (int k = 0; k < c->trace_n; ++k) {
-    fprintf(f, "%2d", k);
-    for (int q = 0; q < 7; ++q) fprintf(f, " %8.2f", (h[8 * k + q] - t0) / 100.0);
-    // all workgroups of the launch: first / last entry, first / last end
-    long long e0 = 0, e1 = 0, x0 = 0, x1 = 0; int nw = 0;
-    for (int wg = 0; wg < 128; ++wg) {
-      const long long en = h[64 * 8 + 256 * k + 2 * wg], ex = h[64 * 8 + 256 * k + 2 * wg + 1];
-      if (!en || !ex) continue;
-      if (!nw || en < e0) e0 = en; if (!nw || en > e1) e1 = en;
-      if (!nw || ex < x0) x0 = ex; if (!nw || ex > x1) x1 = ex;
-      ++nw;
-    }
-    if (nw) fprintf(f, "  | %3d wgs: entry %8.2f..%8.2f  end %8.2f..%8.2f", nw, (e0 - t0) / 100.0, (e1 - t0) / 100.0, (x0 - t0) / 100.0, (x1 - t0) / 100.0);
-    fprintf(f, "\n");
-  }
-  fclose(f);
-  return 0;
-}
-
 
 // ------------------------------------------------------------------------------------------------ decode v3: hoisted taps (decode3_kernels.h)
 // chain piece j (j = -1 .. T-1), caller's stream:
@@ -1368,8 +1086,7 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
 static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st) {
   const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
   const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * c->aepre_layers;
-  const PieceGate gate = c->gate_next; c->gate_next = PieceGate{nullptr, 0u, nullptr, 0u, nullptr};
-  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f, gate);
+  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1407,7 +1124,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     HIPCHK(hipGetLastError());
   }
   size_t first_gemm = 1;
-  if (c->hc2_rowop && AD.size() > 1 && AD[1].wpp && AD[1].tap_off[1] == -1) {
+  if (AD.size() > 1 && AD[1].wpp && AD[1].tap_off[1] == -1) {
     // HC_2 over its cone rows + its presum row: a row operation on the cached V.W / Q.W products (no GEMM, no separate LN pass)
     RowHc2Params q; memset(&q, 0, sizeof(q));
     const int R = c->cone_len[1];
@@ -1429,26 +1146,10 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     if (!AD[i].wpp) continue;
     const int R = c->cone_len[i], Rb = R - 1;                          // Rb cone rows at offsets < 0, then the presum row (offset 0)
     float* pout = w.pb3[i] + (long)par * w.pb3_set[i];
-    if (R > c->bulk3_small_rows && c->bulk3_fused) {
-      // many rows (HC_2, HC_3): 16-row x ALL-column items with the layer-norm / gate in the epilogue (hconv16_kernel): one round of
-      // MFMA-bound workgroups, no pre-norm round trip and no separate row pass; presum rows leave through presum_out
-      ConvParams q; memset(&q, 0, sizeof(q));
-      const View& in = w.ad[i - 1]; const View& out = w.ad[i];
-      q.in = in.p + (long)par * in.set; q.in_bstride = in.bstride; q.in_row0 = in.row0; q.in_stride = in.stride;
-      q.cin = AD[i].cin; q.cin_p = AD[i].cin_p; q.ntaps = AD[i].ntaps;
-      for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = AD[i].tap_off[t3];
-      q.M = B * R; q.R = R; q.offs = c->cone3_dev[i]; q.step = nullptr; q.t_base_val = f;
-      q.wp = AD[i].wp16; q.bias = AD[i].bias; q.g1 = AD[i].g1; q.b1 = AD[i].b1; q.g2 = AD[i].g2; q.b2 = AD[i].b2; q.cout = AD[i].cout;
-      q.out = out.p + (long)par * out.set; q.out_bstride = out.bstride; q.out_row0 = out.row0; q.out_stride = out.stride; q.out_tmul = 1;
-      q.act = ACT_NONE;
-      q.presum_out = pout + (long)(R - 1) * 2 * AD[i].cout; q.presum_rstride = (long)R * 2 * AD[i].cout;
-      HIPCHK(launch_hconv16(ConvShape{EPI_HC, 2 * AD[i].cout / 16 / 8, 8}, q, 0, sb));
-      continue;
-    }
     SplitExtra ex; ex.mask_last = 1;
     // few rows (the last cone layers): 16-row x 16-channel-group items spread them over (rows / 16) x 16 short workgroups instead
     // of one latency-bound round of a handful of 32-row items
-    const int mf = (R <= c->bulk3_small_rows) ? 16 : 32;          // by rows per utterance, not by B: results stay bitwise shard-invariant
+    const int mf = (R <= 16) ? 16 : 32;          // by rows per utterance, not by B: results stay bitwise shard-invariant
     CHK(run_split(c, mf, AD[i], B, R, c->cone3_dev[i], f, PRO_RAW, nullptr, nullptr, w.ad[i - 1], pout, sb, nullptr, nullptr, 16, nullptr, 0, &ex));
     if (Rb <= 0) continue;
     LnRowsParams q; memset(&q, 0, sizeof(q));
@@ -1502,9 +1203,8 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   if (c->sig_next) { p.sig = c->ctr_chain; p.sig_val = c->sig_next; c->sig_next = 0; }
   if (c->wait2_next) {
     if (!(ex && ex->presum)) return fail(DCTTS_ERR_STATE, "chain3: the in-kernel wait guards a presum addend");
-    p.wait2 = c->gate_ctr + 32; p.wait_val = c->wait2_next; p.gate_err = (int*)(c->gate_ctr + 64); c->wait2_next = 0;
+    p.wait2 = c->wait_ctr + 32; p.wait_val = c->wait2_next; p.gate_err = (int*)(c->wait_ctr + 64); c->wait2_next = 0;
   }
-  if (c->gate_next.sig || c->gate_next.wait) { p.sig = c->gate_next.sig; p.sig_val = c->gate_next.sig_val; p.wait = c->gate_next.wait; p.wait_val = c->gate_next.wait_val; p.gate_err = c->gate_next.err; c->gate_next = PieceGate{nullptr, 0u, nullptr, 0u, nullptr}; }
   const dim3 grid(L.hc ? L.cout / 16 : (L.cout + 31) / 32, (B + 7) / 8);
   // measurement (dctts_hip_debug.h): HIP events on the launch stream around sampled launches of the time-dominant decode kernel
   // Consecutive launches of the kernel share ONE event pair (a pair around every 5 us launch measures its own marker packets:
@@ -1513,8 +1213,8 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   if (prof && !c->prof_run_e0) { HIPCHK(hipEventCreate(&c->prof_run_e0)); HIPCHK(hipEventRecord(c->prof_run_e0, st)); c->prof_run_n = 0; }
   if (!prof) CHK(prof_close_run(c, st));
 #define C3(PRO_, HC_) hipLaunchKernelGGL((chain3_kernel<PRO_, HC_>), grid, dim3(512), 0, st, p)
-  if (pro == PRO_LN_HC && L.hc && !L.tap2 && g_trace_ctx && g_trace_ctx->trace_on && g_trace_ctx->trace_n < 64) {   // DCTTS_TRACE: stamped instantiation
-    p.ts = g_trace_ctx->trace_buf + 32 * 64 * g_trace_ctx->trace_n++;
+  if (pro == PRO_LN_HC && L.hc && !L.tap2 && c->trace_on && c->trace_n < 64) {   // DCTTS_TRACE: stamped instantiation
+    p.ts = c->trace_buf + 32 * 64 * c->trace_n++;
     hipLaunchKernelGGL((chain3_kernel<PRO_LN_HC, true, false, true>), grid, dim3(512), 0, st, p);
   } else
   if (L.tap2 && pro == PRO_LN_C) hipLaunchKernelGGL((chain3_kernel<PRO_LN_C, true, true>), grid, dim3(512), 0, st, p);
@@ -1531,77 +1231,6 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   return 0;
 }
 
-
-// ---- hcgroup_kernel plumbing: one HcGroupParams per (frame, network) in device memory; exchange buffers + flags + error word
-struct GroupMem { float* xch[2]; float* sch[2]; unsigned* flags[2]; int* err; int bpad; };
-static GroupMem group_mem(dctts_ctx* c, int B) {
-  GroupMem m; const int bpad = (B + 7) / 8 * 8;
-  float* base = c->group_xch;
-  m.bpad = bpad;
-  for (int n = 0; n < 2; ++n) { m.xch[n] = base; base += (size_t)2 * bpad * 512; m.sch[n] = base; base += (size_t)2 * bpad * 64; }
-  for (int n = 0; n < 2; ++n) { m.flags[n] = (unsigned*)base; base += (size_t)(bpad / 8) * 16; }
-  m.err = (int*)base;
-  return m;
-}
-static size_t group_mem_floats(int B) { const int bpad = (B + 7) / 8 * 8; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * (bpad / 8) * 16 + 64; }
-
-static int v3_group_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
-  const std::string g = geom("grp", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p);
-  if (c->group_tab && c->group_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->group_tab) { (void)hipFree(c->group_tab); c->group_tab = nullptr; }
-  if (c->group_xch) { (void)hipFree(c->group_xch); c->group_xch = nullptr; }
-  HIPCHK(hipMalloc((void**)&c->group_xch, group_mem_floats(B) * sizeof(float)));
-  HIPCHK(hipMemset(c->group_xch, 0, group_mem_floats(B) * sizeof(float)));
-  if (!c->group_err_host) { HIPCHK(hipHostMalloc((void**)&c->group_err_host, sizeof(int), 0)); *c->group_err_host = 0; }
-  const GroupMem m = group_mem(c, B);
-  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
-  auto rowp = [](const View& v, long par, int j) { return v.p + par * v.set + (v.row0 + j) * (long)v.stride; };
-  std::vector<HcGroupParams> tab((size_t)2 * T);
-  for (int j = 0; j < T; ++j) {
-    const long par = j & 1;
-    for (int net = 0; net < 2; ++net) {                       // 0 = AudioDec highway layers of frame j, 1 = AudioEnc highway layers of frame j
-      HcGroupParams p; memset(&p, 0, sizeof(p));
-      const std::vector<DevLayer>& Lr = net ? AE : AD;
-      size_t i0 = 0; while (i0 < Lr.size() && !Lr[i0].hc) ++i0;
-      size_t i1 = i0; while (i1 < Lr.size() && Lr[i1].hc) ++i1;
-      const int L = (int)(i1 - i0);
-      if (i0 == 0 || L < 2 || L > 10 || Lr[i0 - 1].cout != 256 || Lr[i0 - 1].act != ACT_NONE) return fail(DCTTS_ERR_STATE, "v3 groups: a run of 2..10 highway layers after a linear 256-channel layer");
-      p.B = B; p.L = L;
-      const std::vector<float*>& P = net ? w.pe : w.pd; const std::vector<float*>& S = net ? w.se : w.sd;
-      const std::vector<View>& H = net ? w.ae : w.ad;
-      p.P0 = P[i0 - 1]; p.p0_bs = 256; p.stats0 = S[i0 - 1]; p.pg1 = Lr[i0 - 1].g1; p.pb1 = Lr[i0 - 1].b1;
-      for (int k = 0; k < L; ++k) {
-        const size_t i = i0 + k; const DevLayer& Ly = Lr[i];
-        if (Ly.cout != 256 || Ly.cin != 256 || !Ly.wp16 || !Ly.wp16c) return fail(DCTTS_ERR_STATE, "v3 groups: 256-channel causal k=3 highway layers only");
-        HcGroupLayer& q = p.lay[k];
-        q.wp = Ly.wp16; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2; q.tap2 = Ly.tap2 ? 1 : 0;
-        if (net) { q.presum = w.pse[i] + par * w.pse_set; q.presum_bs = 512; }
-        else { q.presum = w.pb3[i] + par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 512; q.presum_bs = c->cone_len[i] * 512; }
-        const View& hin = H[i - 1];                             // this layer's input rows
-        const bool keep = net ? true : (k + 1 == L);            // AudioEnc: every row is history; AudioDec: only the residual the next launch (C_8) needs
-        if (keep) { q.xm = rowp(hin, net ? 0 : par, j); q.xm_bs = (int)(hin.bstride * hin.stride); }
-        if (Ly.tap2) { q.xt = rowp(hin, 0, j) - hin.stride; q.xt_bs = (int)(hin.bstride * hin.stride); }
-        else { q.xt = q.wp; q.xt_bs = 0; }
-      }
-      p.pout = P[i1 - 1]; p.stats_out = S[i1 - 1];
-      p.xch = m.xch[net]; p.sch = m.sch[net]; p.xch_set = m.bpad * 512; p.sch_set = m.bpad * 64;
-      p.uses0 = (unsigned)j * (unsigned)(L / 2); p.uses1 = (unsigned)j * (unsigned)((L - 1) / 2); p.err = m.err;   // layers 0 .. L-2 publish: copy 0 ceil((L-1)/2) times, copy 1 floor((L-1)/2)
-      tab[(size_t)2 * j + net] = p;
-    }
-  }
-  HIPCHK(hipMalloc(&c->group_tab, tab.size() * sizeof(HcGroupParams)));
-  HIPCHK(hipMemcpy(c->group_tab, tab.data(), tab.size() * sizeof(HcGroupParams), hipMemcpyHostToDevice));
-  c->group_geom = g;
-  return 0;
-}
-
-static int v3_group_launch(dctts_ctx* c, int B, int j, int net, hipStream_t st) {
-  const HcGroupParams* p = (const HcGroupParams*)c->group_tab + (size_t)2 * j + net;
-  hipLaunchKernelGGL((hcgroup_kernel<0>), dim3(16, (B + 7) / 8), dim3(512), 0, st, p);
-  HIPCHK(hipGetLastError());
-  return 0;
-}
 
 
 // ---- mlp_rows_kernel plumbing: one MlpRowsParams per frame in device memory
@@ -1644,112 +1273,11 @@ static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
 static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
   CHK(prof_close_run(c, st));
   const MlpRowsParams* pm = (const MlpRowsParams*)c->mlp_tab + j;
-  const int R = c->mlp_rows;
-  if (g_trace_ctx && g_trace_ctx->trace_on) {                     // DCTTS_TRACE: stamped instantiation, stamps at the end of the trace buffer
-    long long* ts = c->trace_buf + 64 * 64 * 32 - 64;
-    if (R == 4) hipLaunchKernelGGL((mlp_rows_kernel<4, true>), dim3((B + 3) / 4), dim3(512), 0, st, pm, ts);
-    else hipLaunchKernelGGL((mlp_rows_kernel<2, true>), dim3((B + 1) / 2), dim3(512), 0, st, pm, ts);
+  if (c->trace_on) {                                              // DCTTS_TRACE: stamped instantiation, stamps at the end of the trace buffer
+    hipLaunchKernelGGL((mlp_rows_kernel<2, true>), dim3((B + 1) / 2), dim3(512), 0, st, pm, c->trace_buf + 64 * 64 * 32 - 64);
   } else {
-    if (R == 4) hipLaunchKernelGGL((mlp_rows_kernel<4, false>), dim3((B + 3) / 4), dim3(512), 0, st, pm, (long long*)nullptr);
-    else hipLaunchKernelGGL((mlp_rows_kernel<2, false>), dim3((B + 1) / 2), dim3(512), 0, st, pm, (long long*)nullptr);
+    hipLaunchKernelGGL((mlp_rows_kernel<2, false>), dim3((B + 1) / 2), dim3(512), 0, st, pm, (long long*)nullptr);
   }
-  HIPCHK(hipGetLastError());
-  return 0;
-}
-
-// ---- rowchain_kernel plumbing: per chain piece (j = -1 .. T-1) one RowChainParams + its pass table, in device memory
-static constexpr int RC_MAXP = 48;
-static int v3_rowchain_table(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, bool insig, bool gate) {
-  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
-  const size_t la = AE.size() - 1;
-  const std::string g = geom("rowchain", B, T, N) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.pse[la]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" +
-                        std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" +
-                        std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.logits.p) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)gate);
-  if (c->rc_tab && c->rc_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->rc_tab) { (void)hipFree(c->rc_tab); c->rc_tab = nullptr; }
-  if (c->rc_par) { (void)hipFree(c->rc_par); c->rc_par = nullptr; }
-  const int d = c->cfg.d;
-  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
-  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
-  if (d != 256 || lh < 1 || nh < 1 || !c->ad_c1q.wrc[0]) return fail(DCTTS_ERR_STATE, "rowchain: unexpected layer structure");
-  auto rowp = [](const View& v, int j) { return v.p + (long)(j & 1) * v.set + (v.row0 + j) * (long)v.stride; };
-  auto bs = [](const View& v) { return (int)(v.bstride * v.stride); };
-  HIPCHK(hipMalloc(&c->rc_tab, (size_t)(T + 1) * RC_MAXP * sizeof(RowPass)));
-  HIPCHK(hipMalloc(&c->rc_par, (size_t)(T + 1) * sizeof(RowChainParams)));
-  std::vector<RowPass> tab((size_t)(T + 1) * RC_MAXP);
-  std::vector<RowChainParams> par((size_t)(T + 1));
-  for (int j = -1; j < T; ++j) {
-    RowPass* P = &tab[(size_t)(j + 1) * RC_MAXP]; int n = 0;
-    RowChainParams q; memset(&q, 0, sizeof(q));
-    int nxt = 0;                                                            // dilation-1 layers seen so far (each owns one xp slot)
-    auto c_layer = [&](const DevLayer& L, float* xm, int xm_bs, int flags) -> int {
-      if (!L.wrc[0] || L.hc || L.ntaps != 1 || n >= RC_MAXP) return fail(DCTTS_ERR_STATE, "rowchain: unsupported k=1 layer");
-      RowPass r; memset(&r, 0, sizeof(r));
-      r.w = L.wrc[0]; r.add = L.bias; r.g = L.g1; r.be = L.b1; r.xm = xm; r.xm_bs = xm_bs; r.cin = L.cin_real; r.ncols = L.cout;
-      r.fresh = 1; r.fin = FIN_C; r.relu = (L.act == ACT_RELU) ? 1 : 0; r.flags = flags;
-      P[n++] = r; return 0;
-    };
-    auto hc_layer = [&](const DevLayer& L, const float* presum, int presum_bs, const float* xt, int xt_bs, float* xm, int xm_bs, int flags) -> int {
-      if (!L.wrc[3] || !L.hc || L.cout != 256 || L.cin != 256 || !presum || n + 4 > RC_MAXP) return fail(DCTTS_ERR_STATE, "rowchain: unsupported highway layer");
-      int slot = 0;
-      if (L.tap2) { if (nxt >= 2) return fail(DCTTS_ERR_STATE, "rowchain: more than two dilation-1 layers"); q.xt[nxt] = xt; q.xt_bs[nxt] = xt_bs; slot = ++nxt; }
-      for (int pass = (L.tap2 ? 0 : 2); pass < 4; ++pass) {               // [tap -1: gate, info,] centre tap: gate, info
-        RowPass r; memset(&r, 0, sizeof(r));
-        const int half = pass & 1, centre = pass >> 1;
-        r.w = L.wrc[pass]; r.cin = 256; r.ncols = 256;
-        r.add = presum + half * 256; r.add_bs = presum_bs; r.g = half ? L.g2 : L.g1; r.be = half ? L.b2 : L.b1;
-        r.src = centre ? 0 : slot; r.accsel = half; r.fresh = (centre && L.tap2) ? 0 : 1;
-        if (pass == 3) { r.fin = FIN_HC; r.xm = xm; r.xm_bs = xm_bs; r.flags = flags; }
-        P[n++] = r;
-      }
-      return 0;
-    };
-    if (j >= 0) {
-      for (size_t i = 1; i <= lh; ++i) {
-        if (!AD[i].wp16c) return fail(DCTTS_ERR_STATE, "rowchain: AudioDec highway layers are k = 3");
-        const float* ps = w.pb3[i] + (long)(j & 1) * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout;
-        CHK(hc_layer(AD[i], ps, c->cone_len[i] * 2 * AD[i].cout, nullptr, 0, i < lh ? rowp(w.ad[i], j) : nullptr, i < lh ? bs(w.ad[i]) : 0, 0));
-      }
-      for (size_t i = lh + 1; i < AD.size(); ++i) CHK(c_layer(AD[i], nullptr, 0, i + 1 == AD.size() ? RP_MEL : 0));
-    }
-    const int j1 = j + 1;
-    if (j1 < T) {
-      for (size_t i = 0; i < nh; ++i) CHK(c_layer(AE[i], rowp(w.ae[i], j1), bs(w.ae[i]), 0));
-      for (size_t i = nh; i <= la; ++i) {
-        if (!AE[i].wp16c && !AE[i].tap2) return fail(DCTTS_ERR_STATE, "rowchain: AudioEnc highway layers are k = 3");
-        CHK(hc_layer(AE[i], w.pse[i] + (long)(j1 & 1) * w.pse_set, 2 * AE[i].cout, rowp(w.ae[i - 1], j1) - w.ae[i - 1].stride, bs(w.ae[i - 1]),
-                     rowp(w.ae[i], j1), bs(w.ae[i]), i == la ? RP_ATTN : 0));
-      }
-      RowPass r; memset(&r, 0, sizeof(r));                                // AudioDec C_1 of frame j+1: presum from the attention step + Q . W_bot
-      const DevLayer& L = c->ad_c1q;
-      r.w = L.wrc[0]; r.add = L.bias; r.g = L.g1; r.be = L.b1; r.cin = 256; r.ncols = 256; r.fresh = 1; r.fin = FIN_C1;
-      r.xm = rowp(w.ad[0], j1); r.xm_bs = bs(w.ad[0]); r.raw = rowp(w.c1q, j1); r.raw_bs = bs(w.c1q);
-      if (n >= RC_MAXP) return fail(DCTTS_ERR_STATE, "rowchain: pass table overflow");
-      P[n++] = r;
-    }
-    q.B = B; q.frame = j; q.first = 0; q.npass = n; q.init = (j < 0) ? 1 : 0;
-    q.tab = (const RowPass*)c->rc_tab + (size_t)(j + 1) * RC_MAXP;
-    if (j >= 0) { q.x1 = rowp(w.ad[0], j); q.x1_bs = bs(w.ad[0]); }
-    q.K = w.kv.p; q.k_stride = 2 * d; q.VW = w.vw; q.vw_stride = d; q.kv_bstride = N; q.N = N; q.win = c->cfg.attention_win_size;
-    q.pm_all = w.pm_all; q.c1_bias = c->audiodec[0].bias;
-    q.ypad = w.ypad.p; q.y_bstride = w.ypad.bstride; q.y_row = w.ypad.row0 + 1 + j; q.y_stride = w.ypad.stride;
-    q.logits = w.logits.p; q.l_bstride = w.logits.bstride; q.l_row = j; q.l_stride = w.logits.stride;
-    if (insig && j >= 0) { q.sig = c->ctr_chain; q.sig_val = (unsigned)(j + 1); }
-    if (gate && j >= 0) { q.sig = c->gate_ctr; q.sig_val = (unsigned)(j + 1); q.wait = c->gate_ctr + 32; q.wait_val = (unsigned)(j + 1); q.gate_err = (int*)(c->gate_ctr + 64); }
-    par[(size_t)(j + 1)] = q;
-  }
-  HIPCHK(hipMemcpy(c->rc_tab, tab.data(), tab.size() * sizeof(RowPass), hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(c->rc_par, par.data(), par.size() * sizeof(RowChainParams), hipMemcpyHostToDevice));
-  c->rc_geom = g;
-  return 0;
-}
-
-static int v3_rowchain_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
-  CHK(prof_close_run(c, st));
-  const RowChainParams* q = (const RowChainParams*)c->rc_par + (j + 1);
-  if (g_trace_ctx && g_trace_ctx->trace_on) hipLaunchKernelGGL((rowchain_kernel<2, true>), dim3((B + 1) / 2), dim3(512), 0, st, q, c->trace_buf);   // DCTTS_TRACE: stamped instantiation
-  else hipLaunchKernelGGL((rowchain_kernel<2, false>), dim3((B + 1) / 2), dim3(512), 0, st, q, (long long*)nullptr);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1758,10 +1286,8 @@ static int v3_rowchain_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
   const int par = j & 1;
-  size_t first = 1;
-  if (c->chain_group) { CHK(v3_group_launch(c, B, j, 0, sm)); while (first < AD.size() && AD[first].hc) ++first; }
-  for (size_t i = first; i < AD.size(); ++i) {
-    if (c->chain_mlp && !AD[i].hc) break;                       // C_8 .. C_11 run inside mlp_rows_kernel (launched by the caller)
+  for (size_t i = 1; i < AD.size(); ++i) {
+    if (!AD[i].hc) break;                                       // C_8 .. C_11 run inside mlp_rows_kernel (launched by the caller)
     SplitExtra ex;
     if (AD[i].wp16c) { ex.presum = w.pb3[i] + (long)par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 2 * AD[i].cout; ex.presum_rstride = c->cone_len[i] * 2 * AD[i].cout; }
     CHK(run_chain3(c, AD[i], B, j, &AD[i - 1], w.pd[i - 1], w.sd[i - 1], (AD[i - 1].hc && i >= 2) ? &w.ad[i - 2] : nullptr, &w.ad[i - 1], nullptr,
@@ -1776,16 +1302,9 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
   const std::vector<DevLayer>& AE = c->ae_c;
   const std::vector<DevLayer>& AD = c->ad_c;
   for (size_t i = 0; i < AE.size(); ++i) {
-    if (c->chain_mlp && j > 0 && !AE[i].hc) continue;           // C_1 .. C_3 of frame j ran inside frame j-1's mlp_rows_kernel
-    if (i == 0 && j > 0) {
-      const size_t la = AD.size() - 1;
-      RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
-      n.act = ACT_SIGMOID;
-      CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1));
-    } else if (i == 0) {
+    if (j > 0 && !AE[i].hc) continue;                           // C_1 .. C_3 of frame j ran inside frame j-1's mlp_rows_kernel
+    if (i == 0) {                                               // frame 0 only: S[0] is the zero row
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
-    } else if (c->chain_group && AE[i].hc) {
-      if (!AE[i - 1].hc) CHK(v3_group_launch(c, B, j, 1, sm));      // the whole run of highway layers; the other indices of the run are covered by it
     } else {
       SplitExtra ex;
       if (AE[i].wp16c) { ex.presum = w.pse[i] + (long)(j & 1) * w.pse_set; ex.presum_rstride = 2 * AE[i].cout; }
@@ -1807,30 +1326,12 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
   return run_chain3(c, c->ad_c1q, B, j, nullptr, nullptr, nullptr, nullptr, nullptr, &w.ae[la], w.pd[0], w.sd[0], &ex, sm);
 }
 
-// the last frame's mel row: same arithmetic as every other frame's (AudioEnc C_1's prologue), without the rest of the piece
-static int v3_final_mel(dctts_ctx* c, const DecodeWs& w, int B, int T, hipStream_t sm) {
-  const std::vector<DevLayer>& AD = c->ad_c;
-  const size_t la = AD.size() - 1;
-  RowNorm n = make_norm(AD[la], w.pd[la], nullptr);
-  n.act = ACT_SIGMOID;
-  return run_split(c, 16, c->ae_c[0], B, 1, nullptr, T, PRO_MEL, &n, &w.ypad, w.ypad, w.pe[0], sm, w.sd[la], w.se[0], 0, &w.logits, -1);
-}
-
 static int write_trace3(dctts_ctx* c, int j) {
   std::vector<long long> h(64 * 64 * 32);
   HIPCHK(hipMemcpy(h.data(), c->trace_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
   if (c->trace_file.empty()) return 0;
   FILE* f = fopen(c->trace_file.c_str(), "w");
   if (!f) return 0;
-  if (c->chain_row) {
-    double tot = 0; for (int q = 1; q <= 7; ++q) tot += (double)h[q];
-    fprintf(f, "# rowchain_kernel, chain piece %d, workgroup 0 / wave 0: %.2f us (100 MHz wall clock), %lld passes, %.0f shader clocks (%.0f MHz); share per section\n", j, h[0] / 100.0, h[8], tot, tot / (h[0] / 100.0));
-    const char* nm[7] = {"launch prologue", "waiting for a pass's first rows", "FMA loop + later waits + issuing the next pass", "fold, reduce-scatter, wave statistics", "barrier 1 (all waves done with the pass)",
-                         "combine, normalise, gate, stores", "barrier 2 (new rows visible) + attention step"};
-    for (int q = 0; q < 7; ++q) fprintf(f, "%5.1f%%  %6.2f us  %s\n", 100.0 * h[q + 1] / tot, h[q + 1] / tot * h[0] / 100.0, nm[q]);
-    fclose(f);
-    return 0;
-  }
   long long t0 = 0;
   for (int k = 0; k < c->trace_n; ++k) for (int wg = 0; wg < 64; ++wg) { const long long e = h[(k * 64 + wg) * 32]; if (e && (!t0 || e < t0)) t0 = e; }
   fprintf(f, "# chain3_kernel<LN_HC, HC> launches of chain piece %d: microseconds (100 MHz wall clock) since the first entry of the piece\n", j);
@@ -1870,20 +1371,15 @@ static int write_trace3(dctts_ctx* c, int j) {
 }
 
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
-  CHK(decode_v2_init(c));
-  // how the two streams meet: in-kernel gates (default) > stream memory operations > events
-  const bool gate = c->sync_gate && !c->chain_group && c->v3_skip == 0;
-  if (gate && !c->gate_ctr) {
-    HIPCHK(hipMalloc((void**)&c->gate_ctr, 128 * sizeof(unsigned)));
-    HIPCHK(hipMemset(c->gate_ctr, 0, 128 * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void**)&c->gate_err_host, sizeof(int), 0)); *c->gate_err_host = 0;
-  }
-  if (gate && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: a piece gate of the previous decode timed out (piece_gate)");
-  if (c->sync_values && !gate && !c->ctr_chain) {            // a device without stream memory operations meets through events
+  CHK(decode_streams_init(c));
+  // How the two streams meet.  Default: stream memory operations on two counters; the chain's counter is written by the
+  // first launch of the NEXT chain piece, and (chain_wait_inkernel) the chain's wait for the bulk's counter sits inside that launch too.
+  // Fallback (no stream memory operations on the device, or DCTTS_SYNC_VALUES=0, which rocprofv3 --pmc needs): events.
+  if (c->sync_values && !c->ctr_chain) {
     int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
     if (!can) c->sync_values = 0;
   }
-  const bool vs = c->sync_values != 0 && !gate;
+  const bool vs = c->sync_values != 0;
   if (vs && !c->ctr_chain) {
     // Stream memory operations: a write packet after a piece, a compare-and-wait packet before the piece that needs it.  The
     // command processor polls the counter itself: no signal objects, no interrupt, and (measured) ~10 us less per frame on the
@@ -1891,83 +1387,63 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     HIPCHK(hipExtMallocWithFlags((void**)&c->ctr_chain, 8, hipMallocSignalMemory));
     HIPCHK(hipExtMallocWithFlags((void**)&c->ctr_bulk, 8, hipMallocSignalMemory));
   }
-  // the chain's counter is written by the first launch of the NEXT piece ("I run, so everything before me is complete and released")
-  // instead of a write-value packet behind the piece: one command-processor round trip less per frame on the critical stream
-  const bool insig = vs && c->sig_inkernel && !c->chain_group && c->v3_skip != 2;
-  // ... and the chain's wait for the bulk's counter sits inside the piece's first launch (chain3_kernel: wait2): the counter then
-  // lives in plain device memory (the bulk's write-value operation writes it, the launch polls it)
-  const bool cwait = insig && c->chain_wait_inkernel && !c->chain_row && c->v3_skip == 0;
-  if (cwait && !c->gate_ctr) {
-    HIPCHK(hipMalloc((void**)&c->gate_ctr, 128 * sizeof(unsigned)));
-    HIPCHK(hipMemset(c->gate_ctr, 0, 128 * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void**)&c->gate_err_host, sizeof(int), 0)); *c->gate_err_host = 0;
+  const bool insig = vs;                                    // the chain's counter is written by the first launch of the next piece
+  const bool cwait = vs && c->chain_wait_inkernel;          // the chain's wait for the bulk's counter happens inside that launch (chain3_kernel: wait2)
+  if (cwait && !c->wait_ctr) {
+    HIPCHK(hipMalloc((void**)&c->wait_ctr, 128 * sizeof(unsigned)));
+    HIPCHK(hipMemset(c->wait_ctr, 0, 128 * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void**)&c->wait_err_host, sizeof(int), 0)); *c->wait_err_host = 0;
   }
-  if (cwait && *c->gate_err_host) {                        // reported once: this call fails, the next one starts clean
-    *c->gate_err_host = 0;
-    HIPCHK(hipMemset(c->gate_ctr + 64, 0, sizeof(int)));
-    return fail(DCTTS_ERR_STATE, "decode: the in-kernel wait of the previous decode timed out (chain3_kernel): its results were invalid");
+  if (cwait && *c->wait_err_host) {
+    // the previous decode's in-kernel wait timed out and nobody asked (dctts_decode_status reports and clears it): refuse once, so the
+    // failure cannot go unnoticed, then start clean
+    *c->wait_err_host = 0;
+    HIPCHK(hipMemset(c->wait_ctr + 64, 0, sizeof(int)));
+    return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-kernel wait for the side stream timed out and its results were invalid (dctts_decode_status was not consulted)");
   }
   CHK(v3_aepre_table(c, w, B));
-  if (c->chain_row) CHK(v3_rowchain_table(c, w, B, N, T, insig, gate));
-  else if (c->chain_mlp) CHK(v3_mlp_table(c, w, B, T));
-  if (c->chain_group && !c->chain_row) {
-    if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off of the previous decode timed out (hcgroup_kernel)");
-    CHK(v3_group_table(c, w, B, T));
-    const GroupMem m = group_mem(c, B);
-    HIPCHK(hipMemsetAsync(m.xch[0], 0xFF, (size_t)2 * (2 * m.bpad * 512 + 2 * m.bpad * 64) * sizeof(float), st));   // exchange words: stamp 1 (the first use expects 0)
-    HIPCHK(hipMemsetAsync(m.err, 0, sizeof(int), st));
-  }
+  CHK(v3_mlp_table(c, w, B, T));
   hipStream_t sb = c->s_bulk;
-  // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch; 2 = the chain piece too.  Every
-  // piece only waits at its start and records at its end, so the host issues 2 graph launches + 4 event operations per frame.
-  const bool gr = c->use_graph != 0, gr_chain = c->use_graph == 2;
+  // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch (the chain launches stay eager: a graph
+  // launch per chain piece costs ~10 us of start-up on the critical path)
+  const bool gr = c->use_graph != 0;
   auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
-    if (c->chain_row) return v3_rowchain_launch(c, B, j, s);
     c->sig_next = (insig && j >= 0) ? (unsigned)(j + 1) : 0u;          // written by the piece's first launch (AudioDec HC_2)
     c->wait2_next = (cwait && j >= 0) ? (unsigned)(j + 1) : 0u;        // ... which also waits for bulk piece j
-    if (gate && j >= 0) c->gate_next = PieceGate{c->gate_ctr, (unsigned)(j + 1), c->gate_ctr + 32, (unsigned)(j + 1), (int*)(c->gate_ctr + 64)};   // publish "pieces < j done", wait for bulk piece j
-    if (j >= 0) CHK(v3_chain_dec(c, w, B, j, s));
-    if (j >= 0 && c->chain_mlp) CHK(v3_mlp_launch(c, B, j, s));   // AudioDec C_8..C_11, mel frame j, AudioEnc C_1..C_3 of frame j+1
+    if (j >= 0) { CHK(v3_chain_dec(c, w, B, j, s)); CHK(v3_mlp_launch(c, B, j, s)); }   // AudioDec HC_2 .. HC_7; C_8 .. C_11, mel frame j, AudioEnc C_1 .. C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
-    return c->chain_mlp ? 0 : v3_final_mel(c, w, B, T, s);
-  };
-  auto bulk_rest = [&](int f, hipStream_t s) -> int {        // bulk piece f; its first launch (the grouped presum launch) carries the gate
-    if (gate && f >= 1) c->gate_next = PieceGate{c->gate_ctr + 32, (unsigned)f, c->gate_ctr, (unsigned)f, (int*)(c->gate_ctr + 64)};   // publish "bulk pieces < f done", wait for chain pieces <= f-2
-    return v3_bulk_rest(c, w, B, N, T, f, s);
+    return 0;
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->bulk3_small_rows) + ":" + std::to_string(c->bulk3_fused) + ":" + std::to_string(c->hc2_rowop) + ":" + std::to_string(c->chain_group) + ":" + std::to_string((size_t)c->group_tab) + ":" + std::to_string(c->chain_mlp) + ":" + std::to_string(c->mlp_rows) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string(c->chain_row) + ":" + std::to_string((size_t)c->rc_par) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)gate) + ":" + std::to_string((int)cwait) + ":" +
-                          std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" +
+                          std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
-      destroy_graphs2(c);
+      destroy_graphs(c);
       hipStream_t cs;
       HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
       const int prof_keep = c->prof_id; c->prof_id = -1;
-      c->bulk3_g.assign(T, nullptr); c->chain3_g.assign(T + 1, nullptr);
+      c->bulk3_g.assign(T, nullptr);
       int rc = 0;
-      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return bulk_rest(f, cs); });
-      for (int j = -1; gr_chain && j < T && rc == 0; ++j) rc = capture_piece(cs, &c->chain3_g[j + 1], [&]() { return chain_piece(j, cs); });
+      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, T, f, cs); });
       c->prof_id = prof_keep;
       HIPCHK(hipStreamDestroy(cs));
-      if (rc != 0) { destroy_graphs2(c); return rc; }
+      if (rc != 0) { destroy_graphs(c); return rc; }
       c->graphs3_geom = g;
     }
   }
-  if (gate || cwait) HIPCHK(hipMemsetAsync(c->gate_ctr, 0, 64 * sizeof(unsigned), st));      // both counters; st is ordered after the previous decode's last piece, and that piece after all bulk work
+  if (cwait) HIPCHK(hipMemsetAsync(c->wait_ctr, 0, 64 * sizeof(unsigned), st));      // st is ordered after the previous decode's last piece, and that piece after all bulk work
   if (vs) {
-    HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 0u, 0));              // st is ordered after the previous decode's last piece, and that piece after all bulk work
+    HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 0u, 0));
     HIPCHK(hipStreamWriteValue32(st, c->ctr_bulk, 0u, 0));
   }
   CHK(v3_vw(c, w, B, N, st));                                              // V . W_top, once per batch
   CHK(v3_aepre(c, B, 0, st));                                              // row 0's AudioEnc presums (= the biases: every tap reads padding)
   HIPCHK(hipEventRecord(c->ev_fork, st));
   HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
-  const int skip = c->v3_skip;                                             // timing experiments only: 1 = no bulk work, 2 = no chain work, 3 = no bulk work and no events between the streams
-  const int tstep = gr_chain ? -1 : c->trace_frame;
+  const int tstep = c->trace_frame;
   auto bulk_piece = [&](int f) -> int {
-    if (skip != 1 && skip != 3) { if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(bulk_rest(f, sb)); }
-    if (gate) { if (f == T - 1) { hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(64), 0, sb, c->gate_ctr + 32, (unsigned)T); HIPCHK(hipGetLastError()); } return 0; }
-    if (skip != 3) { if (vs) HIPCHK(hipStreamWriteValue32(sb, cwait ? (void*)(c->gate_ctr + 32) : (void*)c->ctr_bulk, (uint32_t)(f + 1), 0)); else HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb)); }
+    if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, T, f, sb));
+    if (vs) HIPCHK(hipStreamWriteValue32(sb, cwait ? (void*)(c->wait_ctr + 32) : (void*)c->ctr_bulk, (uint32_t)(f + 1), 0)); else HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb));
     return 0;
   };
   // DCTTS_PIECETIME=<frame>: timing events around 8 consecutive chain / bulk pieces starting there (measurement only)
@@ -1975,39 +1451,38 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   hipEvent_t pe_c[9][2], pe_b[9][2];
   if (pt0 >= 0) for (int i = 0; i < 9; ++i) for (int k = 0; k < 2; ++k) { HIPCHK(hipEventCreate(&pe_c[i][k])); HIPCHK(hipEventCreate(&pe_b[i][k])); }
   auto ptime = [&](int j) { return pt0 >= 0 && j >= pt0 && j < pt0 + 8; };
-  const auto host_t0 = std::chrono::steady_clock::now();
   CHK(bulk_piece(0));
-  if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[0], st)); else CHK(chain_piece(-1, st));
-  if (gate) {} else if (vs) { if (!insig) HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 1u, 0)); } else HIPCHK(hipEventRecord(c->ev_chain[3], st));
+  CHK(chain_piece(-1, st));
+  if (!vs) HIPCHK(hipEventRecord(c->ev_chain[3], st));
   for (int j = 0; j < T; ++j) {
     if (j + 1 < T) {
       // bulk piece j+1 needs attnq(j) / C1Q[j]: end of chain piece j-1
-      if (gate) {} else if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(sb, c->ctr_chain, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0)); }
+      if (vs) HIPCHK(hipStreamWaitValue32(sb, c->ctr_chain, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][0], sb));
       CHK(bulk_piece(j + 1));
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][1], sb));
     }
-    if (gate || cwait) {} else if (skip != 3) { if (vs) HIPCHK(hipStreamWaitValue32(st, c->ctr_bulk, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0)); }
+    if (!cwait) { if (vs) HIPCHK(hipStreamWaitValue32(st, c->ctr_bulk, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0)); }
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][0], st));
     if (j == tstep) {
       if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
       HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long), st));
-      c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
+      c->trace_on = true; c->trace_n = 0;
     }
     c->prof_frame = (j & 15) == 8;
-    if (skip != 2) { if (gr_chain) HIPCHK(hipGraphLaunch(c->chain3_g[j + 1], st)); else CHK(chain_piece(j, st)); }
+    CHK(chain_piece(j, st));
     CHK(prof_close_run(c, st));
     c->prof_frame = false;
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][1], st));
-    if (gate) {} else if (skip != 3) { if (vs) { if (!insig) HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, (uint32_t)(j + 2), 0)); } else HIPCHK(hipEventRecord(c->ev_chain[j & 3], st)); }
+    if (!vs) HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
     if (c->trace_on) {
-      c->trace_on = false; g_trace_ctx = nullptr;
+      c->trace_on = false;
       HIPCHK(hipStreamSynchronize(st));
       CHK(write_trace3(c, j));
     }
   }
-  if (gate || cwait) HIPCHK(hipMemcpyAsync(c->gate_err_host, c->gate_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (c->chain_group && !c->chain_row) HIPCHK(hipMemcpyAsync(c->group_err_host, group_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
+  // the chain's last piece is on `st`; the bulk stream's last piece was consumed by it, so `st` is ordered after all decode work.
+  if (cwait) HIPCHK(hipMemcpyAsync(c->wait_err_host, c->wait_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
     for (int i = 0; i < 8; ++i) {
@@ -2020,10 +1495,6 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     }
     for (int i = 0; i < 9; ++i) for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(pe_c[i][k]); (void)hipEventDestroy(pe_b[i][k]); }
   }
-  if (c->hosttime) {
-    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
-    fprintf(stderr, "[dctts] decode v3: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
-  }
   return 0;
 }
 
@@ -2031,77 +1502,19 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
-  const bool v2 = (c->decode_mode == 1), v3 = (c->decode_mode == 3 || c->decode_mode == 4);
-  if (v2) CHK(decode_v2_init(c));
-  if (!v2 && !v3) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }     // v1 uses one copy of every buffer
+  const bool v3 = (c->decode_mode == 3);
+  if (!v3) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // the simple form uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
-  HIPCHK(hipMemsetAsync(w.step, 0, 256, st));                              // v1's device-side frame counter
+  HIPCHK(hipMemsetAsync(w.step, 0, 256, st));                              // the simple form's device-side frame counter
   HIPCHK(hipMemsetAsync(w.pm_all, 0, (size_t)B * sizeof(int), st));      // prev_max_attentions = zeros (synthesize.py:46)
+  if (!c->init_pm.empty()) {                                               // test hook (dctts_hip_debug.h): a seeded start state for this one decode
+    if ((int)c->init_pm.size() != B) { c->init_pm.clear(); return fail(DCTTS_ERR_ARG, "decode: the seeded prev_max_attentions must have B entries"); }
+    HIPCHK(hipMemcpyAsync(w.pm_all, c->init_pm.data(), (size_t)B * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    c->init_pm.clear();
+  }
   if (v3) {
     CHK(decode_v3(c, w, B, N, T, st));
-  } else if (v2) {
-    hipStream_t sb = c->s_bulk;
-    // use_graph: 0 = every launch eager; 1 = bulk pieces as per-frame graphs, chain launches eager (default: a graph launch per
-    // chain piece costs ~11 us of start-up on the critical path, the bulk's is hidden); 2 = both as graphs
-    const bool gr = c->use_graph != 0;
-    const bool gr_chain = c->use_graph == 2;
-    if (gr) {
-      const std::string g = geom("graph2", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string(c->fuse_mlp) + ":" + std::to_string(c->chain_rows) + ":" + std::to_string(c->use_graph) + ":" + std::to_string((size_t)w.kv.p);
-      if (c->bulk_g.empty() || c->graphs2_geom != g) {
-        destroy_graphs2(c);
-        hipStream_t cs;
-        HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        const int prof_keep = c->prof_id; c->prof_id = -1;
-        c->chain_g.assign(T, nullptr); c->bulk_g.assign(T, nullptr);
-        int rc = 0;
-        if (gr_chain) rc = capture_piece(cs, &c->pro_g, [&]() {                                     // frame 0's AudioEnc + attention
-          if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, cs)); return v2_audioenc_attn(c, w, B, N, 0, cs, true); }
-          return v2_audioenc_attn(c, w, B, N, 0, cs); });
-        for (int j = 0; j < T && rc == 0; ++j) {
-          if (gr_chain) rc = capture_piece(cs, &c->chain_g[j], [&]() { return v2_chain_piece(c, w, B, N, j, j + 1 < T, cs); });
-          if (rc == 0 && j >= 1) rc = capture_piece(cs, &c->bulk_g[j], [&]() { return v2_bulk_piece(c, w, B, N, j, cs); });
-        }
-        c->prof_id = prof_keep;
-        HIPCHK(hipStreamDestroy(cs));
-        if (rc != 0) { destroy_graphs2(c); return rc; }
-        c->graphs2_geom = g;
-      }
-    }
-    const int tstep = gr_chain ? -1 : c->trace_frame;
-    // the bulk stream joins the caller's stream at the start (TextEnc, resets)
-    HIPCHK(hipEventRecord(c->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
-    const auto host_t0 = std::chrono::steady_clock::now();
-    // pipeline prologue = chain piece -1: frame 0's AudioEnc + attention
-    if (gr_chain) HIPCHK(hipGraphLaunch(c->pro_g, st));
-    else if (c->fuse_mlp) { CHK(run_rowmlp(c, w, B, 0, false, true, st)); CHK(v2_audioenc_attn(c, w, B, N, 0, st, true)); }
-    else CHK(v2_audioenc_attn(c, w, B, N, 0, st));
-    HIPCHK(hipEventRecord(c->ev_chain[3], st));
-    for (int j = 0; j < T; ++j) {
-      // bulk piece f = j+1 needs attention(j) (end of chain piece j-1) and overlaps chain piece j
-      if (j + 1 < T) {
-        HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));
-        if (gr) HIPCHK(hipGraphLaunch(c->bulk_g[j + 1], sb)); else CHK(v2_bulk_piece(c, w, B, N, j + 1, sb));
-        HIPCHK(hipEventRecord(c->ev_bulk[(j + 1) & 3], sb));
-      }
-      if (j >= 1) HIPCHK(hipStreamWaitEvent(st, c->ev_bulk[j & 3], 0));      // chain piece j reads frame j's cone rows
-      if (j == tstep) {
-        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * (8 + 256) * sizeof(long long))); }
-        HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * (8 + 256) * sizeof(long long), st));
-        c->trace_on = true; c->trace_n = 0; g_trace_ctx = c;
-      }
-      if (gr_chain) HIPCHK(hipGraphLaunch(c->chain_g[j], st)); else CHK(v2_chain_piece(c, w, B, N, j, j + 1 < T, st));
-      HIPCHK(hipEventRecord(c->ev_chain[j & 3], st));
-      if (c->trace_on) {
-        c->trace_on = false; g_trace_ctx = nullptr;
-        HIPCHK(hipStreamSynchronize(st));
-        CHK(write_trace(c, j));
-      }
-    }
-    if (c->hosttime) {
-      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_t0).count();
-      fprintf(stderr, "[dctts] decode: host enqueue of %d frames took %.1f us (%.1f us per frame)\n", T, us, us / T);
-    }
   } else if (c->use_graph) {
     const std::string g = geom("graph1", B, T, N) + ":" + std::to_string((size_t)w.kv.p);   // the captured launches bake in the TextEnc output pointer
     if (!c->graph_exec || c->graph_geom != g) {
@@ -2152,25 +1565,26 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 
 extern "C" int dctts_decode_status(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
-  if (c->group_err_host && *c->group_err_host) return fail(DCTTS_ERR_STATE, "decode: an in-launch hand-off timed out (hcgroup_kernel); results of that decode are invalid");
-  if (c->gate_err_host && *c->gate_err_host) return fail(DCTTS_ERR_STATE, "decode: a piece gate timed out (piece_gate: one stream never saw the other's counter); results of that decode are invalid");
+  if (c->wait_err_host && *c->wait_err_host) {              // reported once: the error word is cleared so that the next decode starts clean
+    DevGuard dev_guard(c);
+    *c->wait_err_host = 0;
+    (void)hipMemset(c->wait_ctr + 64, 0, sizeof(int));
+    return fail(DCTTS_ERR_STATE, "decode: the in-kernel wait for the side stream timed out (chain3_kernel): the results of that decode are invalid");
+  }
   return 0;
 }
 
 extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
-  if (!c || enable < 0 || enable > 2) return fail(DCTTS_ERR_ARG, "decode graph mode must be 0, 1 or 2");
+  if (!c || enable < 0 || enable > 1) return fail(DCTTS_ERR_ARG, "decode graph mode must be 0 or 1");
   c->use_graph = enable;
   return 0;
 }
 
 extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
-  if (!c || mode < 0 || mode > 4) return fail(DCTTS_ERR_ARG, "decode mode must be 0 .. 4");
-  c->decode_mode = (mode >= 3) ? mode : (mode ? 1 : 0);
-  c->chain_row = (mode == 4) ? 1 : 0;
-  c->fuse_mlp = (mode == 2) ? 1 : 0;
+  if (!c || (mode != 0 && mode != 3)) return fail(DCTTS_ERR_ARG, "decode mode must be 3 (two-stream incremental form, the default) or 0 (simple one-stream form, cross-check)");
+  c->decode_mode = mode;
   return 0;
 }
-
 
 // ------------------------------------------------------------------------------------------------ per-layer test hook
 // Runs ONE device layer of a network on a caller tensor X (B,T,Cin) -> out (B,T',Cout); T' = 2T for a
@@ -2212,6 +1626,13 @@ extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const
 __global__ void __launch_bounds__(256) calib_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+extern "C" int dctts_debug_seed_prev_max(dctts_ctx* c, const int32_t* prev_max, int B) {
+  if (!c || !prev_max || B <= 0) return fail(DCTTS_ERR_ARG, "seed_prev_max: bad argument");
+  for (int b = 0; b < B; ++b) if (prev_max[b] < 0 || prev_max[b] >= c->cfg.max_N) return fail(DCTTS_ERR_ARG, "seed_prev_max: values must lie in [0, max_N)");
+  c->init_pm.assign(prev_max, prev_max + B);
+  return 0;
+}
+
 extern "C" int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream) {
   hipLaunchKernelGGL(calib_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, nfloats / 4);
   HIPCHK(hipGetLastError());
@@ -2219,22 +1640,6 @@ extern "C" int dctts_debug_copy(const float* src, float* dst, size_t nfloats, vo
 }
 
 // ------------------------------------------------------------------------------------------------ profiling aid
-// Measurement aid: a stream restricted to CUs [cu_first, cu_first + cu_count) (hipExtStreamCreateWithCUMask), to probe how the
-// throughput phases behave on a partition of the chip while the latency-bound decode runs on the rest.
-extern "C" int dctts_debug_stream_create(int cu_first, int cu_count, void** stream) {
-  if (!stream || cu_first < 0 || cu_count < 1 || cu_first + cu_count > 1024) return fail(DCTTS_ERR_ARG, "bad CU range");
-  uint32_t mask[32]; memset(mask, 0, sizeof(mask));
-  for (int i = cu_first; i < cu_first + cu_count; ++i) mask[i >> 5] |= 1u << (i & 31);
-  hipStream_t s = nullptr;
-  HIPCHK(hipExtStreamCreateWithCUMask(&s, 32, mask));
-  *stream = (void*)s;
-  return 0;
-}
-extern "C" int dctts_debug_stream_destroy(void* stream) {
-  if (stream) HIPCHK(hipStreamDestroy((hipStream_t)stream));
-  return 0;
-}
-
 extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   if (kernel_id >= 0) c->prof_rows = 0;

@@ -243,8 +243,8 @@ struct Chain3Params {
   const float* xt; int xt_bs;        // TAP2: the previous time step's input row (tap -1 of a dilation-1 layer) at xt + b * xt_bs
   long long* ts;                     // TS instantiation only (measurement): 8 wall-clock stamps per workgroup
   unsigned* sig; unsigned sig_val;   // first launch of a chain piece: *sig = sig_val ("every earlier piece is complete": the bulk stream waits for it)
-  const unsigned* wait; unsigned wait_val; int* gate_err;   // ... and, when set, wait for *wait >= wait_val before anything is loaded (piece_gate)
-  const unsigned* wait2;             // light form of the same wait (first launch of a chain piece): only the epilogue addend comes from the other
+  unsigned wait_val; int* gate_err;  // value wait2 waits for; error word raised when the bounded wait gives up (dctts_decode_status)
+  const unsigned* wait2;             // first launch of a chain piece: only the epilogue addend comes from the other
                                      // stream, so every other load is issued first, then *wait2 >= wait_val is polled, then the addend is read past
                                      // the (possibly stale) L2 with an sc1 load: no stream operation and no cache invalidate on the chain's stream
 };
@@ -262,9 +262,8 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
   DCTTS_SGPR(p.B); DCTTS_SGPR(p.P); DCTTS_SGPR(p.p_bs); DCTTS_SGPR(p.stats); DCTTS_SGPR(p.res); DCTTS_SGPR(p.res_bs);
   DCTTS_SGPR(p.g1); DCTTS_SGPR(p.b1); DCTTS_SGPR(p.g2); DCTTS_SGPR(p.b2); DCTTS_SGPR(p.relu); DCTTS_SGPR(p.xm); DCTTS_SGPR(p.xm_bs);
   DCTTS_SGPR(p.wp); DCTTS_SGPR(p.add); DCTTS_SGPR(p.add_bs); DCTTS_SGPR(p.pout); DCTTS_SGPR(p.np_out); DCTTS_SGPR(p.stats_out);
-  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.sig); DCTTS_SGPR(p.sig_val); DCTTS_SGPR(p.wait); DCTTS_SGPR(p.wait2);
+  DCTTS_SGPR(p.raw); DCTTS_SGPR(p.raw_bs); DCTTS_SGPR(p.cout); DCTTS_SGPR(p.sig); DCTTS_SGPR(p.sig_val); DCTTS_SGPR(p.wait2);
   if constexpr (TAP2) { DCTTS_SGPR(p.xt); DCTTS_SGPR(p.xt_bs); }
-  if (p.wait) piece_gate(p.sig, p.sig_val, p.wait, p.wait_val, p.gate_err, (blockIdx.x | blockIdx.y) == 0);        // first launch of a chain piece: publish, then wait for the bulk stream's rows of this frame
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int grp = blockIdx.x, m0 = blockIdx.y * 8;
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
@@ -357,7 +356,7 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
 #undef C3_PIN_T2
   // This launch runs, so every earlier launch of the stream has completed and released its stores: say so to the other stream.
   // (A stream write-value packet after the previous piece says the same ~6 us of command-processor time later.)
-  if (p.sig && !p.wait && (blockIdx.x | blockIdx.y) == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (p.sig && (blockIdx.x | blockIdx.y) == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if constexpr (TS) t_landed = wall_clock64();
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
   float4 bq0[2], bq1[2], av[2], h2v[2], rsv[2], g1v[2], b1v[2], g2v[2], b2v[2], st[4];
@@ -453,248 +452,6 @@ __global__ void __launch_bounds__(512) chain3_kernel(const Chain3Params p) {
       if (wave == 0) { o[0] = t_in; o[1] = t_issued; o[2] = t_landed; o[3] = t_mfma; o[4] = t_sync; o[5] = wall_clock64(); }
       o[8 + wave] = t_in; o[16 + wave] = t_landed; o[24 + wave] = t_mfma;
     }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------------- chain: a run of highway layers in ONE launch
-// hcgroup_kernel: L consecutive chain highway layers (AudioEnc HC_4..HC_13, AudioDec HC_2..HC_7) for the newest row, one persistent
-// launch instead of L dependent ones.  Work split and arithmetic are chain3_kernel's (grid = 16 column groups x row tiles of 8
-// utterances, K = 256 over 8 waves, fixed-order LDS reduction, deferred layer-norm through partial statistics); what changes is
-// how a layer's output reaches the next layer:
-//   * the 16 workgroups of a row tile exchange pre-norm rows + partial statistics through device memory inside the launch:
-//     write-through (sc1) stores of self-validating words (a 1-bit stamp in the mantissa LSB), polled with sc1 loads by the
-//     lanes that need them -- placement-independent, no fence, no flag (first version: sc1 payload + drain + flag + poll + sc1
-//     read = 5.3 us per layer, as much as a launch).  Two parity copies of the exchange buffers: a workgroup can only publish
-//     layer g+1 after it consumed every slice of layer g, so nobody can still be reading layer g-1's copy;
-//   * everything that does not depend on the predecessor -- the next layer's weights, its presum, the layer-norm parameters, a
-//     dilation-1 layer's history row -- is requested BEFORE the poll, so only the exchanged rows pay a memory round trip;
-//   * the highway residual (the layer's own input row) never leaves the registers it was rebuilt in.
-// A dependent launch costs ~1.45 us of boundary + kernel-argument fetch + a cold start on every load (stamps: 5.3 us per layer);
-// the in-launch hand-off costs one drained store + flag + poll + one sc1 load round trip.
-// Every spin is bounded: a workgroup that gives up raises *err and still writes its outputs, the host checks err after the decode.
-struct HcGroupLayer {
-  const float* wp;                       // [tile][16 or 32 k-groups][lane][4]
-  const float* presum; int presum_bs;    // bias + older taps of row b at presum + b * presum_bs
-  const float* g1; const float* b1; const float* g2; const float* b2;   // THIS layer's H1 / H2 layer-norm parameters (used by the next layer's rebuild)
-  float* xm; int xm_bs;                  // this layer's INPUT row is kept at xm + b * xm_bs (history / residual for later launches); nullptr = not kept
-  const float* xt; int xt_bs;            // tap2: the input history row one time step back
-  int tap2; int pad_;
-};
-struct HcGroupParams {
-  int B, L;
-  const float* P0; int p0_bs; const float* stats0;     // the pre-group producer's pre-norm rows (256 channels, a C layer without activation) + statistics
-  const float* pg1; const float* pb1;                   // its layer-norm parameters
-  HcGroupLayer lay[10];
-  float* pout; float* stats_out;                        // the LAST layer's pre-norm rows [b][512] and statistics [b][16][4]
-  float* xch; float* sch;                               // exchange buffers: [2][B_pad][512] pre-norm rows, [2][B_pad][16][4] statistics
-  unsigned uses0, uses1;                                // uses of exchange copy 0 / 1 before this launch (frame * publishes per frame of that copy)
-  int xch_set, sch_set;                                 // floats between the two parity copies
-  int* err;
-};
-
-template <int DUMMY = 0>
-__global__ void __launch_bounds__(512) hcgroup_kernel(const HcGroupParams* __restrict__ pp) {
-  __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
-  typedef const __attribute__((address_space(4))) HcGroupParams CP;
-  CP& p = *(CP*)pp;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = blockIdx.x, tile = blockIdx.y, m0 = tile * 8;
-  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
-  const int b = m0 + arow;
-  const bool valid = arow < 8 && b < p.B;
-  const unsigned bb = valid ? (unsigned)b : 0u;
-  const int erow = aq * 4 + (wave & 3), etile = wave >> 2, ecol = lane & 15;
-  const int eb = m0 + erow;
-  const bool wr = erow < 8 && eb < p.B;
-  const int pcol = etile * 256 + grp * 16 + ecol;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-
-  // ---- layer 0: everything by plain loads (the producer is an earlier launch)
-  f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2] = {z4, z4}, vg1[2] = {z4, z4}, vbe1[2] = {z4, z4}, vst[4] = {z4, z4, z4, z4};
-  float addv = 0.f;
-  {
-    const bool t2 = p.lay[0].tap2 != 0;
-    const unsigned nkg = t2 ? 32u : 16u, kc = t2 ? 16u : 0u;
-    const float* wb = p.lay[0].wp + lane * 4;
-    const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
-    if (t2) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { vtb0[e] = z4; vtb1[e] = z4; }
-    }
-    if (valid) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-        va[e] = ldv(p.P0, bb * (unsigned)p.p0_bs + ch);
-        vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
-        if (t2) vta[e] = ldv(p.lay[0].xt, bb * (unsigned)p.lay[0].xt_bs + ch);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
-    }
-    if (wr) addv = p.lay[0].presum[(unsigned)(eb * p.lay[0].presum_bs) + (unsigned)pcol];
-    asm volatile("; hcgroup: layer 0 loads in flight" : "+v"(vb0[0]), "+v"(vb0[1]), "+v"(vb1[0]), "+v"(vb1[1]), "+v"(vtb0[0]), "+v"(vtb0[1]), "+v"(vtb1[0]), "+v"(vtb1[1]),
-                 "+v"(vta[0]), "+v"(vta[1]), "+v"(va[0]), "+v"(va[1]), "+v"(vg1[0]), "+v"(vg1[1]), "+v"(vbe1[0]), "+v"(vbe1[1]),
-                 "+v"(vst[0]), "+v"(vst[1]), "+v"(vst[2]), "+v"(vst[3]), "+v"(addv));
-  }
-  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-  float4 x[2];                            // the current layer's input row fragments (also the next rebuild's highway residual)
-  {
-    float4 st[4] = {f4(vst[0]), f4(vst[1]), f4(vst[2]), f4(vst[3])};
-    float m1, r1;
-    combine_stats(st, 0, m1, r1);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const f32x4 h = va[e], g = vg1[e], be = vbe1[e];
-      x[e] = make_float4((h[0] - m1) * r1 * g[0] + be[0], (h[1] - m1) * r1 * g[1] + be[1], (h[2] - m1) * r1 * g[2] + be[2], (h[3] - m1) * r1 * g[3] + be[3]);
-      if (!valid) x[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-
-  for (int g = 0; g < p.L; ++g) {
-    const bool last = (g + 1 == p.L);
-    const bool t2 = p.lay[g].tap2 != 0;
-    // ---- contraction of layer g
-    f32x4 acc0 = z4, acc1 = z4;
-    if (t2) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const f32x4 a = valid ? vta[e] : z4, b0 = vtb0[e], b1 = vtb1[e];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[i], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[i], acc1, 0, 0, 0); }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float4 a = x[e]; const f32x4 b0 = vb0[e], b1 = vb1[e];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[2], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[3], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
-    // ---- requests that do not depend on the other workgroups: the next layer's weights / presum / history row, this layer's LN parameters
-    f32x4 ng1[2] = {z4, z4}, nb1[2] = {z4, z4}, ng2[2] = {z4, z4}, nb2[2] = {z4, z4};
-    float naddv = 0.f;
-    if (!last) {
-      const bool nt2 = p.lay[g + 1].tap2 != 0;
-      const unsigned nkg = nt2 ? 32u : 16u, kc = nt2 ? 16u : 0u;
-      const float* wb = p.lay[g + 1].wp + lane * 4;
-      const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
-      if (nt2) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
-      }
-      if (valid) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-          ng1[e] = ldv(p.lay[g].g1, ch); nb1[e] = ldv(p.lay[g].b1, ch); ng2[e] = ldv(p.lay[g].g2, ch); nb2[e] = ldv(p.lay[g].b2, ch);
-          if (nt2) vta[e] = ldv(p.lay[g + 1].xt, bb * (unsigned)p.lay[g + 1].xt_bs + ch);
-        }
-      }
-      if (wr) naddv = p.lay[g + 1].presum[(unsigned)(eb * p.lay[g + 1].presum_bs) + (unsigned)pcol];
-    }
-    // this layer's input row is kept for later launches (history / residual): column group 0 stores it
-    if (p.lay[g].xm && grp == 0 && valid) {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(p.lay[g].xm + (long)b * p.lay[g].xm_bs + (8 * e + wave) * 16 + c4) = x[e];
-    }
-    __syncthreads();
-    float v_ = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + etile) * 4 + (wave & 3)) * 64 + lane];
-    v_ += addv;
-    const float mg = row16_sum(v_) * (1.0f / 16.0f);
-    const float dv = v_ - mg;
-    const float m2g = row16_sum(dv * dv);
-    if (last) {
-      if (wr) p.pout[(long)eb * 512 + pcol] = v_;
-      if (wr && ecol == 0) { float* so = p.stats_out + ((long)eb * 16 + grp) * 4 + etile * 2; so[0] = mg; so[1] = m2g; }
-      break;
-    }
-    // ---- publish this workgroup's slice of layer g: write-through stores of SELF-VALIDATING words.  Every exchanged float carries
-    //      a 1-bit sequence stamp in its mantissa LSB (the use count of this parity copy of the exchange buffer, mod 2), so a
-    //      consumer polls the data itself: no drain, no flag, no second round trip, and a torn 16-byte read is harmless (each
-    //      word validates on its own).  One bit is enough: a workgroup can be at most one layer ahead of another (it needs every
-    //      slice of layer g before it can publish g+1), so a word holds either the previous use of this copy (other stamp) or
-    //      the current one.  The host fills the buffers with 0xFF bytes before each decode (stamp 1; the first use expects 0).
-    //      Cost: the exchanged pre-norm values and statistics are perturbed by at most 1 ulp, deterministically.
-    const int par = g & 1;
-    const unsigned stamp = ((par ? p.uses1 : p.uses0) + (unsigned)(g >> 1)) & 1u;   // running use count of this parity copy since the decode started
-    auto stamped = [&](float v) { return __uint_as_float((__float_as_uint(v) & ~1u) | stamp); };
-    if (wr) {
-      __hip_atomic_store(p.xch + (long)par * p.xch_set + (long)eb * 512 + pcol, stamped(v_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ecol == 0) {
-        float* so = p.sch + (long)par * p.sch_set + ((long)eb * 16 + grp) * 4 + etile * 2;
-        __hip_atomic_store(so, stamped(mg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(so + 1, stamped(m2g), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    // ---- poll the exchanged rows (sc1 loads: served past this CU's L1) until every word of this lane carries the stamp; bounded
-    f32x4 h1[2] = {z4, z4}, h2[2] = {z4, z4}, st4[4] = {z4, z4, z4, z4};
-    {
-      const float* xr = p.xch + (long)par * p.xch_set + (long)bb * 512 + wave * 16 + c4;     // channels 16 w + c4; +128 floats = the second k-group
-      const float* sr = p.sch + (long)par * p.sch_set + (long)bb * 64 + aq * 16;
-      unsigned spins = 0;
-      for (;;) {
-        // loads and their wait in ONE asm statement: the compiler does not count asm loads in vmcnt, so nothing may touch the
-        // destination registers before the wait
-        f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
-        asm volatile(
-            "global_load_dwordx4 %0, %8, off sc1\n\t"
-            "global_load_dwordx4 %1, %8, off offset:512 sc1\n\t"
-            "global_load_dwordx4 %2, %8, off offset:1024 sc1\n\t"
-            "global_load_dwordx4 %3, %8, off offset:1536 sc1\n\t"
-            "global_load_dwordx4 %4, %9, off sc1\n\t"
-            "global_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
-            "global_load_dwordx4 %6, %9, off offset:32 sc1\n\t"
-            "global_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-            : "v"(xr), "v"(sr)
-            : "memory");
-        unsigned bad = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          bad |= (__float_as_uint(t0[i]) ^ stamp) | (__float_as_uint(t1[i]) ^ stamp) | (__float_as_uint(t2[i]) ^ stamp) | (__float_as_uint(t3[i]) ^ stamp) |
-                 (__float_as_uint(t4[i]) ^ stamp) | (__float_as_uint(t5[i]) ^ stamp) | (__float_as_uint(t6[i]) ^ stamp) | (__float_as_uint(t7[i]) ^ stamp);
-        const bool ok = !valid || (bad & 1u) == 0u;
-        if (__all(ok)) { h1[0] = t0; h1[1] = t1; h2[0] = t2; h2[1] = t3; st4[0] = t4; st4[1] = t5; st4[2] = t6; st4[3] = t7; break; }
-        if (++spins > 20000u || ((spins & 255u) == 0u && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          if (lane == 0) __hip_atomic_store(p.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          h1[0] = t0; h1[1] = t1; h2[0] = t2; h2[1] = t3; st4[0] = t4; st4[1] = t5; st4[2] = t6; st4[3] = t7;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (!valid) { h1[0] = h1[1] = h2[0] = h2[1] = z4; st4[0] = st4[1] = st4[2] = st4[3] = z4; }
-    }
-    // ---- rebuild the next layer's input: gate(LN(exchanged rows)) mixed with this layer's input (the highway residual, still in registers)
-    {
-      float4 st[4] = {f4(st4[0]), f4(st4[1]), f4(st4[2]), f4(st4[3])};
-      float m1, r1, m2, r2;
-      combine_stats(st, 0, m1, r1); combine_stats(st, 1, m2, r2);
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const f32x4 a1 = h1[e], a2 = h2[e], g1 = ng1[e], b1 = nb1[e], g2 = ng2[e], b2 = nb2[e];
-        const float4 xr = x[e];
-        float4 o;
-        { const float s_ = sigmoid_fast((a1[0] - m1) * r1 * g1[0] + b1[0]); o.x = s_ * ((a2[0] - m2) * r2 * g2[0] + b2[0]) + (1.0f - s_) * xr.x; }
-        { const float s_ = sigmoid_fast((a1[1] - m1) * r1 * g1[1] + b1[1]); o.y = s_ * ((a2[1] - m2) * r2 * g2[1] + b2[1]) + (1.0f - s_) * xr.y; }
-        { const float s_ = sigmoid_fast((a1[2] - m1) * r1 * g1[2] + b1[2]); o.z = s_ * ((a2[2] - m2) * r2 * g2[2] + b2[2]) + (1.0f - s_) * xr.z; }
-        { const float s_ = sigmoid_fast((a1[3] - m1) * r1 * g1[3] + b1[3]); o.w = s_ * ((a2[3] - m2) * r2 * g2[3] + b2[3]) + (1.0f - s_) * xr.w; }
-        x[e] = valid ? o : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    addv = naddv;
   }
 }
 
@@ -888,313 +645,6 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     stampt();
   }
   if constexpr (TS) { if (ts && blockIdx.x == 0 && tid == 0) for (int i = 0; i < 32; ++i) ts[i] = i < nts ? tst[i] : 0; }
-}
-
-// ---------------------------------------------------------------------------------------------------------------- chain: a whole chain piece in ONE launch
-// rowchain_kernel: every newest-row layer of a chain piece -- AudioDec HC_2..HC_7, C_8..C_11 (+ mel frame j), AudioEnc C_1..C_3 and
-// HC_4..HC_13 of frame j+1, its attention row and AudioDec C_1 -- split by ROWS: a workgroup owns R = 2 utterances and every
-// column, utterances never interact, so NOTHING is exchanged between workgroups and the 19 dependent launches of a piece become
-// one.  The launch is a sequence of 44 "passes", each one 256 x 256 weight matrix (a highway layer = its gate half + its info
-// half, + two more for the in-chain tap of a dilation-1 layer; a k=1 layer = one), driven by a pass table in LDS.
-//
-// What bounds it (measured, DESIGN.md "rowchain"): a CU issues at most one instruction per wave every 4 cycles, and pulls ~64 B per
-// clock through its vector memory path: 256 KB of weights per pass = 1.7-2.1 us.  The first version of this kernel (K split over
-// waves, partial sums through LDS, finishes on 2 of 8 waves, run-time row clipping) spent 800 instructions per wave and pass and
-// was ISSUE-bound at 3.4 us per pass.  This one is built to stay under the weight stream:
-//   - weights are re-packed per pass as [wave][i = 0..31][lane][4]: one wave-level load = 1 KB contiguous, its address is a scalar
-//     base + a lane constant + an immediate (no address arithmetic in the loop); rows past Cin / columns past Cout are zero in
-//     the packed copy, so there is no clipping code either;
-//   - wave w owns output columns [32w, 32w + 32) for ALL k; lane = (kg, cg): k in [32 kg, 32 kg + 32), columns 32w + 4cg .. + 3.
-//     The sum over the 8 k-groups is a reduce-scatter inside the wave (v_permlane32_swap, v_permlane16_swap, DPP row_ror:8: 15
-//     instructions for a highway layer), after which every lane owns ONE (row, column) of the layer's output: no partial sums in LDS;
-//   - layer-norm statistics: per wave over its 32 columns (half-wave DPP sums), 16 bytes per (wave, row) through LDS, Chan's
-//     combine in every lane; all 8 waves finish the layer together (~150 instructions each);
-//   - 32 weight loads per wave are always in flight: registers are refilled with the next pass's rows right after the FMAs that read
-//     them, and the waits are counted (s_waitcnt vmcnt(n)), so a pass starts when its first 8 rows have landed.
-// Only 16 workgroups run at B = 32, which leaves the bulk stream's cone GEMMs 240 CUs.
-enum { FIN_NONE = 0, FIN_C = 1, FIN_HC = 2, FIN_C1 = 3 };
-enum { RP_MEL = 1, RP_ATTN = 2 };
-struct RowPass {                        // 24 dwords
-  const float* w;                       // this pass's 256 x 256 weights, packed [wave][i][lane][4]: W[k = 32 (lane >> 3) + i][32 wave + 4 (lane & 7) + e]
-  const float* add;                     // finish addend of this half: bias vector (add_bs == 0) or presum row of utterance b at add + b * add_bs
-  const float* g; const float* be;      // layer-norm parameters of this half
-  float* xm;                            // finish: the new row is also stored at xm + b * xm_bs (history / next piece); nullptr = not kept
-  float* raw;                           // FIN_C1: the bare contraction (Q . W_bot) -> raw + b * raw_bs
-  int cin, pad0, ncols;                 // real input / output channels (the packed copy is zero beyond them; ncols also sizes the layer norm)
-  int src;                              // 0: contract the current rows; 1, 2: the previous time step's row held in xp[src - 1] (dilation-1 tap)
-  int accsel, fresh;                    // accumulator A / B; fresh = start it from zero
-  int fin, relu, flags;
-  int add_bs, xm_bs, raw_bs;
-};
-static_assert(sizeof(RowPass) == 96, "RowPass is copied to LDS as 24 dwords");
-struct RowChainParams {
-  int B, frame, first, npass;           // passes [first, first + npass) of the table run in this launch
-  int init;                             // 0: the rows start as x1[b] (AudioDec C_1's output, kept by the previous piece); 1: zeros (frame 0: S[0] = 0)
-  const RowPass* tab;                   // the piece's pass table (device memory)
-  const float* x1; int x1_bs;           // [b][256]
-  const float* xt[2]; int xt_bs[2];     // previous-time-step input rows of the (at most two) dilation-1 layers, at xt[i] + b * xt_bs[i]
-  const float* K; const float* VW; int k_stride; int vw_stride; long kv_bstride; int N, win; int* pm_all; const float* c1_bias;   // attention (RP_ATTN)
-  float* ypad; long y_bstride; long y_row; int y_stride;      // RP_MEL: sigmoid(logits) -> ypad[b][y_row]; logits -> logits[b][l_row]
-  float* logits; long l_bstride; long l_row; int l_stride;
-  unsigned* sig; unsigned sig_val;     // *sig = sig_val at launch ("every earlier piece is complete"); nullptr = none
-  const unsigned* wait; unsigned wait_val; int* gate_err;   // when set: wait for *wait >= wait_val before anything is loaded (piece_gate)
-};
-
-// index of channel c inside a row kept in LDS: k-groups of 32 channels padded to 36 floats, so that the 8 k-groups of a wave read 8 different banks
-__device__ __forceinline__ int rc_xidx(int c) { return (c >> 5) * 36 + (c & 31); }
-constexpr int RC_XS = 288;              // floats per LDS row (8 x 36)
-
-// a + b with the two operands exchanged across half-waves / 16-lane rows: the lower half (row) ends up with the total of `a`, the upper with the total of `b`
-__device__ __forceinline__ float rc_swap32_add(float a, float b) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float rc_swap16_add(float a, float b) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// sum over the 8 k-groups (lane bits 3..5) of a[r][e], scattered: the lane with k-group kg returns the total of a[kg >> 2][kg & 3]
-__device__ __forceinline__ float rc_reduce_scatter(const f32x4 (&a)[2], bool bit3) {
-  const float t0 = rc_swap32_add(a[0][0], a[1][0]), t1 = rc_swap32_add(a[0][1], a[1][1]);     // lane bit 5 = row
-  const float t2 = rc_swap32_add(a[0][2], a[1][2]), t3 = rc_swap32_add(a[0][3], a[1][3]);
-  const float u0 = rc_swap16_add(t0, t2), u1 = rc_swap16_add(t1, t3);                         // lane bit 4 = e >> 1
-  const float keep = bit3 ? u1 : u0, send = bit3 ? u0 : u1;                                   // lane bit 3 = e & 1
-  return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
-}
-// sum over the 32 lanes of this lane's half-wave (= one utterance's 32 columns), in all of them
-__device__ __forceinline__ float rc_half_sum(float v) {
-  v = row16_sum(v);
-  return rc_swap16_add(v, v);
-}
-
-template <int R, bool TS = false>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) rowchain_kernel(const RowChainParams* __restrict__ pp, long long* __restrict__ ts) {
-  static_assert(R == 2, "the in-wave reduce-scatter maps lane bit 5 to the utterance");
-  // TS (measurement, DCTTS_TRACE): shader-clock time accumulated per section in SGPRs -- no vector registers, so the instrumented kernel is the same kernel
-  unsigned long long t_last = 0, t_acc[7] = {0, 0, 0, 0, 0, 0, 0}, t_real0 = 0;
-  auto tick = [&](int i) { if constexpr (TS) { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); t_acc[i] += t - t_last; t_last = t; } };
-  if constexpr (TS) { asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_real0), "=s"(t_last) :: "memory"); }
-  typedef const __attribute__((address_space(4))) RowChainParams CP;
-  typedef const __attribute__((address_space(1))) float* gptr;
-  typedef const __attribute__((address_space(1))) f32x4* gv4;
-  typedef __attribute__((address_space(1))) float* gwptr;            // stores through generic pointers are FLAT: they make vmcnt out-of-order and every wait a vmcnt(0)
-  typedef __attribute__((address_space(1))) f32x4* gv4w;
-  CP& p = *(CP*)pp;
-  if (p.wait) piece_gate(p.sig, p.sig_val, p.wait, p.wait_val, p.gate_err, blockIdx.x == 0);
-  constexpr int MAXP = 48;
-  __shared__ __attribute__((aligned(16))) float xs[R * RC_XS];                 // the current rows
-  __shared__ __attribute__((aligned(16))) float xp[2 * R * RC_XS];             // previous-time-step rows of the dilation-1 layers
-  __shared__ __attribute__((aligned(16))) float ps[R * 256];                   // AudioDec C_1's presum (from the attention step)
-  __shared__ __attribute__((aligned(16))) float kvs[R * 2 * MAXWIN * 256];     // the attention window's K rows | VW rows
-  __shared__ __attribute__((aligned(16))) float stats[8 * R * 4];              // per (wave, row): mean, M2 of the gate half | of the info half
-  __shared__ int s_tab[MAXP * 24];
-  auto rfl = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-  const int tid = threadIdx.x, lane = tid & 63, wave = rfl(tid >> 6);
-  const int kg = lane >> 3, cg = lane & 7;
-  const int b0 = blockIdx.x * R, c0 = lane * 4;
-  const int er = kg >> 2, ecol = 32 * wave + 4 * cg + (kg & 3);                // the (row, column) this lane owns after a reduce-scatter
-  const bool bit3 = (kg & 1) != 0;
-  const int eb = b0 + er, ebc = eb < p.B ? eb : 0;
-  const bool rowok = eb < p.B;
-  const int exi = er * RC_XS + rc_xidx(ecol);
-  const int first = p.first, npass = p.npass;
-  for (int i = tid; i < npass * 24; i += 512) s_tab[i] = reinterpret_cast<const int*>(p.tab + first)[i];
-  struct PDesc { gptr w, add, g, be; gwptr xm; gwptr raw; int ncols, src, accsel, fresh, fin, relu, flags, add_bs, xm_bs, raw_bs; };
-  auto desc = [&](int i) {                 // pass i of this launch, from LDS (uniform reads -> scalars)
-    const int* q = &s_tab[i * 24];
-    auto u64 = [&](int k) { return ((unsigned long long)(unsigned)rfl(q[2 * k + 1]) << 32) | (unsigned)rfl(q[2 * k]); };
-    PDesc d;
-    d.w = (gptr)u64(0); d.add = (gptr)u64(1); d.g = (gptr)u64(2); d.be = (gptr)u64(3); d.xm = (gwptr)u64(4); d.raw = (gwptr)u64(5);
-    d.ncols = rfl(q[14]); d.src = rfl(q[15]); d.accsel = rfl(q[16]); d.fresh = rfl(q[17]);
-    d.fin = rfl(q[18]); d.relu = rfl(q[19]); d.flags = rfl(q[20]); d.add_bs = rfl(q[21]); d.xm_bs = rfl(q[22]); d.raw_bs = rfl(q[23]);
-    return d;
-  };
-  f32x4 w4[32]; float padd, pg, pbe;        // 32 weight rows of this lane's k-group (x 4 columns): one whole pass in flight
-  const unsigned voff = (unsigned)((wave * 32 * 64 + lane) * 4);               // floats; row i of the lane's k-group is 256 floats further per i
-  auto load_row = [&](gptr w, int i) { return *(gv4)(w + (unsigned)(i * 256) + voff); };
-  auto load_params = [&](const PDesc& d) {
-    const int cc = (ecol < d.ncols) ? ecol : 0;
-    padd = d.add[(size_t)ebc * d.add_bs + cc]; pg = d.g[cc]; pbe = d.be[cc];
-  };
-  // ---- launch prologue: the first rows, the dilation-1 layers' previous rows, and everything the attention step will read
-  //      (the window is known when the piece starts, so its K / VW rows are fetched here, not in the middle of the chain)
-  int pm = 0, nkeys = 0;
-  {
-    {
-      const int r = tid >> 8, col = tid & 255, b = b0 + r;                     // 512 threads = R x 256 elements
-      float x = 0.f;
-      if (p.init == 0 && b < p.B) x = ((gptr)p.x1)[(size_t)b * p.x1_bs + col];
-      xs[r * RC_XS + rc_xidx(col)] = x;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float y = 0.f;
-        if (p.xt[i] && b < p.B) y = ((gptr)p.xt[i])[(size_t)b * p.xt_bs[i] + col];
-        xp[(i * R + r) * RC_XS + rc_xidx(col)] = y;
-      }
-    }
-    if (wave < R) {
-      const int mb = b0 + wave < p.B ? b0 + wave : 0;
-      pm = p.pm_all[(long)(p.frame + 1) * p.B + mb];                           // the attention step of this piece is frame j+1's
-      nkeys = p.N - pm; if (nkeys > p.win) nkeys = p.win;
-#pragma unroll
-      for (int k = 0; k < MAXWIN; ++k) {
-        const long row = (long)mb * p.kv_bstride + pm + (k < nkeys ? k : 0);
-        *reinterpret_cast<f32x4*>(&kvs[((wave * 2 + 0) * MAXWIN + k) * 256 + c0]) = *(gv4)((gptr)p.K + row * p.k_stride + c0);
-        *reinterpret_cast<f32x4*>(&kvs[((wave * 2 + 1) * MAXWIN + k) * 256 + c0]) = *(gv4)((gptr)p.VW + row * p.vw_stride + c0);
-      }
-      pm = rfl(pm); nkeys = rfl(nkeys);
-      *reinterpret_cast<f32x4*>(&ps[wave * 256 + c0]) = *(gv4)((gptr)p.c1_bias + c0);          // the presum starts as AudioDec C_1's bias
-    }
-  }
-  if (p.sig && !p.wait && blockIdx.x == 0 && tid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();                                                    // s_tab, xs, xp
-  tick(0);                                  // [0] launch prologue
-  PDesc cur = desc(0);
-  {
-    load_params(cur);                       // issue ORDER matters: the waits below count loads (s_waitcnt vmcnt(n)); left alone the compiler issues
-    asm volatile("" ::: "memory");          // these in reverse, and the loop's first wait, merged with this path, degrades to vmcnt(0)
-#pragma unroll
-    for (int u = 0; u < 32; ++u) { w4[u] = load_row(cur.w, u); if ((u & 3) == 3) asm volatile("" ::: "memory"); }
-  }
-  f32x4 accA[R], accB[R]; float sadd = 0.f, sg = 0.f, sbe = 0.f;      // sadd / sg / sbe: the gate half's finish parameters, kept until the info half is done
-#pragma unroll
-  for (int r = 0; r < R; ++r) { accA[r] = f32x4{0.f, 0.f, 0.f, 0.f}; accB[r] = accA[r]; }
-  for (int l = 0; l < npass; ++l) {
-    const PDesc nxt = desc(l + 1 < npass ? l + 1 : l);
-    const float* xsrc = (cur.src == 0 ? xs : &xp[(cur.src - 1) * R * RC_XS]) + kg * 36;
-#define DCTTS_W8(o) "+v"(w4[o]), "+v"(w4[o + 1]), "+v"(w4[o + 2]), "+v"(w4[o + 3]), "+v"(w4[o + 4]), "+v"(w4[o + 5]), "+v"(w4[o + 6]), "+v"(w4[o + 7])
-    asm volatile("; rowchain: parameters + rows 0-7 landed" : "+v"(padd), "+v"(pg), "+v"(pbe), DCTTS_W8(0) :: "memory");
-    const float cadd = padd, cg_ = pg, cbe = pbe;
-    load_params(nxt);                       // first in the queue: the next pass's pin waits for them and for 8 rows, not for all 32
-    tick(1);                                // [1] waiting for the pass's first rows (+ the table read)
-    f32x4 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u4 = 0; u4 < 8; ++u4) {
-      if (u4 == 2) asm volatile("; rowchain: rows 8-15 landed" : DCTTS_W8(8) :: "memory");
-      if (u4 == 4) asm volatile("; rowchain: rows 16-23 landed" : DCTTS_W8(16) :: "memory");
-      if (u4 == 6) asm volatile("; rowchain: rows 24-31 landed" : DCTTS_W8(24) :: "memory");
-      f32x4 xv[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) xv[r] = *reinterpret_cast<const f32x4*>(&xsrc[r * RC_XS + 4 * u4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const f32x4 wq = w4[4 * u4 + i];
-#pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] += xv[r][i] * wq;
-      }
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 4; ++i) w4[4 * u4 + i] = load_row(nxt.w, 4 * u4 + i);                 // the next pass's rows into the registers just read
-    }
-#undef DCTTS_W8
-    tick(2);                                // [2] the FMA loop, its later waits, issuing the next pass's loads
-    // fold this pass into its accumulator
-    if (cur.accsel == 0) {
-#pragma unroll
-      for (int r = 0; r < R; ++r) accA[r] = cur.fresh ? acc[r] : accA[r] + acc[r];
-      if (cur.fin == FIN_NONE) { sadd = cadd; sg = cg_; sbe = cbe; }
-    } else {
-#pragma unroll
-      for (int r = 0; r < R; ++r) accB[r] = cur.fresh ? acc[r] : accB[r] + acc[r];
-    }
-    const int fin = cur.fin, relu = cur.relu, flags = cur.flags, ncols = cur.ncols;
-    const gwptr xm = cur.xm; const gwptr rawp = cur.raw; const int xm_bs = cur.xm_bs, raw_bs = cur.raw_bs;
-    cur = nxt;
-    if (fin == FIN_NONE) continue;
-    // ---- finish a layer: every lane ends up with ONE (row, column) of its output
-    const bool valid = ecol < ncols;
-    int nw = ncols - 32 * wave; nw = nw < 0 ? 0 : (nw > 32 ? 32 : nw);         // columns of this wave that exist
-    const float rnw = nw > 0 ? 1.0f / (float)nw : 0.f;
-    float h1 = rc_reduce_scatter(accA, bit3), h2 = 0.f, part = h1;
-    if (fin == FIN_HC) { h1 += sadd; h2 = rc_reduce_scatter(accB, bit3) + cadd; }
-    else if (fin == FIN_C1) h1 += ps[er * 256 + ecol];
-    else h1 += cadd;
-    {
-      const float m1 = rc_half_sum(valid ? h1 : 0.f) * rnw, m2 = rc_half_sum(valid ? h2 : 0.f) * rnw;
-      const float d1 = valid ? h1 - m1 : 0.f, d2 = valid ? h2 - m2 : 0.f;
-      const float q1 = rc_half_sum(d1 * d1), q2 = rc_half_sum(d2 * d2);
-      if ((lane & 31) == 0) *reinterpret_cast<f32x4*>(&stats[(wave * R + er) * 4]) = f32x4{m1, q1, m2, q2};
-    }
-    tick(3);                                // [3] fold, reduce-scatter, wave statistics
-    lds_barrier();
-    tick(4);                                // [4] barrier: all waves done with the pass
-    float mean1 = 0.f, mean2 = 0.f, M1 = 0.f, M2 = 0.f;
-    {
-      f32x4 st[8];
-#pragma unroll
-      for (int w = 0; w < 8; ++w) st[w] = *reinterpret_cast<const f32x4*>(&stats[(w * R + er) * 4]);
-      const float invn = 1.0f / (float)ncols;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) { int n = ncols - 32 * w; n = n < 0 ? 0 : (n > 32 ? 32 : n); mean1 += (float)n * st[w][0]; mean2 += (float)n * st[w][2]; }
-      mean1 *= invn; mean2 *= invn;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) {                                            // Chan et al.: M2 = sum M2_w + n_w (mean_w - mean)^2
-        int n = ncols - 32 * w; n = n < 0 ? 0 : (n > 32 ? 32 : n);
-        const float e1 = st[w][0] - mean1, e2 = st[w][2] - mean2;
-        M1 += st[w][1] + (float)n * e1 * e1; M2 += st[w][3] + (float)n * e2 * e2;
-      }
-      M1 = 1.0f / sqrtf(M1 * invn + 1e-12f); M2 = 1.0f / sqrtf(M2 * invn + 1e-12f);        // -> 1 / sigma
-    }
-    float o = 0.f;
-    if (fin == FIN_HC) {
-      const float n1 = (h1 - mean1) * M1 * sg + sbe, n2 = (h2 - mean2) * M2 * cg_ + cbe;
-      const float s_ = sigmoidf_(n1);
-      o = s_ * n2 + (1.0f - s_) * xs[exi];
-    } else if (valid) {
-      if (fin == FIN_C1 && rawp && rowok) rawp[(size_t)eb * raw_bs + ecol] = part;             // C1Q[b][j+1] = Q . W_bot
-      o = (h1 - mean1) * M1 * cg_ + cbe;
-      if (relu) o = fmaxf(o, 0.f);
-      if (flags & RP_MEL) {                                          // logits of mel frame j (networks.py:202-209); Y[j] = sigmoid (:210)
-        if (rowok) ((gwptr)p.logits)[((long)eb * p.l_bstride + p.l_row) * p.l_stride + ecol] = o;
-        o = sigmoidf_(o);
-        if (rowok) ((gwptr)p.ypad)[((long)eb * p.y_bstride + p.y_row) * p.y_stride + ecol] = o;
-      }
-    }
-    xs[exi] = o;                                                     // columns >= ncols are zero
-    if (xm && rowok && valid) xm[(size_t)eb * xm_bs + ecol] = o;
-    tick(5);                                // [5] combine, normalise, gate, stores
-    lds_barrier();
-    if (flags & RP_ATTN) {
-      if (wave < R) {
-        // attention row of frame j+1 on Q = the row just finished (networks.py:140-151 with the <= 3 allowed keys): the next window
-        // and AudioDec C_1's presum; K / VW rows were fetched at launch.  One wave per utterance, lane = 4 channels.
-        const f32x4 q = *reinterpret_cast<const f32x4*>(&xs[wave * RC_XS + rc_xidx(c0)]);
-        const float scale = 1.0f / 16.0f;                            // rsqrt(d), d = 256
-        float lg[MAXWIN], a[MAXWIN];
-#pragma unroll
-        for (int k = 0; k < MAXWIN; ++k) {
-          const f32x4 kk = *reinterpret_cast<const f32x4*>(&kvs[((wave * 2 + 0) * MAXWIN + k) * 256 + c0]);
-          float s_ = q[0] * kk[0]; s_ = fmaf(q[1], kk[1], s_); s_ = fmaf(q[2], kk[2], s_); s_ = fmaf(q[3], kk[3], s_);
-          const float t = wave_sum(s_) * scale;
-          lg[k] = k < nkeys ? t : -INFINITY;
-        }
-        float mx = lg[0];
-#pragma unroll
-        for (int k = 1; k < MAXWIN; ++k) mx = fmaxf(mx, lg[k]);
-        float se = 0.f;
-#pragma unroll
-        for (int k = 0; k < MAXWIN; ++k) { a[k] = k < nkeys ? expf(lg[k] - mx) : 0.f; se += a[k]; }
-        const float inv = 1.0f / se;
-        int am = 0; float best = a[0] * inv; a[0] = best;
-#pragma unroll
-        for (int k = 1; k < MAXWIN; ++k) { a[k] *= inv; if (a[k] > best) { best = a[k]; am = k; } }     // post-softmax arg-max, first index on ties
-        f32x4 y = *reinterpret_cast<const f32x4*>(&ps[wave * 256 + c0]);
-#pragma unroll
-        for (int k = 0; k < MAXWIN; ++k) y += a[k] * *reinterpret_cast<const f32x4*>(&kvs[((wave * 2 + 1) * MAXWIN + k) * 256 + c0]);   // a[k] = 0 outside the window
-        *reinterpret_cast<f32x4*>(&ps[wave * 256 + c0]) = y;
-        if (lane == 0 && b0 + wave < p.B) p.pm_all[(long)(p.frame + 2) * p.B + b0 + wave] = pm + am;    // max_attentions[:, j+1] (synthesize.py:54)
-      }
-      lds_barrier();
-    }
-    tick(6);                                // [6] barrier: the new rows are visible (+ the attention step)
-  }
-  if constexpr (TS) {
-    unsigned long long t_real1;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_real1) :: "memory");
-    if (blockIdx.x == 0 && threadIdx.x == 0) { ts[0] = t_real1 - t_real0; ts[1] = t_acc[0]; ts[2] = t_acc[1]; ts[3] = t_acc[2]; ts[4] = t_acc[3]; ts[5] = t_acc[4]; ts[6] = t_acc[5]; ts[7] = t_acc[6]; ts[8] = npass; }
-  }
 }
 
 }  // namespace dctts

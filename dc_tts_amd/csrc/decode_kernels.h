@@ -619,41 +619,11 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
 // Several independent layers of the same shape in ONE launch (v3: the presums of AudioEnc's ten causal k = 3 layers for the
 // next frame).  tab[layer] is a frame-independent descriptor in device memory; the frame index is a kernel argument.
 // grid = nlayers * items_per_layer, one item per workgroup.
-// ---- the two decode streams meet INSIDE the first launch of each piece (no stream operation between pieces).
-// A launch that runs knows that every earlier launch of its stream has completed and released its stores, so the first launch of
-// piece n publishes "pieces < n of my stream are complete" (*sig = sig_val) and then waits until the OTHER stream has published what
-// piece n needs (*wait >= wait_val), followed by an agent-scope acquire: HSA's release (kernel end) -> atomic store -> atomic
-// load -> acquire chain, the same one a stream write-value / wait-value pair builds out of two extra launches (~4-6 us each on
-// the critical stream).  The wait is bounded: on a time-out the launch raises *err and carries on (the host reports it,
-// dctts_decode_status), it never hangs the queue.
-struct PieceGate { unsigned* sig; unsigned sig_val; const unsigned* wait; unsigned wait_val; int* err; };
-__device__ __forceinline__ void piece_gate(unsigned* sig, unsigned sig_val, const unsigned* wait, unsigned wait_val, int* err, bool first_wg) {
-  if (threadIdx.x == 0) {
-    if (sig && first_wg) __hip_atomic_store(sig, sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wait) {
-      bool ok = false;
-      for (int i = 0; i < (1 << 20) && !ok; ++i) {                        // ~1 us per poll: gives up after about a second
-        ok = __hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_val;
-        if (!ok) __builtin_amdgcn_s_sleep(8);
-      }
-      if (!ok && err) atomicOr(err, 1);
-    }
-  }
-  if (wait) {
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-
-// the last bulk piece has no successor to publish its completion
-__global__ void set_word_kernel(unsigned* p, unsigned v) { if (threadIdx.x == 0) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 typedef const __attribute__((address_space(4))) SplitParams ConstSplitParams;   // constant address space: uniform field reads are scalar loads
 template <int NG>
-__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step, const PieceGate gate) {
+__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ long s_prow[2][32];
-  if (gate.sig || gate.wait) piece_gate(gate.sig, gate.sig_val, gate.wait, gate.wait_val, gate.err, blockIdx.x == 0);     // first launch of a bulk piece
   const int layer = blockIdx.x / items_per_layer, item = blockIdx.x - layer * items_per_layer;
   ConstSplitParams& p = *((ConstSplitParams*)tab + layer);
   hbulk_body<NG, ConstSplitParams>(p, step, item, items_per_layer, items_per_layer, smem, s_prow);
@@ -681,63 +651,6 @@ __global__ void __launch_bounds__(256) ln_rows_kernel(const LnRowsParams p) {
   *reinterpret_cast<float4*>(p.x + par * p.x_set + ((long)b * p.x_bstride + p.x_row0 + t) * p.x_stride + lane * 4) = x;
 }
 
-// Newest-frame attention (row offset 0): rebuilds Q[j] from AudioEnc's last pre-norm rows, materialises it
-// into the Q history, runs the 3-key windowed softmax, writes R[j] and the arg-max for the next frame.
-// grid ceil(Bg/4), block 256 (wave per utterance).
-struct AttnRow0Params {
-  int Bg, b0, B; const int* step; int step_val;
-  RowNorm nrm;                                              // Q[j] = gate(LN(P_last[b]))  (R == 1: prow = b)
-  float* qhist; long q_bstride; long q_row0; int q_stride;
-  const float* K; const float* V; int kv_stride; long kv_bstride; int N, d, win;
-  int* pm_all;
-  float* rbuf; long r_bstride; long r_row0; long r_set;
-};
-
-__global__ void __launch_bounds__(256) attention_row0_kernel(const AttnRow0Params p) {
-  const int lane = threadIdx.x & 63, bl = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bl >= p.Bg) return;
-  const int b = p.b0 + bl, j = p.step_val + (p.step ? *p.step : 0), c0 = lane * 4;
-  const float4 q = norm_row_hc(p.nrm, (long)b, b, j, lane);
-  *reinterpret_cast<float4*>(p.qhist + ((long)b * p.q_bstride + p.q_row0 + j) * p.q_stride + c0) = q;
-  const int pm = p.pm_all[(long)j * p.B + b];
-  const float scale = 1.0f / sqrtf((float)p.d);
-  float lg[3]; float4 vv[3];
-  int nk = p.N - pm; if (nk > p.win) nk = p.win;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    lg[k] = -INFINITY; vv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k < nk) {
-      const long row = (long)b * p.kv_bstride + pm + k;
-      const float4 kk = ld4(p.K + row * p.kv_stride + c0);
-      vv[k] = ld4(p.V + row * p.kv_stride + c0);
-      float a = q.x * kk.x; a = fmaf(q.y, kk.y, a); a = fmaf(q.z, kk.z, a); a = fmaf(q.w, kk.w, a);
-      lg[k] = wave_sum(a) * scale;
-    }
-  }
-  float mx = lg[0];
-#pragma unroll
-  for (int k = 1; k < 3; ++k) mx = fmaxf(mx, lg[k]);
-  float e[3], se = 0.f;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { e[k] = (k < nk) ? expf(lg[k] - mx) : 0.f; se += e[k]; }
-  const float inv = 1.0f / se;
-  // tf.argmax of the POST-softmax row, first index on ties (networks.py:148-149): two logits an ulp apart can give equal
-  // probabilities, and the reference then keeps the lower index
-  int am = 0; float pbest = e[0] * inv;
-#pragma unroll
-  for (int k = 1; k < 3; ++k) { const float a = e[k] * inv; if (a > pbest) { pbest = a; am = k; } }
-  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float a = e[k] * inv;
-    o.x = fmaf(a, vv[k].x, o.x); o.y = fmaf(a, vv[k].y, o.y); o.z = fmaf(a, vv[k].z, o.z); o.w = fmaf(a, vv[k].w, o.w);
-  }
-  float* rrow = p.rbuf + (long)(j & 1) * p.r_set + ((long)b * p.r_bstride + p.r_row0 + j) * (2 * p.d);
-  *reinterpret_cast<float4*>(rrow + c0) = o;
-  *reinterpret_cast<float4*>(rrow + p.d + c0) = q;
-  if (lane == 0) p.pm_all[(long)(j + 1) * p.B + b] = pm + am;
-}
-
 // Row-per-workgroup chain of k=1 conv layers (a per-row MLP): AudioDec C_8..C_11 + sigmoid (mel frame j), then
 // AudioEnc C_1..C_3 of frame j+1 on the frame just produced -- seven dependent layers in ONE launch.
 // One workgroup = one utterance row.  64 k MACs per layer are trivial, so plain VALU FMAs: wave w owns a K slice,
@@ -752,124 +665,5 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-struct RowMlpLayer { const float* w; const float* bias; const float* g; const float* be; int cin; int cout; int act; int pad_; };
-struct RowMlpParams {
-  int B, b0, frame;
-  int pro; RowNorm nrm;                                        // PRO_LN_HC: input row rebuilt from pre-norm rows (prow = b); PRO_RAW: xsrc row
-  const float* xsrc; long xs_bstride; long xs_row0; int xs_stride; int cin0;
-  int nlayers; RowMlpLayer L[8];
-  int mel_layer;                                               // index of the layer whose LN output is the mel logits (-1: none)
-  float* ypad; long y_bstride; long y_row0; int y_stride;      // sigmoid(logits) -> row y_row0 + frame (y_row0 includes the +1 shift)
-  float* logits; long l_bstride; int l_stride;
-  float* xout; long xo_bstride; long xo_row0; int xo_stride; int xo_frame_add;   // last layer's activation row -> frame + xo_frame_add
-};
-
-__global__ void __launch_bounds__(512) rowmlp_kernel(const RowMlpParams p) {
-  __shared__ __attribute__((aligned(16))) float xs[256];        // current layer input
-  __shared__ __attribute__((aligned(16))) float part[8 * 256];  // per-wave partial sums
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = p.b0 + blockIdx.x;
-  const int c = lane * 4;
-
-  // This wave's K slice of a layer's weights: up to 32 float4 per lane, ALL issued together (the layer is bound by
-  // streaming 256 KB through one CU; fewer loads in flight would make it latency-bound instead).
-  float4 wv[32];
-  auto load_w = [&](int l) {
-    const RowMlpLayer& Ly = p.L[l];
-    const int kw = Ly.cin >> 3;                                  // cin is a multiple of 8 (80, 256)
-    if (c < Ly.cout) {
-      const float* wp = Ly.w + (long)(wave * kw) * Ly.cout + c;
-#pragma unroll
-      for (int u = 0; u < 32; ++u) if (u < kw) wv[u] = ld4(wp + (long)u * Ly.cout);
-    }
-  };
-  // bias / gamma / beta of a layer are needed by wave 0 right after the reduction: fetch them one layer ahead and BEFORE the
-  // weight prefetch (vmcnt retires in order: a late parameter load would wait behind 32 weight loads)
-  float4 pb = make_float4(0.f, 0.f, 0.f, 0.f), pg = pb, pe = pb, nb = pb, ng = pb, ne = pb;
-  auto load_par = [&](int l, float4& b_, float4& g_, float4& e_) {
-    const RowMlpLayer& Ly = p.L[l];
-    if (wave == 0 && c < Ly.cout) { b_ = ld4(Ly.bias + c); g_ = ld4(Ly.g + c); e_ = ld4(Ly.be + c); }
-  };
-  load_par(0, pb, pg, pe);
-  load_w(0);
-  if (wave == 0) {
-    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (p.pro == PRO_LN_HC) x = norm_row_hc(p.nrm, (long)b, b, p.frame, lane, p.frame & 1);
-    else if (c < p.cin0) x = ld4(p.xsrc + ((long)b * p.xs_bstride + p.xs_row0 + p.frame) * p.xs_stride + c);
-    *reinterpret_cast<float4*>(&xs[c]) = x;
-  }
-  __syncthreads();
-  for (int l = 0; l < p.nlayers; ++l) {
-    const RowMlpLayer& Ly = p.L[l];
-    const int kw = Ly.cin >> 3, k0 = wave * kw;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < Ly.cout) {
-#pragma unroll
-      for (int u = 0; u < 32; ++u) if (u < kw) {
-        const float xk = xs[k0 + u];
-        acc.x = fmaf(xk, wv[u].x, acc.x); acc.y = fmaf(xk, wv[u].y, acc.y); acc.z = fmaf(xk, wv[u].z, acc.z); acc.w = fmaf(xk, wv[u].w, acc.w);
-      }
-    }
-    if (l + 1 < p.nlayers) { load_par(l + 1, nb, ng, ne); load_w(l + 1); }   // next layer's parameters + weights fly during the reduction + layer-norm
-    *reinterpret_cast<float4*>(&part[wave * 256 + c]) = acc;
-    lds_barrier();      // LDS-only barrier: the prefetched weight loads stay in flight across it
-    // ---- wave 0: reduce the 8 partials, bias, layer-norm over cout, activation; becomes the next layer's input
-    if (wave == 0) {
-      const bool in = c < Ly.cout;
-      float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) {
-        y = pb;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { const float4 q = *reinterpret_cast<const float4*>(&part[w * 256 + c]); y.x += q.x; y.y += q.y; y.z += q.z; y.w += q.w; }
-      }
-      const float invn = 1.0f / (float)Ly.cout;
-      const float mean = wave_sum(y.x + y.y + y.z + y.w) * invn;
-      float4 d = in ? make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float rs = 1.0f / sqrtf(wave_sum(d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w) * invn + 1e-12f);
-      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) {
-        const float4 g = pg, be = pe;
-        o = make_float4(d.x * rs * g.x + be.x, d.y * rs * g.y + be.y, d.z * rs * g.z + be.z, d.w * rs * g.w + be.w);
-        if (Ly.act == ACT_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        if (l == p.mel_layer) {
-          *reinterpret_cast<float4*>(p.logits + ((long)b * p.l_bstride + p.frame) * p.l_stride + c) = o;
-          o = make_float4(sigmoidf_(o.x), sigmoidf_(o.y), sigmoidf_(o.z), sigmoidf_(o.w));
-          *reinterpret_cast<float4*>(p.ypad + ((long)b * p.y_bstride + p.y_row0 + p.frame) * p.y_stride + c) = o;
-        }
-        if (l + 1 == p.nlayers && p.xout)
-          *reinterpret_cast<float4*>(p.xout + ((long)b * p.xo_bstride + p.xo_row0 + p.frame + p.xo_frame_add) * p.xo_stride + c) = o;
-      }
-      *reinterpret_cast<float4*>(&xs[c]) = o;                   // channels >= cout are zero: the next layer's K padding
-    }
-    pb = nb; pg = ng; pe = ne;
-    lds_barrier();      // LDS-only barrier: the prefetched weight loads stay in flight across it
-  }
-}
-
-// End of the chain: mel frame j = sigmoid(LN(P_last[b])) over n_mels channels -> S[j+1] (ypad row j+1) and the
-// raw logits.  grid ceil(Bg/4), block 256 (wave per utterance).  n_mels <= 128.
-struct FinalizeParams {
-  int Bg, b0; const int* step; int step_val;
-  const float* P; int np; const float* g; const float* be; int n;
-  float* ypad; long y_bstride; long y_row0; int y_stride;       // y_row0 already includes the +1 shift (train.py:51)
-  float* logits; long l_bstride; int l_stride;
-};
-
-__global__ void __launch_bounds__(256) finalize_kernel(const FinalizeParams p) {
-  const int lane = threadIdx.x & 63, bl = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (bl >= p.Bg) return;
-  const int b = p.b0 + bl, j = p.step_val + (p.step ? *p.step : 0);
-  const float* row = p.P + (long)b * p.np;
-  const int c0 = lane, c1 = lane + 64;
-  const float x0 = (c0 < p.n) ? row[c0] : 0.f, x1 = (c1 < p.n) ? row[c1] : 0.f;
-  const float invn = 1.0f / (float)p.n;
-  const float mean = wave_sum(x0 + x1) * invn;
-  const float d0 = (c0 < p.n) ? x0 - mean : 0.f, d1 = (c1 < p.n) ? x1 - mean : 0.f;
-  const float rs = 1.0f / sqrtf(wave_sum(d0 * d0 + d1 * d1) * invn + 1e-12f);
-  float* yrow = p.ypad + ((long)b * p.y_bstride + p.y_row0 + j) * p.y_stride;
-  float* lrow = p.logits + ((long)b * p.l_bstride + j) * p.l_stride;
-  if (c0 < p.n) { const float y = d0 * rs * p.g[c0] + p.be[c0]; lrow[c0] = y; yrow[c0] = sigmoidf_(y); }
-  if (c1 < p.n) { const float y = d1 * rs * p.g[c1] + p.be[c1]; lrow[c1] = y; yrow[c1] = sigmoidf_(y); }
-}
 
 }  // namespace dctts

@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(256) c_fwd_rows_kernel(const CFwdRowsParams p)
 }
 
 // tf.layers.dropout(training=True) (modules.py:139,195,245): y = x * keep / (1 - rate).  The keep bit of element i under `key` is a
-// counter-based hash (splitmix64 of key + i), so the backward pass regenerates the same mask from the same key: dx = dy * keep / (1 - rate).
+// counter-based hash (splitmix64(splitmix64(key) + i)), so the backward pass regenerates the same mask from the same key: dx = dy * keep / (1 - rate).
 // (TensorFlow's own random stream cannot be reproduced; oracle/train_ref.dropout_mask restates this hash.)
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
   z += 0x9E3779B97F4A7C15ull;
@@ -507,7 +507,9 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, unsigned long long key, float rate, float scale) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const float u = (float)(splitmix64(key + (unsigned long long)i) >> 40) * (1.0f / 16777216.0f);     // 24 uniform bits in [0, 1)
+  // the key is hashed BEFORE the element counter is added: layer keys differ in their low bits only (+1 per layer), and splitmix64(key + i)
+  // would make the masks of consecutive layers one random stream shifted by one element (mask[l+1][i] == mask[l][i+1])
+  const float u = (float)(splitmix64(splitmix64(key) + (unsigned long long)i) >> 40) * (1.0f / 16777216.0f);     // 24 uniform bits in [0, 1)
   y[i] = u >= rate ? x[i] * scale : 0.f;
 }
 

@@ -78,17 +78,27 @@ class Engine:
             pass
 
     def set_decode_graph(self, enable):
-        """False/0: eager launches; True/1: side-stream work as per-frame hipGraphs (default); 2: chain pieces as graphs too."""
-        self._ok(self.lib.dctts_set_decode_graph(self._h, int(enable)))
+        """False/0: eager launches; True/1: the side stream's work as one hipGraph per frame (default)."""
+        self._ok(self.lib.dctts_set_decode_graph(self._h, int(bool(enable))))
 
     def set_decode_mode(self, mode: int):
-        """3 (default): round-2 decode (hoisted taps, row-op cone layers); 4: as 3 with one row-split launch per chain piece;
-        1 / 2: round-1 split kernels; 0: fused full-row kernels."""
+        """3 (default): two-stream incremental decode (hoisted taps, row-op cone layers); 0: fused full-row kernels on one stream (cross-check)."""
         self._ok(self.lib.dctts_set_decode_mode(self._h, int(mode)))
 
     def decode_status(self):
         """Raise if a decode on this engine failed on the device (call after synchronising); see dctts_decode_status."""
         self._ok(self.lib.dctts_decode_status(self._h))
+
+    def synchronize(self):
+        """Wait for everything issued on the current stream and raise if a decode's bounded in-kernel wait gave up (its outputs are then invalid).
+        Call this before trusting / downloading the results of text2mel() or synthesize()."""
+        torch.cuda.current_stream(self.device).synchronize()
+        self.decode_status()
+
+    def debug_seed_prev_max(self, prev_max):
+        """Test hook (dctts_hip_debug.h): the next decode starts from these prev_max_attentions instead of zeros."""
+        a = np.ascontiguousarray(np.asarray(prev_max, dtype=np.int32))
+        self._ok(self.lib.dctts_debug_seed_prev_max(self._h, a.ctypes.data_as(ctypes.c_void_p), int(a.shape[0])))
 
     def device_bytes(self) -> int:
         return int(self.lib.dctts_device_bytes(self._h))

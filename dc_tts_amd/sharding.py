@@ -88,6 +88,6 @@ def gpu_synth(engine) -> Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray, np
             h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
             h.copy_(t, non_blocking=True)
             outs.append(h)
-        torch.cuda.synchronize()
+        engine.synchronize()                                           # waits for the copies AND raises if the decode's bounded in-kernel wait gave up
         return tuple(h.numpy() for h in outs)
     return run

@@ -70,6 +70,7 @@ def main(argv=None):
     eng = Engine(W, hp)
     L = load_data("synthesize", args.text, hp)
     Y, Z, _ = eng.synthesize(torch.from_numpy(L).to(eng.device))
+    eng.synchronize()                                                   # results are only trusted once the decode reported no time-out
     os.makedirs(args.out, exist_ok=True)
     if args.save_spectrograms or args.no_wav:
         for i in range(L.shape[0]):

@@ -365,7 +365,9 @@ def write_checkpoint(prefix: str, tensors: Dict[str, np.ndarray], keys_per_block
 
     for i in range(0, len(entries), keys_per_block):
         chunk = entries[i:i + keys_per_block]
-        index.append((chunk[-1][0] + b"\xff", emit(_table_block(chunk))))
+        # index key of a block: >= its last key and < the first key of the next block (table format).  The last key itself is always legal;
+        # last_key + b"\xff" is NOT when the next key extends the last one past a byte below 0xff ("X" + "\xff" > "X/Adam").
+        index.append((chunk[-1][0], emit(_table_block(chunk))))
     footer = emit(_table_block([])) + emit(_table_block(index, restart_interval=1))
     out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", TABLE_MAGIC)
     os.makedirs(os.path.dirname(os.path.abspath(prefix)), exist_ok=True)
@@ -385,6 +387,9 @@ def save_checkpoint(logdir: str, variables: Dict[str, np.ndarray], global_step: 
     for suffix, d in (slots or {}).items():
         for n, v in d.items():
             t[n + "/" + suffix] = np.asarray(v)
+    if slots:                                               # tf.train.AdamOptimizer's two non-slot variables (beta^t after t = global_step updates)
+        t["beta1_power"] = np.asarray(0.9 ** global_step, dtype=np.float32)
+        t["beta2_power"] = np.asarray(0.999 ** global_step, dtype=np.float32)
     write_checkpoint(prefix, t)
     with open(os.path.join(logdir, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "{0}"\nall_model_checkpoint_paths: "{0}"\n'.format(os.path.basename(prefix)))

@@ -456,6 +456,12 @@ def plot_alignment(alignment, gs: str, dir: str) -> str:
     return path
 
 
+def initial_variables(hp, seed: int = 0):
+    """Where a from-scratch run of train.py starts: `synthetic_weights(..., perturb=False)`."""
+    from .weights import synthetic_weights
+    return synthetic_weights(hp, seed=seed, perturb=False)
+
+
 def main(argv=None, hp=None, save_every: int = 1000, batches=None, init_seed: int = 0) -> int:
     """`python -m dc_tts_amd.train <num>` = train.py:137-162.  num: 1 trains Text2Mel, 2 trains SSRN, each into `<hp.logdir>-<num>`.
     Variables start from the reference's initialisers (dc_tts_amd.weights.synthetic_weights) or, when the log directory holds a
@@ -478,7 +484,9 @@ def main(argv=None, hp=None, save_every: int = 1000, batches=None, init_seed: in
     if args.logdir: hp = hp.replace(logdir=args.logdir)
     if args.num_iterations is not None: hp = hp.replace(num_iterations=args.num_iterations)
     num = args.num
-    g = TrainGraph(num, synthetic_weights(hp, seed=init_seed), hp)
+    # the reference's initialisers (modules.py / tf.layers defaults): variance-scaling truncated-normal kernels, truncated normal 0.1 for the
+    # embedding, layer-norm gamma = 1, beta = 0, conv bias = 0 -- perturb=False; the perturbed variant is for parity tests only
+    g = TrainGraph(num, initial_variables(hp, init_seed), hp)
     logdir = hp.logdir + "-" + str(num)
     resumed = g.restore(logdir)
     print("Training Graph loaded" + (" (resumed at global_step %d)" % g.global_step if resumed else ""), file=sys.stderr)

@@ -86,30 +86,30 @@ int dctts_text2mel_decode(dctts_ctx* ctx, const int32_t* L, int B, int N, int T,
 int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y, float* Z,
                      int64_t* max_attentions, void* stream);
 
-/* Status of the decodes issued so far on this context; call after synchronising their stream.  0, or DCTTS_ERR_STATE if the
- * opt-in persistent highway-group kernel (DCTTS_GROUP=1) gave up waiting for another workgroup's hand-off (every spin is bounded). */
+/* Status of the decodes issued so far on this context; call after synchronising their stream.  0, or DCTTS_ERR_STATE when the
+ * first launch of a chain piece gave up waiting for the side stream's counter (the wait is bounded at about a second: a stalled side
+ * stream must not hang the queue): the outputs of that decode are invalid.  Reports once and clears; a failure that nobody asked
+ * about makes the NEXT decode call on the context fail instead of running.  dc_tts_amd.Engine.synchronize() calls this. */
 int dctts_decode_status(dctts_ctx* ctx);
 
 /* Decode launch mode: 0 = every launch eager; 1 (default) = the side-stream (bulk) work of each frame is one hipGraph launch,
- * the latency-critical chain launches stay eager; 2 = chain pieces are per-frame hipGraphs too (measured slower: a graph launch per
- * piece costs more start-up latency than 25 eager launches cost host time). */
+ * the latency-critical chain launches stay eager (a graph launch per chain piece was measured: ~10 us more per frame). */
 int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
-/* Decode algorithm form (results agree to fp32 re-association; all are the exact-parity incremental decode):
- * 3 = (default) round-2 form: column-split chain kernels that contract only each layer's centre tap (older taps arrive as presums
- *     computed on the bulk stream), AudioDec C_1 / HC_2 cone rows as row operations on cached V.W / Q.W products (csrc/decode3_kernels.h),
- * 4 = as 3, with each chain piece (the newest row of 27 layers + the attention row) as ONE row-split launch: 2 utterances per
- *     workgroup stream every layer's weights through one CU (rowchain_kernel).  Bound by what a CU can pull (~100 GB/s): 140 us
- *     per piece against ~125 us for 19 column-split launches, so it is not the default; kept as a measured alternative,
- * 1 = round-1 form: column-split kernels with deferred layer-norm; the newest-frame chain and the bulk cone on two streams,
- * 2 = as 1, with the k=1 layers around the mel frame as one row-per-workgroup launch (measured slower),
- * 0 = fused full-row kernels on one stream (one workgroup per 32-row block; the simplest form, kept as a cross-check). */
+/* Decode algorithm form (results agree to fp32 re-association; both are the exact-parity incremental decode):
+ * 3 = (default) column-split chain kernels that contract only each layer's centre tap on the caller's stream (older taps arrive as
+ *     presums computed on a side stream), AudioDec C_1 / HC_2 cone rows as row operations on cached V.W / Q.W products
+ *     (csrc/decode3_kernels.h),
+ * 0 = fused full-row kernels on one stream with a device-side frame counter (one workgroup per 32-row block): the simplest form, a
+ *     different implementation of the same arithmetic, kept as a cross-check.
+ * The forms measured and dropped in rounds 1-2 (two-stream split kernels, one row-split launch per chain piece, persistent highway
+ * groups, in-kernel gates) are in the git history up to commit 19f2cbe. */
 int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
 
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
 size_t dctts_device_bytes(const dctts_ctx* ctx);
 
-/* Test / measurement hooks (per-layer test entry, CU-masked streams, calibration copy, kernel timing) are declared in
+/* Test / measurement hooks (per-layer test entry, calibration copy, kernel timing) are declared in
  * dctts_hip_debug.h: they are not part of the drop-in surface. */
 
 /* ------------------------------------------------------------------------------------------------

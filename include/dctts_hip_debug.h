@@ -1,6 +1,6 @@
 /* dctts_hip_debug.h -- test and measurement hooks of libdctts_hip.so.  NOT part of the drop-in surface (include/dctts_hip.h):
  * nothing a consumer of the synthesis path needs lives here.  Used by tests/ (per-layer parity), bench.py (kernel timing for the
- * roofline objects) and tools/ (PMC calibration, CU-masked streams).
+ * roofline objects) and tools/ (PMC calibration).
  * Environment variables the library reads ONCE, in dctts_create (measurement / A-B only; see tools/README.md): DCTTS_*.
  * DCTTS_TRACE=<frame> + DCTTS_TRACE_FILE=<path> make a decode write in-kernel wall-clock stamps of that frame's chain launches. */
 #ifndef DCTTS_HIP_DEBUG_H
@@ -17,10 +17,11 @@ extern "C" {
  * each D layer occupying two consecutive indices.  Synchronises (allocates a scratch copy of X). */
 int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X, int B, int T, float* out, void* stream);
 
-/* Measurement aid: create / destroy a stream restricted to CUs [cu_first, cu_first + cu_count) (hipExtStreamCreateWithCUMask);
- * any entry point above accepts it as `stream`. */
-int dctts_debug_stream_create(int cu_first, int cu_count, void** stream);
-int dctts_debug_stream_destroy(void* stream);
+/* Test hook: the NEXT decode on this context (dctts_text2mel_decode / dctts_synthesize) starts from these prev_max_attentions
+ * (host array, B values in [0, max_N)) instead of the reference's zeros (synthesize.py:46), then the seed is dropped.  Random weights
+ * never walk the attention to the end of a 180-character text, so this is how tests put the window on keys max_N-3 .. max_N-1 at the
+ * production geometry (networks.py:142-147: the window clipped to 2, then 1 keys; the cached V.W / V.W.W tables read at their last rows). */
+int dctts_debug_seed_prev_max(dctts_ctx* ctx, const int32_t* prev_max, int B);
 
 /* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
 int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
@@ -31,7 +32,7 @@ int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream)
  *   epi*10000 + NT*100 + NW   every launch of hconv_kernel<epi, NT, NW> (epi 0 = C, 1 = HC), e.g. 10808 = SSRN HC_11 / HC_12;
  *   DCTTS_PROF_CHAIN_HC       the decode's time-dominant kernel, chain3_kernel<LN_HC, HC> (newest-row highway layers), on every
  *                             16th frame only (events around every 5 us launch would change what they measure); eager chain only;
- *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (cone GEMMs of the decode's bulk stream); eager decode only (graph mode 0). */
+ *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (cone GEMMs of the decode's side stream); eager decode only (graph mode 0). */
 #define DCTTS_PROF_CHAIN_HC 30000
 #define DCTTS_PROF_BULK_GEMM 30001
 int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);

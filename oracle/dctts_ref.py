@@ -223,13 +223,15 @@ def text2mel_graph(L, mels, prev_max_attentions, W, hp, dtype=np.float32, KV=Non
     return dict(K=K, V=V, Q=Q, R=R, alignments=alignments, max_attentions=max_att, Y_logits=logits, Y=Y)
 
 
-def synthesize(L, W, hp, dtype=np.float32, recompute_textenc=False, run_ssrn=True, trace=None):
+def synthesize(L, W, hp, dtype=np.float32, recompute_textenc=False, run_ssrn=True, trace=None, prev0=None):
     """synthesize.py:45-57: 210 x full Text2Mel graph, keep row j, feed prev_max; then one SSRN pass.
+    ``prev0`` (tests only) replaces the zeros the reference starts prev_max_attentions from (:46), so that the end-of-text
+    window regimes can be reached at max_N = 180 with random weights.
 
     Returns (Y (B,max_T,n_mels), Z (B,4*max_T,1025) or None, max_att_trajectory (B,max_T) int64)."""
     B = L.shape[0]
     Y = np.zeros((B, hp.max_T, hp.n_mels), dtype)                                   # :45
-    prev = np.zeros((B,), np.int32)                                                 # :46
+    prev = np.zeros((B,), np.int32) if prev0 is None else np.asarray(prev0, np.int32).copy()   # :46
     traj = np.zeros((B, hp.max_T), np.int64)
     KV = None
     for j in range(hp.max_T):                                                       # :47

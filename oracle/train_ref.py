@@ -160,12 +160,17 @@ def embed_bwd(ids, dy, vocab):
 
 def dropout_mask(key, n, rate):
     """Keep mask of tf.layers.dropout as THIS implementation draws it (csrc/train_kernels.h: dropout_kernel): element i is kept iff the
-    top 24 bits of splitmix64(key + i), as a fraction, are >= rate.  (TensorFlow's random stream cannot be reproduced.)"""
-    with np.errstate(over="ignore"):
-        z = (np.uint64(key) + np.arange(n, dtype=np.uint64)) + np.uint64(0x9E3779B97F4A7C15)
+    top 24 bits of splitmix64(splitmix64(key) + i), as a fraction, are >= rate (the key is hashed first: layer keys differ only in their low
+    bits, and splitmix64(key + i) would make consecutive layers' masks shifted copies of one stream).  (TensorFlow's random stream cannot be
+    reproduced.)"""
+    def mix(z):
+        z = z + np.uint64(0x9E3779B97F4A7C15)
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
-        z = z ^ (z >> np.uint64(31))
+        return z ^ (z >> np.uint64(31))
+    with np.errstate(over="ignore"):
+        k = mix(np.array([int(key) & 0xFFFFFFFFFFFFFFFF], dtype=np.uint64))[0]
+        z = mix(k + np.arange(n, dtype=np.uint64))
     u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / 16777216.0)
     return u >= np.float32(rate)
 
@@ -180,6 +185,50 @@ def layer_key(seed, step, prefix, index):
     """The dropout key of layer `index` of network `prefix` at training step `step` (dc_tts_amd/train.py uses the same rule)."""
     h = sum((i + 1) * ord(ch) for i, ch in enumerate(prefix)) % 65521
     return (int(seed) * 1000003 + int(step)) * 4294967296 + h * 65536 + int(index)
+
+
+# ----------------------------------------------------------------------------- networks.py, the four stacks layer by layer
+# Spelled out here, line by line from networks.py, NOT imported from dc_tts_amd.layers: the oracle and the product must not share the
+# structure one is supposed to check in the other.  (scope, kind, taps, dilation, activation); LJ hyper-parameters (hyperparams.py:7-47)
+# only enter through the variable shapes.  The scope index is the reference's running counter `i`.
+class _L:
+    def __init__(self, scope, kind, size=1, rate=1, act="none"):
+        self.scope, self.kind, self.size, self.rate, self.act = scope, kind, size, rate, act
+
+
+TEXTENC_LAYERS = [                                  # networks.py:14-71
+    _L("embed_1", "E"),                             # :24-27
+    _L("C_2", "C", act="relu"),                     # :28-35
+    _L("C_3", "C"),                                 # :36-42
+    _L("HC_4", "HC", 3, 1), _L("HC_5", "HC", 3, 3), _L("HC_6", "HC", 3, 9), _L("HC_7", "HC", 3, 27),       # :44-52, first round of j = 0..3 (rate 3^j)
+    _L("HC_8", "HC", 3, 1), _L("HC_9", "HC", 3, 3), _L("HC_10", "HC", 3, 9), _L("HC_11", "HC", 3, 27),     # second round
+    _L("HC_12", "HC", 3, 1), _L("HC_13", "HC", 3, 1),                                                      # :53-59
+    _L("HC_14", "HC", 1, 1), _L("HC_15", "HC", 1, 1),                                                      # :61-67
+]
+AUDIOENC_LAYERS = [                                 # networks.py:73-124, padding CAUSAL
+    _L("C_1", "C", act="relu"), _L("C_2", "C", act="relu"), _L("C_3", "C"),                               # :82-105
+    _L("HC_4", "HC", 3, 1), _L("HC_5", "HC", 3, 3), _L("HC_6", "HC", 3, 9), _L("HC_7", "HC", 3, 27),       # :106-114
+    _L("HC_8", "HC", 3, 1), _L("HC_9", "HC", 3, 3), _L("HC_10", "HC", 3, 9), _L("HC_11", "HC", 3, 27),
+    _L("HC_12", "HC", 3, 3), _L("HC_13", "HC", 3, 3),                                                      # :115-122 (rate 3)
+]
+AUDIODEC_LAYERS = [                                 # networks.py:157-212, padding CAUSAL
+    _L("C_1", "C"),                                                                                        # :167-174
+    _L("HC_2", "HC", 3, 1), _L("HC_3", "HC", 3, 3), _L("HC_4", "HC", 3, 9), _L("HC_5", "HC", 3, 27),       # :175-182
+    _L("HC_6", "HC", 3, 1), _L("HC_7", "HC", 3, 1),                                                        # :184-191
+    _L("C_8", "C", act="relu"), _L("C_9", "C", act="relu"), _L("C_10", "C", act="relu"),                 # :192-200
+    _L("C_11", "C"),                                                                                       # :202-209 (sigmoid applied outside, :210)
+]
+SSRN_LAYERS = [                                     # networks.py:214-292, padding SAME
+    _L("C_1", "C"),                                                                                        # :226-232
+    _L("HC_2", "HC", 3, 1), _L("HC_3", "HC", 3, 3),                                                        # :233-239
+    _L("D_4", "D", 3), _L("HC_5", "HC", 3, 1), _L("HC_6", "HC", 3, 3),                                     # :240-252, first round
+    _L("D_7", "D", 3), _L("HC_8", "HC", 3, 1), _L("HC_9", "HC", 3, 3),                                     # second round
+    _L("C_10", "C"),                                                                                       # :254-260
+    _L("HC_11", "HC", 3, 1), _L("HC_12", "HC", 3, 1),                                                      # :261-267
+    _L("C_13", "C"),                                                                                       # :269-275
+    _L("C_14", "C", act="relu"), _L("C_15", "C", act="relu"),                                              # :277-284
+    _L("C_16", "C"),                                                                                       # :285-290 (sigmoid applied outside, :291)
+]
 
 
 # ----------------------------------------------------------------------------- networks.py, one network forward / backward
@@ -198,7 +247,7 @@ _NAMES = {"HC": {"kernel": "/conv1d/kernel", "bias": "/conv1d/bias", "g1": "/H1/
 
 
 def network_forward(layers, W, prefix, x, padding, drop=None):
-    """One network of networks.py as its layer list (dc_tts_amd.layers.*_layers): returns (output, inputs of every layer).
+    """One network of networks.py as its layer list (TEXTENC_LAYERS ... SSRN_LAYERS above): returns (output, inputs of every layer).
     x: the first layer's input (character ids when that layer is the embedding).  drop = (rate, seed, step): training=True, i.e.
     dropout behind every block but the embedding (modules.py:139,195,245)."""
     xs = []
@@ -303,14 +352,13 @@ def train_step(num, W, m, v, global_step, batch, hp, dropout_seed=None):
     trained, clip + Adam with the Noam learning rate.  W / m / v: {TF variable name: float64 array}, updated in place.
     batch: num == 1: (L ids (B, N), mels (B, T, n_mels));  num == 2: (mels (B, T, n_mels), mags (B, 4T, n_linear)).
     Returns the losses (loss_mels, loss_bd1, loss_att) or (loss_mags, loss_bd2)."""
-    from dc_tts_amd.layers import audiodec_layers, audioenc_layers, ssrn_layers, textenc_layers
     grads = {}
     drop = None if dropout_seed is None else (hp.dropout_rate, dropout_seed, global_step)      # training=True (train.py:55-72)
     if num == 1:
         L, mels = batch
         d = hp.d
         S = np.concatenate((np.zeros_like(mels[:, :1]), mels[:, :-1]), 1)                    # train.py:51
-        te, ae, ad = textenc_layers(hp), audioenc_layers(hp), audiodec_layers(hp)
+        te, ae, ad = TEXTENC_LAYERS, AUDIOENC_LAYERS, AUDIODEC_LAYERS
         KV, xs_te = network_forward(te, W, "Text2Mel/TextEnc", L, "same", drop)
         K, V = KV[..., :d], KV[..., d:]
         Q, xs_ae = network_forward(ae, W, "Text2Mel/AudioEnc", S, "causal", drop)
@@ -324,7 +372,7 @@ def train_step(num, W, m, v, global_step, batch, hp, dropout_seed=None):
         _, g = network_backward(te, W, "Text2Mel/TextEnc", xs_te, np.concatenate((dK, dV), -1), "same", drop); grads.update(g)
     else:
         mels, mags = batch
-        layers = ssrn_layers(hp)
+        layers = SSRN_LAYERS
         logits, xs = network_forward(layers, W, "SSRN", mels, "same", drop)
         Z = O.sigmoid(logits)
         losses, (dZ, dlog) = ssrn_losses(Z, logits, mags)

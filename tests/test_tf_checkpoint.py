@@ -184,3 +184,44 @@ def test_crc32c_vector_path_equals_byte_loop():
         assert C.crc32c(a[k:], C.crc32c(a[:k])) == ref                    # continuation across the two paths
     z = bytes(200000)
     assert C.crc32c(z) == C._crc_scalar(z, 0xFFFFFFFF) ^ 0xFFFFFFFF
+
+
+def test_index_keys_bound_their_blocks_for_a_seeking_reader(tmp_path):
+    """Table format: the index key of a data block is >= the block's last key and < the next block's first key, so that a reader that SEEKS
+    (TensorFlow's BundleReader) lands in the right block.  With Adam slots the keys 'X' < 'X/Adam' < 'X/Adam_1' straddle block boundaries,
+    where 'last key + 0xff' would overshoot ('X\\xff' > 'X/Adam'); the writer must stay legal there, and store beta1_power / beta2_power."""
+    import struct
+    from dc_tts_amd import tf_checkpoint as C
+    rng = np.random.default_rng(0)
+    names = [f"SSRN/C_{i}/conv1d/kernel" for i in range(1, 30)]
+    var = {n: rng.standard_normal((3, 2)).astype(np.float32) for n in names}
+    slots = {"Adam": {n: np.zeros((3, 2), np.float32) for n in names}, "Adam_1": {n: np.ones((3, 2), np.float32) for n in names}}
+    prefix = C.save_checkpoint(str(tmp_path), var, 2000, slots)
+    data = open(prefix + ".index", "rb").read()
+    footer = data[-48:]
+    pos = 0
+    _, pos = C._varint(footer, pos); _, pos = C._varint(footer, pos)
+    io, pos = C._varint(footer, pos); isz, pos = C._varint(footer, pos)
+    blocks = []
+    for ikey, handle in C._block_entries(C._read_block(data, io, isz, True)):
+        bo, p2 = C._varint(handle, 0); bs, _ = C._varint(handle, p2)
+        keys = [k for k, _ in C._block_entries(C._read_block(data, bo, bs, True))]
+        blocks.append((ikey, keys))
+    # tiny blocks so that every kind of boundary occurs
+    C.write_checkpoint(str(tmp_path / "small"), {**var, **{n + "/Adam": v for n, v in slots["Adam"].items()}, **{n + "/Adam_1": v for n, v in slots["Adam_1"].items()}}, keys_per_block=2)
+    data2 = open(str(tmp_path / "small") + ".index", "rb").read()
+    f2 = data2[-48:]; pos = 0
+    _, pos = C._varint(f2, pos); _, pos = C._varint(f2, pos)
+    io, pos = C._varint(f2, pos); isz, pos = C._varint(f2, pos)
+    for ikey, handle in C._block_entries(C._read_block(data2, io, isz, True)):
+        bo, p2 = C._varint(handle, 0); bs, _ = C._varint(handle, p2)
+        blocks.append((ikey, [k for k, _ in C._block_entries(C._read_block(data2, bo, bs, True))]))
+    assert len(blocks) > 40
+    prev_file_last = None
+    for i, (ikey, keys) in enumerate(blocks):
+        assert keys == sorted(keys) and ikey >= keys[-1]
+        if i + 1 < len(blocks) and blocks[i + 1][1][0] > keys[-1]:          # same file: the next block's first key
+            assert ikey < blocks[i + 1][1][0], (ikey, blocks[i + 1][1][0])
+    t = C.read_checkpoint(prefix)
+    assert abs(float(t["beta1_power"]) - 0.9 ** 2000) < 1e-12 and abs(float(t["beta2_power"]) - 0.999 ** 2000) < 1e-6
+    assert int(t["gs/global_step"]) == 2000

@@ -104,3 +104,24 @@ def test_loop_reads_the_batch_queue(fake, tmp_path):
     assert g.global_step == 3 and all(b[0][0] == 4 and b[0][1] % 4 == 0 and b[1][2] == hp.n_mels for b in g.batches)
     assert TRN.main(["2", "--data", root, "--prepro-dir", pre, "--logdir", h.logdir, "--num-iterations", "0"], hp=hp.replace(B=4), save_every=50) == 0
     assert fake.made[-1].batches[0][1][2] == hp.n_linear and fake.made[-1].batches[0][1][1] == 4 * fake.made[-1].batches[0][0][1]
+
+
+def test_from_scratch_run_starts_from_the_reference_initialisers():
+    """train.py starts from tf.layers / tf.contrib defaults: layer-norm gamma = 1 and beta = 0 (modules.py:60-63), conv bias = 0, truncated-normal
+    variance-scaling kernels, truncated normal 0.1 embedding (modules.py:31-35).  `train.main` must not start from the perturbed test weights."""
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.train import initial_variables
+    W = initial_variables(hp, 3)
+    n = {"gamma": 0, "beta": 0, "bias": 0, "kernel": 0, "lookup_table": 0}
+    for name, a in W.items():
+        leaf = name.rsplit("/", 1)[-1]
+        n[leaf] += 1
+        if leaf == "gamma": assert (a == 1).all(), name
+        elif leaf in ("beta", "bias"): assert (a == 0).all(), name
+        elif leaf == "kernel":
+            fan_in = a.shape[1] * a.shape[2] if "conv2d_transpose" in name else a.shape[0] * a.shape[1]
+            sd = np.sqrt(1.3 * 2.0 / fan_in)
+            assert np.abs(a).max() <= 2.0 * sd / 0.87962566 * 1.0001 and 0.8 * sd < a.std() < 1.2 * sd, name    # truncated at two standard deviations of the untruncated normal
+        else:
+            assert np.abs(a).max() <= 0.2 * 1.0001 / 0.87962566 and a.std() > 0.05, name
+    assert all(v > 0 for v in n.values())

@@ -200,3 +200,25 @@ def test_backward_oracle_against_torch_autograd():
     np.testing.assert_allclose(dQ, tq.grad.numpy(), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(dK, tk.grad.numpy(), rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(dV, tv.grad.numpy(), rtol=1e-9, atol=1e-11)
+
+
+def test_dropout_masks_of_neighbouring_layers_are_independent():
+    """tf.layers.dropout draws an independent mask per layer.  The keys of consecutive layers differ by 1 (layer_key), so a counter hash of
+    key + i would make layer l+1's mask layer l's shifted by one element; with the key hashed first no small shift lines them up."""
+    from oracle import train_ref as TR
+    n, rate = 1 << 16, 0.05
+    for prefix in ("Text2Mel/AudioEnc", "SSRN"):
+        masks = [TR.dropout_mask(TR.layer_key(7, 123, prefix, li), n, rate) for li in range(3)]
+        for m in masks:
+            assert abs((~m).mean() - rate) < 0.01
+        for a, b in ((0, 1), (1, 2), (0, 2)):
+            for shift in range(-3, 4):
+                x = masks[a][max(0, shift): n + min(0, shift)]
+                y = masks[b][max(0, -shift): n - max(0, shift)]
+                agree = float((x == y).mean())
+                # independent Bernoulli(0.95) masks agree on 0.95^2 + 0.05^2 = 0.905 of the elements
+                assert abs(agree - 0.905) < 0.01, (prefix, a, b, shift, agree)
+    # and the masks of the same layer at consecutive steps / seeds differ as well
+    m0 = TR.dropout_mask(TR.layer_key(7, 123, "SSRN", 0), n, rate)
+    m1 = TR.dropout_mask(TR.layer_key(7, 124, "SSRN", 0), n, rate)
+    assert abs(float((m0 == m1).mean()) - 0.905) < 0.01
