@@ -33,8 +33,10 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PROF_SSRN_HC = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
-PROF_CHAIN_HC = 30000             # include/dctts_hip_debug.h: chain3_kernel<LN_HC, HC>, sampled every 16th frame
-PROF_BULK_GEMM = 30001            # hbulk_kernel<12> (eager decode only)
+PROF_SSRN_HC_TAIL = 50000 + 1 * 10000 + 16 * 100 + 8     # hconv16_kernel<EPI_HC, NT=16, NW=8>: the 16-row tail launch of the same layers
+PROF_SSRN_C1025 = 0 * 10000 + 3 * 100 + 11               # hconv_kernel<EPI_C, NT=3, NW=11>: SSRN C_13 .. C_16 (1025 columns)
+PROF_XGROUP = 30002               # include/dctts_hip_debug.h: xgroup_kernel, sampled every 16th frame (prof_rows counts layers)
+PROF_XCONE = 30003                # xcone_kernel (eager decode only)
 
 
 def both_roofs(flop, nbytes, ms):
@@ -46,14 +48,31 @@ def both_roofs(flop, nbytes, ms):
 
 
 def cpu_baseline(hp, W):
-    """The oracle (a port: numpy restatement of the reference, TF being uninstallable here) timed on the host cores, on a
-    bounded sample: a few steps of the reference's full-recompute loop (synthesize.py:47-54, TextEnc recomputed every step as the
-    reference does) for a small batch, plus one SSRN pass, prorated per mel frame.  BASELINE.md section 3 also asks for the
-    oracle's INCREMENTAL variant (oracle/incremental_ref.py: the algorithm the HIP path runs, in numpy), so that the algorithmic
-    and the hardware speed-up can be told apart."""
+    """The reference's algorithm restated for the CPU (TensorFlow is not installable here), timed on the GPU box's host cores on a bounded
+    sample, as BASELINE.md section 3 prescribes: torch-CPU fp32 with torch.set_num_threads(all cores) -- oracle/torch_ref.py, a few steps of the
+    full-recompute loop (synthesize.py:47-54, TextEnc recomputed every step as the reference does) plus one SSRN pass, prorated per mel frame.
+    Beside it: the numpy oracle on the same sample (what rounds 1-2 reported), and the oracle's INCREMENTAL variant (oracle/incremental_ref.py:
+    the algorithm the HIP path runs), so that the algorithmic and the hardware speed-up can be told apart."""
+    import torch as _torch
     from dc_tts_amd.weights import synthetic_text
     from oracle import dctts_ref as O
+    from oracle import torch_ref as TR
     from oracle.incremental_ref import incremental_decode_v3
+    ncpu = os.cpu_count() or 1
+    _torch.set_num_threads(ncpu)
+    Bt, steps_t = 8, 3
+    Lt = synthetic_text(hp, B=Bt, seed=99)
+    TR.synthesize(Lt, W, hp, steps=1, run_ssrn=False)         # warm the thread pool
+    t0 = time.perf_counter()
+    Yt, _, _ = TR.synthesize(Lt, W, hp, steps=steps_t, run_ssrn=False)
+    t_step_t = (time.perf_counter() - t0) / steps_t           # seconds per loop step for Bt utterances
+    Pt = TR.params(W)
+    t0 = time.perf_counter()
+    with _torch.no_grad():
+        TR.SSRN(_torch.from_numpy(Yt), Pt, hp)
+    t_ssrn_t = (time.perf_counter() - t0) / Bt                # seconds per utterance
+    per_frame_t = t_step_t / Bt + t_ssrn_t / hp.max_T         # one loop step yields one mel frame per utterance
+    # ---- the numpy oracle on the same kind of sample
     Bs, steps = 2, 3
     L = synthetic_text(hp, B=Bs, seed=99)
     Y = np.zeros((Bs, hp.max_T, hp.n_mels), np.float32)
@@ -64,11 +83,11 @@ def cpu_baseline(hp, W):
         g = O.text2mel_graph(L, Y, prev, W, hp)               # full graph incl. TextEnc, like the reference
         Y[:, j, :] = g["Y"][:, j, :]
         prev = g["max_attentions"][:, j].astype(np.int32)
-    t_step = (time.perf_counter() - t0) / steps               # seconds per loop step for Bs utterances
+    t_step = (time.perf_counter() - t0) / steps
     t0 = time.perf_counter()
     O.SSRN(Y[:1], W, hp)
-    t_ssrn = time.perf_counter() - t0                         # seconds per utterance
-    per_frame = t_step / Bs + t_ssrn / hp.max_T               # one loop step yields one mel frame per utterance
+    t_ssrn = time.perf_counter() - t0
+    per_frame = t_step / Bs + t_ssrn / hp.max_T
     Ti = 120                                                  # > 85: the full AudioDec cone is re-evaluated in the later steps
     t0 = time.perf_counter()
     incremental_decode_v3(L, W, hp.replace(max_T=Ti), np.float32)
@@ -76,17 +95,18 @@ def cpu_baseline(hp, W):
     per_frame_inc = t_inc + t_ssrn / hp.max_T
     try:                                                      # threads numpy's BLAS actually runs on (the matmuls are the work)
         from threadpoolctl import threadpool_info
-        cores = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
+        cores_np = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
     except Exception:
-        cores = os.cpu_count()
-    return {"value": 1.0 / per_frame, "unit": "mel frames/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": f"{steps} steps of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, "
-                      f"B={Bs}, N={hp.max_N}, T={hp.max_T}) + 1 SSRN pass (B=1), numpy fp32 (BLAS threads = cores), "
-                      f"prorated per mel frame",
-            "rtf": per_frame / hp.seconds_per_mel_frame,
+        cores_np = ncpu
+    return {"value": 1.0 / per_frame_t, "unit": "mel frames/s", "cores": _torch.get_num_threads(), "host_cores": ncpu, "kind": "port",
+            "sample": f"{steps_t} steps of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, B={Bt}, N={hp.max_N}, "
+                      f"T={hp.max_T}) + 1 SSRN pass (B={Bt}), torch-CPU fp32 with torch.set_num_threads({ncpu}) (oracle/torch_ref.py), prorated per mel frame",
+            "rtf": per_frame_t / hp.seconds_per_mel_frame,
+            "numpy_variant": {"value": 1.0 / per_frame, "unit": "mel frames/s", "cores": cores_np, "rtf": per_frame / hp.seconds_per_mel_frame,
+                              "sample": f"the same loop in numpy fp32 (oracle/dctts_ref.py, B={Bs}, {steps} steps + 1 SSRN pass at B=1; BLAS threads = cores)"},
             "incremental_variant": {"value": 1.0 / per_frame_inc, "unit": "mel frames/s", "rtf": per_frame_inc / hp.seconds_per_mel_frame,
                                     "sample": f"oracle/incremental_ref.incremental_decode_v3 (the HIP path's algorithm in numpy: TextEnc once, "
-                                              f"cached AudioEnc, cone re-evaluation), B={Bs}, T={Ti}, + the same SSRN pass, prorated per mel frame",
+                                              f"cached AudioEnc, cone re-evaluation), B={Bs}, T={Ti}, + the numpy SSRN pass, prorated per mel frame",
                                     "algorithmic_speedup_over_reference_loop": round(per_frame / per_frame_inc, 1)}}
 
 
@@ -155,6 +175,34 @@ def timed(fn, reps=3):
     return e0.elapsed_time(e1) / reps
 
 
+def cached_synthetic_weights(hp, seed, rank, world):
+    """The seeded random-init weights (209.5 MB, ~3 s to draw): rank 0 draws them once per box and leaves them in /tmp, the other ranks (and the
+    runs at the next N) load the file instead of drawing the same numbers again."""
+    from dc_tts_amd.weights import synthetic_weights
+    import torch.distributed as dist
+    path = os.path.join("/tmp", f"dctts_synthetic_weights_seed{seed}_N{hp.max_N}.npz")
+    def load():
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}
+    if rank == 0 and not os.path.exists(path):
+        W = synthetic_weights(hp, seed=seed, perturb=True)
+        tmp = path + f".{os.getpid()}.tmp.npz"
+        try:
+            np.savez(tmp, **W); os.replace(tmp, path)
+        except OSError:
+            pass                                                   # a read-only /tmp costs nothing but the cache
+    else:
+        W = None
+    if world > 1:
+        dist.barrier()
+    if W is None:
+        try:
+            W = load()
+        except Exception:
+            W = synthetic_weights(hp, seed=seed, perturb=True)
+    return W
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,8 +211,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU (BASELINE: 32)")
     ap.add_argument("--max-T", type=int, default=210)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--graph-mode", type=int, default=1, help="0 eager, 1 bulk pieces as hipGraphs (default), 2 chain pieces too")
-    ap.add_argument("--decode-mode", type=int, default=3, help="3 = default (round-2 decode: hoisted taps, row-op cone layers), 4 = as 3 with one row-split launch per chain piece, 1 / 2 = round-1 split kernels, 0 = fused full-row kernels")
+    ap.add_argument("--graph-mode", type=int, default=0, help="0 eager (default: the side stream is 4 launches per frame since round 3), 1 the side stream's work of a frame as one hipGraph")
+    ap.add_argument("--decode-mode", type=int, default=3, help="3 = default (two-stream incremental decode), 0 = fused full-row kernels on one stream (cross-check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vocoder", action="store_true", help="skip the untimed vocoder-tail section (SURVEY 8f-2)")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed per-kernel passes and the other BASELINE configs")
@@ -199,7 +247,7 @@ def main():
 
     hp = hp0.replace(max_T=args.max_T)
     B, T = args.batch, hp.max_T
-    W = synthetic_weights(hp, seed=1234, perturb=True)
+    W = cached_synthetic_weights(hp, 1234, rank, world)
     gm = 0 if args.no_graph else args.graph_mode
     eng = Engine(W, hp, device=local, decode_graph=gm)
     eng.set_decode_mode(args.decode_mode)
@@ -214,8 +262,8 @@ def main():
     for _ in range(args.warmup):
         eng.synthesize(L)
     barrier()
-    chain_prof = args.decode_mode == 3 and gm != 2          # the sampled launches must be eager launches
-    eng.prof_enable(PROF_CHAIN_HC if chain_prof else -1)
+    chain_prof = args.decode_mode == 3
+    eng.prof_enable(PROF_XGROUP if chain_prof else -1)       # HIP events on the launch stream around the xgroup_kernel launches of every 16th frame
     t0 = time.perf_counter()
     for _ in range(args.steps):
         Y, Z, mx = eng.synthesize(L)
@@ -225,7 +273,7 @@ def main():
         dist.barrier()
     elapsed = t1 - t0
     eng.prof_enable(-1)
-    n_chain, chain_ms = eng.prof_collect()
+    n_chain, chain_ms = eng.prof_collect(); chain_layers = eng.prof_rows()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)                     # measurement only: no collective on the data path
@@ -254,27 +302,30 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         d = hp.d
-        # ---- roofline: the kernel that dominates the step by time.  Algorithmic work of ONE launch (B rows, 256 -> 2 x 256, fp32):
-        #      weights 256 x 512, presum + pre-norm rows in + out (B x 512 each), partial statistics in + out (B x 64 each), highway
-        #      residual in + rebuilt row out (B x 256 each), LN parameters (4 x 256)
-        c3_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + 2 * B * d + 4 * d)
-        c3_flop = 2.0 * B * d * 2 * d
+        # ---- roofline: the kernel that dominates the step by time on the critical stream: xgroup_kernel, a run of newest-row highway
+        #      layers of the decode chain (6 layers of AudioDec or 10 of AudioEnc per launch, 2 launches per frame).  Algorithmic work of
+        #      ONE LAYER of one launch (B rows, 256 -> 2 x 256, fp32): weights 256 x 512; presum rows in, pre-norm rows out, pre-norm rows in
+        #      (B x 512 each); partial statistics out + in (B x 64 each); the kept input row out (B x 256); LN parameters (4 x 256)
+        lay_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + B * d + 4 * d)
+        lay_flop = 2.0 * B * d * 2 * d
         roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "chain3_kernel<LN_HC,HC>: one newest-row highway layer of the decode (AudioEnc HC_5..13 / AudioDec HC_3..7: rebuild "
-                          "the input row from the producer's pre-norm row, 32 x 256 x 512 contraction on 16x16x4 fp32 MFMA, partial LN "
-                          "statistics out); 14 of the 19 dependent launches of a frame's chain piece, ~35 % of the step time",
+                "kernel": "xgroup_kernel: a run of newest-row highway layers of the decode chain as ONE launch (AudioDec HC_2..HC_7 = 6 layers, AudioEnc "
+                          "HC_4..HC_13 = 10 layers): per layer a 32 x 256 x 512 contraction on 16x16x4 fp32 MFMA split over 16 workgroups of a 4-utterance "
+                          "team, layer-norm statistics and pre-norm rows exchanged through the L2 of the ONE XCD the team runs on; 2 launches per frame",
                 "launches": n_chain, "sampled": "every 16th frame of the timed region", "avg_launch_ms": None,
-                "algorithmic_bytes_per_launch": c3_bytes, "flop_per_launch": c3_flop,
-                "note": "latency-bound: ~1.45 us of launch boundary + one memory round trip + an 8-wave reduction per 5 us launch; the "
-                        "fraction of either roof is what a 64-workgroup, 19-deep dependent chain leaves (DESIGN.md section 4)"}
-        if n_chain > 0:
+                "layers_per_launch": None, "algorithmic_bytes_per_layer": lay_bytes, "flop_per_layer": lay_flop,
+                "note": "latency-bound: 16 dependent all-to-all layers per frame; a layer costs one L2 round trip for the exchanged rows, an 8-wave "
+                        "reduction and a team barrier (an L2 atomic), not a memory stream (DESIGN.md section 2c)"}
+        if n_chain > 0 and chain_layers > 0:
             avg = chain_ms / n_chain
-            roof.update(avg_launch_ms=round(avg, 5), achieved=round(c3_bytes / (avg * 1e-3) / 1e9, 1),
-                        frac=round(c3_bytes / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), frac_mfma=round(c3_flop / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
-        tj = os.path.join(ROOT, "profiles", "r02_pmc_chain.json")
+            lpl = chain_layers / n_chain
+            roof.update(avg_launch_ms=round(avg, 5), layers_per_launch=round(lpl, 2), algorithmic_bytes_per_launch=lay_bytes * lpl,
+                        achieved=round(lay_bytes * lpl / (avg * 1e-3) / 1e9, 1),
+                        frac=round(lay_bytes * lpl / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), frac_mfma=round(lay_flop * lpl / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
+        tj = os.path.join(ROOT, "profiles", "r03_pmc_xgroup.json")
         if os.path.exists(tj):
             roof["traffic"] = json.load(open(tj)).get("hbm_bytes_per_launch")
-            roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: profiles/r02_pmc.md)"
+            roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: profiles/r03_pmc_xgroup.json)"
         flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6      # SURVEY 8d, per mel frame and utterance
         out = {
             "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
@@ -323,8 +374,9 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     res["phase_rooflines"] = {
         "textenc": both_roofs(B * 2 * 3.0789e9, 68.6e6 + B * 0.37e6, ms_te),
         "decode": dict(both_roofs(B * T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 + B * 125e3), dec_ms),
-                       bound="latency: 19 dependent launches per frame on the critical path (+ one stream wait); the cone work of AudioDec C_1 / HC_2 runs as row "
-                             "operations on cached products, so fewer FLOPs are EXECUTED than the algorithmic count used here (DESIGN.md section 2)"),
+                       bound="latency: 16 dependent all-to-all highway layers (2 launches) + 7 k=1 layers (1 launch) + attention + AudioDec C_1 per frame on the "
+                             "critical stream, beside the cone re-evaluation on the side stream; the cone work of AudioDec C_1 / HC_2 runs as row operations on "
+                             "cached products, so fewer FLOPs are EXECUTED than the algorithmic count used here (DESIGN.md section 2)"),
         "ssrn": both_roofs(B * T * 187.310e6, B * (67200 + 3444000) + 113641532.0, ms_ssrn),
     }
     res["roofline_frac_decode_phase_mfma"] = res["phase_rooflines"]["decode"]["frac_mfma"]
@@ -341,17 +393,31 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
         kern.append(dict(kernel="hconv_kernel<EPI_HC,NT=8,NW=8> (SSRN HC_11 / HC_12: 1024 ch, k=3, fused LN + gate): the largest kernel by FLOPs",
                          bound="mfma", launches=n, avg_launch_ms=round(ms / n, 4), rows_per_launch=rpl, layer_rows=B * 4 * T,
                          **both_roofs(2.0 * rpl * 3 * C * 2 * C, 4.0 * (rpl * C * 2 + 3 * C * 2 * C), ms / n)))
+    F = hp.n_linear
+    for kid, what, K_, N_ in ((PROF_SSRN_HC_TAIL, "hconv16_kernel<EPI_HC,NT=16,NW=8> (SSRN HC_11 / HC_12: the 16-row tail launch, 144 workgroups)", 3 * 2 * c, 2 * 2 * c),
+                              (PROF_SSRN_C1025, "hconv_kernel<EPI_C,NT=3,NW=11> (SSRN C_14 / C_15 / C_16 and C_13: 1025 columns, k=1, fused LN + activation)", None, F)):
+        eng.prof_enable(kid)
+        for _ in range(2):
+            eng.ssrn(Y, want_logits=False)
+        torch.cuda.synchronize(); eng.prof_enable(-1)
+        n, ms = eng.prof_collect(); rows = eng.prof_rows()
+        if n:
+            rpl = rows / n
+            Kk = K_ if K_ is not None else (3 * F + 2 * c) / 4.0          # C_13 reads 1024 channels, C_14..C_16 1025: mean over the four launches of a pass
+            kern.append(dict(kernel=what, bound="mfma", launches=n, avg_launch_ms=round(ms / n, 4), rows_per_launch=rpl, layer_rows=B * 4 * T,
+                             **both_roofs(2.0 * rpl * Kk * N_, 4.0 * (rpl * (Kk + N_ / (2 if K_ else 1)) + Kk * N_), ms / n)))
     if args.decode_mode == 3:
         eng.set_decode_graph(0); eng.text2mel(L); torch.cuda.synchronize()
-        eng.prof_enable(PROF_BULK_GEMM); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
+        eng.prof_enable(PROF_XCONE); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
         n, ms = eng.prof_collect(); rows = eng.prof_rows()
         eng.set_decode_graph(gm)
         if n:
             rpl = rows / n
-            kern.append(dict(kernel="hbulk_kernel<12> (decode bulk stream: AudioDec HC_3 cone rows + presum row, 256 ch, k=3, split-K over 8 waves)",
+            kern.append(dict(kernel="xcone_kernel (decode side stream: AudioDec HC_3 .. HC_7 over the cone rows of a frame + their layer-norm / gate row passes, "
+                                    "256 ch, k=3; one launch, 16-workgroup teams inside one XCD)",
                              bound="mfma", launches=n, avg_launch_ms=round(ms / n, 5), rows_per_launch=rpl,
-                             **both_roofs(2.0 * rpl * 3 * d * 2 * d, 4.0 * (rpl * (d + 2 * d) + 3 * d * 2 * d), ms / n),
-                             note="eager decode pass (graph mode 0) so that events can bracket the launches; runs concurrently with the chain"))
+                             **both_roofs(2.0 * rpl * 3 * d * 2 * d, 4.0 * (rpl * (d + 2 * d + d) + 5 * 3 * d * 2 * d), ms / n),
+                             note="eager decode pass (graph mode 0) so that events can bracket the launches; frames >= 100 (full-size cones); runs concurrently with the chain"))
     res["kernels"] = kern
     # ---- host transfer (PCIe-inclusive figure, reported beside `value`, never as it)
     Lh = L.cpu().pin_memory()

@@ -22,6 +22,8 @@
 #include "decode3_kernels.h"
 #include "hconv_kernel.h"
 #include "hconv16_kernel.h"
+#include "xgroup_kernel.h"
+#include "xcone_kernel.h"
 
 using namespace dctts;
 
@@ -135,6 +137,16 @@ struct dctts_ctx {
   std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;   // one small linear graph per frame for the side stream, frame index baked into every launch
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
   void* mlp_tab = nullptr; std::string mlp_geom;
+  // runs of chain highway layers as one launch whose workgroups meet inside one XCD (xgroup_kernel.h); DCTTS_XGROUP=0: one launch per layer
+  int xgroup = 1;
+  bool xg_on = false, xc_on = false;   // this decode uses them
+  bool xgroup_ok = true;               // cleared for good when a decode reports that the placement assumption (block b on XCD b % 8) does not hold here
+  void* xg_tab = nullptr; std::string xg_geom;   // per chain piece: [T + 1][2] XGroupParams (AudioDec run of frame j, AudioEnc run of frame j + 1)
+  float* xg_mem = nullptr;             // exchange buffers (2 networks x 2 parity copies of rows + statistics), team barriers, error word: one allocation
+  int* xg_err_host = nullptr;          // pinned copy of the error word, refreshed after every decode (dctts_decode_status)
+  // the tail of AudioDec's cone (HC_3 .. HC_7 and their row passes) as one launch per frame on the side stream (xcone_kernel.h); DCTTS_XCONE=0: nine launches
+  int xcone = 1;
+  void* xc_tab = nullptr; std::string xc_geom;   // per frame: XConeParams
   hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr};
   int sync_values = 1;                 // the two streams meet through stream memory operations (hipStreamWriteValue32 / WaitValue32 on two counters) instead of events
@@ -347,7 +359,7 @@ static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
   geti("DCTTS_TAIL_SPLIT", &c->tail_split);
   { int r = c->bulk_cap; geti("DCTTS_BULK_CAP", &r); if (r >= 8 && r <= 4096) c->bulk_cap = r; }
-  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel);
+  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone);
   geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
@@ -402,6 +414,10 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->iota_dev) (void)hipFree(c->iota_dev);
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
   if (c->mlp_tab) (void)hipFree(c->mlp_tab);
+  if (c->xg_tab) (void)hipFree(c->xg_tab);
+  if (c->xc_tab) (void)hipFree(c->xc_tab);
+  if (c->xg_mem) (void)hipFree(c->xg_mem);
+  if (c->xg_err_host) (void)hipHostFree(c->xg_err_host);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;
@@ -623,7 +639,14 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   }
   HIPCHK(launch_hconv(L.shape, p, st, tiles32));
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
-  if (m_tail < p.M) { p.wp = L.wp16r; HIPCHK(launch_hconv16(L.shape16, p, m_tail, st)); }
+  if (m_tail < p.M) {
+    p.wp = L.wp16r;
+    const bool prof16 = (c->prof_id == 50000 + L.shape16.epi * 10000 + L.shape16.nt * 100 + L.shape16.nw);      // the 16-row tail launch of the same layer
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (prof16) { HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1)); HIPCHK(hipEventRecord(t0, st)); }
+    HIPCHK(launch_hconv16(L.shape16, p, m_tail, st));
+    if (prof16) { HIPCHK(hipEventRecord(t1, st)); c->prof_ev.emplace_back(t0, t1); c->prof_cnt.push_back(1); c->prof_rows += p.M - m_tail; }
+  }
   return 0;
 }
 
@@ -1142,6 +1165,16 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     HIPCHK(hipGetLastError());
     first_gemm = 2;
   }
+  if (c->xc_on && first_gemm == 2) {                                        // HC_3 .. HC_7 and their row passes: one launch, teams inside one XCD (xcone_kernel.h)
+    const XConeParams* xp = (const XConeParams*)c->xc_tab + f;
+    const bool prof = c->prof_id == DCTTS_PROF_XCONE && f >= 100 && (f & 15) == 8;          // full-size cones only; eager decode only (graph mode 0)
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, sb)); }
+    hipLaunchKernelGGL(xcone_kernel, dim3(128 * (((B + 3) / 4 + 7) / 8)), dim3(512), 0, sb, xp);
+    HIPCHK(hipGetLastError());
+    if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < AD.size(); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
+    return 0;
+  }
   for (size_t i = first_gemm; i < AD.size(); ++i) {
     if (!AD[i].wpp) continue;
     const int R = c->cone_len[i], Rb = R - 1;                          // Rb cone rows at offsets < 0, then the presum row (offset 0)
@@ -1233,6 +1266,136 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
 
 
 
+// ---- xgroup_kernel plumbing: one XGroupParams per (chain piece, network) in device memory; exchange buffers + team barriers + error word
+struct XgMem { float* xch[2]; float* sch[2]; unsigned* bar; unsigned* bar_cone; int* err; int bpad; size_t bar_words; };
+static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
+static XgMem xg_mem(dctts_ctx* c, int B) {
+  XgMem m; m.bpad = (B + 3) / 4 * 4;
+  float* q = c->xg_mem;
+  for (int n = 0; n < 2; ++n) { m.xch[n] = q; q += (size_t)2 * m.bpad * 512; m.sch[n] = q; q += (size_t)2 * m.bpad * 64; }
+  m.bar_words = (size_t)((m.bpad / 4 + 7) / 8 * 8) * 32;
+  m.bar = (unsigned*)q; q += m.bar_words;                     // the chain's teams (xgroup_kernel)
+  m.bar_cone = (unsigned*)q; q += m.bar_words;                // the side stream's teams (xcone_kernel): the two run concurrently
+  m.err = (int*)q;
+  return m;
+}
+
+// Chain piece j (j = -1 .. T-1) launches, in this order: the AudioDec run of frame j (j >= 0), ..., the AudioEnc run of frame j + 1 (j + 1 < T).
+// The team barriers count arrivals monotonically over the whole decode, so every launch is told the count it starts from.
+static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
+  const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
+                        std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->ctr_chain) + ":" + std::to_string((size_t)c->wait_ctr);
+  if (c->xg_tab && c->xg_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->xg_tab) { (void)hipFree(c->xg_tab); c->xg_tab = nullptr; }
+  if (c->xg_mem) { (void)hipFree(c->xg_mem); c->xg_mem = nullptr; }
+  HIPCHK(hipMalloc((void**)&c->xg_mem, xg_mem_floats(B) * sizeof(float)));
+  HIPCHK(hipMemset(c->xg_mem, 0, xg_mem_floats(B) * sizeof(float)));
+  if (!c->xg_err_host) { HIPCHK(hipHostMalloc((void**)&c->xg_err_host, sizeof(int), 0)); *c->xg_err_host = 0; }
+  const XgMem m = xg_mem(c, B);
+  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
+  auto rowp = [](const View& v, long par, int j) { return v.p + par * v.set + (v.row0 + j) * (long)v.stride; };
+  std::vector<XGroupParams> tab((size_t)2 * (T + 1));
+  unsigned arrivals = 0;
+  for (int piece = -1; piece < T; ++piece) {
+    for (int net = 0; net < 2; ++net) {                         // 0 = AudioDec highway layers of frame `piece`, 1 = AudioEnc highway layers of frame `piece + 1`
+      const int j = net ? piece + 1 : piece;
+      XGroupParams p; memset(&p, 0, sizeof(p));
+      if (j < 0 || j >= T) { tab[(size_t)2 * (piece + 1) + net] = p; continue; }
+      const long par = j & 1;
+      const std::vector<DevLayer>& Lr = net ? AE : AD;
+      size_t i0 = 0; while (i0 < Lr.size() && !Lr[i0].hc) ++i0;
+      size_t i1 = i0; while (i1 < Lr.size() && Lr[i1].hc) ++i1;
+      const int L = (int)(i1 - i0);
+      if (i0 == 0 || L < 2 || L > 10 || Lr[i0 - 1].cout != 256 || Lr[i0 - 1].act != ACT_NONE) return fail(DCTTS_ERR_STATE, "xgroup: a run of 2..10 highway layers after a linear 256-channel layer");
+      p.B = B; p.L = L;
+      const std::vector<float*>& P = net ? w.pe : w.pd; const std::vector<float*>& S = net ? w.se : w.sd;
+      const std::vector<View>& H = net ? w.ae : w.ad;
+      p.P0 = P[i0 - 1]; p.p0_bs = 256; p.stats0 = S[i0 - 1]; p.pg1 = Lr[i0 - 1].g1; p.pb1 = Lr[i0 - 1].b1;
+      for (int k = 0; k < L; ++k) {
+        const size_t i = i0 + k; const DevLayer& Ly = Lr[i];
+        if (Ly.cout != 256 || Ly.cin != 256 || !Ly.wp16 || !Ly.wp16c) return fail(DCTTS_ERR_STATE, "xgroup: 256-channel causal k=3 highway layers only");
+        XGroupLayer& q = p.lay[k];
+        q.wp = Ly.wp16; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2; q.tap2 = Ly.tap2 ? 1 : 0;
+        if (net) { q.presum = w.pse[i] + par * w.pse_set; q.presum_bs = 512; }
+        else { q.presum = w.pb3[i] + par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 512; q.presum_bs = c->cone_len[i] * 512; }
+        const View& hin = H[i - 1];                             // this layer's input rows
+        const bool keep = net ? true : (k + 1 == L);            // AudioEnc: every row is history; AudioDec: only the residual the next launch (C_8) needs
+        if (keep) { q.xm = rowp(hin, net ? 0 : par, j); q.xm_bs = (int)(hin.bstride * hin.stride); }
+        if (Ly.tap2) { q.xt = rowp(hin, 0, j) - hin.stride; q.xt_bs = (int)(hin.bstride * hin.stride); }
+        else { q.xt = q.wp; q.xt_bs = 0; }
+      }
+      p.pout = P[i1 - 1]; p.stats_out = S[i1 - 1];
+      p.xch = m.xch[net]; p.sch = m.sch[net]; p.xch_set = m.bpad * 512; p.sch_set = m.bpad * 64;
+      p.bar = m.bar; p.bar_base = arrivals; p.err = m.err;
+      arrivals += (unsigned)(L - 1) * 16u;
+      if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
+        if (insig) { p.sig = c->ctr_chain; p.sig_val = (unsigned)(j + 1); }
+        if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
+      }
+      tab[(size_t)2 * (piece + 1) + net] = p;
+    }
+  }
+  HIPCHK(hipMalloc(&c->xg_tab, tab.size() * sizeof(XGroupParams)));
+  HIPCHK(hipMemcpy(c->xg_tab, tab.data(), tab.size() * sizeof(XGroupParams), hipMemcpyHostToDevice));
+  c->xg_geom = g;
+  return 0;
+}
+
+static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t st) {
+  const XGroupParams* p = (const XGroupParams*)c->xg_tab + (size_t)2 * (piece + 1) + net;
+  const int teams = (B + 3) / 4;
+  // measurement (dctts_hip_debug.h): HIP events on the launch stream around the launches of every 16th frame
+  const bool prof = c->prof_id == DCTTS_PROF_XGROUP && c->prof_frame;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
+  hipLaunchKernelGGL(xgroup_kernel, dim3(128 * ((teams + 7) / 8)), dim3(512), 0, st, p);
+  HIPCHK(hipGetLastError());
+  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += (net ? 10 : 6); }   // prof_rows counts LAYERS here
+  return 0;
+}
+
+// ---- xcone_kernel plumbing: one XConeParams per frame in device memory (layers HC_3 .. HC_7 of AudioDec's cone, parity copies folded in)
+static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
+  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem);
+  if (c->xc_tab && c->xc_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->xc_tab) { (void)hipFree(c->xc_tab); c->xc_tab = nullptr; }
+  const std::vector<DevLayer>& AD = c->audiodec;
+  const XgMem m = xg_mem(c, B);
+  size_t i0 = 2, i1 = i0; while (i1 < AD.size() && AD[i1].hc) ++i1;     // HC_3 .. the last highway layer
+  const int L = (int)(i1 - i0);
+  if (L < 1 || L > 5) return fail(DCTTS_ERR_STATE, "xcone: 1..5 highway layers behind HC_2");
+  std::vector<XConeParams> tab((size_t)T);
+  for (int f = 0; f < T; ++f) {
+    const long par = f & 1;
+    XConeParams p; memset(&p, 0, sizeof(p));
+    p.B = B; p.L = L; p.frame = f;
+    for (int k = 0; k < L; ++k) {
+      const size_t i = i0 + k; const DevLayer& Ly = AD[i];
+      if (Ly.cout != 256 || Ly.cin != 256 || Ly.cin_p != 256 || Ly.ntaps != 3 || Ly.tap_off[2] != 0 || !Ly.wp16 || c->cone_len[i] > 64) return fail(DCTTS_ERR_STATE, "xcone: causal k=3 highway layers over 256 channels, <= 64 cone rows");
+      XConeLayer& q = p.lay[k];
+      q.wp = Ly.wp16; q.bias = Ly.bias; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2;
+      const View& in = w.ad[i - 1]; const View& out = w.ad[i];
+      q.xin = in.p + par * in.set; q.xin_bstride = in.bstride; q.xin_row0 = in.row0; q.xin_stride = in.stride;
+      q.xout = out.p + par * out.set; q.xout_bstride = out.bstride; q.xout_row0 = out.row0; q.xout_stride = out.stride;
+      q.pout = w.pb3[i] + par * w.pb3_set[i];
+      q.offs = c->cone3_dev[i]; q.R = c->cone_len[i];
+      for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = Ly.tap_off[t3];
+    }
+    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(2 * L - 1) * 16u; p.err = m.err;
+    if (f == c->trace_frame) {                                  // DCTTS_TRACE: this frame's launch records its phase boundaries
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
+      p.ts = c->trace_buf + 64 * 64 * 32 - 192;
+    }
+    tab[f] = p;
+  }
+  HIPCHK(hipMalloc(&c->xc_tab, tab.size() * sizeof(XConeParams)));
+  HIPCHK(hipMemcpy(c->xc_tab, tab.data(), tab.size() * sizeof(XConeParams), hipMemcpyHostToDevice));
+  c->xc_geom = g;
+  return 0;
+}
+
 // ---- mlp_rows_kernel plumbing: one MlpRowsParams per frame in device memory
 static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   const std::string g = geom("mlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]);
@@ -1286,6 +1449,7 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
   const int par = j & 1;
+  if (c->xg_on) { c->sig_next = 0; c->wait2_next = 0; return v3_xgroup_launch(c, B, j, 0, sm); }   // HC_2 .. HC_7 as one launch (its table entry carries the piece's signal / wait)
   for (size_t i = 1; i < AD.size(); ++i) {
     if (!AD[i].hc) break;                                       // C_8 .. C_11 run inside mlp_rows_kernel (launched by the caller)
     SplitExtra ex;
@@ -1305,6 +1469,8 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
     if (j > 0 && !AE[i].hc) continue;                           // C_1 .. C_3 of frame j ran inside frame j-1's mlp_rows_kernel
     if (i == 0) {                                               // frame 0 only: S[0] is the zero row
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
+    } else if (c->xg_on && AE[i].hc) {
+      if (!AE[i - 1].hc) CHK(v3_xgroup_launch(c, B, j - 1, 1, sm));    // the whole run of highway layers (HC_4 .. HC_13) of frame j, launched from chain piece j - 1
     } else {
       SplitExtra ex;
       if (AE[i].wp16c) { ex.presum = w.pse[i] + (long)(j & 1) * w.pse_set; ex.presum_rstride = 2 * AE[i].cout; }
@@ -1358,6 +1524,14 @@ static int write_trace3(dctts_ctx* c, int j) {
     fprintf(f, "\n");
   }
   {
+    const long long* o = &h[64 * 64 * 32 - 192];
+    if (o[0]) {
+      fprintf(f, "# xcone_kernel (workgroup 0, thread 0), microseconds since its entry; per layer: row tables | contraction done | barrier passed | row pass done | barrier passed\n ");
+      for (int i = 1; i < 60 && o[i]; ++i) fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0);
+      fprintf(f, "\n");
+    }
+  }
+  {
     const long long* o = &h[64 * 64 * 32 - 64];
     if (o[0]) {
       fprintf(f, "# mlp_rows_kernel (workgroup 0, thread 0), microseconds since its entry: rows rebuilt | per layer: loads landed, FMAs done, partial sums exchanged, row finished\n");
@@ -1403,6 +1577,19 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   }
   CHK(v3_aepre_table(c, w, B));
   CHK(v3_mlp_table(c, w, B, T));
+  c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->trace_frame < 0 && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (the trace / that timing id look at chain3_kernel launches)
+  c->xc_on = c->xcone != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_BULK_GEMM;
+  if (c->xg_on || c->xc_on) {
+    if (c->xg_err_host && *c->xg_err_host) {
+      // the previous decode's team hand-offs failed and nobody asked (dctts_decode_status): refuse once, and never use the kernel again if it was the placement
+      *c->xg_err_host = 0; c->xgroup_ok = false;
+      return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-launch hand-offs failed (xgroup_kernel) and its results were invalid (dctts_decode_status was not consulted)");
+    }
+    CHK(v3_xgroup_table(c, w, B, T, insig, cwait));            // (also allocates the memory both kernels meet through)
+    if (c->xc_on) CHK(v3_xcone_table(c, w, B, T));
+    const XgMem m = xg_mem(c, B);
+    HIPCHK(hipMemsetAsync(m.bar, 0, (2 * m.bar_words + 64) * sizeof(unsigned), st));      // both sets of team barriers and the error word
+  }
   hipStream_t sb = c->s_bulk;
   // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch (the chain launches stay eager: a graph
   // launch per chain piece costs ~10 us of start-up on the critical path)
@@ -1415,7 +1602,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     return 0;
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((size_t)c->xc_tab) + ":" +
                           std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs(c);
@@ -1466,7 +1653,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     if (ptime(j)) HIPCHK(hipEventRecord(pe_c[j - pt0][0], st));
     if (j == tstep) {
       if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
-      HIPCHK(hipMemsetAsync(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long), st));
+      HIPCHK(hipMemsetAsync(c->trace_buf, 0, (64 * 64 * 32 - 192) * sizeof(long long), st));      // (the last 192 words hold xcone's / mlp_rows' stamps)
+      HIPCHK(hipMemsetAsync(c->trace_buf + 64 * 64 * 32 - 64, 0, 64 * sizeof(long long), st));
       c->trace_on = true; c->trace_n = 0;
     }
     c->prof_frame = (j & 15) == 8;
@@ -1483,6 +1671,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   }
   // the chain's last piece is on `st`; the bulk stream's last piece was consumed by it, so `st` is ordered after all decode work.
   if (cwait) HIPCHK(hipMemcpyAsync(c->wait_err_host, c->wait_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (c->xg_on || c->xc_on) HIPCHK(hipMemcpyAsync(c->xg_err_host, xg_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
     for (int i = 0; i < 8; ++i) {
@@ -1565,6 +1754,10 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 
 extern "C" int dctts_decode_status(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  if (c->xg_err_host && *c->xg_err_host) {                  // reported once; a placement failure switches the kernel off for good
+    *c->xg_err_host = 0; c->xgroup_ok = false;
+    return fail(DCTTS_ERR_STATE, "decode: a bounded wait inside xgroup_kernel gave up (a team of workgroups was not on one XCD, or the side stream never arrived): the results of that decode are invalid; further decodes run one launch per layer");
+  }
   if (c->wait_err_host && *c->wait_err_host) {              // reported once: the error word is cleared so that the next decode starts clean
     DevGuard dev_guard(c);
     *c->wait_err_host = 0;

@@ -1,0 +1,193 @@
+// xcone_kernel.h -- the tail of AudioDec's dependency cone (HC_3 .. HC_7, networks.py:175-191) for one decode frame as ONE launch whose
+// workgroups meet inside one XCD.
+//
+// Exact parity with synthesize.py:47-54 makes every frame re-evaluate AudioDec over the shrinking cone of rows its newest row depends on
+// (46 / 16 / 6 / 4 / 1 rows per utterance for HC_3 .. HC_7, the last one of each being the presum row the chain finishes).  As launches that
+// is, per frame and on the side stream, five small GEMMs and four layer-norm row passes = nine dependent launches, 99 us of which ~35 are
+// arithmetic: hbulk_kernel<12> re-reads its weights for every 32-row item, the 16-row launches and the row passes are launch latency.
+//
+// Same idea as xgroup_kernel.h: a team of 16 workgroups that the command processor put on ONE XCD (blocks b, b + 8, b + 16 ...) owns four
+// utterances; a workgroup owns one column group (16 gate + 16 info columns) and keeps that slice of a layer's weights (96 KB) in registers
+// while it walks over the team's row tiles; pre-norm rows go to the XCD's L2 with plain stores; the team meets at an L2 atomic; then the
+// team's waves normalise / gate the rows (one wave per row, two-pass layer-norm, highway mix: modules.py:189-193) and store the layer's
+// output rows, meet again, and go on to the next layer.  The only thing a workgroup ever trusts is its team's barrier word reaching the
+// count in ITS OWN L2 (which proves the team is on this XCD); every spin is bounded and raises the error word (dctts_decode_status).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "decode3_kernels.h"
+
+namespace dctts {
+
+struct XConeLayer {
+  const float* wp;                       // 16-column tiles, all three taps: [tile = 2 grp + h][48 k-groups][lane][4]
+  const float* bias;                     // [512]
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  const float* xin; long xin_bstride; long xin_row0; int xin_stride;     // this layer's input rows (frame parity folded into the pointer)
+  float* xout; long xout_bstride; long xout_row0; int xout_stride;       // this layer's output rows (cone rows at offsets < 0)
+  float* pout;                           // pre-norm rows [b * R + r][512]; row R - 1 of an utterance is the presum row of the chain
+  const int* offs; int R;                // cone offsets < 0 (descending) followed by 0; rows per utterance
+  int tap_off[3];
+};
+struct XConeParams {
+  int B, L, frame;
+  XConeLayer lay[5];
+  unsigned* bar; unsigned bar_base;      // team barriers: bar[team * 32] counts arrivals since the decode started; value before this launch
+  int* err;
+  long long* ts;                         // measurement (DCTTS_TRACE): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
+};
+
+__device__ __forceinline__ bool xcone_barrier(unsigned* bar, unsigned target, int* err, bool go) {
+  // caller: all stores of the phase issued; every thread calls this
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this thread's stores are in the L2
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);          // no sc1: executes in the XCD's L2
+    if (go) {
+      int spins = 0;
+      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {     // sc1 load: past the L1, served by the L2
+        if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { atomicOr(err, 1); break; }
+      }
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
+// grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads
+__global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restrict__ pp) {
+  __shared__ __attribute__((aligned(16))) float red[2][8 * 2 * 4 * 64];      // split-K partial sums, double-buffered: one barrier per row tile
+  __shared__ int s_go;
+  __shared__ int s_xoff[256];            // per local row m of the team (M <= 4 * 64): element offset of its input row t in xin, -1 = the row does not exist (t < 0)
+  __shared__ int s_prow[256];            // ... its pre-norm row index in pout
+  typedef const __attribute__((address_space(4))) XConeParams CP;
+  CP& p = *(CP*)pp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
+  const int grp = bq & 15, team = bx + 8 * (bq >> 4), b0 = team * 4;
+  if (b0 >= p.B) return;
+  const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
+  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+  const int etile = wave >> 2, ecol = lane & 15, ej = wave & 3;
+  const int pcol = etile * 256 + grp * 16 + ecol;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned* const bar = p.bar + team * 32;
+  if (tid == 0) s_go = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting
+  unsigned arrived = p.bar_base;
+  const int frame = p.frame;
+  int nts = 0;
+  auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 60) p.ts[nts++] = wall_clock64(); };
+  stamp();
+
+  // this workgroup's slice of a layer's weights: wave w owns k-groups w, w + 8, ... (tap i >> 1, channels 128 (i & 1) + 16 w), two tiles.  The
+  // next layer's slice is requested at the start of this layer's contraction (it depends on nothing), so only the first one is waited for cold.
+  f32x4 bq0[6], bq1[6], nq0[6], nq1[6];
+  auto load_w = [&](int layer, f32x4 (&q0)[6], f32x4 (&q1)[6]) {
+    const float* wb = p.lay[layer].wp + lane * 4;
+    const unsigned w0 = (unsigned)(grp * 2) * 48u * 256u, w1 = w0 + 48u * 256u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { q0[i] = ldv(wb, w0 + (unsigned)(wave + 8 * i) * 256u); q1[i] = ldv(wb, w1 + (unsigned)(wave + 8 * i) * 256u); }
+  };
+  load_w(0, bq0, bq1);
+  for (int li = 0; li < p.L; ++li) {
+    const int R = p.lay[li].R, M = nb * R, ntile = (M + 15) >> 4;
+    const float bias = p.lay[li].bias[pcol];
+    const float* xin = p.lay[li].xin;
+    const long xbs = p.lay[li].xin_bstride, xr0 = p.lay[li].xin_row0; const int xs = p.lay[li].xin_stride;
+    const int to0 = p.lay[li].tap_off[0] * xs, to1 = p.lay[li].tap_off[1] * xs;        // (tap 2 is the row itself: causal)
+    float* pout = p.lay[li].pout;
+    // ---- row tables of the layer (the two integer divisions and the offset-table read happen once per row, not once per tile and lane)
+    if (tid < 256) {
+      int xo = -1, pr = 0;
+      if (tid < M) {
+        const int bl = tid / R, r = tid - bl * R;
+        const int t = frame + p.lay[li].offs[r];
+        if (t >= 0) xo = (int)(((long)(b0 + bl) * xbs + xr0 + t) * xs);
+        pr = ((b0 + bl) * R + r) | ((r == R - 1) ? (1 << 30) : 0);                       // bit 30: presum row (its centre tap belongs to the chain)
+      }
+      s_xoff[tid] = xo; s_prow[tid] = pr;
+    }
+    __syncthreads();
+    auto load_a = [&](int tile, f32x4 (&a)[6]) {
+      const int m = tile * 16 + arow;
+      const int xo = s_xoff[m < 256 ? m : 255];
+      const bool ok = m < M && xo >= 0;
+      const bool pre = (s_prow[m < 256 ? m : 255] >> 30) & 1;
+      const float* xrow = xin + (ok ? xo : 0) + 16 * wave + c4;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const int tap = i >> 1;
+        const int toff = (tap == 0) ? to0 : ((tap == 1) ? to1 : 0);
+        a[i] = *reinterpret_cast<const f32x4*>(xrow + toff + 128 * (i & 1));
+        if (!ok || (pre && tap == 2)) a[i] = z4;
+      }
+    };
+    stamp();                                                                   // row tables done
+    f32x4 a[6], an[6];
+    load_a(0, a);
+    if (li + 1 < p.L) load_w(li + 1, nq0, nq1);                               // lands while this layer's tiles are contracted
+    for (int tile = 0; tile < ntile; ++tile) {
+      if (tile + 1 < ntile) load_a(tile + 1, an);                             // the next tile's rows are in flight during this tile's MFMAs
+      f32x4 acc0 = z4, acc1 = z4;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bq0[i][e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bq1[i][e], acc1, 0, 0, 0);
+        }
+      }
+      float* rb = red[tile & 1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { rb[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; rb[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+      lds_barrier();                                                           // LDS only: the next tile's loads keep flying
+      float v_ = bias;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v_ += rb[((w * 2 + etile) * 4 + ej) * 64 + lane];
+      {
+        const int me = tile * 16 + aq * 4 + ej;                               // the row this thread finishes
+        if (me < M && s_xoff[me] >= 0) pout[(long)(s_prow[me] & 0x3fffffff) * 512 + pcol] = v_;
+      }
+      if (tile + 1 < ntile) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] = an[i];
+      }
+    }
+    // ---- the team's pre-norm rows of this layer are complete
+    stamp();                                                                   // contraction done
+    arrived += 16u;
+    xcone_barrier(bar, arrived, p.err, s_go != 0);
+    stamp();                                                                   // barrier passed
+    if (li + 1 == p.L) break;                                                  // the last layer only leaves its presum rows
+    // ---- layer-norm / gate / highway mix of the cone rows (offsets < 0): one wave per row, the team's 128 waves in turn
+    const int Rb = R - 1;
+    if (Rb > 0) {
+      RowNorm n; n.P = pout; n.np = 512; n.g1 = p.lay[li].g1; n.b1 = p.lay[li].b1; n.g2 = p.lay[li].g2; n.b2 = p.lay[li].b2; n.act = ACT_NONE; n.ngroups = 16;
+      n.res = nullptr; n.res_bstride = 0; n.res_row0 = 0; n.res_stride = 0; n.res_set = 0;
+      float* xout = p.lay[li].xout;
+      const long obs = p.lay[li].xout_bstride, or0 = p.lay[li].xout_row0; const int os = p.lay[li].xout_stride;
+      const int c = lane * 4;
+      for (int q = grp * 8 + wave; q < nb * Rb; q += 128) {
+        const int bl = q / Rb, r = q - bl * Rb;
+        const int m = bl * R + r;
+        const int xo = s_xoff[m];
+        if (xo < 0) continue;                                                  // wave-uniform: the row does not exist yet (t < 0)
+        const long prow = (long)(s_prow[m] & 0x3fffffff);
+        const float4 h1 = ld4(pout + prow * 512 + c), h2 = ld4(pout + prow * 512 + 256 + c);
+        const float4 xr = ld4(xin + xo + c);                                   // the layer's own input row (modules.py:171,193)
+        const float4 o = norm_hc_regs(n, h1, h2, xr, lane);
+        const int t = (int)((long)xo / xs - ((long)(b0 + bl) * xbs + xr0));
+        *reinterpret_cast<float4*>(xout + ((long)(b0 + bl) * obs + or0 + t) * os + c) = o;
+      }
+    }
+    stamp();                                                                   // row pass done
+    arrived += 16u;
+    xcone_barrier(bar, arrived, p.err, s_go != 0);
+    stamp();                                                                   // barrier passed
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { bq0[i] = nq0[i]; bq1[i] = nq1[i]; }
+  }
+}
+
+}  // namespace dctts

@@ -1,0 +1,273 @@
+// xgroup_kernel.h -- a run of newest-row highway layers of the decode chain as ONE launch whose workgroups meet inside one XCD.
+//
+// The chain of a decode frame (synthesize.py:47-54 for the newest row) is 16 dependent highway layers (AudioDec HC_2..HC_7, then AudioEnc
+// HC_4..HC_13, modules.py:143-197), and every layer is an all-to-all: a workgroup that owns 16 of the 256 channels needs all 256 channels of
+// the previous layer's row.  As dependent launches a layer costs ~5.3 us (1.45 us of launch boundary + a cold start on every load + the work);
+// round 2's persistent variant with hand-offs through device memory (sc1 stores polled with sc1 loads) cost about the same, because the
+// eight XCDs' L2s are not coherent with each other and every hand-off is a trip over the fabric.
+//
+// MI355X-specific observation this kernel is built on (tools/micro/xcd_handoff.hip, profiles/r03_xcd_handoff.txt): the command processor
+// deals the workgroups of a launch to the XCDs round-robin -- block b runs on XCD b % 8 -- and INSIDE an XCD the L2 is the coherence point:
+// a plain store stays in it, a load that bypasses the CU's L1 (sc1) is served from it, an atomic without sc1 executes in it.  A team of 16
+// workgroups on one XCD gets through "publish 512 B, barrier, read everybody's slice" in ~1.05 us, against 1.7 us with agent-scope operations
+// over the fabric and ~3 us for a launch boundary + cold loads.
+//
+// So: grid = 128 workgroups for B = 32; block b belongs to team b % 8 (= its XCD) and owns column group (b / 8) % 16; a team owns FOUR
+// utterances (the newest row of each) and all 16 column groups, i.e. everything a layer's layer-norm needs.  Per layer a workgroup contracts
+// K = 256 for its (gate, info) pair of 16-column tiles over 8 waves (chain3_kernel's arithmetic: 16x16x4 fp32 MFMA, fixed-order LDS reduction,
+// partial layer-norm statistics per column group), publishes 4 x 32 pre-norm values + statistics with plain stores, arrives at the team's
+// barrier (an L2 atomic), and reads the other 15 slices past its L1.  Everything that does not depend on the predecessor -- the next layer's
+// weights, presum, layer-norm parameters, a dilation-1 layer's history row -- is requested before the barrier.
+//
+// Placement is used for SPEED; CORRECTNESS does not rest on it: the only thing a workgroup ever trusts is its team's barrier word reaching the
+// count of 16 arrivals IN ITS OWN L2 -- which can only happen if all 16 atomics executed in that L2, i.e. if the whole team is on this XCD, and
+// then their plain stores are in this L2 as well.  (In a process with other launches in flight a launch does not start at XCD 0: block b runs
+// on XCD (b + k) % 8 for some k, which keeps blocks b, b + 8, b + 16 ... together; the team rule needs no more than that.)  If a team is ever
+// split, its barrier cannot complete: every spin is bounded, the error word is raised, dctts_decode_status reports the decode as invalid, and
+// the host stops using this kernel (dctts_api.hip: xgroup_ok) in favour of one launch per layer (chain3_kernel), which assumes nothing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "decode3_kernels.h"
+
+namespace dctts {
+
+struct XGroupLayer {
+  const float* wp;                       // [tile][16 or 32 k-groups][lane][4]
+  const float* presum; int presum_bs;    // bias + older taps of row b at presum + b * presum_bs
+  const float* g1; const float* b1; const float* g2; const float* b2;   // THIS layer's H1 / H2 layer-norm parameters (used by the next layer's rebuild)
+  float* xm; int xm_bs;                  // this layer's INPUT row is kept at xm + b * xm_bs (history / residual for later launches); nullptr = not kept
+  const float* xt; int xt_bs;            // tap2: the input history row one time step back
+  int tap2; int pad_;
+};
+struct XGroupParams {
+  int B, L;
+  const float* P0; int p0_bs; const float* stats0;     // the pre-group producer's pre-norm rows (256 channels, a C layer without activation) + statistics
+  const float* pg1; const float* pb1;                   // its layer-norm parameters
+  XGroupLayer lay[10];
+  float* pout; float* stats_out;                        // the LAST layer's pre-norm rows [b][512] and statistics [b][16][4]
+  float* xch; float* sch;                               // exchange buffers: [2][B_pad][512] pre-norm rows, [2][B_pad][16][4] statistics
+  int xch_set, sch_set;                                 // floats between the two parity copies
+  unsigned* bar; unsigned bar_base;                     // team barriers: bar[team * 32] counts arrivals since the decode started; value before this launch
+  int* err;                                             // error word: bit 0 = a bounded wait gave up (a split team, or the side stream never arrived)
+  unsigned* sig; unsigned sig_val;                      // first launch of a chain piece: *sig = sig_val ("every earlier piece of this stream is complete")
+  const unsigned* wait2; unsigned wait_val;             // first launch of a chain piece: the presums come from the side stream: poll *wait2 >= wait_val first
+};
+
+__device__ __forceinline__ unsigned xg_xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 0xfu;
+}
+
+// grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads
+__global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) {
+  __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
+  __shared__ int s_go;
+  typedef const __attribute__((address_space(4))) XGroupParams CP;
+  CP& p = *(CP*)pp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
+  const int grp = bq & 15, team = bx + 8 * (bq >> 4), m0 = team * 4;
+  if (m0 >= p.B) return;                                                   // a team without utterances (B not a multiple of 32): uniform per workgroup
+  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+  const int b = m0 + arow;
+  const bool valid = arow < 4 && b < p.B;
+  const unsigned bb = valid ? (unsigned)b : 0u;
+  const int erow = aq * 4 + (wave & 3), etile = wave >> 2, ecol = lane & 15;
+  const int eb = m0 + erow;
+  const bool wr = erow < 4 && eb < p.B;
+  const int pcol = etile * 256 + grp * 16 + ecol;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned* const bar = p.bar + team * 32;
+
+  // ---- layer 0: everything that does not come from the side stream by plain loads (the producer is an earlier launch)
+  f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2] = {z4, z4}, vg1[2] = {z4, z4}, vbe1[2] = {z4, z4}, vst[4] = {z4, z4, z4, z4};
+  {
+    const bool t2 = p.lay[0].tap2 != 0;
+    const unsigned nkg = t2 ? 32u : 16u, kc = t2 ? 16u : 0u;
+    const float* wb = p.lay[0].wp + lane * 4;
+    const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
+    if (t2) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { vtb0[e] = z4; vtb1[e] = z4; }
+    }
+    if (valid) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
+        va[e] = ldv(p.P0, bb * (unsigned)p.p0_bs + ch);
+        vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
+        if (t2) vta[e] = ldv(p.lay[0].xt, bb * (unsigned)p.lay[0].xt_bs + ch);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
+    }
+  }
+  // ---- placement check, the stream signal, and the wait for the side stream (first launch of a chain piece), while those loads are in flight
+  if (tid == 0) {
+    int go = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
+    if (p.sig && blockIdx.x == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.wait2 && go) {
+      bool ok = false;
+      for (int i = 0; i < (1 << 20) && !ok; ++i) {                         // bounded: about a second
+        ok = __hip_atomic_load(p.wait2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+        if (!ok) __builtin_amdgcn_s_sleep(16);                              // 128 pollers over the fabric: ~0.4 us apart is plenty, and spares the side stream's bandwidth
+      }
+      if (!ok) atomicOr(p.err, 1);
+    }
+    s_go = go;
+  }
+  __syncthreads();
+  const bool team_ok = s_go != 0;                                          // a misplaced workgroup still arrives at every barrier (its team-mates time out), but skips the waits
+  float addv = 0.f;
+  if (wr) {                                                                // presum of layer 0: written by the side stream -> read past the L1 / a possibly stale line
+    const float* ap = p.lay[0].presum + (unsigned)(eb * p.lay[0].presum_bs) + (unsigned)pcol;
+    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(addv) : "v"(ap) : "memory");
+  }
+  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+  float4 x[2];                            // the current layer's input row fragments (also the next rebuild's highway residual)
+  {
+    float4 st[4] = {f4(vst[0]), f4(vst[1]), f4(vst[2]), f4(vst[3])};
+    float m1, r1;
+    combine_stats(st, 0, m1, r1);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const f32x4 h = va[e], g = vg1[e], be = vbe1[e];
+      x[e] = make_float4((h[0] - m1) * r1 * g[0] + be[0], (h[1] - m1) * r1 * g[1] + be[1], (h[2] - m1) * r1 * g[2] + be[2], (h[3] - m1) * r1 * g[3] + be[3]);
+      if (!valid) x[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+
+  for (int g = 0; g < p.L; ++g) {
+    const bool last = (g + 1 == p.L);
+    const bool t2 = p.lay[g].tap2 != 0;
+    // ---- contraction of layer g
+    f32x4 acc0 = z4, acc1 = z4;
+    if (t2) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4 a = valid ? vta[e] : z4, b0 = vtb0[e], b1 = vtb1[e];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[i], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[i], acc1, 0, 0, 0); }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float4 a = x[e]; const f32x4 b0 = vb0[e], b1 = vb1[e];
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[0], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[2], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[3], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+    // ---- requests that do not depend on the other workgroups: the next layer's weights / presum / history row, this layer's LN parameters
+    f32x4 ng1[2] = {z4, z4}, nb1[2] = {z4, z4}, ng2[2] = {z4, z4}, nb2[2] = {z4, z4};
+    float naddv = 0.f;
+    if (!last) {
+      const bool nt2 = p.lay[g + 1].tap2 != 0;
+      const unsigned nkg = nt2 ? 32u : 16u, kc = nt2 ? 16u : 0u;
+      const float* wb = p.lay[g + 1].wp + lane * 4;
+      const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
+      if (nt2) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+      }
+      if (valid) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
+          ng1[e] = ldv(p.lay[g].g1, ch); nb1[e] = ldv(p.lay[g].b1, ch); ng2[e] = ldv(p.lay[g].g2, ch); nb2[e] = ldv(p.lay[g].b2, ch);
+          if (nt2) vta[e] = ldv(p.lay[g + 1].xt, bb * (unsigned)p.lay[g + 1].xt_bs + ch);
+        }
+      }
+      if (wr) naddv = p.lay[g + 1].presum[(unsigned)(eb * p.lay[g + 1].presum_bs) + (unsigned)pcol];      // behind the wait for the side stream; never read before in this launch
+    }
+    // this layer's input row is kept for later launches (history / residual): column group 0 stores it
+    if (p.lay[g].xm && grp == 0 && valid) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(p.lay[g].xm + (long)b * p.lay[g].xm_bs + (8 * e + wave) * 16 + c4) = x[e];
+    }
+    __syncthreads();
+    float v_ = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + etile) * 4 + (wave & 3)) * 64 + lane];
+    v_ += addv;
+    const float mg = row16_sum(v_) * (1.0f / 16.0f);
+    const float dv = v_ - mg;
+    const float m2g = row16_sum(dv * dv);
+    if (last) {
+      if (wr) p.pout[(long)eb * 512 + pcol] = v_;
+      if (wr && ecol == 0) { float* so = p.stats_out + ((long)eb * 16 + grp) * 4 + etile * 2; so[0] = mg; so[1] = m2g; }
+      break;
+    }
+    // ---- publish this workgroup's slice of layer g with PLAIN stores (they stay in this XCD's L2), then arrive at the team's barrier
+    const int par = g & 1;
+    if (wr) {
+      p.xch[(long)par * p.xch_set + (long)eb * 512 + pcol] = v_;
+      if (ecol == 0) { float* so = p.sch + (long)par * p.sch_set + ((long)eb * 16 + grp) * 4 + etile * 2; so[0] = mg; so[1] = m2g; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the stores are in the L2 (and the prefetches have landed)
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        // no sc1: executes in the XCD's L2
+      const unsigned target = p.bar_base + (unsigned)(g + 1) * 16u;
+      if (team_ok) {
+        int spins = 0;
+        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // sc1 load: past the L1, served by the L2
+          if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { atomicOr(p.err, 1); break; }   // bounded (~20 ms), and nobody keeps waiting once anybody gave up
+        }
+      }
+    }
+    __syncthreads();
+    // ---- the team's rows of layer g, past the L1
+    f32x4 h1[2], h2[2], st4[4];
+    {
+      const float* xr = p.xch + (long)par * p.xch_set + (long)bb * 512 + wave * 16 + c4;     // channels 16 w + c4; +128 floats = the second k-group
+      const float* sr = p.sch + (long)par * p.sch_set + (long)bb * 64 + aq * 16;
+      asm volatile(
+          "global_load_dwordx4 %0, %8, off sc1\n\t"
+          "global_load_dwordx4 %1, %8, off offset:512 sc1\n\t"
+          "global_load_dwordx4 %2, %8, off offset:1024 sc1\n\t"
+          "global_load_dwordx4 %3, %8, off offset:1536 sc1\n\t"
+          "global_load_dwordx4 %4, %9, off sc1\n\t"
+          "global_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
+          "global_load_dwordx4 %6, %9, off offset:32 sc1\n\t"
+          "global_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(h1[0]), "=&v"(h1[1]), "=&v"(h2[0]), "=&v"(h2[1]), "=&v"(st4[0]), "=&v"(st4[1]), "=&v"(st4[2]), "=&v"(st4[3])
+          : "v"(xr), "v"(sr)
+          : "memory");
+      if (!valid) { h1[0] = h1[1] = h2[0] = h2[1] = z4; st4[0] = st4[1] = st4[2] = st4[3] = z4; }
+    }
+    // ---- rebuild the next layer's input: gate(LN(exchanged rows)) mixed with this layer's input (the highway residual, still in registers)
+    {
+      float4 st[4] = {f4(st4[0]), f4(st4[1]), f4(st4[2]), f4(st4[3])};
+      float m1, r1, m2, r2;
+      combine_stats(st, 0, m1, r1); combine_stats(st, 1, m2, r2);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4 a1 = h1[e], a2 = h2[e], g1 = ng1[e], b1 = nb1[e], g2 = ng2[e], b2 = nb2[e];
+        const float4 xr = x[e];
+        float4 o;
+        { const float s_ = sigmoid_fast((a1[0] - m1) * r1 * g1[0] + b1[0]); o.x = s_ * ((a2[0] - m2) * r2 * g2[0] + b2[0]) + (1.0f - s_) * xr.x; }
+        { const float s_ = sigmoid_fast((a1[1] - m1) * r1 * g1[1] + b1[1]); o.y = s_ * ((a2[1] - m2) * r2 * g2[1] + b2[1]) + (1.0f - s_) * xr.y; }
+        { const float s_ = sigmoid_fast((a1[2] - m1) * r1 * g1[2] + b1[2]); o.z = s_ * ((a2[2] - m2) * r2 * g2[2] + b2[2]) + (1.0f - s_) * xr.z; }
+        { const float s_ = sigmoid_fast((a1[3] - m1) * r1 * g1[3] + b1[3]); o.w = s_ * ((a2[3] - m2) * r2 * g2[3] + b2[3]) + (1.0f - s_) * xr.w; }
+        x[e] = valid ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    addv = naddv;
+  }
+}
+
+}  // namespace dctts

@@ -39,7 +39,7 @@ class Engine:
     """Owns the device-resident packed weights and workspaces for one GPU."""
 
     def __init__(self, weights: Dict[str, np.ndarray], hp: Hyperparams = _hp, device: Optional[int] = None,
-                 decode_graph: bool = True):
+                 decode_graph: bool = False):
         if not torch.cuda.is_available():
             raise DcttsError("dc_tts_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()

@@ -30,11 +30,17 @@ int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream)
  * kernel while enabled; collect() synchronises those events, returns the number of launches and their summed duration,
  * and clears the list.  kernel_id:
  *   epi*10000 + NT*100 + NW   every launch of hconv_kernel<epi, NT, NW> (epi 0 = C, 1 = HC), e.g. 10808 = SSRN HC_11 / HC_12;
- *   DCTTS_PROF_CHAIN_HC       the decode's time-dominant kernel, chain3_kernel<LN_HC, HC> (newest-row highway layers), on every
- *                             16th frame only (events around every 5 us launch would change what they measure); eager chain only;
- *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (cone GEMMs of the decode's side stream); eager decode only (graph mode 0). */
+ *   50000 + epi*10000 + NT*100 + NW   the 16-row tail launches hconv16_kernel<epi, NT, NW> of the layers that are split by rows, e.g. 61608 = HC_11 / HC_12's tail;
+ *   DCTTS_PROF_XGROUP         xgroup_kernel (a run of newest-row highway layers of the decode chain as one launch), on every 16th frame only;
+ *                             prof_rows then counts LAYERS (6 for the AudioDec run, 10 for the AudioEnc run);
+ *   DCTTS_PROF_XCONE          xcone_kernel (the tail of AudioDec's cone on the side stream), frames >= 100, every 16th; eager decode only (graph mode 0);
+ *   DCTTS_PROF_CHAIN_HC       chain3_kernel<LN_HC, HC> (one newest-row highway layer per launch: the form used when DCTTS_XGROUP=0), every 16th frame;
+ *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (the cone GEMM of HC_3 when DCTTS_XCONE=0); eager decode only.  Enabling either of the last two
+ *                             switches the corresponding team kernel off for the decodes that follow. */
 #define DCTTS_PROF_CHAIN_HC 30000
 #define DCTTS_PROF_BULK_GEMM 30001
+#define DCTTS_PROF_XGROUP 30002
+#define DCTTS_PROF_XCONE 30003
 int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);
 int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
 /* Output rows those launches covered, summed since the last prof_enable (a layer's rows may be split between the

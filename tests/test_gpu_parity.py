@@ -566,3 +566,25 @@ def test_two_ranks_share_gpu_gather_equals_single_process(weights, tmp_path):
     np.testing.assert_array_equal(g["traj"], mx.cpu().numpy())
     np.testing.assert_array_equal(g["Y"], Y.cpu().numpy())
     assert maxabs(g["Z"], Z.cpu().numpy()) < 1e-5
+
+
+def test_bench_two_ranks_through_torch_distributed_run():
+    """The driver's multi-GPU launch line on the one GPU of the test box: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
+    (gloo, both ranks on cuda:0).  Rank 0's untimed extras run while rank 1 sits in dist.barrier(): nothing may time out; ONE JSON line with
+    n_gpus = 2, weak scaling, the whole-job value, the gather, the roofline object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--batch", "8", "--max-T", "24", "--no-cpu-baseline", "--no-vocoder", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["steps"] == 2 and out["dtype"] == "f32"
+    assert abs(out["value"] - 2 * 8 * 24 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3         # whole-job frames over the max-over-ranks time
+    assert out["gather"]["bytes_per_rank"] == 8 * 96 * 1025 * 4 and "roofline" in out and out["config"]["sharding"].startswith("2 x 8")

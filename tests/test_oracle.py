@@ -232,3 +232,20 @@ def test_golden_config1_loop(weights):
     Y, Z, traj = O.synthesize(g["L"], weights, h, np.float32, run_ssrn=False)
     np.testing.assert_array_equal(traj, g["traj"])
     np.testing.assert_allclose(Y, g["Y"], atol=5e-5)
+
+
+def test_torch_restatement_matches_the_numpy_oracle():
+    """oracle/torch_ref.py (what bench.py's cpu_baseline leg times on all host cores) is the same arithmetic as the
+    numpy oracle: a few steps of the full-graph loop and one SSRN pass agree to fp32 re-association, trajectory integer-exact."""
+    import numpy as np
+    from dc_tts_amd.hyperparams import hp
+    from dc_tts_amd.weights import synthetic_text, synthetic_weights
+    from oracle import dctts_ref as O
+    from oracle import torch_ref as TR
+    h = hp.replace(max_T=6)
+    W = synthetic_weights(h, seed=1234, perturb=True)
+    L = synthetic_text(h, B=2, seed=3)
+    Yn, Zn, tn = O.synthesize(L, W, h, np.float32)
+    Yt, Zt, tt = TR.synthesize(L, W, h)
+    np.testing.assert_array_equal(tn, tt)
+    assert np.abs(Yn - Yt).max() < 2e-5 and np.abs(Zn - Zt).max() < 2e-4

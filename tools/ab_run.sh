@@ -1,17 +1,6 @@
-# A/B of two builds of the library (dc_tts_amd/lib/libdctts_hip_base.so = the build before a change, libdctts_hip.so = the current one):
-# parity tests of the current build, SSRN / TextEnc phase times of both, per-launch tables of both.
 set -u
-R=$PWD; OUT=$R/gpurun_out/ab; mkdir -p $OUT
-timeout 300 python -m pytest tests/test_gpu_parity.py -q -x  > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
-for rep in 1 2; do
-for lib in base new; do
-  if [ $lib = base ]; then export DCTTS_AB_LIB=$R/dc_tts_amd/lib/libdctts_hip_base.so; else unset DCTTS_AB_LIB; fi
-  echo "== $lib"; timeout 100 python tools/ssrn_time.py 32 128 2>&1 | grep "B="
-done; done | tee $OUT/ab.txt
-cd /tmp; export TMPDIR=/tmp
-for lib in base new; do
-  if [ $lib = base ]; then export DCTTS_AB_LIB=$R/dc_tts_amd/lib/libdctts_hip_base.so; else unset DCTTS_AB_LIB; fi
-  timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT/layers_$lib -- python $R/tools/layer_trace.py > $OUT/layers_$lib.log 2>&1
-  python $R/tools/layer_trace_table.py $OUT/layers_$lib > $OUT/layers_$lib.txt
-done
-paste $OUT/layers_base.txt $OUT/layers_new.txt | cut -c1-60,100-160 | awk 'NR>1'
+R=$PWD; OUT=$R/gpurun_out/xg; mkdir -p $OUT
+timeout 400 python -m pytest tests/test_gpu_parity.py -q -x -k "decode_vs_oracle or end_of_text or golden" > $OUT/pytest.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest.log; tail -3 $OUT/pytest.log
+for rep in 1 2; do echo "== xgroup+xcone GM=0"; GM=0 timeout 100 python tools/decode_time.py 2>&1 | grep -E "text2mel|rror"; done | tee $OUT/ab3.txt
+GM=0 DCTTS_PIECETIME=100 timeout 100 python tools/decode_time.py 2>&1 | grep -E "frame 10[2-4]" | tee -a $OUT/ab3.txt
+GM=0 bash tools/decode_probe.sh 2>&1 | head -12 | tee -a $OUT/ab3.txt

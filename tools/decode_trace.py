@@ -4,6 +4,8 @@ import sys, os, torch
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 out = os.environ.setdefault('DCTTS_TRACE_FILE', 'gpurun_out/decode_trace.txt')
 os.environ.setdefault('DCTTS_TRACE', '150')
+import dc_tts_amd._lib as _L0
+if os.environ.get("DCTTS_AB_LIB"): _L0.LIB_PATH = os.environ["DCTTS_AB_LIB"]
 from dc_tts_amd.engine import Engine
 from dc_tts_amd.hyperparams import hp
 from dc_tts_amd.weights import synthetic_weights, synthetic_text
