@@ -1106,10 +1106,14 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
 }
 
 // AudioEnc presums for row f (into parity copy f & 1): bias + the taps that are final a whole chain piece before row f is computed
-static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st) {
+// part 0: everything; 1: AudioEnc's presums only (the first aepre_layers - 3 descriptors); 2: the three C1QW descriptors only
+static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st, int part = 0) {
   const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
   const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * c->aepre_layers;
-  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(c->aepre_layers * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f);
+  int n = c->aepre_layers;
+  if (part == 1) n -= 3;
+  if (part == 2) { tab += c->aepre_layers - 3; n = 3; }
+  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(n * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1132,7 +1136,8 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
   const int par = f & 1;
   // one grouped launch: AudioEnc presums of row f+1 (consumed by chain piece f; inputs are rows <= f-1) and the newest row (f-1) of
   // the C1Q . diag(gamma1) W2 cache that rowhc2_kernel reads below
-  CHK(v3_aepre(c, B, f + 1, sb));
+  // (with the team kernels the side stream is the longer one: AudioEnc's presums then run on the chain's stream, in front of the piece that uses them)
+  CHK(v3_aepre(c, B, f + 1, sb, c->xc_on ? 2 : 0));
   if (c->cone_len[0] > 1) {
     RowC1Params q; memset(&q, 0, sizeof(q));
     q.B = B; q.R = c->cone_len[0] - 1; q.offs = c->cone3_dev[0]; q.frame = f;
@@ -1597,6 +1602,9 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   auto chain_piece = [&](int j, hipStream_t s) -> int {      // j = -1: AudioEnc / attention / AudioDec C_1 of frame 0 only
     c->sig_next = (insig && j >= 0) ? (unsigned)(j + 1) : 0u;          // written by the piece's first launch (AudioDec HC_2)
     c->wait2_next = (cwait && j >= 0) ? (unsigned)(j + 1) : 0u;        // ... which also waits for bulk piece j
+    // AudioEnc's presums of row j+1 (inputs: rows <= j-1, final since piece j-2): when the side stream is the longer one they run here, while this
+    // piece would otherwise wait for it, instead of in front of the cone work
+    if (j >= 0 && c->xc_on && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, 1));
     if (j >= 0) { CHK(v3_chain_dec(c, w, B, j, s)); CHK(v3_mlp_launch(c, B, j, s)); }   // AudioDec HC_2 .. HC_7; C_8 .. C_11, mel frame j, AudioEnc C_1 .. C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
     return 0;

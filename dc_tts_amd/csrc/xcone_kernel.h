@@ -57,7 +57,7 @@ __device__ __forceinline__ bool xcone_barrier(unsigned* bar, unsigned target, in
 
 // grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads
 __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restrict__ pp) {
-  __shared__ __attribute__((aligned(16))) float red[2][8 * 2 * 4 * 64];      // split-K partial sums, double-buffered: one barrier per row tile
+  __shared__ __attribute__((aligned(16))) float red[2][2 * 8 * 2 * 4 * 64];  // split-K partial sums of two row tiles, double-buffered: one barrier per pass
   __shared__ int s_go;
   __shared__ int s_xoff[256];            // per local row m of the team (M <= 4 * 64): element offset of its input row t in xin, -1 = the row does not exist (t < 0)
   __shared__ int s_prow[256];            // ... its pre-norm row index in pout
@@ -80,14 +80,15 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 60) p.ts[nts++] = wall_clock64(); };
   stamp();
 
-  // this workgroup's slice of a layer's weights: wave w owns k-groups w, w + 8, ... (tap i >> 1, channels 128 (i & 1) + 16 w), two tiles.  The
-  // next layer's slice is requested at the start of this layer's contraction (it depends on nothing), so only the first one is waited for cold.
-  f32x4 bq0[6], bq1[6], nq0[6], nq1[6];
+  // this workgroup's slice of a layer's weights, two column tiles.  Wave w owns the SIX CONSECUTIVE k-groups 6 w .. 6 w + 5 (k = 96 w .. 96 w + 95 of
+  // the 768 = 3 taps x 256 channels), not w, w + 8, ...: its six A requests per row then cover 384 contiguous bytes = three whole 128-byte
+  // lines.  (With one 64-byte piece per row and request, in-kernel stamps showed a pass's 96 KB of rows taking ~4 us to land: ~25 GB/s per CU.)
+  f32x4 bq0[6], bq1[6];
   auto load_w = [&](int layer, f32x4 (&q0)[6], f32x4 (&q1)[6]) {
     const float* wb = p.lay[layer].wp + lane * 4;
     const unsigned w0 = (unsigned)(grp * 2) * 48u * 256u, w1 = w0 + 48u * 256u;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { q0[i] = ldv(wb, w0 + (unsigned)(wave + 8 * i) * 256u); q1[i] = ldv(wb, w1 + (unsigned)(wave + 8 * i) * 256u); }
+    for (int i = 0; i < 6; ++i) { q0[i] = ldv(wb, w0 + (unsigned)(6 * wave + i) * 256u); q1[i] = ldv(wb, w1 + (unsigned)(6 * wave + i) * 256u); }
   };
   load_w(0, bq0, bq1);
   for (int li = 0; li < p.L; ++li) {
@@ -109,50 +110,73 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       s_xoff[tid] = xo; s_prow[tid] = pr;
     }
     __syncthreads();
-    auto load_a = [&](int tile, f32x4 (&a)[6]) {
+    // A fragments of a row tile, RAW: lane (arow, aq) requests row tile * 16 + arow, channels c .. c + 3 of k-group (wave, i).  Rows that do
+    // not exist / a presum row's centre tap must read as zero: the request goes to a readable address and `fix_a` zeroes the registers --
+    // LATER, where the values are consumed: a select right behind a load is a use, and the wait for it would sit in front of the MFMAs
+    // the load is supposed to hide behind (first version: vmcnt(5) .. vmcnt(0) right after the six requests, 2.7 us per tile instead of 1.3).
+    auto load_a = [&](int tile, f32x4 (&a)[6], int& flags) {
       const int m = tile * 16 + arow;
-      const int xo = s_xoff[m < 256 ? m : 255];
+      const int mi = m < 256 ? m : 255;
+      const int xo = s_xoff[mi];
       const bool ok = m < M && xo >= 0;
-      const bool pre = (s_prow[m < 256 ? m : 255] >> 30) & 1;
-      const float* xrow = xin + (ok ? xo : 0) + 16 * wave + c4;
+      flags = (ok ? 1 : 0) | (((s_prow[mi] >> 30) & 1) ? 2 : 0);
+      const float* xrow = xin + (ok ? xo : 0) + c4;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const int tap = i >> 1;
+        const int g = 6 * wave + i, tap = g >> 4;                              // wave-uniform
         const int toff = (tap == 0) ? to0 : ((tap == 1) ? to1 : 0);
-        a[i] = *reinterpret_cast<const f32x4*>(xrow + toff + 128 * (i & 1));
-        if (!ok || (pre && tap == 2)) a[i] = z4;
+        a[i] = *reinterpret_cast<const f32x4*>(xrow + toff + 16 * (g & 15));
       }
     };
-    stamp();                                                                   // row tables done
-    f32x4 a[6], an[6];
-    load_a(0, a);
-    if (li + 1 < p.L) load_w(li + 1, nq0, nq1);                               // lands while this layer's tiles are contracted
-    for (int tile = 0; tile < ntile; ++tile) {
-      if (tile + 1 < ntile) load_a(tile + 1, an);                             // the next tile's rows are in flight during this tile's MFMAs
-      f32x4 acc0 = z4, acc1 = z4;
+    auto fix_a = [&](f32x4 (&a)[6], const f32x4 (&raw)[6], int flags) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) a[i] = (!(flags & 1) || ((flags & 2) && ((6 * wave + i) >> 4) == 2)) ? z4 : raw[i];
+    };
+    // Two row tiles per pass: their 96 MFMAs per wave go back to back, then ONE barrier and one fixed-order reduction for both (in-kernel stamps:
+    // with one tile per pass a tile cost 2.9 us, 1.3 of them MFMA; the rest -- LDS round trip, barrier, address set-up -- is paid per pass).
+    f32x4 a0[6], a1[6], n0[6], n1[6];
+    int f0 = 0, f1 = 0;
+    load_a(0, n0, f0); fix_a(a0, n0, f0);
+    if (ntile > 1) { load_a(1, n1, f1); fix_a(a1, n1, f1); }
+    for (int tile = 0; tile < ntile; tile += 2) {
+      const bool two = tile + 1 < ntile;                                      // uniform
+      if (tile + 2 < ntile) load_a(tile + 2, n0, f0);                         // the next pass's rows are in flight during this pass's MFMAs
+      if (tile + 3 < ntile) load_a(tile + 3, n1, f1);
+      f32x4 acc0 = z4, acc1 = z4, acc2 = z4, acc3 = z4;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bq0[i][e], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bq1[i][e], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq0[i][e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq1[i][e], acc1, 0, 0, 0);
         }
       }
-      float* rb = red[tile & 1];
+      if (two) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { rb[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; rb[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
-      lds_barrier();                                                           // LDS only: the next tile's loads keep flying
-      float v_ = bias;
+        for (int i = 0; i < 6; ++i) {
 #pragma unroll
-      for (int w = 0; w < 8; ++w) v_ += rb[((w * 2 + etile) * 4 + ej) * 64 + lane];
+          for (int e = 0; e < 4; ++e) {
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bq0[i][e], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bq1[i][e], acc3, 0, 0, 0);
+          }
+        }
+      }
+      float* rb = red[(tile >> 1) & 1];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        rb[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; rb[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j];
+        rb[4096 + ((wave * 2 + 0) * 4 + j) * 64 + lane] = acc2[j]; rb[4096 + ((wave * 2 + 1) * 4 + j) * 64 + lane] = acc3[j];
+      }
+      lds_barrier();                                                           // LDS only: the next pass's loads keep flying
+      float v0 = bias, v1 = bias;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { v0 += rb[((w * 2 + etile) * 4 + ej) * 64 + lane]; v1 += rb[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
       {
-        const int me = tile * 16 + aq * 4 + ej;                               // the row this thread finishes
-        if (me < M && s_xoff[me] >= 0) pout[(long)(s_prow[me] & 0x3fffffff) * 512 + pcol] = v_;
+        const int me = tile * 16 + aq * 4 + ej;                               // the rows this thread finishes
+        if (me < M && s_xoff[me] >= 0) pout[(long)(s_prow[me] & 0x3fffffff) * 512 + pcol] = v0;
+        if (two && me + 16 < M && s_xoff[me + 16] >= 0) pout[(long)(s_prow[me + 16] & 0x3fffffff) * 512 + pcol] = v1;
       }
-      if (tile + 1 < ntile) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a[i] = an[i];
-      }
+      fix_a(a0, n0, f0); fix_a(a1, n1, f1);
     }
     // ---- the team's pre-norm rows of this layer are complete
     stamp();                                                                   // contraction done
@@ -160,6 +184,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     xcone_barrier(bar, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
     if (li + 1 == p.L) break;                                                  // the last layer only leaves its presum rows
+    load_w(li + 1, bq0, bq1);                                                  // the next layer's slice lands while this layer's rows are normalised
     // ---- layer-norm / gate / highway mix of the cone rows (offsets < 0): one wave per row, the team's 128 waves in turn
     const int Rb = R - 1;
     if (Rb > 0) {
@@ -185,8 +210,6 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     arrived += 16u;
     xcone_barrier(bar, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { bq0[i] = nq0[i]; bq1[i] = nq1[i]; }
   }
 }
 
