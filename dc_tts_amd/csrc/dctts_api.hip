@@ -139,6 +139,7 @@ struct dctts_ctx {
   void* mlp_tab = nullptr; std::string mlp_geom;
   // runs of chain highway layers as one launch whose workgroups meet inside one XCD (xgroup_kernel.h); DCTTS_XGROUP=0: one launch per layer
   int xgroup = 1;
+  bool c1qw_chain = false;             // the C1Q . W2 row rides in the chain's AudioEnc presum launch (decode_v3)
   bool xg_on = false, xc_on = false;   // this decode uses them
   bool xgroup_ok = true;               // cleared for good when a decode reports that the placement assumption (block b on XCD b % 8) does not hold here
   void* xg_tab = nullptr; std::string xg_geom;   // per chain piece: [T + 1][2] XGroupParams (AudioDec run of frame j, AudioEnc run of frame j + 1)
@@ -152,11 +153,12 @@ struct dctts_ctx {
   int sync_values = 1;                 // the two streams meet through stream memory operations (hipStreamWriteValue32 / WaitValue32 on two counters) instead of events
                                        // (DCTTS_SYNC_VALUES=0; rocprofv3 --pmc needs events: read_env)
   uint32_t* ctr_chain = nullptr; uint32_t* ctr_bulk = nullptr;   // signal memory: chain pieces done + 1, bulk pieces done
+  unsigned* sig_ptr = nullptr;         // ... the counter itself: signal memory (stream wait operations on the side stream) or wait_ctr[0] (the side stream polls in-kernel)
   unsigned sig_next = 0;               // value the next run_chain3 launch writes to the chain's counter (0 = none)
   int chain_wait_inkernel = 1;         // the chain's wait for the bulk's counter happens inside the piece's first launch (sc1 read of the one operand the bulk
                                        // produced for it) instead of a wait-value operation in front of it (DCTTS_CHAIN_WAIT=0)
   unsigned wait2_next = 0;             // counter value the next run_chain3 launch waits for (0 = none)
-  unsigned* wait_ctr = nullptr;        // device memory: [32] bulk pieces complete (written by the bulk's write-value operation, polled in-kernel), [64] error word
+  unsigned* wait_ctr = nullptr;        // device memory, polled in-kernel: [0] chain pieces done + 1, [32] bulk pieces complete (written by xcone_kernel's last team, or a write-value operation), [64] error word
   int* wait_err_host = nullptr;        // pinned copy of the error word, refreshed after every decode (dctts_decode_status)
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
@@ -1065,8 +1067,8 @@ static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
 // bulk piece f (f = 0 .. T-1), side stream, after chain piece f-2, overlapping chain piece f-1:
 //     AudioEnc presums for row f (one grouped launch) | C_1 cone rows (rowc1_kernel) | per k=3 AudioDec layer: cone rows + the
 //     presum row of frame f in one GEMM, then LN / gate of the cone rows.
-static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
-  const std::string g = std::to_string(B) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p);
+static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahead) {
+  const std::string g = std::to_string(B) + ":" + std::to_string((int)c1qw_ahead) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p);
   if (c->aepre_tab && c->aepre_geom == g) return 0;
   std::vector<SplitParams> tab;
   const std::vector<DevLayer>& AP = c->ae_p;
@@ -1092,6 +1094,7 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
           h.ntaps = 2; h.tap_off[0] = h.tap_off[1] = -2; h.cin = H.cin; h.cin_p = H.cin_p;
           h.wp = H.wp; h.bias = H.bias; h.cout = H.cout; h.hc = 1; h.np_out = 6 * H.cout; h.pout = w.c1qw.p + (long)q * 2 * H.cout;
           h.abs_bstride = w.c1qw.bstride; h.abs_row0 = w.c1qw.row0; h.abs_toff = -2;
+          h.step_val = c1qw_ahead ? 1 : 0;       // launched from the chain's stream, one piece earlier (decode_v3): the row is the chain's newest C1Q row
           tab.push_back(h);
         }
       }
@@ -1107,13 +1110,14 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B) {
 
 // AudioEnc presums for row f (into parity copy f & 1): bias + the taps that are final a whole chain piece before row f is computed
 // part 0: everything; 1: AudioEnc's presums only (the first aepre_layers - 3 descriptors); 2: the three C1QW descriptors only
-static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st, int part = 0) {
+static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st, int part = 0, unsigned wait_val = 0) {
   const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
   const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * c->aepre_layers;
   int n = c->aepre_layers;
   if (part == 1) n -= 3;
   if (part == 2) { tab += c->aepre_layers - 3; n = 3; }
-  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(n * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f);
+  hipLaunchKernelGGL((hbulk_group_kernel<8>), dim3(n * ipl), dim3(512), hsplit_smem(32), st, tab, ipl, f,
+                     wait_val ? (const unsigned*)c->wait_ctr : nullptr, wait_val, (int*)(c->wait_ctr + 64));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1130,14 +1134,15 @@ static int v3_vw(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t st) 
   return 0;
 }
 
-static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, int f, hipStream_t sb) {
+static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, int f, hipStream_t sb, unsigned wait_val) {
   const int d = c->cfg.d;
   const std::vector<DevLayer>& AD = c->audiodec;
   const int par = f & 1;
   // one grouped launch: AudioEnc presums of row f+1 (consumed by chain piece f; inputs are rows <= f-1) and the newest row (f-1) of
   // the C1Q . diag(gamma1) W2 cache that rowhc2_kernel reads below
   // (with the team kernels the side stream is the longer one: AudioEnc's presums then run on the chain's stream, in front of the piece that uses them)
-  CHK(v3_aepre(c, B, f + 1, sb, c->xc_on ? 2 : 0));
+  // (wait_val != 0: the launch first polls the chain's counter for that value -- the piece's input row comes from the chain's stream)
+  if (!c->c1qw_chain) CHK(v3_aepre(c, B, f + 1, sb, c->xc_on ? 2 : 0, wait_val));
   if (c->cone_len[0] > 1) {
     RowC1Params q; memset(&q, 0, sizeof(q));
     q.B = B; q.R = c->cone_len[0] - 1; q.offs = c->cone3_dev[0]; q.frame = f;
@@ -1170,7 +1175,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     HIPCHK(hipGetLastError());
     first_gemm = 2;
   }
-  if (c->xc_on && first_gemm == 2) {                                        // HC_3 .. HC_7 and their row passes: one launch, teams inside one XCD (xcone_kernel.h)
+  if (c->xc_on) {                                        // HC_3 .. HC_7 and their row passes: one launch, teams inside one XCD (xcone_kernel.h)
     const XConeParams* xp = (const XConeParams*)c->xc_tab + f;
     const bool prof = c->prof_id == DCTTS_PROF_XCONE && f >= 100 && (f & 15) == 8;          // full-size cones only; eager decode only (graph mode 0)
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1238,7 +1243,7 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
   if (ex && ex->presum) { p.add = ex->presum; p.add_bs = ex->presum_rstride; }
   if (ex && ex->raw) { p.raw = row(*ex->raw); p.raw_bs = (int)(ex->raw->bstride * ex->raw->stride); }
   p.pout = pout; p.np_out = L.hc ? 2 * L.cout : L.cout; p.stats_out = stats_out; p.cout = L.cout;
-  if (c->sig_next) { p.sig = c->ctr_chain; p.sig_val = c->sig_next; c->sig_next = 0; }
+  if (c->sig_next) { p.sig = c->sig_ptr; p.sig_val = c->sig_next; c->sig_next = 0; }
   if (c->wait2_next) {
     if (!(ex && ex->presum)) return fail(DCTTS_ERR_STATE, "chain3: the in-kernel wait guards a presum addend");
     p.wait2 = c->wait_ctr + 32; p.wait_val = c->wait2_next; p.gate_err = (int*)(c->wait_ctr + 64); c->wait2_next = 0;
@@ -1289,7 +1294,7 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
 // The team barriers count arrivals monotonically over the whole decode, so every launch is told the count it starts from.
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
-                        std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->ctr_chain) + ":" + std::to_string((size_t)c->wait_ctr);
+                        std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr);
   if (c->xg_tab && c->xg_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xg_tab) { (void)hipFree(c->xg_tab); c->xg_tab = nullptr; }
@@ -1335,7 +1340,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       p.bar = m.bar; p.bar_base = arrivals; p.err = m.err;
       arrivals += (unsigned)(L - 1) * 16u;
       if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
-        if (insig) { p.sig = c->ctr_chain; p.sig_val = (unsigned)(j + 1); }
+        if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
       }
       tab[(size_t)2 * (piece + 1) + net] = p;
@@ -1361,8 +1366,8 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
 }
 
 // ---- xcone_kernel plumbing: one XConeParams per frame in device memory (layers HC_3 .. HC_7 of AudioDec's cone, parity copies folded in)
-static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
-  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem);
+static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig) {
+  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr);
   if (c->xc_tab && c->xc_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xc_tab) { (void)hipFree(c->xc_tab); c->xc_tab = nullptr; }
@@ -1389,6 +1394,11 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
       for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = Ly.tap_off[t3];
     }
     p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(2 * L - 1) * 16u; p.err = m.err;
+    if (insig) {                                                // the launch's last team publishes "side-stream piece f complete" itself
+      p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)((B + 3) / 4);
+      p.sig = c->wait_ctr + 32; p.sig_val = (unsigned)(f + 1);
+      if (f + 1 < T) { p.wait = c->wait_ctr; p.wait_val = (unsigned)(f + 1); p.wait_err = (int*)(c->wait_ctr + 64); }      // what side-stream piece f + 1 starts from
+    }
     if (f == c->trace_frame) {                                  // DCTTS_TRACE: this frame's launch records its phase boundaries
       if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
       p.ts = c->trace_buf + 64 * 64 * 32 - 192;
@@ -1580,10 +1590,18 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     HIPCHK(hipMemset(c->wait_ctr + 64, 0, sizeof(int)));
     return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-kernel wait for the side stream timed out and its results were invalid (dctts_decode_status was not consulted)");
   }
-  CHK(v3_aepre_table(c, w, B));
   CHK(v3_mlp_table(c, w, B, T));
   c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->trace_frame < 0 && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (the trace / that timing id look at chain3_kernel launches)
-  c->xc_on = c->xcone != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_BULK_GEMM;
+  c->xc_on = c->xcone != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_BULK_GEMM &&
+             c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;      // (behind rowhc2_kernel)
+  // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's
+  // counter, and xcone_kernel's last team writes the side stream's
+  const bool bsig = cwait && c->xc_on;
+  // ... and the one small GEMM in front of the cone work (the newest row of the C1Q . W2 cache) rides in the chain's AudioEnc presum launch one piece
+  // earlier: its input is the chain's own newest row, and the counter the side stream waits for is written by the launch behind it
+  c->c1qw_chain = vs && c->xc_on;
+  CHK(v3_aepre_table(c, w, B, c->c1qw_chain));
+  c->sig_ptr = cwait ? c->wait_ctr : (unsigned*)c->ctr_chain;
   if (c->xg_on || c->xc_on) {
     if (c->xg_err_host && *c->xg_err_host) {
       // the previous decode's team hand-offs failed and nobody asked (dctts_decode_status): refuse once, and never use the kernel again if it was the placement
@@ -1591,7 +1609,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-launch hand-offs failed (xgroup_kernel) and its results were invalid (dctts_decode_status was not consulted)");
     }
     CHK(v3_xgroup_table(c, w, B, T, insig, cwait));            // (also allocates the memory both kernels meet through)
-    if (c->xc_on) CHK(v3_xcone_table(c, w, B, T));
+    if (c->xc_on) CHK(v3_xcone_table(c, w, B, T, bsig));
     const XgMem m = xg_mem(c, B);
     HIPCHK(hipMemsetAsync(m.bar, 0, (2 * m.bar_words + 64) * sizeof(unsigned), st));      // both sets of team barriers and the error word
   }
@@ -1604,13 +1622,13 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     c->wait2_next = (cwait && j >= 0) ? (unsigned)(j + 1) : 0u;        // ... which also waits for bulk piece j
     // AudioEnc's presums of row j+1 (inputs: rows <= j-1, final since piece j-2): when the side stream is the longer one they run here, while this
     // piece would otherwise wait for it, instead of in front of the cone work
-    if (j >= 0 && c->xc_on && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, 1));
+    if (j >= 0 && c->xc_on && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, c->c1qw_chain ? 0 : 1));
     if (j >= 0) { CHK(v3_chain_dec(c, w, B, j, s)); CHK(v3_mlp_launch(c, B, j, s)); }   // AudioDec HC_2 .. HC_7; C_8 .. C_11, mel frame j, AudioEnc C_1 .. C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
     return 0;
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((size_t)c->xc_tab) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((size_t)c->xc_tab) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
                           std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs(c);
@@ -1619,7 +1637,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       const int prof_keep = c->prof_id; c->prof_id = -1;
       c->bulk3_g.assign(T, nullptr);
       int rc = 0;
-      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, T, f, cs); });
+      for (int f = 0; f < T && rc == 0; ++f) rc = capture_piece(cs, &c->bulk3_g[f], [&]() { return v3_bulk_rest(c, w, B, N, T, f, cs, (cwait && f > 0) ? (unsigned)f : 0u); });
       c->prof_id = prof_keep;
       HIPCHK(hipStreamDestroy(cs));
       if (rc != 0) { destroy_graphs(c); return rc; }
@@ -1637,7 +1655,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
   const int tstep = c->trace_frame;
   auto bulk_piece = [&](int f) -> int {
-    if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, T, f, sb));
+    if (gr) HIPCHK(hipGraphLaunch(c->bulk3_g[f], sb)); else CHK(v3_bulk_rest(c, w, B, N, T, f, sb, (cwait && f > 0) ? (unsigned)f : 0u));
+    if (bsig) return 0;
     if (vs) HIPCHK(hipStreamWriteValue32(sb, cwait ? (void*)(c->wait_ctr + 32) : (void*)c->ctr_bulk, (uint32_t)(f + 1), 0)); else HIPCHK(hipEventRecord(c->ev_bulk[f & 3], sb));
     return 0;
   };
@@ -1652,7 +1671,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   for (int j = 0; j < T; ++j) {
     if (j + 1 < T) {
       // bulk piece j+1 needs attnq(j) / C1Q[j]: end of chain piece j-1
-      if (vs) HIPCHK(hipStreamWaitValue32(sb, c->ctr_chain, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));
+      if (cwait) {} else if (vs) HIPCHK(hipStreamWaitValue32(sb, c->ctr_chain, (uint32_t)(j + 1), hipStreamWaitValueGte, 0xFFFFFFFFu)); else HIPCHK(hipStreamWaitEvent(sb, c->ev_chain[(j - 1) & 3], 0));
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][0], sb));
       CHK(bulk_piece(j + 1));
       if (ptime(j + 1)) HIPCHK(hipEventRecord(pe_b[j + 1 - pt0][1], sb));

@@ -621,12 +621,28 @@ __global__ void __launch_bounds__(512) hbulk_kernel(const SplitParams p) {
 // grid = nlayers * items_per_layer, one item per workgroup.
 typedef const __attribute__((address_space(4))) SplitParams ConstSplitParams;   // constant address space: uniform field reads are scalar loads
 template <int NG>
-__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step) {
+__global__ void __launch_bounds__(512) hbulk_group_kernel(const SplitParams* __restrict__ tab, const int items_per_layer, const int step,
+                                                          const unsigned* __restrict__ wait, const unsigned wait_val, int* __restrict__ wait_err) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ long s_prow[2][32];
+  if (wait) {
+    // first launch of a side-stream piece: its input row comes from the chain's stream.  Poll the chain's counter here instead of a
+    // stream wait operation in front of the launch (~5 us of command-processor time per frame on the longer stream).  Bounded; a
+    // time-out raises the decode's error word (dctts_decode_status).
+    if (threadIdx.x == 0) {
+      bool ok = false;
+      for (int i = 0; i < (1 << 20) && !ok; ++i) {
+        ok = __hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_val;
+        if (!ok) __builtin_amdgcn_s_sleep(16);
+      }
+      if (!ok) atomicOr(wait_err, 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+  }
   const int layer = blockIdx.x / items_per_layer, item = blockIdx.x - layer * items_per_layer;
   ConstSplitParams& p = *((ConstSplitParams*)tab + layer);
-  hbulk_body<NG, ConstSplitParams>(p, step, item, items_per_layer, items_per_layer, smem, s_prow);
+  hbulk_body<NG, ConstSplitParams>(p, step + p.step_val, item, items_per_layer, items_per_layer, smem, s_prow);      // (step_val: a descriptor's own frame offset)
 }
 
 // Row kernel for the bulk branch: X[b][t] = act / gate (LN(P[b*R + r])) for cone rows at offsets < 0.

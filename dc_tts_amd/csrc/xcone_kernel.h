@@ -35,6 +35,10 @@ struct XConeParams {
   XConeLayer lay[5];
   unsigned* bar; unsigned bar_base;      // team barriers: bar[team * 32] counts arrivals since the decode started; value before this launch
   int* err;
+  unsigned* done; unsigned done_target;  // teams that finished since the decode started; the team that brings it to done_target ...
+  unsigned* sig; unsigned sig_val;       // ... tells the chain's stream that this piece is complete (instead of a stream write operation behind the launch)
+  const unsigned* wait; unsigned wait_val;                // then: the NEXT side-stream piece needs the chain's counter at wait_val; the team leaders poll it here
+  int* wait_err;                                          //   (instead of a stream wait operation in front of that piece); a time-out raises this word
   long long* ts;                         // measurement (DCTTS_TRACE): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
 };
 
@@ -210,6 +214,22 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     arrived += 16u;
     xcone_barrier(bar, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
+  }
+  // ---- the team's rows are in this XCD's L2 (every team-mate has passed the last barrier behind its stores): write them back, count the
+  // team, and let the last team publish the piece to the chain's stream, which polls `sig` in its next launch (chain3_kernel / xgroup_kernel: wait2)
+  if (p.done && grp == 0 && tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const unsigned old = __hip_atomic_fetch_add(p.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // sc1: the teams are on different XCDs, this one must not stay in an L2
+    if (old + 1u == p.done_target) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.wait && s_go) {
+      // the chain writes that value when its piece `frame` STARTS, i.e. before it waits for this launch: no cycle; normally it is there already
+      bool ok = false;
+      for (int i = 0; i < (1 << 20) && !ok; ++i) {
+        ok = __hip_atomic_load(p.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+        if (!ok) __builtin_amdgcn_s_sleep(16);
+      }
+      if (!ok) atomicOr(p.wait_err, 1);
+    }
   }
 }
 
