@@ -139,6 +139,7 @@ struct dctts_ctx {
   void* mlp_tab = nullptr; std::string mlp_geom;
   // runs of chain highway layers as one launch whose workgroups meet inside one XCD (xgroup_kernel.h); DCTTS_XGROUP=0: one launch per layer
   int xgroup = 1;
+  bool ae_pass = false; int xg_T = 0;  // AudioEnc's presums and the C1Q . W2 row ride in the AudioDec run's xgroup_kernel launch (passengers); frames of the xgroup table
   bool c1qw_chain = false;             // the C1Q . W2 row rides in the chain's AudioEnc presum launch (decode_v3)
   bool xg_on = false, xc_on = false;   // this decode uses them
   bool xgroup_ok = true;               // cleared for good when a decode reports that the placement assumption (block b on XCD b % 8) does not hold here
@@ -1038,6 +1039,7 @@ static int decode_streams_init(dctts_ctx* c) {
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_group_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  HIPCHK(hipFuncSetAttribute((const void*)xgroup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));      // (its passengers: hbulk_body items)
   return 0;
 }
 
@@ -1153,6 +1155,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     q.N = N; q.d = d; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
     q.x = w.ad[0].p; q.x_bstride = w.ad[0].bstride; q.x_row0 = w.ad[0].row0; q.x_stride = w.ad[0].stride; q.x_set = w.ad[0].set;
     q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
+    if (c->ae_pass && f > 0) { q.wait = c->wait_ctr + 16; q.wait_val = (unsigned)f; q.wait_err = (int*)(c->wait_ctr + 64); }      // row f - 1 of the C1Q . W2 cache: passengers of chain piece f - 1
     hipLaunchKernelGGL(rowc1_kernel, dim3((q.R + 3) / 4, B), dim3(256), 0, sb, q);
     HIPCHK(hipGetLastError());
   }
@@ -1294,7 +1297,8 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
 // The team barriers count arrivals monotonically over the whole decode, so every launch is told the count it starts from.
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
-                        std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr);
+                        std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
+                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass);
   if (c->xg_tab && c->xg_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xg_tab) { (void)hipFree(c->xg_tab); c->xg_tab = nullptr; }
@@ -1342,13 +1346,21 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
         if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
+        if (c->ae_pass && j + 1 < T) {
+          // passengers: AudioEnc's presums of row j + 1 (inputs: rows <= j - 1; the AudioEnc run of frame j + 1 follows on this stream) and row j of
+          // the C1Q . W2 cache (the table's last three descriptors), which side-stream piece j + 1 needs behind its first launch
+          const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
+          p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers;
+          p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;
+          p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
+        }
       }
       tab[(size_t)2 * (piece + 1) + net] = p;
     }
   }
   HIPCHK(hipMalloc(&c->xg_tab, tab.size() * sizeof(XGroupParams)));
   HIPCHK(hipMemcpy(c->xg_tab, tab.data(), tab.size() * sizeof(XGroupParams), hipMemcpyHostToDevice));
-  c->xg_geom = g;
+  c->xg_geom = g; c->xg_T = T;
   return 0;
 }
 
@@ -1356,12 +1368,14 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
   const XGroupParams* p = (const XGroupParams*)c->xg_tab + (size_t)2 * (piece + 1) + net;
   const int teams = (B + 3) / 4;
   // measurement (dctts_hip_debug.h): HIP events on the launch stream around the launches of every 16th frame
-  const bool prof = c->prof_id == DCTTS_PROF_XGROUP && c->prof_frame;
+  // (the AudioEnc runs only: ten layers and nothing else in the launch)
+  const bool prof = c->prof_id == DCTTS_PROF_XGROUP && c->prof_frame && net == 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-  hipLaunchKernelGGL(xgroup_kernel, dim3(128 * ((teams + 7) / 8)), dim3(512), 0, st, p);
+  const int pass = (net == 0 && c->ae_pass && piece >= 0 && piece + 1 < c->xg_T) ? c->aepre_layers * (((B + 31) / 32) * (c->cfg.d / 32)) : 0;     // as in the table
+  hipLaunchKernelGGL(xgroup_kernel, dim3(128 * ((teams + 7) / 8) + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
   HIPCHK(hipGetLastError());
-  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += (net ? 10 : 6); }   // prof_rows counts LAYERS here
+  if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }   // prof_rows counts LAYERS here
   return 0;
 }
 
@@ -1600,6 +1614,9 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   // ... and the one small GEMM in front of the cone work (the newest row of the C1Q . W2 cache) rides in the chain's AudioEnc presum launch one piece
   // earlier: its input is the chain's own newest row, and the counter the side stream waits for is written by the launch behind it
   c->c1qw_chain = vs && c->xc_on;
+  // ... or, with both team kernels, in no launch of its own at all: the AudioEnc presums and that row are passengers of the chain's AudioDec launch
+  // (xgroup_kernel.h); the side stream's first launch (rowc1_kernel) polls the row's own counter before it ends
+  c->ae_pass = bsig && c->xg_on && c->cone_len[0] > 1;
   CHK(v3_aepre_table(c, w, B, c->c1qw_chain));
   c->sig_ptr = cwait ? c->wait_ctr : (unsigned*)c->ctr_chain;
   if (c->xg_on || c->xc_on) {
@@ -1622,13 +1639,13 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     c->wait2_next = (cwait && j >= 0) ? (unsigned)(j + 1) : 0u;        // ... which also waits for bulk piece j
     // AudioEnc's presums of row j+1 (inputs: rows <= j-1, final since piece j-2): when the side stream is the longer one they run here, while this
     // piece would otherwise wait for it, instead of in front of the cone work
-    if (j >= 0 && c->xc_on && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, c->c1qw_chain ? 0 : 1));
+    if (j >= 0 && c->xc_on && !c->ae_pass && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, c->c1qw_chain ? 0 : 1));
     if (j >= 0) { CHK(v3_chain_dec(c, w, B, j, s)); CHK(v3_mlp_launch(c, B, j, s)); }   // AudioDec HC_2 .. HC_7; C_8 .. C_11, mel frame j, AudioEnc C_1 .. C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
     return 0;
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((size_t)c->xc_tab) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)c->xc_tab) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
                           std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs(c);

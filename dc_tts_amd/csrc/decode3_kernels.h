@@ -70,9 +70,24 @@ struct RowC1Params {
   int N, d, win; const int* pm_all;
   float* x; long x_bstride; long x_row0; int x_stride; long x_set;   // AudioDec C_1 output rows, parity copy frame & 1
   float* scal; long s_bstride; long s_row0;                          // per row: (mean, rstd of the pre-norm row, a_0, a_1, a_2, -, -, -) for rowhc2_kernel
+  // the launch behind this one (rowhc2_kernel) needs the newest C1Q . W2 row, computed by passengers of the chain's xgroup_kernel launch:
+  // ONE thread of this launch polls their counter before it exits (bounded; a time-out raises wait_err), so the stream cannot go on before
+  const unsigned* wait; unsigned wait_val; int* wait_err;
 };
 
+__device__ __forceinline__ void rowc1_row(const RowC1Params& p);
 __global__ void __launch_bounds__(256) rowc1_kernel(const RowC1Params p) {
+  rowc1_row(p);
+  if (p.wait && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    bool ok = false;
+    for (int i = 0; i < (1 << 20) && !ok; ++i) {
+      ok = __hip_atomic_load(p.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+      if (!ok) __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) atomicOr(p.wait_err, 1);
+  }
+}
+__device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
   if (r >= p.R) return;
   const int t = p.frame + p.offs[r];

@@ -53,6 +53,13 @@ struct XGroupParams {
   int* err;                                             // error word: bit 0 = a bounded wait gave up (a split team, or the side stream never arrived)
   unsigned* sig; unsigned sig_val;                      // first launch of a chain piece: *sig = sig_val ("every earlier piece of this stream is complete")
   const unsigned* wait2; unsigned wait_val;             // first launch of a chain piece: the presums come from the side stream: poll *wait2 >= wait_val first
+  // passengers: independent small GEMMs (hbulk_body items, decode_kernels.h) that ride in this launch on compute units nobody is using while the
+  // teams run -- in the AudioDec run's launch, the AudioEnc presums of the next frame (consumed by the AudioEnc run that follows on this stream)
+  // and the newest row of the C1Q . W2 cache, which the NEXT side-stream piece needs: those workgroups count themselves and the last one
+  // publishes psig_val (rowc1_kernel's tail polls it on the side stream)
+  const SplitParams* ptab; int p_blocks, p_ipl, p_step; // descriptors; workgroups behind the teams' (p_blocks = descriptors * p_ipl); items per descriptor; frame index
+  int p_count_from;                                     // descriptors >= this one are counted (and are dispatched first)
+  unsigned* pdone; unsigned pdone_target; unsigned* psig; unsigned psig_val;
 };
 
 __device__ __forceinline__ unsigned xg_xcc_id() {
@@ -61,12 +68,33 @@ __device__ __forceinline__ unsigned xg_xcc_id() {
   return v & 0xfu;
 }
 
-// grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads
+// grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads (+ p_blocks passengers, with hsplit_smem(32) bytes of dynamic LDS)
 __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) {
   __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
   __shared__ int s_go;
   typedef const __attribute__((address_space(4))) XGroupParams CP;
   CP& p = *(CP*)pp;
+  if (p.p_blocks) {
+    const int first = (int)gridDim.x - p.p_blocks;
+    if ((int)blockIdx.x >= first) {
+      extern __shared__ __attribute__((aligned(16))) float pass_smem[];
+      __shared__ long s_prow[2][32];
+      const int nd = p.p_blocks / p.p_ipl, q = (int)blockIdx.x - first, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
+      const int ncount = nd - p.p_count_from, layer = qd < ncount ? p.p_count_from + qd : qd - ncount;
+      ConstSplitParams& sp = *((ConstSplitParams*)p.ptab + layer);
+      hbulk_body<8, ConstSplitParams>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, pass_smem, s_prow);
+      if (p.pdone && layer >= p.p_count_from) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                   // every thread's stores are out
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // ... and written back past this XCD's L2
+          const unsigned old = __hip_atomic_fetch_add(p.pdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (old + 1u == p.pdone_target) __hip_atomic_store(p.psig, p.psig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+      return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   const int grp = bq & 15, team = bx + 8 * (bq >> 4), m0 = team * 4;
