@@ -1298,7 +1298,7 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
                         std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
-                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass);
+                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string(c->trace_frame);
   if (c->xg_tab && c->xg_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xg_tab) { (void)hipFree(c->xg_tab); c->xg_tab = nullptr; }
@@ -1354,6 +1354,10 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
           p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;
           p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
         }
+      }
+      if (piece == c->trace_frame) {                            // DCTTS_TRACE: this piece's two launches record their phase boundaries
+        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
+        p.ts = c->trace_buf + 64 * 64 * 32 - 192 - 256 * (2 - net);
       }
       tab[(size_t)2 * (piece + 1) + net] = p;
     }
@@ -1552,6 +1556,14 @@ static int write_trace3(dctts_ctx* c, int j) {
     for (int q = 5; q < 8; ++q) { std::sort(ph[q].begin(), ph[q].end()); fprintf(f, " %6.2f", ph[q][ph[q].size() / 2]); }
     fprintf(f, "\n");
   }
+  for (int net = 0; net < 2; ++net) {
+    const long long* o = &h[64 * 64 * 32 - 192 - 256 * (2 - net)];
+    if (!o[0]) continue;
+    fprintf(f, "# xgroup_kernel, %s run (workgroup 0, thread 0), microseconds since its entry: first row built | per layer: contraction + partial sums written, slice reduced, published, barrier passed, exchanged rows landed\n ", net ? "AudioEnc" : "AudioDec");
+    fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
+    for (int i = 2; i < 120 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, ((i - 2) % 5 == 4) ? " |" : "");
+    fprintf(f, "\n");
+  }
   {
     const long long* o = &h[64 * 64 * 32 - 192];
     if (o[0]) {
@@ -1605,7 +1617,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-kernel wait for the side stream timed out and its results were invalid (dctts_decode_status was not consulted)");
   }
   CHK(v3_mlp_table(c, w, B, T));
-  c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->trace_frame < 0 && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (the trace / that timing id look at chain3_kernel launches)
+  c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (that timing id looks at chain3_kernel launches; so does DCTTS_TRACE with DCTTS_XGROUP=0)
   c->xc_on = c->xcone != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_BULK_GEMM &&
              c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;      // (behind rowhc2_kernel)
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's

@@ -60,6 +60,7 @@ struct XGroupParams {
   const SplitParams* ptab; int p_blocks, p_ipl, p_step; // descriptors; workgroups behind the teams' (p_blocks = descriptors * p_ipl); items per descriptor; frame index
   int p_count_from;                                     // descriptors >= this one are counted (and are dispatched first)
   unsigned* pdone; unsigned pdone_target; unsigned* psig; unsigned psig_val;
+  long long* ts;                                        // measurement (DCTTS_TRACE): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
 };
 
 __device__ __forceinline__ unsigned xg_xcc_id() {
@@ -109,6 +110,9 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   const int pcol = etile * 256 + grp * 16 + ecol;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.bar + team * 32;
+  int nts = 0;
+  auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); };
+  stamp();
 
   // ---- layer 0: everything that does not come from the side stream by plain loads (the producer is an earlier launch)
   f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2] = {z4, z4}, vg1[2] = {z4, z4}, vbe1[2] = {z4, z4}, vst[4] = {z4, z4, z4, z4};
@@ -173,6 +177,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     }
   }
 
+  stamp();                                                                 // first input row built (the wait for the side stream is in here)
   for (int g = 0; g < p.L; ++g) {
     const bool last = (g + 1 == p.L);
     const bool t2 = p.lay[g].tap2 != 0;
@@ -225,6 +230,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
 #pragma unroll
       for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(p.lay[g].xm + (long)b * p.lay[g].xm_bs + (8 * e + wave) * 16 + c4) = x[e];
     }
+    stamp();                                                               // contraction issued, partial sums written, prefetches issued
     __syncthreads();
     float v_ = 0.f;
 #pragma unroll
@@ -233,6 +239,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     const float mg = row16_sum(v_) * (1.0f / 16.0f);
     const float dv = v_ - mg;
     const float m2g = row16_sum(dv * dv);
+    stamp();                                                               // slice reduced, statistics
     if (last) {
       if (wr) p.pout[(long)eb * 512 + pcol] = v_;
       if (wr && ecol == 0) { float* so = p.stats_out + ((long)eb * 16 + grp) * 4 + etile * 2; so[0] = mg; so[1] = m2g; }
@@ -245,23 +252,31 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       if (ecol == 0) { float* so = p.sch + (long)par * p.sch_set + ((long)eb * 16 + grp) * 4 + etile * 2; so[0] = mg; so[1] = m2g; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // the stores are in the L2 (and the prefetches have landed)
+    stamp();                                                               // published
     __syncthreads();
-    if (tid == 0) {
-      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        // no sc1: executes in the XCD's L2
+    // The team's barrier: every workgroup writes the layer's sequence number into ITS word of the team's line (a plain store: it stays in the XCD's
+    // L2), and polls all sixteen words with one 64-byte request.  No read-modify-write: sixteen atomics on one word take ~25 ns each in the L2, and
+    // the pollers' reads of that word queue in between (measured: 128 arrivals per layer cost 3-5 us).
+    if (wave == 0) {
       const unsigned target = p.bar_base + (unsigned)(g + 1) * 16u;
+      if (lane == 0) __hip_atomic_store(bar + grp, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (team_ok) {
         int spins = 0;
-        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {   // sc1 load: past the L1, served by the L2
-          if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { atomicOr(p.err, 1); break; }   // bounded (~20 ms), and nobody keeps waiting once anybody gave up
+        for (;;) {
+          const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;   // sc1 loads: past the L1, served by the L2
+          if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
+          if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(p.err, 1); break; }   // bounded (~20 ms), and nobody keeps waiting once anybody gave up
         }
       }
     }
     __syncthreads();
+    stamp();                                                               // team barrier passed
     // ---- the team's rows of layer g, past the L1
-    f32x4 h1[2], h2[2], st4[4];
-    {
+    f32x4 h1[2] = {z4, z4}, h2[2] = {z4, z4}, st4[4] = {z4, z4, z4, z4};
+    if (valid) {                                                           // 16 of the 64 lanes: the requests of the others would only queue in front of these
       const float* xr = p.xch + (long)par * p.xch_set + (long)bb * 512 + wave * 16 + c4;     // channels 16 w + c4; +128 floats = the second k-group
       const float* sr = p.sch + (long)par * p.sch_set + (long)bb * 64 + aq * 16;
+      f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
       asm volatile(
           "global_load_dwordx4 %0, %8, off sc1\n\t"
           "global_load_dwordx4 %1, %8, off offset:512 sc1\n\t"
@@ -272,11 +287,12 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
           "global_load_dwordx4 %6, %9, off offset:32 sc1\n\t"
           "global_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
           "s_waitcnt vmcnt(0)"
-          : "=&v"(h1[0]), "=&v"(h1[1]), "=&v"(h2[0]), "=&v"(h2[1]), "=&v"(st4[0]), "=&v"(st4[1]), "=&v"(st4[2]), "=&v"(st4[3])
+          : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
           : "v"(xr), "v"(sr)
           : "memory");
-      if (!valid) { h1[0] = h1[1] = h2[0] = h2[1] = z4; st4[0] = st4[1] = st4[2] = st4[3] = z4; }
+      h1[0] = t0; h1[1] = t1; h2[0] = t2; h2[1] = t3; st4[0] = t4; st4[1] = t5; st4[2] = t6; st4[3] = t7;
     }
+    stamp();                                                               // exchanged rows landed
     // ---- rebuild the next layer's input: gate(LN(exchanged rows)) mixed with this layer's input (the highway residual, still in registers)
     {
       float4 st[4] = {f4(st4[0]), f4(st4[1]), f4(st4[2]), f4(st4[3])};
