@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "decode3_kernels.h"
+#include "xgroup_kernel.h"
 
 namespace dctts {
 
@@ -42,19 +43,22 @@ struct XConeParams {
   long long* ts;                         // measurement (DCTTS_TRACE): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
 };
 
-__device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned target, int* err, bool go) {
+__device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned xcc, unsigned target, int* err, bool go) {
   // caller: all stores of the phase issued; every thread calls this.  Same barrier as xgroup_kernel's: one word per workgroup in the team's line,
   // plain stores, one 64-byte poll -- no read-modify-write on a shared word.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this thread's stores are in the L2
   __syncthreads();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
-    if (lane == 0) __hip_atomic_store(bar + grp, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);    // stays in the XCD's L2
+    const unsigned mine = (target << 4) | xcc;                              // (the writer's XCD rides in the word: see xgroup_kernel.h)
+    if (lane == 0) __hip_atomic_store(bar + grp, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // stays in the XCD's L2
     if (go) {
       int spins = 0;
       for (;;) {
-        const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;     // sc1 loads: past the L1, served by the L2
-        if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
+        const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;       // sc1 loads: past the L1, served by the L2
+        const bool there = (int)((v >> 4) - target) >= 0;
+        if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(err, 3); break; }         // a split team
+        if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
         if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(err, 1); break; }
       }
     }
@@ -81,6 +85,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   const int pcol = etile * 256 + grp * 16 + ecol;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.bar + team * 32;
+  const unsigned xcc = xg_xcc_id();
   if (tid == 0) s_go = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting
   unsigned arrived = p.bar_base;
   const int frame = p.frame;
@@ -189,7 +194,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     // ---- the team's pre-norm rows of this layer are complete
     stamp();                                                                   // contraction done
     arrived += 16u;
-    xcone_barrier(bar, grp, arrived, p.err, s_go != 0);
+    xcone_barrier(bar, grp, xcc, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
     if (li + 1 == p.L) break;                                                  // the last layer only leaves its presum rows
     load_w(li + 1, bq0, bq1);                                                  // the next layer's slice lands while this layer's rows are normalised
@@ -216,7 +221,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     }
     stamp();                                                                   // row pass done
     arrived += 16u;
-    xcone_barrier(bar, grp, arrived, p.err, s_go != 0);
+    xcone_barrier(bar, grp, xcc, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
   }
   // ---- the team's rows are in this XCD's L2 (every team-mate has passed the last barrier behind its stores): write them back, count the

@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   const int pcol = etile * 256 + grp * 16 + ecol;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.bar + team * 32;
+  const unsigned xcc = xg_xcc_id();
   int nts = 0;
   auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); };
   stamp();
@@ -257,14 +258,17 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     // The team's barrier: every workgroup writes the layer's sequence number into ITS word of the team's line (a plain store: it stays in the XCD's
     // L2), and polls all sixteen words with one 64-byte request.  No read-modify-write: sixteen atomics on one word take ~25 ns each in the L2, and
     // the pollers' reads of that word queue in between (measured: 128 arrivals per layer cost 3-5 us).
+    // The word also carries the XCD the writer runs on: a word from another XCD (should its line ever get here through memory) is an error, never a pass.
     if (wave == 0) {
-      const unsigned target = p.bar_base + (unsigned)(g + 1) * 16u;
-      if (lane == 0) __hip_atomic_store(bar + grp, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const unsigned target = p.bar_base + (unsigned)(g + 1) * 16u, mine = (target << 4) | xcc;
+      if (lane == 0) __hip_atomic_store(bar + grp, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (team_ok) {
         int spins = 0;
         for (;;) {
-          const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;   // sc1 loads: past the L1, served by the L2
-          if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
+          const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;   // sc1 loads: past the L1, served by the L2
+          const bool there = (int)((v >> 4) - target) >= 0;
+          if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(p.err, 3); break; }      // a split team
+          if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
           if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(p.err, 1); break; }   // bounded (~20 ms), and nobody keeps waiting once anybody gave up
         }
       }

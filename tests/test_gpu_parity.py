@@ -327,11 +327,13 @@ def test_decode_vs_oracle_loop(weights, graph, mode):
     assert trajr.max() > 10
 
 
-@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0"])
+@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0"])
 def test_decode_stream_meeting_variants(weights, knob):
-    """The chain and side streams of the decode meet through stream memory operations with the chain's wait inside its first launch (default),
-    with the wait as a stream operation (DCTTS_CHAIN_WAIT=0), or through events (DCTTS_SYNC_VALUES=0: what rocprofv3 --pmc needs); the knobs
-    are read when a context is created.  Every variant must reproduce the oracle loop: trajectory integer-exact."""
+    """The chain and side streams of the decode meet inside kernels (default: counters polled / written by the launches themselves, passenger
+    workgroups), with stream wait / write operations (DCTTS_CHAIN_WAIT=0), or through events (DCTTS_SYNC_VALUES=0: what rocprofv3 --pmc
+    needs); DCTTS_XGROUP=0 / DCTTS_XCONE=0 run the chain's / the side stream's highway layers as one launch per layer instead of the
+    team kernels (the form a decode falls back to after a failed team hand-off).  The knobs are read when a context is created.  Every
+    variant must reproduce the oracle loop: trajectory integer-exact."""
     from dc_tts_amd.engine import Engine
     T = 100
     name, val = knob.split("=")
