@@ -76,13 +76,22 @@ def cpu_baseline(hp, W):
             TR.SSRN(_torch.from_numpy(Yt), Pt, hp)
         t_ssrn = (time.perf_counter() - t0) / Bt                 # seconds per utterance
         return t_step / Bt + t_ssrn / hp.max_T                   # one loop step yields one mel frame per utterance
-    # BASELINE.md section 3 prescribes all host cores.  On the 256-core GPU box that is far from torch's operating point for these small
-    # convolutions (measured in this round, profiles/r03_bench_allcores.json: 0.03 mel frames/s at set_num_threads(256), 67 s per loop step), so the
-    # leg climbs through thread counts and stops as soon as more threads are clearly slower; `value` is the BEST count tried, `cores` says which.
+    # BASELINE.md section 3 prescribes all host cores.  The GPU box shows 256 cores but its container is granted 16 (cgroup cpu.max): with
+    # set_num_threads(256) the sample runs at 0.03 mel frames/s (profiles/r03_bench_allcores.json: 67 s per loop step, spinning threads), with 64
+    # at 17.6, with 16 at 68.  So "all cores" = the cores this process may use; the leg climbs through thread counts up to that and stops as
+    # soon as more threads are clearly slower; `value` is the BEST count tried, `cores` says which.
     try:
         navail = len(os.sched_getaffinity(0))
     except Exception:
         navail = ncpu
+    quota = None
+    try:                                                      # cgroup v2 CPU quota of this container ("max" = none): the GPU box shows 256 cores and grants 16
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+            navail = min(navail, quota)
+    except Exception:
+        pass
     tried = {}
     t_leg0 = time.perf_counter()
     for th in sorted({min(16, navail), min(64, navail), navail}):
@@ -119,13 +128,14 @@ def cpu_baseline(hp, W):
         cores_np = max([int(i.get("num_threads", 1)) for i in threadpool_info() if i.get("user_api") == "blas"] or [1])
     except Exception:
         cores_np = ncpu
-    return {"value": 1.0 / per_frame_t, "unit": "mel frames/s", "cores": best_th, "host_cores": ncpu, "usable_cores": navail, "kind": "port",
+    return {"value": 1.0 / per_frame_t, "unit": "mel frames/s", "cores": best_th, "host_cores": ncpu, "usable_cores": navail, "cgroup_cpu_quota_cores": quota, "kind": "port",
             "sample": f"{steps_t} step of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, B={Bt}, N={hp.max_N}, "
                       f"T={hp.max_T}) + 1 SSRN pass (B={Bt}), torch-CPU fp32 (oracle/torch_ref.py) at torch.set_num_threads({best_th}) = the fastest of the "
                       f"thread counts tried, one untimed warm-up step each, prorated per mel frame",
             "rtf": per_frame_t / hp.seconds_per_mel_frame,
             "torch_threads_tried": {str(th): {"value": 1.0 / v, "unit": "mel frames/s", "rtf": v / hp.seconds_per_mel_frame} for th, v in sorted(tried.items())},
-            "torch_all_cores_note": "set_num_threads(256), the same sample: 0.03 mel frames/s (profiles/r03_bench_allcores.json); the climb stops once more threads are >1.5x slower",
+            "torch_more_threads_note": "the GPU box's container has a CPU quota of 16 cores beside 256 visible ones: set_num_threads(64) gives 17.6, "
+                                       "set_num_threads(256) 0.03 mel frames/s on the same sample (profiles/r03_bench_allcores.json, gpurun_out of round 3)",
             "numpy_variant": {"value": 1.0 / per_frame, "unit": "mel frames/s", "cores": cores_np, "rtf": per_frame / hp.seconds_per_mel_frame,
                               "sample": f"the same loop in numpy fp32 (oracle/dctts_ref.py, B={Bs}, {steps} steps + 1 SSRN pass at B=1; BLAS threads = cores)"},
             "incremental_variant": {"value": 1.0 / per_frame_inc, "unit": "mel frames/s", "rtf": per_frame_inc / hp.seconds_per_mel_frame,

@@ -9,6 +9,9 @@
 //   (2) a team of T workgroups runs L dependent layers (each: publish 512 B, barrier, read everybody's 512 B, verify):
 //       mode 0 = team on one XCD, L2-local protocol (plain stores, workgroup-scope atomic, sc1 polls / loads)
 //       mode 1 = team spread over all XCDs, agent-scope protocol (sc1 stores / atomics / loads)
+//       mode 2 = team on one XCD, no read-modify-write: every workgroup stores the layer number into ITS word of one line, wave 0 polls the
+//                T words with one request (what xgroup_kernel / xcone_kernel use since: T atomics on one word serialise in the L2, and the
+//                pollers' reads of that word queue in between)
 // Every spin is bounded; a time-out raises an error word and every workgroup leaves.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/xcd_handoff.hip -o tools/micro/kp_xcd_handoff
 #include <hip/hip_runtime.h>
@@ -49,9 +52,9 @@ __global__ void __launch_bounds__(512) team_kernel(const TeamParams p) {
   __shared__ int s_ok;
   const int tid = threadIdx.x;
   const unsigned xcc = xcc_id();
-  if (p.mode == 0 && (int)xcc != p.want_xcc) return;
+  if (p.mode != 1 && (int)xcc != p.want_xcc) return;
   if (tid == 0) {
-    unsigned* cnt = p.census + (p.mode == 0 ? xcc : 0);
+    unsigned* cnt = p.census + (p.mode != 1 ? xcc : 0);
     const unsigned s = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_slot = (s < (unsigned)p.T) ? (int)s : -1;
     int ok = 1;
@@ -74,12 +77,23 @@ __global__ void __launch_bounds__(512) team_kernel(const TeamParams p) {
     float* mine = p.buf + ((size_t)(l & 1) * p.T + slot) * 128;
     const float val = (float)(l * 131 + slot);
     if (tid < 128) {
-      if (p.mode == 0) mine[tid] = val + (float)tid;                                                     // plain store: stays in this XCD's L2
+      if (p.mode != 1) mine[tid] = val + (float)tid;                                                     // plain store: stays in this XCD's L2
       else __hip_atomic_store(mine + tid, val + (float)tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 store: written through
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
+    if (p.mode == 2) {
+      if (tid < 64) {
+        if (tid == 0) __hip_atomic_store(p.bar + slot, (unsigned)(l + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);       // plain store
+        int spins = 0, ok = 1;
+        for (;;) {
+          const unsigned v = tid < p.T ? __hip_atomic_load(p.bar + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (unsigned)(l + 1);
+          if (__builtin_amdgcn_ballot_w64(v < (unsigned)(l + 1)) == 0ull) break;
+          if (++spins > (1 << 18)) { ok = 0; if (tid == 0) atomicOr(p.err, 1); break; }
+        }
+        if (tid == 0) s_ok = ok;
+      }
+    } else if (tid == 0) {
       const unsigned target = (unsigned)(l + 1) * (unsigned)p.T;
       if (p.mode == 0) __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // no sc1: executes in the XCD's L2
       else __hip_atomic_fetch_add(p.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -131,14 +145,14 @@ int main() {
   // ---- (2) team runs
   const int L = 208;
   for (int T : {16, 32, 64}) {
-    for (int mode : {0, 1}) {
+    for (int mode : {0, 2, 1}) {
       unsigned *d_census, *d_bar; float* d_buf; long long* d_st; int* d_err;
-      CK(hipMalloc(&d_census, 64)); CK(hipMalloc(&d_bar, 64)); CK(hipMalloc(&d_buf, (size_t)2 * T * 128 * 4)); CK(hipMalloc(&d_st, (size_t)T * 16)); CK(hipMalloc(&d_err, 8));
+      CK(hipMalloc(&d_census, 64)); CK(hipMalloc(&d_bar, 256)); CK(hipMalloc(&d_buf, (size_t)2 * T * 128 * 4)); CK(hipMalloc(&d_st, (size_t)T * 16)); CK(hipMalloc(&d_err, 8));
       double best = 1e30; int errs[2] = {0, 0}; int done = 0;
       for (int rep = 0; rep < 5; ++rep) {
-        CK(hipMemset(d_census, 0, 64)); CK(hipMemset(d_bar, 0, 64)); CK(hipMemset(d_buf, 0, (size_t)2 * T * 128 * 4)); CK(hipMemset(d_st, 0, (size_t)T * 16)); CK(hipMemset(d_err, 0, 8));
+        CK(hipMemset(d_census, 0, 64)); CK(hipMemset(d_bar, 0, 256)); CK(hipMemset(d_buf, 0, (size_t)2 * T * 128 * 4)); CK(hipMemset(d_st, 0, (size_t)T * 16)); CK(hipMemset(d_err, 0, 8));
         TeamParams p{d_census, d_bar, d_buf, d_st, d_err, T, L, mode, 3};
-        const int grid = (mode == 0) ? 8 * T + 64 : T;           // mode 0: every XCD gets >= T candidates, only XCD 3's first T stay
+        const int grid = (mode != 1) ? 8 * T + 64 : T;           // mode 0: every XCD gets >= T candidates, only XCD 3's first T stay
         hipLaunchKernelGGL(team_kernel, dim3(grid), dim3(512), 0, 0, p);
         CK(hipDeviceSynchronize());
         std::vector<long long> st(T * 2);
@@ -149,7 +163,7 @@ int main() {
         if (done == T && !errs[0]) { const double us = (b - a) / 100.0 / (L - 8); if (us < best) best = us; }
       }
       printf("team of %2d workgroups x 512 threads, %s: %.3f us per dependent layer (publish 512 B, barrier, read %d KB past L1, verify)   [%d finished, time-out %d, bad words %d]\n",
-             T, mode == 0 ? "ONE XCD, L2-local protocol       " : "all XCDs, agent-scope protocol   ", best, T / 2, done, errs[0], errs[1]);
+             T, mode == 0 ? "ONE XCD, L2 atomic counter       " : mode == 2 ? "ONE XCD, one flag word per group " : "all XCDs, agent-scope protocol   ", best, T / 2, done, errs[0], errs[1]);
       CK(hipFree(d_census)); CK(hipFree(d_bar)); CK(hipFree(d_buf)); CK(hipFree(d_st)); CK(hipFree(d_err));
     }
   }
