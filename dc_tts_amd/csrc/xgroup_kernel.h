@@ -9,19 +9,20 @@
 // MI355X-specific observation this kernel is built on (tools/micro/xcd_handoff.hip, profiles/r03_xcd_handoff.txt): the command processor
 // deals the workgroups of a launch to the XCDs round-robin -- block b runs on XCD b % 8 -- and INSIDE an XCD the L2 is the coherence point:
 // a plain store stays in it, a load that bypasses the CU's L1 (sc1) is served from it, an atomic without sc1 executes in it.  A team of 16
-// workgroups on one XCD gets through "publish 512 B, barrier, read everybody's slice" in ~1.05 us, against 1.7 us with agent-scope operations
-// over the fabric and ~3 us for a launch boundary + cold loads.
+// workgroups on one XCD gets through "publish 512 B, barrier, read everybody's slice" in 0.87 us with one flag word per workgroup (1.02 us with
+// an L2 atomic counter), against 1.8 us with agent-scope operations over the fabric and ~3 us for a launch boundary + cold loads.
 //
 // So: grid = 128 workgroups for B = 32; block b belongs to team b % 8 (= its XCD) and owns column group (b / 8) % 16; a team owns FOUR
 // utterances (the newest row of each) and all 16 column groups, i.e. everything a layer's layer-norm needs.  Per layer a workgroup contracts
 // K = 256 for its (gate, info) pair of 16-column tiles over 8 waves (chain3_kernel's arithmetic: 16x16x4 fp32 MFMA, fixed-order LDS reduction,
 // partial layer-norm statistics per column group), publishes 4 x 32 pre-norm values + statistics with plain stores, arrives at the team's
-// barrier (an L2 atomic), and reads the other 15 slices past its L1.  Everything that does not depend on the predecessor -- the next layer's
+// barrier (its own word of the team's 64-byte line: no read-modify-write), and reads the other 15 slices past its L1.  Everything that does not depend on the predecessor -- the next layer's
 // weights, presum, layer-norm parameters, a dilation-1 layer's history row -- is requested before the barrier.
 //
-// Placement is used for SPEED; CORRECTNESS does not rest on it: the only thing a workgroup ever trusts is its team's barrier word reaching the
-// count of 16 arrivals IN ITS OWN L2 -- which can only happen if all 16 atomics executed in that L2, i.e. if the whole team is on this XCD, and
-// then their plain stores are in this L2 as well.  (In a process with other launches in flight a launch does not start at XCD 0: block b runs
+// Placement is used for SPEED; CORRECTNESS does not rest on it: the only thing a workgroup ever trusts is what it reads in ITS OWN L2 -- sixteen
+// barrier words that carry the layer's sequence number AND the XCD their writer runs on (HW_REG_XCC_ID).  Words written on this XCD are in this L2
+// together with their writers' plain stores (each writer drains its stores before its word); a word from another XCD, should its line ever get
+// here through memory, is an error, not a pass.  (In a process with other launches in flight a launch does not start at XCD 0: block b runs
 // on XCD (b + k) % 8 for some k, which keeps blocks b, b + 8, b + 16 ... together; the team rule needs no more than that.)  If a team is ever
 // split, its barrier cannot complete: every spin is bounded, the error word is raised, dctts_decode_status reports the decode as invalid, and
 // the host stops using this kernel (dctts_api.hip: xgroup_ok) in favour of one launch per layer (chain3_kernel), which assumes nothing.
