@@ -765,8 +765,10 @@ static int write_trace3(dctts_ctx* c, int j) {
 
 static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipStream_t st) {
   CHK(decode_streams_init(c));
-  // How the two streams meet.  Default: stream memory operations on two counters; the chain's counter is written by the
-  // first launch of the NEXT chain piece, and (chain_wait_inkernel) the chain's wait for the bulk's counter sits inside that launch too.
+  // How the two streams meet (DESIGN.md sections 2b / 2c).  Default (chain_wait_inkernel): two counters in device memory that kernels poll and
+  // write themselves -- the chain's is written by the first launch of the NEXT chain piece and polled by xcone_kernel's tail, the side stream's
+  // is written by xcone_kernel's last team and polled by the chain piece's first launch; no stream operation per frame.  DCTTS_CHAIN_WAIT=0:
+  // the same counters as stream memory operations (hipStreamWriteValue32 / hipStreamWaitValue32) around the pieces.
   // Fallback (no stream memory operations on the device, or DCTTS_SYNC_VALUES=0, which rocprofv3 --pmc needs): events.
   if (c->sync_values && !c->ctr_chain) {
     int can = 0; (void)hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c->device);
