@@ -58,6 +58,31 @@ __device__ __forceinline__ int window_softmax(const float4 q, const float* Krow0
   return nk;
 }
 
+// The same on key rows that are already in registers (requested up front with clamped, always-valid addresses: a load behind `k < nk` is waited for
+// at the branch's join, one dependent round trip per key).  Same arithmetic in the same order as window_softmax.
+__device__ __forceinline__ int window_softmax_regs(const float4 q, const f32x4 (&kr)[MAXWIN], int pm, int N, int win, float scale, float (&a)[MAXWIN], int& am) {
+  int nk = N - pm; if (nk > win) nk = win;
+  float lg[MAXWIN];
+#pragma unroll
+  for (int k = 0; k < MAXWIN; ++k) {
+    float s_ = q.x * kr[k][0]; s_ = fmaf(q.y, kr[k][1], s_); s_ = fmaf(q.z, kr[k][2], s_); s_ = fmaf(q.w, kr[k][3], s_);
+    const float l = wave_sum(s_) * scale;
+    lg[k] = (k < nk) ? l : -INFINITY;
+  }
+  float mx = lg[0];
+#pragma unroll
+  for (int k = 1; k < MAXWIN; ++k) mx = fmaxf(mx, lg[k]);
+  float se = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXWIN; ++k) { a[k] = (k < nk) ? expf(lg[k] - mx) : 0.f; se += a[k]; }
+  const float inv = 1.0f / se;
+  am = 0;
+  float best = a[0] * inv; a[0] = best;
+#pragma unroll
+  for (int k = 1; k < MAXWIN; ++k) { a[k] *= inv; if (a[k] > best) { best = a[k]; am = k; } }   // post-softmax arg-max, first index on ties
+  return nk;
+}
+
 // ---------------------------------------------------------------------------------------------------------------- bulk: C_1 cone rows
 // x1[b][t] = LN(bias + sum_k a_k VW[b][p+k] + C1Q[b][t]) * gamma + beta for the cone rows t = frame + offs[r] (offs < 0).
 // grid (ceil(R / 4), B), block 256: one wave per row, lane = 4 channels.
@@ -88,25 +113,35 @@ __global__ void __launch_bounds__(256) rowc1_kernel(const RowC1Params p) {
   }
 }
 __device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
-  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // wave-uniform
   if (r >= p.R) return;
   const int t = p.frame + p.offs[r];
   if (t < 0) return;
   const int c0 = lane * 4;
   const int pm = p.pm_all[(long)p.frame * p.B + b];
-  const float4 q = ld4(p.Qh + ((long)b * p.q_bstride + p.q_row0 + t) * p.q_stride + c0);
-  const float4 cq = ld4(p.C1Q + ((long)b * p.c_bstride + p.c_row0 + t) * p.c_stride + c0);
-  const float4 bi = ld4(p.bias + c0), g = ld4(p.g + c0), be = ld4(p.be + c0);
-  float a[MAXWIN]; int am;
-  const long kv0 = (long)b * p.kv_bstride + pm;
-  const int nk = window_softmax(q, p.K + kv0 * p.k_stride, p.k_stride, c0, pm, p.N, p.win, 1.0f / sqrtf((float)p.d), a, am);
-  float4 y = make_float4(bi.x + cq.x, bi.y + cq.y, bi.z + cq.z, bi.w + cq.w);
+  auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
+  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+  // every request of the row in one batch (keys beyond the window: clamped into the utterance, weight exactly 0)
+  f32x4 vq = ldq(p.Qh + ((long)b * p.q_bstride + p.q_row0 + t) * p.q_stride + c0);
+  f32x4 vcq = ldq(p.C1Q + ((long)b * p.c_bstride + p.c_row0 + t) * p.c_stride + c0);
+  f32x4 vbi = ldq(p.bias + c0), vg = ldq(p.g + c0), vbe = ldq(p.be + c0);
+  f32x4 kr[MAXWIN], vr[MAXWIN];
 #pragma unroll
   for (int k = 0; k < MAXWIN; ++k) {
-    if (k < nk) {
-      const float4 v = ld4(p.VW + (kv0 + k) * p.vw_stride + c0);
-      y.x = fmaf(a[k], v.x, y.x); y.y = fmaf(a[k], v.y, y.y); y.z = fmaf(a[k], v.z, y.z); y.w = fmaf(a[k], v.w, y.w);
-    }
+    int n = pm + k; if (n > p.N - 1) n = p.N - 1;
+    kr[k] = ldq(p.K + ((long)b * p.kv_bstride + n) * p.k_stride + c0);
+    vr[k] = ldq(p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride + c0);
+  }
+  asm volatile("; rowc1: all operands requested" : "+v"(vq), "+v"(vcq), "+v"(vbi), "+v"(vg), "+v"(vbe), "+v"(kr[0]), "+v"(kr[1]), "+v"(kr[2]), "+v"(vr[0]), "+v"(vr[1]), "+v"(vr[2]));
+  const float4 q = f4(vq), cq = f4(vcq), bi = f4(vbi), g = f4(vg), be = f4(vbe);
+  float a[MAXWIN]; int am;
+  const int nk = window_softmax_regs(q, kr, pm, p.N, p.win, 1.0f / sqrtf((float)p.d), a, am);
+  (void)nk;
+  float4 y = make_float4(bi.x + cq.x, bi.y + cq.y, bi.z + cq.z, bi.w + cq.w);
+#pragma unroll
+  for (int k = 0; k < MAXWIN; ++k) {                                  // a[k] == 0 beyond the window
+    y.x = fmaf(a[k], vr[k][0], y.x); y.y = fmaf(a[k], vr[k][1], y.y); y.z = fmaf(a[k], vr[k][2], y.z); y.w = fmaf(a[k], vr[k][3], y.w);
   }
   const float mean = wave_sum(y.x + y.y + y.z + y.w) * (1.0f / 256.0f);
   const float4 dv = make_float4(y.x - mean, y.y - mean, y.z - mean, y.w - mean);
@@ -144,55 +179,82 @@ struct RowHc2Params {
   int N, win; const int* pm_all;
 };
 
+// Straight-line on purpose: a load behind a uniform branch is waited for at the join (`s_waitcnt vmcnt(0)`), which made the taps' and keys' loads
+// three to four dependent round trips in the branchy form (13.8 us per launch).  Here everything a row needs is requested in two batches -- what
+// depends only on the row (constants, C1QW, scalars, residual) while the window position is on its way, then the nine VWW rows -- with clamped,
+// always-valid addresses; a tap that does not exist (t' < 0, or the centre tap of the presum row) is dropped by a select, a key beyond the
+// window has weight exactly 0 (window_softmax).
 __global__ void __launch_bounds__(256) rowhc2_kernel(const RowHc2Params p) {
-  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  const int lane = threadIdx.x & 63, b = blockIdx.y;
+  const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // wave-uniform: the row's table entries are scalar loads
   if (r >= p.R) return;
   const int t = p.frame + p.offs[r];
   if (t < 0) return;
   const bool pre_row = (r == p.R - 1);
   const int c0 = lane * 4;
   const int pm = p.pm_all[(long)p.frame * p.B + b];
-  int nk = p.N - pm; if (nk > p.win) nk = p.win;
-  float4 h1 = ld4(p.bias + c0), h2 = ld4(p.bias + 256 + c0);
   const long par = p.frame & 1;
+  auto ldq = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
+  // ---- batch 1: independent of the window
+  f32x4 h1 = ldq(p.bias + c0), h2 = ldq(p.bias + 256 + c0);
+  f32x4 e1[3], e2[3], u1[3], u2[3], cs1[3], cs2[3], w1[3], w2[3], s4[3]; float a2[3]; bool ok[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int tp = t + p.tap_off[q];
-    if (tp < 0 || (pre_row && q == 2)) continue;                      // causal zero padding / the chain contracts the centre tap
-    const float* sc = p.scal + ((long)b * p.s_bstride + p.s_row0 + tp) * 8;
-    const float4 s4 = ld4(sc); const float a2 = sc[4];
-    const float m = s4.x, rs = s4.y;
-    const float a[3] = {s4.z, s4.w, a2};
+    ok[q] = tp >= 0 && !(pre_row && q == 2);                          // causal zero padding / the chain contracts the centre tap
+    const int tc = tp < 0 ? 0 : tp;
+    const float* sc = p.scal + ((long)b * p.s_bstride + p.s_row0 + tc) * 8;
+    s4[q] = ldq(sc); a2[q] = sc[4];
     const float* cq = p.consts + q * 3 * 512;
-    float4 u1 = ld4(cq + 512 + c0), u2 = ld4(cq + 512 + 256 + c0);   // b1 . Wt_q
-    const float4 cs1 = ld4(cq + 1024 + c0), cs2 = ld4(cq + 1024 + 256 + c0);
-    u1.x = fmaf(-m, cs1.x, u1.x); u1.y = fmaf(-m, cs1.y, u1.y); u1.z = fmaf(-m, cs1.z, u1.z); u1.w = fmaf(-m, cs1.w, u1.w);
-    u2.x = fmaf(-m, cs2.x, u2.x); u2.y = fmaf(-m, cs2.y, u2.y); u2.z = fmaf(-m, cs2.z, u2.z); u2.w = fmaf(-m, cs2.w, u2.w);
-    const float* cw = p.C1QW + ((long)b * p.c_bstride + p.c_row0 + tp) * 1536 + q * 512;
-    const float4 w1 = ld4(cw + c0), w2 = ld4(cw + 256 + c0);
-    u1.x += w1.x; u1.y += w1.y; u1.z += w1.z; u1.w += w1.w;
-    u2.x += w2.x; u2.y += w2.y; u2.z += w2.z; u2.w += w2.w;
+    e1[q] = ldq(cq + c0); e2[q] = ldq(cq + 256 + c0);                  // beta1 . W2[q]
+    u1[q] = ldq(cq + 512 + c0); u2[q] = ldq(cq + 512 + 256 + c0);      // b1 . Wt_q
+    cs1[q] = ldq(cq + 1024 + c0); cs2[q] = ldq(cq + 1024 + 256 + c0);  // 1^T Wt_q
+    const float* cw = p.C1QW + ((long)b * p.c_bstride + p.c_row0 + tc) * 1536 + q * 512;
+    w1[q] = ldq(cw + c0); w2[q] = ldq(cw + 256 + c0);
+  }
+  f32x4 xr = ldq(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + t) * p.x1_stride + c0);
+  f32x4 lg1 = ldq(p.g1 + c0), lb1 = ldq(p.b1 + c0), lg2 = ldq(p.g2 + c0), lb2 = ldq(p.b2 + c0);      // HC_2's own layer-norm parameters
+  // ---- batch 2: the window's rows of VWW (keys clamped into the utterance: their weight is 0)
+  f32x4 v1[3][3], v2[3][3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      if (k < nk) {
-        const float* vw = p.VWW + ((long)b * p.kv_bstride + pm + k) * 1536 + q * 512;
-        const float4 v1 = ld4(vw + c0), v2 = ld4(vw + 256 + c0);
-        u1.x = fmaf(a[k], v1.x, u1.x); u1.y = fmaf(a[k], v1.y, u1.y); u1.z = fmaf(a[k], v1.z, u1.z); u1.w = fmaf(a[k], v1.w, u1.w);
-        u2.x = fmaf(a[k], v2.x, u2.x); u2.y = fmaf(a[k], v2.y, u2.y); u2.z = fmaf(a[k], v2.z, u2.z); u2.w = fmaf(a[k], v2.w, u2.w);
-      }
+  for (int k = 0; k < 3; ++k) {
+    int n = pm + k; if (n > p.N - 1) n = p.N - 1;
+    const float* vw = p.VWW + ((long)b * p.kv_bstride + n) * 1536;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { v1[q][k] = ldq(vw + q * 512 + c0); v2[q][k] = ldq(vw + q * 512 + 256 + c0); }
+  }
+  // every request above is out before anything is used (left alone, the scheduler sinks each load into the branch that consumes it)
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    asm volatile("; rowhc2: row-only operands of a tap" : "+v"(e1[q]), "+v"(e2[q]), "+v"(u1[q]), "+v"(u2[q]), "+v"(cs1[q]), "+v"(cs2[q]), "+v"(w1[q]), "+v"(w2[q]));
+  }
+  asm volatile("; rowhc2: row operands" : "+v"(h1), "+v"(h2), "+v"(xr), "+v"(lg1), "+v"(lb1), "+v"(lg2), "+v"(lb2));
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    asm volatile("; rowhc2: window operands of a tap" : "+v"(v1[q][0]), "+v"(v1[q][1]), "+v"(v1[q][2]), "+v"(v2[q][0]), "+v"(v2[q][1]), "+v"(v2[q][2]));
+  }
+  int nk = p.N - pm; if (nk > p.win) nk = p.win;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float m = s4[q][0], rs = s4[q][1];
+    const float a[3] = {s4[q][2], nk > 1 ? s4[q][3] : 0.f, nk > 2 ? a2[q] : 0.f};    // a key beyond the window has weight 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float x1 = fmaf(-m, cs1[q][i], u1[q][i]) + w1[q][i];
+      float x2 = fmaf(-m, cs2[q][i], u2[q][i]) + w2[q][i];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { x1 = fmaf(a[k], v1[q][k][i], x1); x2 = fmaf(a[k], v2[q][k][i], x2); }
+      const float d1 = fmaf(rs, x1, e1[q][i]), d2 = fmaf(rs, x2, e2[q][i]);
+      h1[i] += ok[q] ? d1 : 0.f; h2[i] += ok[q] ? d2 : 0.f;            // a select, not a factor: the operands of a dropped tap may be anything
     }
-    const float4 e1 = ld4(cq + c0), e2 = ld4(cq + 256 + c0);          // beta1 . W2[q]
-    h1.x += fmaf(rs, u1.x, e1.x); h1.y += fmaf(rs, u1.y, e1.y); h1.z += fmaf(rs, u1.z, e1.z); h1.w += fmaf(rs, u1.w, e1.w);
-    h2.x += fmaf(rs, u2.x, e2.x); h2.y += fmaf(rs, u2.y, e2.y); h2.z += fmaf(rs, u2.z, e2.z); h2.w += fmaf(rs, u2.w, e2.w);
   }
   if (pre_row) {
     float* pr = p.presum + (long)b * p.presum_rstride;
-    *reinterpret_cast<float4*>(pr + c0) = h1; *reinterpret_cast<float4*>(pr + 256 + c0) = h2;
+    *reinterpret_cast<f32x4*>(pr + c0) = h1; *reinterpret_cast<f32x4*>(pr + 256 + c0) = h2;
     return;
   }
-  RowNorm n; n.g1 = p.g1; n.b1 = p.b1; n.g2 = p.g2; n.b2 = p.b2;
-  const float4 xr = ld4(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + t) * p.x1_stride + c0);
-  const float4 o = norm_hc_regs(n, h1, h2, xr, lane);
+  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+  const float4 o = norm_hc_vals(f4(h1), f4(h2), f4(xr), f4(lg1), f4(lb1), f4(lg2), f4(lb2));
   *reinterpret_cast<float4*>(p.x2 + par * p.x2_set + ((long)b * p.x2_bstride + p.x2_row0 + t) * p.x2_stride + c0) = o;
 }
 
@@ -211,22 +273,35 @@ struct AttnQParams {
 };
 
 __global__ void __launch_bounds__(256) attnq_kernel(const AttnQParams p) {
-  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // wave-uniform: the window position is a scalar load
   if (b >= p.B) return;
   const int j = p.frame, c0 = lane * 4;
-  const float4 q = norm_row_hc(p.nrm, (long)b, b, j, lane);
-  *reinterpret_cast<float4*>(p.qhist + ((long)b * p.q_bstride + p.q_row0 + j) * p.q_stride + c0) = q;
   const int pm = p.pm_all[(long)j * p.B + b];
-  float a[MAXWIN]; int am;
-  const long kv0 = (long)b * p.kv_bstride + pm;
-  const int nk = window_softmax(q, p.K + kv0 * p.k_stride, p.k_stride, c0, pm, p.N, p.win, 1.0f / sqrtf((float)p.d), a, am);
-  float4 y = ld4(p.bias + c0);
+  auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
+  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+  // one batch of requests: the window's K / VW rows depend only on the window position (known since the previous frame), not on Q[j]
+  const RowNorm& n = p.nrm;
+  f32x4 vh1 = ldq(n.P + (long)b * n.np + c0), vh2 = ldq(n.P + (long)b * n.np + 256 + c0);
+  f32x4 vxr = ldq(n.res + ((long)b * n.res_bstride + n.res_row0 + j) * n.res_stride + c0);
+  f32x4 lg1 = ldq(n.g1 + c0), lb1 = ldq(n.b1 + c0), lg2 = ldq(n.g2 + c0), lb2 = ldq(n.b2 + c0), vbias = ldq(p.bias + c0);
+  f32x4 kr[MAXWIN], vr[MAXWIN];
 #pragma unroll
   for (int k = 0; k < MAXWIN; ++k) {
-    if (k < nk) {
-      const float4 v = ld4(p.VW + (kv0 + k) * p.vw_stride + c0);
-      y.x = fmaf(a[k], v.x, y.x); y.y = fmaf(a[k], v.y, y.y); y.z = fmaf(a[k], v.z, y.z); y.w = fmaf(a[k], v.w, y.w);
-    }
+    int nn = pm + k; if (nn > p.N - 1) nn = p.N - 1;                  // beyond the window: clamped into the utterance, weight exactly 0
+    kr[k] = ldq(p.K + ((long)b * p.kv_bstride + nn) * p.k_stride + c0);
+    vr[k] = ldq(p.VW + ((long)b * p.kv_bstride + nn) * p.vw_stride + c0);
+  }
+  asm volatile("; attnq: all operands requested" : "+v"(vh1), "+v"(vh2), "+v"(vxr), "+v"(lg1), "+v"(lb1), "+v"(lg2), "+v"(lb2), "+v"(vbias),
+               "+v"(kr[0]), "+v"(kr[1]), "+v"(kr[2]), "+v"(vr[0]), "+v"(vr[1]), "+v"(vr[2]));
+  const float4 q = norm_hc_vals(f4(vh1), f4(vh2), f4(vxr), f4(lg1), f4(lb1), f4(lg2), f4(lb2));
+  *reinterpret_cast<float4*>(p.qhist + ((long)b * p.q_bstride + p.q_row0 + j) * p.q_stride + c0) = q;
+  float a[MAXWIN]; int am;
+  (void)window_softmax_regs(q, kr, pm, p.N, p.win, 1.0f / sqrtf((float)p.d), a, am);
+  float4 y = f4(vbias);
+#pragma unroll
+  for (int k = 0; k < MAXWIN; ++k) {
+    y.x = fmaf(a[k], vr[k][0], y.x); y.y = fmaf(a[k], vr[k][1], y.y); y.z = fmaf(a[k], vr[k][2], y.z); y.w = fmaf(a[k], vr[k][3], y.w);
   }
   *reinterpret_cast<float4*>(p.presum + (long)b * p.d + c0) = y;
   if (lane == 0) p.pm_all[(long)(j + 1) * p.B + b] = pm + am;       // max_attentions[:, j] (synthesize.py:54)

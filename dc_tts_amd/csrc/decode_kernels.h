@@ -71,8 +71,8 @@ __device__ __forceinline__ float4 norm_c_regs(const RowNorm& n, const float4 x, 
   return y;
 }
 
-__device__ __forceinline__ float4 norm_hc_regs(const RowNorm& n, const float4 h1, const float4 h2, const float4 xr, int lane) {
-  const int c = lane * 4;
+// (layer-norm parameters as values: a caller that requests them early with its other loads passes them in)
+__device__ __forceinline__ float4 norm_hc_vals(const float4 h1, const float4 h2, const float4 xr, const float4 g1, const float4 b1, const float4 g2, const float4 b2) {
   const float m1 = wave_sum(h1.x + h1.y + h1.z + h1.w) * (1.0f / 256.0f);
   const float m2 = wave_sum(h2.x + h2.y + h2.z + h2.w) * (1.0f / 256.0f);
   const float4 d1 = make_float4(h1.x - m1, h1.y - m1, h1.z - m1, h1.w - m1);
@@ -80,13 +80,17 @@ __device__ __forceinline__ float4 norm_hc_regs(const RowNorm& n, const float4 h1
   const float v1 = wave_sum(d1.x * d1.x + d1.y * d1.y + d1.z * d1.z + d1.w * d1.w) * (1.0f / 256.0f);
   const float v2 = wave_sum(d2.x * d2.x + d2.y * d2.y + d2.z * d2.z + d2.w * d2.w) * (1.0f / 256.0f);
   const float r1 = 1.0f / sqrtf(v1 + 1e-12f), r2 = 1.0f / sqrtf(v2 + 1e-12f);
-  const float4 g1 = ld4(n.g1 + c), b1 = ld4(n.b1 + c), g2 = ld4(n.g2 + c), b2 = ld4(n.b2 + c);
   float4 o;
   { const float s = sigmoidf_(d1.x * r1 * g1.x + b1.x); o.x = s * (d2.x * r2 * g2.x + b2.x) + (1.0f - s) * xr.x; }
   { const float s = sigmoidf_(d1.y * r1 * g1.y + b1.y); o.y = s * (d2.y * r2 * g2.y + b2.y) + (1.0f - s) * xr.y; }
   { const float s = sigmoidf_(d1.z * r1 * g1.z + b1.z); o.z = s * (d2.z * r2 * g2.z + b2.z) + (1.0f - s) * xr.z; }
   { const float s = sigmoidf_(d1.w * r1 * g1.w + b1.w); o.w = s * (d2.w * r2 * g2.w + b2.w) + (1.0f - s) * xr.w; }
   return o;
+}
+
+__device__ __forceinline__ float4 norm_hc_regs(const RowNorm& n, const float4 h1, const float4 h2, const float4 xr, int lane) {
+  const int c = lane * 4;
+  return norm_hc_vals(h1, h2, xr, ld4(n.g1 + c), ld4(n.b1 + c), ld4(n.g2 + c), ld4(n.b2 + c));
 }
 
 __device__ __forceinline__ float4 norm_row_c(const RowNorm& n, long prow, int lane) {
