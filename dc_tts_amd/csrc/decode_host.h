@@ -746,7 +746,9 @@ static int write_trace3(dctts_ctx* c, int j) {
     const long long* o = &h[64 * 64 * 32 - 192];
     if (o[0]) {
       fprintf(f, "# xcone_kernel (workgroup 0, thread 0), microseconds since its entry; per layer: row tables | contraction done | barrier passed | row pass done | barrier passed\n ");
-      for (int i = 1; i < 60 && o[i]; ++i) fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0);
+      int last = 0;
+      for (int i = 1; i < 60 && o[i]; ++i) { fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0); last = i; }
+      if (last > 0 && o[101] > o[100]) fprintf(f, "   (shader clock over the launch: %.0f MHz)", (double)(o[101] - o[100]) / ((o[last] - o[0]) / 100.0));
       fprintf(f, "\n");
     }
   }

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   unsigned arrived = p.bar_base;
   const int frame = p.frame;
   int nts = 0;
-  auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 60) p.ts[nts++] = wall_clock64(); };
+  auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 60) { p.ts[100 + (nts > 0)] = clock64(); p.ts[nts++] = wall_clock64(); } };   // ([100], [101]: shader clock at the first / latest stamp)
   stamp();
 
   // this workgroup's slice of a layer's weights, two column tiles.  Wave w owns the SIX CONSECUTIVE k-groups 6 w .. 6 w + 5 (k = 96 w .. 96 w + 95 of

@@ -1,4 +1,4 @@
-# Where a decode frame goes: per-kernel averages of a decode-only kernel trace (eager launches, T = 40)
+# Where a decode frame goes: per-kernel averages of a decode-only kernel trace (eager launches, T = 80) + the timeline of one steady-state frame
 set -u
 R=$PWD; OUT=$R/gpurun_out/dprobe; mkdir -p $OUT; rm -rf $OUT/trace
 cd /tmp; export TMPDIR=/tmp
@@ -7,6 +7,7 @@ python - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-for r in rows[:20]:
+for r in rows[:14]:
     print(f'{int(r["Calls"]):6d} calls  avg {float(r["AverageNs"])/1e3:8.2f} us  total {float(r["TotalDurationNs"])/1e6:8.2f} ms  {r["Percentage"]:>6}%  {r["Name"][:100]}')
 PY
+python $R/tools/trace_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) rowc1 26
