@@ -293,8 +293,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fallback = None
     for _ in range(args.warmup):
         eng.synthesize(L)
+        torch.cuda.synchronize()
+        try:                                                         # a failed team hand-off (workgroups of a team not on one XCD) invalidates THAT decode and switches the
+            eng.decode_status()                                      # library to one launch per layer: a warm-up step may absorb it, the timed region may not (checked below)
+        except RuntimeError as e:
+            fallback = str(e)
+            print(f"[bench] warm-up decode reported: {e}", file=sys.stderr)
     barrier()
     chain_prof = args.decode_mode == 3
     eng.prof_enable(PROF_XGROUP if chain_prof else -1)       # HIP events on the launch stream around the xgroup_kernel launches of every 16th frame
@@ -370,6 +377,7 @@ def main():
             "config": {"workload": f"full Text2Mel autoregressive decode + SSRN, batch={B}/GPU, max_N={hp.max_N}, "
                                    f"max_T={T} mel frames -> ({B},{4 * T},{hp.n_linear}) per GPU; exact-parity incremental decode",
                        "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_mode": args.decode_mode, "decode_graph_mode": gm,
+                       "decode_team_kernels": fallback is None,
                        "sharding": f"{world} x {B} utterances, no collective"},
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
