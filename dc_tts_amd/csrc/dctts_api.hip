@@ -50,6 +50,25 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
   return hipErrorInvalidConfiguration;
 }
 
+#define HCONV_TAIL_CASE(NT_, NW_, BD_, SB_)                                                                       \
+  if (s.epi == EPI_HC && s.nt == NT_ && s.nw == NW_) {                                                            \
+    hipLaunchKernelGGL((hconv_kernel<EPI_HC, NT_, NW_, BD_, SB_, 1>), grid, dim3(NW_ * 64), 0, stream, p);         \
+    hipError_t e_ = hipGetLastError();                                                                            \
+    if (e_ != hipSuccess) return e_;                                                                              \
+    hipLaunchKernelGGL(hc_tail_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, p, (const float*)p.raw_out, 3); \
+    return hipGetLastError();                                                                                     \
+  }
+
+hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_t stream) {
+  const int rows = p.M - p.m_base;
+  if (rows <= 0) return hipSuccess;
+  if (p.ntaps != 3 || !p.raw_out) return hipErrorInvalidValue;
+  const dim3 grid((rows + 31) / 32, 3);
+  HCONV_TAIL_CASE(4, 8, 2, 0)
+  HCONV_TAIL_CASE(8, 8, 1, 1)
+  return hipErrorInvalidConfiguration;
+}
+
 #define HCONV16_CASE(E, NT_, NW_, BD_, SB_)                                                                   \
   if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                             \
     hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_, BD_, SB_>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
@@ -164,6 +183,7 @@ struct dctts_ctx {
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
+  float* tail_ws = nullptr; size_t tail_ws_floats = 0;   // run_conv: the tap-split row tail's partial sums [3][tail rows][2C]
   static constexpr int bulk_cap = 176;   // workgroups of a bulk (cone) launch of hbulk_kernel: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
@@ -407,6 +427,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->wait_err_host) (void)hipHostFree(c->wait_err_host);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
+  if (c->tail_ws) (void)hipFree(c->tail_ws);
   free_ws(c);
   for (Arena& a : c->warena) (void)hipFree(a.base);
   for (int* p : c->cone_dev) (void)hipFree(p);
@@ -639,7 +660,21 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   }
   HIPCHK(launch_hconv(L.shape, p, st, tiles32));
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
-  if (m_tail < p.M) {
+  if (m_tail < p.M && L.shape.epi == EPI_HC && L.ntaps == 3 && !gather && (L.shape.nt == 4 || L.shape.nt == 8) && (L.cout % 256) == 0) {
+    // the row tail of a big highway layer: 32-row items x taps + a finishing pass (hconv_kernel.h: RAW) instead of 16-row items
+    const size_t need = (size_t)3 * (p.M - m_tail) * 2 * L.cout;
+    if (need > c->tail_ws_floats) {
+      if (c->tail_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->tail_ws); c->tail_ws = nullptr; c->tail_ws_floats = 0; }
+      HIPCHK(hipMalloc((void**)&c->tail_ws, need * sizeof(float)));
+      c->tail_ws_floats = need;
+    }
+    p.m_base = m_tail; p.raw_out = c->tail_ws; p.raw_ld = 2 * L.cout;
+    const bool prof16 = (c->prof_id == 50000 + L.shape16.epi * 10000 + L.shape16.nt * 100 + L.shape16.nw);      // (the tail of the same layer, whatever its form)
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (prof16) { HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1)); HIPCHK(hipEventRecord(t0, st)); }
+    HIPCHK(launch_hconv_tail(L.shape, p, st));
+    if (prof16) { HIPCHK(hipEventRecord(t1, st)); c->prof_ev.emplace_back(t0, t1); c->prof_cnt.push_back(1); c->prof_rows += p.M - m_tail; }
+  } else if (m_tail < p.M) {
     p.wp = L.wp16r;
     const bool prof16 = (c->prof_id == 50000 + L.shape16.epi * 10000 + L.shape16.nt * 100 + L.shape16.nw);      // the 16-row tail launch of the same layer
     hipEvent_t t0 = nullptr, t1 = nullptr;

@@ -59,6 +59,9 @@ struct ConvParams {
   int act;
   // ---- decode v3 (hconv16_kernel only): frame index by value, and presum rows
   int t_base_val;         // t_base when step == nullptr
+  // ---- tap-split row tail (hconv_kernel<..., RAW = 1>, grid (row tiles, taps)): rows m_base .. M - 1, workgroup (x, y) contracts tap y only and
+  //      stores its bare partial sums to raw_out[(y * (M - m_base) + m - m_base) * raw_ld + column]; hc_tail_finish_kernel adds the taps and finishes
+  int m_base; float* raw_out; int raw_ld;
   float* presum_out;      // when set: row r == R-1 of every utterance is a PRESUM row -- its last tap is not contracted (the decode chain
   long presum_rstride;    //   does that) and bias + the older taps go, un-normalised, to presum_out[b * presum_rstride + column]
 };
@@ -93,7 +96,11 @@ __device__ __forceinline__ float half_sum32(float v) {
 //   * epilogue without load-behind-branch chains: bias is the accumulators' initial value; the layer-norm parameters and the first residual
 //     rows are requested before the statistics passes; rows that do not exist are handled by predicated stores, not `continue`; the next four
 //     rows' residuals are in flight while four rows are finished; sigmoid on v_exp_f32 / v_rcp_f32.  2 % (HC_11/12) to 6 % (512-channel, 1025-column).
-template <int EPI, int NT, int NW, int BD = 1, int SB = 0>
+//   * RAW = 1 (round 3, the row tail of the big highway layers): what is left after the exact rounds of 32-row items is 0.28 of a round; as 16-row
+//     items on hconv16_kernel it cost 0.57 of a round on 144 of the 256 CUs.  Here it is 32-row items x TAPS: workgroup (x, y) contracts tap y only
+//     (a third of K), 216 workgroups in one round at a third of an item's time, bare partial sums to HBM; hc_tail_finish_kernel (below) adds the three
+//     partials and the bias and finishes the rows (two layer-norms, gate, highway mix).
+template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0>
 __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   constexpr int LDA = 36;
   constexpr int NH = (EPI == EPI_HC) ? 2 : 1;
@@ -110,8 +117,9 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = SB ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int m0 = blockIdx.x * 32;
+  const int m0 = (RAW ? p.m_base : 0) + blockIdx.x * 32;
   const int t_base = p.step ? *p.step : 0;
+  const int tap0 = RAW ? (int)blockIdx.y : 0;
 
   if (tid < 32) {
     const int m = m0 + tid;
@@ -138,8 +146,10 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const int lrow = (tid >> 3) & 31, lc4 = tid & 7;
   const long my_inrow = s_inrow[lrow];
   const int cpt = p.cin_p >> 5;          // chunks per tap
-  const int nch = p.ntaps * cpt;
-  const int KG = nch * 4;                // k-groups of 8
+  const int nch = RAW ? cpt : p.ntaps * cpt;
+  const int KG = nch * 4;                // k-groups of 8 this workgroup contracts
+  const int KGT = RAW ? p.ntaps * cpt * 4 : KG;     // ... of a packed tile; RAW: this workgroup starts at its tap's first k-group
+  const int kg0 = RAW ? tap0 * cpt * 4 : 0;
 
   // Branch-free: a load inside a conditional block makes the wait-count pass fall back to s_waitcnt vmcnt(0) at the join (the
   // weight prefetch behind it then drains twice per chunk).  Rows / columns that must read as zero are redirected to a readable
@@ -149,18 +159,19 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   int ltap = 0, lcit = 0;                  // (tap, chunk in tap) the loader is at: it walks forward one chunk per call, clamped at the last chunk
   auto load_next = [&](bool& ok) -> float4 {
     const int c = lcit * 32 + lc4 * 4;
-    const int toff = (ltap == 0) ? p.tap_off[0] : ((ltap == 1) ? p.tap_off[1] : p.tap_off[2]);
+    const int tq = RAW ? tap0 + ltap : ltap;
+    const int toff = (tq == 0) ? p.tap_off[0] : ((tq == 1) ? p.tap_off[1] : p.tap_off[2]);
     ok = row_ok && c < p.cin;
     const long row = row_ok ? my_inrow + toff : safe_row;
     const float4 v = *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
-    if (!(ltap == p.ntaps - 1 && lcit == cpt - 1)) { if (++lcit == cpt) { lcit = 0; ++ltap; } }
+    if (!(ltap == (RAW ? 1 : p.ntaps) - 1 && lcit == cpt - 1)) { if (++lcit == cpt) { lcit = 0; ++ltap; } }
     return v;
   };
 
   const float4* wq[NT];                    // SB: wave-uniform bases (scalar registers) + the lane as part of the index
 #pragma unroll
   for (int i = 0; i < NT; ++i)
-    wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wave * NT + i) * KG) * 64 + (SB ? 0 : lane);
+    wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wave * NT + i) * KGT + kg0) * 64 + (SB ? 0 : lane);
   const int wl = SB ? lane : 0;
 
   // channel of tile i inside its layer-norm group; the bias is the accumulators' initial value (columns beyond C: zero weights, zero bias -> exactly 0)
@@ -173,7 +184,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
     if (EPI == EPI_HC) { ch_ = (wave * NP + (i >> 1)) * 32 + l31; bidx = (i & 1) * C + ch_; }
     else { ch_ = (wave * NT + i) * 32 + l31; bidx = ch_; }
     chan[i] = ch_; cval[i] = ch_ < C;
-    const float bv = p.bias[cval[i] ? bidx : 0];
+    const float bv = RAW ? 0.f : p.bias[cval[i] ? bidx : 0];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = cval[i] ? bv : 0.f;
   }
@@ -234,6 +245,20 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
     cb = cb1;
   }
 
+  if constexpr (RAW) {                      // bare partial sums of this tap: [tap][row - m_base][2C], natural column order (H1 | H2)
+    static_assert(EPI == EPI_HC, "the tap-split tail exists for highway layers");
+    const long mt = (long)p.M - p.m_base;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int col = (i & 1) * C + chan[i];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
+        if (cval[i] && m0 + row < p.M) p.raw_out[((long)tap0 * mt + (m0 + row - p.m_base)) * p.raw_ld + col] = acc[i][j];
+      }
+    }
+    return;
+  }
   // =====================================================================================
   // Epilogue.  acc[i][j] = conv output (bias included) at row (j&3) + 8*(j>>2) + 4*lhi, column of tile i / lane l31.
   // Requests first, then the two statistics passes, then the stores.
@@ -347,6 +372,71 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   }
 }
 
+// The second half of the tap-split row tail: one wave per row adds the taps' partial sums and the bias, and finishes the row exactly as the fused
+// epilogue does (two-pass layer-norm of both halves, eps 1e-12 inside the root, sigmoid gate on v_exp / v_rcp, highway mix with the layer's input row:
+// modules.py:188-193).  grid ceil(rows / 4), block 256; C in {256, 512, 1024}.
+__global__ void __launch_bounds__(256) hc_tail_finish_kernel(const ConvParams p, const float* __restrict__ part, const int ntap) {
+  const int lane = threadIdx.x & 63;
+  const int m = p.m_base + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  const int b = m / p.R, r = m - b * p.R;
+  const int t = (p.step ? *p.step : 0) + (p.offs ? p.offs[r] : r);
+  if (t < 0) return;
+  const long inrow = (long)b * p.in_bstride + p.in_row0 + t;
+  const long outrow = (long)b * p.out_bstride + p.out_row0 + (long)t * p.out_tmul + p.out_tadd;
+  const int C = p.cout, nq = C >> 8;                              // 256 channels per sweep, 4 per lane
+  const long mt = (long)p.M - p.m_base, mr = m - p.m_base;
+  float4 h1[4], h2[4], xr[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < nq) {
+      const int c = q * 256 + lane * 4;
+      float4 a = *reinterpret_cast<const float4*>(p.bias + c), d = *reinterpret_cast<const float4*>(p.bias + C + c);
+      for (int tp = 0; tp < ntap; ++tp) {
+        const float* pr = part + ((long)tp * mt + mr) * p.raw_ld;
+        const float4 u = *reinterpret_cast<const float4*>(pr + c), v = *reinterpret_cast<const float4*>(pr + C + c);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w; d.x += v.x; d.y += v.y; d.z += v.z; d.w += v.w;
+      }
+      h1[q] = a; h2[q] = d;
+      xr[q] = *reinterpret_cast<const float4*>(p.in + inrow * (long)p.in_stride + c);
+    } else { h1[q] = h2[q] = xr[q] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  const float invC = 1.0f / (float)C;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { s1 += h1[q].x + h1[q].y + h1[q].z + h1[q].w; s2 += h2[q].x + h2[q].y + h2[q].z + h2[q].w; }
+  const float m1 = wsum(s1) * invC, m2 = wsum(s2) * invC;
+  float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < nq) {
+      const float4 a = h1[q], d = h2[q];
+      v1 += (a.x - m1) * (a.x - m1) + (a.y - m1) * (a.y - m1) + (a.z - m1) * (a.z - m1) + (a.w - m1) * (a.w - m1);
+      v2 += (d.x - m2) * (d.x - m2) + (d.y - m2) * (d.y - m2) + (d.z - m2) * (d.z - m2) + (d.w - m2) * (d.w - m2);
+    }
+  }
+  const float r1 = 1.0f / sqrtf(wsum(v1) * invC + 1e-12f), r2 = 1.0f / sqrtf(wsum(v2) * invC + 1e-12f);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q < nq) {
+      const int c = q * 256 + lane * 4;
+      const float4 g1 = *reinterpret_cast<const float4*>(p.g1 + c), b1 = *reinterpret_cast<const float4*>(p.b1 + c);
+      const float4 g2 = *reinterpret_cast<const float4*>(p.g2 + c), b2 = *reinterpret_cast<const float4*>(p.b2 + c);
+      float4 o;
+      { const float gt = fast_sigmoidf_((h1[q].x - m1) * r1 * g1.x + b1.x); o.x = gt * ((h2[q].x - m2) * r2 * g2.x + b2.x) + (1.0f - gt) * xr[q].x; }
+      { const float gt = fast_sigmoidf_((h1[q].y - m1) * r1 * g1.y + b1.y); o.y = gt * ((h2[q].y - m2) * r2 * g2.y + b2.y) + (1.0f - gt) * xr[q].y; }
+      { const float gt = fast_sigmoidf_((h1[q].z - m1) * r1 * g1.z + b1.z); o.z = gt * ((h2[q].z - m2) * r2 * g2.z + b2.z) + (1.0f - gt) * xr[q].z; }
+      { const float gt = fast_sigmoidf_((h1[q].w - m1) * r1 * g1.w + b1.w); o.w = gt * ((h2[q].w - m2) * r2 * g2.w + b2.w) + (1.0f - gt) * xr[q].w; }
+      *reinterpret_cast<float4*>(p.out + outrow * (long)p.out_stride + c) = o;
+    }
+  }
+}
+
 // Host-side launch: picks the (NT, NW) instantiation from the layer's tile count.
 // Returns hipSuccess or the launch error.
 struct ConvShape { int epi, nt, nw; };     // the (BD, SB) of a shape is fixed in launch_hconv (dctts_api.hip)
@@ -370,5 +460,7 @@ inline int shape_tiles(const ConvShape& s) { return s.nt * s.nw; }
 
 // tiles < 0: all of ceil(M / 32); otherwise only the first `tiles` 32-row items (the rest belong to hconv16_kernel).
 hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles = -1);
+// the tap-split row tail of a highway layer with three taps: rows p.m_base .. p.M - 1 (ConvParams::raw_out / raw_ld set); then the finishing pass
+hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_t stream);
 
 }  // namespace dctts

@@ -327,7 +327,7 @@ def test_decode_vs_oracle_loop(weights, graph, mode):
     assert trajr.max() > 10
 
 
-@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0"])
+@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0", "DCTTS_XGROUP=0,DCTTS_XCONE=0"])
 def test_decode_stream_meeting_variants(weights, knob):
     """The chain and side streams of the decode meet inside kernels (default: counters polled / written by the launches themselves, passenger
     workgroups), with stream wait / write operations (DCTTS_CHAIN_WAIT=0), or through events (DCTTS_SYNC_VALUES=0: what rocprofv3 --pmc
@@ -336,14 +336,15 @@ def test_decode_stream_meeting_variants(weights, knob):
     variant must reproduce the oracle loop: trajectory integer-exact."""
     from dc_tts_amd.engine import Engine
     T = 100
-    name, val = knob.split("=")
-    old = os.environ.get(name)
-    os.environ[name] = val
+    pairs = [kv.split("=") for kv in knob.split(",")]              # (both team kernels off = what a decode falls back to after a failed hand-off)
+    old = {name: os.environ.get(name) for name, _ in pairs}
+    for name, val in pairs: os.environ[name] = val
     try:
         eng = Engine(weights, hp.replace(max_T=T))
     finally:
-        if old is None: del os.environ[name]
-        else: os.environ[name] = old
+        for name, _ in pairs:
+            if old[name] is None: del os.environ[name]
+            else: os.environ[name] = old[name]
     L, Yr, trajr, gap = _oracle_decode(weights, T, 3, 21)
     for graph in (0, 1):
         eng.set_decode_graph(graph)
