@@ -64,6 +64,7 @@ hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_
   if (rows <= 0) return hipSuccess;
   if (p.ntaps != 3 || !p.raw_out) return hipErrorInvalidValue;
   const dim3 grid((rows + 31) / 32, 3);
+  HCONV_TAIL_CASE(2, 8, 2, 0)
   HCONV_TAIL_CASE(4, 8, 2, 0)
   HCONV_TAIL_CASE(8, 8, 1, 1)
   return hipErrorInvalidConfiguration;
@@ -110,6 +111,8 @@ struct DevLayer {
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
   float* wp16r = nullptr;         // SSRN 4T-resolution layers: packing for hconv16_kernel (row-tail launches)
+  bool tap_tail = false;          // SSRN highway layers: the rows left over after exact rounds may run as 32-row items x taps (run_conv).  SSRN only: which rows
+                                  //   take that form depends on the batch, and Text2Mel's outputs stay bitwise equal across batch compositions
   ConvShape shape16{0, 0, 0};
   float* wp16 = nullptr;          // decode layers: second packing for 16x16x4 tiles (hsplit_kernel<16>)
   float* wraw = nullptr;          // decode k=1 layers: the kernel in TF layout (Cin, Cout) for mlp_rows_kernel
@@ -578,14 +581,14 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     const std::string s = "SSRN/";
     int i = 1; DevLayer L, L2;
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.n_mels, g.n_mels, cc, ACT_NONE, &L)); c->ssrn.push_back(L);
-    for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L)); c->ssrn.push_back(L); }
+    for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L)); L.tap_tail = true; c->ssrn.push_back(L); }
     for (int rep = 0; rep < 2; ++rep) {
       snprintf(nm, 64, "D_%d", i++); L = DevLayer(); L2 = DevLayer(); CHK(make_D(c, s + nm, cc, &L, &L2)); c->ssrn.push_back(L); c->ssrn.push_back(L2);
-      for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L, false, rep == 1)); c->ssrn.push_back(L); }
+      for (int j = 0, r = 1; j < 2; ++j, r *= 3) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, cc, 3, r, false, &L, false, rep == 1)); L.tap_tail = true; c->ssrn.push_back(L); }
     }
     // everything from HC_8 on runs at 4T rows: those layers also get the 16-row packing for the row-tail launch
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, cc, cc, 2 * cc, ACT_NONE, &L, false, true)); c->ssrn.push_back(L);
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * cc, 3, 1, false, &L, false, true)); c->ssrn.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * cc, 3, 1, false, &L, false, true)); L.tap_tail = true; c->ssrn.push_back(L); }
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * cc, 2 * cc, F, ACT_NONE, &L, false, true)); c->ssrn.push_back(L);
     for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_RELU, &L, false, true)); c->ssrn.push_back(L); }
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_SIGMOID, &L, false, true)); c->ssrn.push_back(L);
@@ -652,15 +655,19 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   const bool prof = (c->prof_id == kid);
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-  // Row split (hconv16_kernel.h): exact rounds of 32-row items on hconv_kernel, a short tail on 16-row items.
+  // Row split: exact rounds of 32-row items on hconv_kernel; what is left over
+  //   * of a highway layer with three taps, when three times as many workgroups still fit in two rounds: 32-row items x TAPS + a finishing pass
+  //     (hconv_kernel.h: RAW) -- a third of an item's time per round instead of a whole one;
+  //   * of the 4T-resolution k = 1 layers, when it is at most 0.6 of a round: 16-row items (hconv16_kernel.h).
   int tiles32 = (p.M + 31) / 32, m_tail = p.M;
-  if (L.wp16r) {
-    const int full = (tiles32 / c->n_cu) * c->n_cu;
-    if ((tiles32 - full) * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
-  }
+  const int full = (tiles32 / c->n_cu) * c->n_cu, left = tiles32 - full;
+  const bool hc3 = L.tap_tail && L.shape.epi == EPI_HC && L.ntaps == 3 && !gather && (L.shape.nt == 2 || L.shape.nt == 4 || L.shape.nt == 8) && (L.cout % 256) == 0 && L.cout <= 1024;
+  const bool tap_tail = hc3 && left > 0 && 3 * left <= 2 * c->n_cu && !rm.step;      // (not in decode mode 0's captured launches: the partial-sum buffer is allocated on demand)
+  if (tap_tail) { tiles32 = full; m_tail = full * 32; }
+  else if (L.wp16r && left * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
   HIPCHK(launch_hconv(L.shape, p, st, tiles32));
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
-  if (m_tail < p.M && L.shape.epi == EPI_HC && L.ntaps == 3 && !gather && (L.shape.nt == 4 || L.shape.nt == 8) && (L.cout % 256) == 0) {
+  if (m_tail < p.M && tap_tail) {
     // the row tail of a big highway layer: 32-row items x taps + a finishing pass (hconv_kernel.h: RAW) instead of 16-row items
     const size_t need = (size_t)3 * (p.M - m_tail) * 2 * L.cout;
     if (need > c->tail_ws_floats) {
