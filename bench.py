@@ -35,7 +35,7 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32 matrix peak
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PROF_SSRN_HC = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
-PROF_SSRN_HC_TAIL = 50000 + 1 * 10000 + 16 * 100 + 8     # hconv16_kernel<EPI_HC, NT=16, NW=8>: the 16-row tail launch of the same layers
+PROF_SSRN_HC_TAIL = 50000 + 1 * 10000 + 16 * 100 + 8     # the row-tail launches of the same layers (tap-split items + finishing pass; the id is the 16-row shape's)
 PROF_SSRN_C1025 = 0 * 10000 + 3 * 100 + 11               # hconv_kernel<EPI_C, NT=3, NW=11>: SSRN C_13 .. C_16 (1025 columns)
 PROF_XGROUP = 30002               # include/dctts_hip_debug.h: xgroup_kernel, sampled every 16th frame (prof_rows counts layers)
 PROF_XCONE = 30003                # xcone_kernel (eager decode only)
@@ -437,7 +437,7 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
                          bound="mfma", launches=n, avg_launch_ms=round(ms / n, 4), rows_per_launch=rpl, layer_rows=B * 4 * T,
                          **both_roofs(2.0 * rpl * 3 * C * 2 * C, 4.0 * (rpl * C * 2 + 3 * C * 2 * C), ms / n)))
     F = hp.n_linear
-    for kid, what, K_, N_ in ((PROF_SSRN_HC_TAIL, "hconv16_kernel<EPI_HC,NT=16,NW=8> (SSRN HC_11 / HC_12: the 16-row tail launch, 144 workgroups)", 3 * 2 * c, 2 * 2 * c),
+    for kid, what, K_, N_ in ((PROF_SSRN_HC_TAIL, "hconv_kernel<EPI_HC,NT=8,NW=8,RAW> + hc_tail_finish_kernel (SSRN HC_11 / HC_12: the rows left after three exact rounds, as 72 32-row items x 3 taps + a finishing pass)", 3 * 2 * c, 2 * 2 * c),
                               (PROF_SSRN_C1025, "hconv_kernel<EPI_C,NT=3,NW=11> (SSRN C_14 / C_15 / C_16 and C_13: 1025 columns, k=1, fused LN + activation)", None, F)):
         eng.prof_enable(kid)
         for _ in range(2):
