@@ -631,6 +631,7 @@ extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
   size_t n = 0;
   for (const Arena& a : c->warena) n += a.size;
   for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
+  n += c->tail_ws_floats * sizeof(float);
   return n;
 }
 

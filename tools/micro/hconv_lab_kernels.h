@@ -340,11 +340,7 @@ namespace dctts {
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// sum over the 32 lanes that share (lane >> 5): four DPP steps inside each 16-lane row, one cross-row exchange
-__device__ __forceinline__ float half_sum32(float v) {
-  v = row16_sum(v);
-  return v + __shfl_xor(v, 16);
-}
+// (half_sum32 -- the sum over the 32 lanes that share lane >> 5 -- is the production kernel's: hconv_kernel.h)
 
 // N2 = N1's K loop (CHK channels per LDS buffer, GPC = CHK / 8 k-groups per chunk, one barrier in the middle of each chunk, A fragments and
 // weight fragments requested one k-group ahead; BD = 2: weight fragments two groups ahead, NO scheduling pin) + an epilogue without load-behind-branch
