@@ -59,14 +59,30 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
     return hipGetLastError();                                                                                     \
   }
 
+#define HCONV_CTAIL_CASE(NT_, NW_, BD_, SB_)                                                                      \
+  if (s.epi == EPI_C && s.nt == NT_ && s.nw == NW_) {                                                             \
+    hipLaunchKernelGGL((hconv_kernel<EPI_C, NT_, NW_, BD_, SB_, 1>), grid, dim3(NW_ * 64), 0, stream, p);          \
+    hipError_t e_ = hipGetLastError();                                                                            \
+    if (e_ != hipSuccess) return e_;                                                                              \
+    hipLaunchKernelGGL(c_tail_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, p, (const float*)p.raw_out, 3); \
+    return hipGetLastError();                                                                                     \
+  }
+
 hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_t stream) {
   const int rows = p.M - p.m_base;
   if (rows <= 0) return hipSuccess;
-  if (p.ntaps != 3 || !p.raw_out) return hipErrorInvalidValue;
+  if (!p.raw_out) return hipErrorInvalidValue;
   const dim3 grid((rows + 31) / 32, 3);
-  HCONV_TAIL_CASE(2, 8, 2, 0)
-  HCONV_TAIL_CASE(4, 8, 2, 0)
-  HCONV_TAIL_CASE(8, 8, 1, 1)
+  if (s.epi == EPI_HC) {
+    if (p.ntaps != 3) return hipErrorInvalidValue;
+    HCONV_TAIL_CASE(2, 8, 2, 0)
+    HCONV_TAIL_CASE(4, 8, 2, 0)
+    HCONV_TAIL_CASE(8, 8, 1, 1)
+  } else {
+    if (p.ntaps != 1 || p.cout > 1280) return hipErrorInvalidValue;
+    HCONV_CTAIL_CASE(4, 8, 1, 1)
+    HCONV_CTAIL_CASE(3, 11, 2, 1)
+  }
   return hipErrorInvalidConfiguration;
 }
 
@@ -663,20 +679,24 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   int tiles32 = (p.M + 31) / 32, m_tail = p.M;
   const int full = (tiles32 / c->n_cu) * c->n_cu, left = tiles32 - full;
   const bool hc3 = L.tap_tail && L.shape.epi == EPI_HC && L.ntaps == 3 && !gather && (L.shape.nt == 2 || L.shape.nt == 4 || L.shape.nt == 8) && (L.cout % 256) == 0 && L.cout <= 1024;
-  const bool tap_tail = hc3 && left > 0 && 3 * left <= 2 * c->n_cu && !rm.step;      // (not in decode mode 0's captured launches: the partial-sum buffer is allocated on demand)
+  // ... and of the 4T-resolution k = 1 layers of SSRN (the ones that carry the 16-row packing): thirds of K instead of taps, same finishing idea
+  const bool c3 = L.wp16r && L.shape.epi == EPI_C && L.ntaps == 1 && !gather && !L.deconv_phase && L.cout <= 1280 &&
+                  ((L.shape.nt == 4 && L.shape.nw == 8) || (L.shape.nt == 3 && L.shape.nw == 11));
+  const bool tap_tail = (hc3 || c3) && left > 0 && 3 * left <= 2 * c->n_cu && !rm.step;      // (not in decode mode 0's captured launches: the partial-sum buffer is allocated on demand)
   if (tap_tail) { tiles32 = full; m_tail = full * 32; }
   else if (L.wp16r && left * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
   HIPCHK(launch_hconv(L.shape, p, st, tiles32));
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
   if (m_tail < p.M && tap_tail) {
     // the row tail of a big highway layer: 32-row items x taps + a finishing pass (hconv_kernel.h: RAW) instead of 16-row items
-    const size_t need = (size_t)3 * (p.M - m_tail) * 2 * L.cout;
+    const int raw_ld = (L.shape.epi == EPI_HC) ? 2 * L.cout : round_up(L.cout, 32);
+    const size_t need = (size_t)3 * (p.M - m_tail) * raw_ld;
     if (need > c->tail_ws_floats) {
       if (c->tail_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->tail_ws); c->tail_ws = nullptr; c->tail_ws_floats = 0; }
       HIPCHK(hipMalloc((void**)&c->tail_ws, need * sizeof(float)));
       c->tail_ws_floats = need;
     }
-    p.m_base = m_tail; p.raw_out = c->tail_ws; p.raw_ld = 2 * L.cout;
+    p.m_base = m_tail; p.raw_out = c->tail_ws; p.raw_ld = raw_ld;
     const bool prof16 = (c->prof_id == 50000 + L.shape16.epi * 10000 + L.shape16.nt * 100 + L.shape16.nw);      // (the tail of the same layer, whatever its form)
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (prof16) { HIPCHK(hipEventCreate(&t0)); HIPCHK(hipEventCreate(&t1)); HIPCHK(hipEventRecord(t0, st)); }

@@ -119,7 +119,8 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const int l31 = lane & 31, lhi = lane >> 5;
   const int m0 = (RAW ? p.m_base : 0) + blockIdx.x * 32;
   const int t_base = p.step ? *p.step : 0;
-  const int tap0 = RAW ? (int)blockIdx.y : 0;
+  // RAW: workgroup y contracts PART y of K -- tap y of a three-tap layer, or the y-th third of the 32-channel chunks of a k = 1 layer
+  const int tap0 = (RAW && p.ntaps == 3) ? (int)blockIdx.y : 0;
 
   if (tid < 32) {
     const int m = m0 + tid;
@@ -146,10 +147,12 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const int lrow = (tid >> 3) & 31, lc4 = tid & 7;
   const long my_inrow = s_inrow[lrow];
   const int cpt = p.cin_p >> 5;          // chunks per tap
-  const int nch = RAW ? cpt : p.ntaps * cpt;
+  const int cpt3 = (cpt + 2) / 3;
+  const int ch0 = (RAW && p.ntaps != 3) ? ((int)blockIdx.y * cpt3 < cpt ? (int)blockIdx.y * cpt3 : cpt - 1) : 0;     // first chunk of this part inside its tap
+  const int nch = RAW ? ((p.ntaps == 3) ? cpt : ((cpt - ch0 < cpt3) ? cpt - ch0 : cpt3)) : p.ntaps * cpt;
   const int KG = nch * 4;                // k-groups of 8 this workgroup contracts
-  const int KGT = RAW ? p.ntaps * cpt * 4 : KG;     // ... of a packed tile; RAW: this workgroup starts at its tap's first k-group
-  const int kg0 = RAW ? tap0 * cpt * 4 : 0;
+  const int KGT = RAW ? p.ntaps * cpt * 4 : KG;     // ... of a packed tile; RAW: this workgroup starts at its part's first k-group
+  const int kg0 = RAW ? (tap0 * cpt + ch0) * 4 : 0;
 
   // Branch-free: a load inside a conditional block makes the wait-count pass fall back to s_waitcnt vmcnt(0) at the join (the
   // weight prefetch behind it then drains twice per chunk).  Rows / columns that must read as zero are redirected to a readable
@@ -158,13 +161,14 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const long safe_row = p.gather ? 0 : p.in_row0;
   int ltap = 0, lcit = 0;                  // (tap, chunk in tap) the loader is at: it walks forward one chunk per call, clamped at the last chunk
   auto load_next = [&](bool& ok) -> float4 {
-    const int c = lcit * 32 + lc4 * 4;
+    const int c = (RAW ? ch0 + lcit : lcit) * 32 + lc4 * 4;
     const int tq = RAW ? tap0 + ltap : ltap;
     const int toff = (tq == 0) ? p.tap_off[0] : ((tq == 1) ? p.tap_off[1] : p.tap_off[2]);
     ok = row_ok && c < p.cin;
     const long row = row_ok ? my_inrow + toff : safe_row;
     const float4 v = *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
-    if (!(ltap == (RAW ? 1 : p.ntaps) - 1 && lcit == cpt - 1)) { if (++lcit == cpt) { lcit = 0; ++ltap; } }
+    if (RAW) { if (lcit < nch - 1) ++lcit; }
+    else if (!(ltap == p.ntaps - 1 && lcit == cpt - 1)) { if (++lcit == cpt) { lcit = 0; ++ltap; } }
     return v;
   };
 
@@ -245,16 +249,22 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
     cb = cb1;
   }
 
-  if constexpr (RAW) {                      // bare partial sums of this tap: [tap][row - m_base][2C], natural column order (H1 | H2)
-    static_assert(EPI == EPI_HC, "the tap-split tail exists for highway layers");
+  if constexpr (RAW) {                      // bare partial sums of this part: [part][row - m_base][raw_ld], natural column order (HC: H1 | H2)
     const long mt = (long)p.M - p.m_base;
+    const int tap0_ = (int)blockIdx.y;
+    if (p.ntaps != 3 && (int)blockIdx.y * cpt3 >= cpt) {      // (a k = 1 layer with fewer than three chunk groups: this part is empty -- zeros)
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
-      const int col = (i & 1) * C + chan[i];
+      const int col = (EPI == EPI_HC) ? (i & 1) * C + chan[i] : chan[i];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         const int row = (j & 3) + 8 * (j >> 2) + 4 * lhi;
-        if (cval[i] && m0 + row < p.M) p.raw_out[((long)tap0 * mt + (m0 + row - p.m_base)) * p.raw_ld + col] = acc[i][j];
+        if (cval[i] && m0 + row < p.M) p.raw_out[((long)tap0_ * mt + (m0 + row - p.m_base)) * p.raw_ld + col] = acc[i][j];
       }
     }
     return;
@@ -433,6 +443,81 @@ __global__ void __launch_bounds__(256) hc_tail_finish_kernel(const ConvParams p,
       { const float gt = fast_sigmoidf_((h1[q].z - m1) * r1 * g1.z + b1.z); o.z = gt * ((h2[q].z - m2) * r2 * g2.z + b2.z) + (1.0f - gt) * xr[q].z; }
       { const float gt = fast_sigmoidf_((h1[q].w - m1) * r1 * g1.w + b1.w); o.w = gt * ((h2[q].w - m2) * r2 * g2.w + b2.w) + (1.0f - gt) * xr[q].w; }
       *reinterpret_cast<float4*>(p.out + outrow * (long)p.out_stride + c) = o;
+    }
+  }
+}
+
+// The same for a k = 1 conv layer (EPI_C) whose row tail was split over thirds of K: bias + the parts, layer-norm over the cout real columns, activation,
+// the optional pre-activation copy (logits) and the zero pad columns, exactly as the fused epilogue.  One wave per row; cout <= 1280.
+__global__ void __launch_bounds__(256) c_tail_finish_kernel(const ConvParams p, const float* __restrict__ part, const int nparts) {
+  const int lane = threadIdx.x & 63;
+  const int m = p.m_base + blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  const int b = m / p.R, r = m - b * p.R;
+  const int t = (p.step ? *p.step : 0) + (p.offs ? p.offs[r] : r);
+  if (t < 0) return;
+  const long outrow = (long)b * p.out_bstride + p.out_row0 + (long)t * p.out_tmul + p.out_tadd;
+  const long out2row = (long)b * p.out2_bstride + p.out2_row0 + t;
+  const int C = p.cout;
+  const long mt = (long)p.M - p.m_base, mr = m - p.m_base;
+  // columns 256 q + 4 lane .. + 3 (16-byte requests; the buffers' rows are padded to a multiple of 32 floats, so a group that straddles cout is readable)
+  float4 y[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int c = q * 256 + lane * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+      v = *reinterpret_cast<const float4*>(p.bias + c);
+      for (int tp = 0; tp < nparts; ++tp) {
+        const float4 u = *reinterpret_cast<const float4*>(part + ((long)tp * mt + mr) * p.raw_ld + c);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+      }
+      if (c + 1 >= C) v.y = 0.f;
+      if (c + 2 >= C) v.z = 0.f;
+      if (c + 3 >= C) v.w = 0.f;
+    }
+    y[q] = v;
+  }
+  auto wsum = [](float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  const float invC = 1.0f / (float)C;
+  float s1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) s1 += y[q].x + y[q].y + y[q].z + y[q].w;
+  const float mean = wsum(s1) * invC;
+  float v1 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int c = q * 256 + lane * 4;
+    const float d0 = (c < C) ? y[q].x - mean : 0.f, d1 = (c + 1 < C) ? y[q].y - mean : 0.f, d2 = (c + 2 < C) ? y[q].z - mean : 0.f, d3 = (c + 3 < C) ? y[q].w - mean : 0.f;
+    v1 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+  }
+  const float rs = 1.0f / sqrtf(wsum(v1) * invC + 1e-12f);
+  float* op = p.out + outrow * (long)p.out_stride;
+  float* op2 = p.out2 ? p.out2 + out2row * (long)p.out2_stride : nullptr;
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    const int c = q * 256 + lane * 4;
+    if (c >= C && c >= p.out_zero_to) continue;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), be = g;
+    if (c + 3 < C) { g = *reinterpret_cast<const float4*>(p.g1 + c); be = *reinterpret_cast<const float4*>(p.b1 + c); }
+    else if (c < C) { g.x = p.g1[c]; be.x = p.b1[c]; if (c + 1 < C) { g.y = p.g1[c + 1]; be.y = p.b1[c + 1]; } if (c + 2 < C) { g.z = p.g1[c + 2]; be.z = p.b1[c + 2]; } }
+    const float yv[4] = {y[q].x, y[q].y, y[q].z, y[q].w}, gv[4] = {g.x, g.y, g.z, g.w}, bv[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ce = c + e;
+      if (ce < C) {
+        float o = (yv[e] - mean) * rs * gv[e] + bv[e];
+        if (op2) op2[ce] = o;
+        if (p.act == ACT_RELU) o = fmaxf(o, 0.f);
+        else if (p.act == ACT_SIGMOID) o = fast_sigmoidf_(o);
+        op[ce] = o;
+      } else if (ce < p.out_zero_to) {
+        op[ce] = 0.f;
+      }
     }
   }
 }
