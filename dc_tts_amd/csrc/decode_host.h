@@ -217,7 +217,8 @@ static int decode_streams_init(dctts_ctx* c) {
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   HIPCHK(hipFuncSetAttribute((const void*)hbulk_group_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  HIPCHK(hipFuncSetAttribute((const void*)xgroup_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));      // (its passengers: hbulk_body items)
+  HIPCHK(hipFuncSetAttribute((const void*)xgroup_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));      // (its passengers: hbulk_body items)
+  HIPCHK(hipFuncSetAttribute((const void*)xgroup_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   return 0;
 }
 
@@ -555,7 +556,8 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
   const int pass = (net == 0 && c->ae_pass && piece >= 0 && piece + 1 < c->xg_T) ? c->aepre_layers * (((B + 31) / 32) * (c->cfg.d / 32)) : 0;     // as in the table
-  hipLaunchKernelGGL(xgroup_kernel, dim3(128 * ((teams + 7) / 8) + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
+  if (piece == c->trace_frame) hipLaunchKernelGGL(xgroup_kernel<true>, dim3(128 * ((teams + 7) / 8) + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);      // DCTTS_TRACE: stamped
+  else hipLaunchKernelGGL(xgroup_kernel<false>, dim3(128 * ((teams + 7) / 8) + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
   HIPCHK(hipGetLastError());
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }   // prof_rows counts LAYERS here
   return 0;

@@ -71,6 +71,7 @@ __device__ __forceinline__ unsigned xg_xcc_id() {
 }
 
 // grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads (+ p_blocks passengers, with hsplit_smem(32) bytes of dynamic LDS)
+template <bool TS = false>                 // TS: the stamped instantiation (DCTTS_TRACE); the production kernel carries no trace of the stamps
 __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) {
   __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
   __shared__ int s_go;
@@ -103,6 +104,9 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   if (m0 >= p.B) return;                                                   // a team without utterances (B not a multiple of 32): uniform per workgroup
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
   const int b = m0 + arow;
+  // Only 4 of the 16 rows of an MFMA tile are utterances.  The other lanes run the same instructions on row 0's addresses: what they compute lands in
+  // output rows nobody reads (MFMA rows are independent), so nothing is masked or zeroed for them -- per layer that was ~100 v_mov / select / exec-mask
+  // instructions per wave, on a path that is bound by instruction issue as much as by latency.
   const bool valid = arow < 4 && b < p.B;
   const unsigned bb = valid ? (unsigned)b : 0u;
   const int erow = aq * 4 + (wave & 3), etile = wave >> 2, ecol = lane & 15;
@@ -113,11 +117,11 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   unsigned* const bar = p.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
   int nts = 0;
-  auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); };
+  auto stamp = [&]() { if constexpr (TS) { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); } };
   stamp();
 
   // ---- layer 0: everything that does not come from the side stream by plain loads (the producer is an earlier launch)
-  f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2] = {z4, z4}, vg1[2] = {z4, z4}, vbe1[2] = {z4, z4}, vst[4] = {z4, z4, z4, z4};
+  f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2], vg1[2], vbe1[2], vst[4];
   {
     const bool t2 = p.lay[0].tap2 != 0;
     const unsigned nkg = t2 ? 32u : 16u, kc = t2 ? 16u : 0u;
@@ -132,7 +136,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
 #pragma unroll
       for (int e = 0; e < 2; ++e) { vtb0[e] = z4; vtb1[e] = z4; }
     }
-    if (valid) {
+    {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
@@ -175,7 +179,6 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     for (int e = 0; e < 2; ++e) {
       const f32x4 h = va[e], g = vg1[e], be = vbe1[e];
       x[e] = make_float4((h[0] - m1) * r1 * g[0] + be[0], (h[1] - m1) * r1 * g[1] + be[1], (h[2] - m1) * r1 * g[2] + be[2], (h[3] - m1) * r1 * g[3] + be[3]);
-      if (!valid) x[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
 
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     if (t2) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const f32x4 a = valid ? vta[e] : z4, b0 = vtb0[e], b1 = vtb1[e];
+        const f32x4 a = vta[e], b0 = vtb0[e], b1 = vtb1[e];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[i], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[i], acc1, 0, 0, 0); }
       }
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
     // ---- requests that do not depend on the other workgroups: the next layer's weights / presum / history row, this layer's LN parameters
-    f32x4 ng1[2] = {z4, z4}, nb1[2] = {z4, z4}, ng2[2] = {z4, z4}, nb2[2] = {z4, z4};
+    f32x4 ng1[2], nb1[2], ng2[2], nb2[2];                                  // (the last layer leaves them unloaded, and leaves the loop before they are used)
     float naddv = 0.f;
     if (!last) {
       const bool nt2 = p.lay[g + 1].tap2 != 0;
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
 #pragma unroll
         for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
       }
-      if (valid) {
+      {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
@@ -277,8 +280,8 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     __syncthreads();
     stamp();                                                               // team barrier passed
     // ---- the team's rows of layer g, past the L1
-    f32x4 h1[2] = {z4, z4}, h2[2] = {z4, z4}, st4[4] = {z4, z4, z4, z4};
-    if (valid) {                                                           // 16 of the 64 lanes: the requests of the others would only queue in front of these
+    f32x4 h1[2], h2[2], st4[4];
+    {
       const float* xr = p.xch + (long)par * p.xch_set + (long)bb * 512 + wave * 16 + c4;     // channels 16 w + c4; +128 floats = the second k-group
       const float* sr = p.sch + (long)par * p.sch_set + (long)bb * 64 + aq * 16;
       f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
@@ -312,7 +315,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
         { const float s_ = sigmoid_fast((a1[1] - m1) * r1 * g1[1] + b1[1]); o.y = s_ * ((a2[1] - m2) * r2 * g2[1] + b2[1]) + (1.0f - s_) * xr.y; }
         { const float s_ = sigmoid_fast((a1[2] - m1) * r1 * g1[2] + b1[2]); o.z = s_ * ((a2[2] - m2) * r2 * g2[2] + b2[2]) + (1.0f - s_) * xr.z; }
         { const float s_ = sigmoid_fast((a1[3] - m1) * r1 * g1[3] + b1[3]); o.w = s_ * ((a2[3] - m2) * r2 * g2[3] + b2[3]) + (1.0f - s_) * xr.w; }
-        x[e] = valid ? o : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[e] = o;
       }
     }
     addv = naddv;
