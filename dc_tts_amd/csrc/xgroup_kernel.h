@@ -64,6 +64,13 @@ struct XGroupParams {
   long long* ts;                                        // measurement (DCTTS_TRACE): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
 };
 
+// a pointer that came out of the LDS copy of the descriptors is generic to the compiler: say "global" (flat loads count in both wait counters)
+__device__ __forceinline__ f32x4 ldg4(const float* base, unsigned off) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(reinterpret_cast<uintptr_t>(base + off));
+}
+__device__ __forceinline__ float ldg1(const float* base, unsigned off) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(base + off));
+}
 __device__ __forceinline__ unsigned xg_xcc_id() {
   unsigned v;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
@@ -75,6 +82,8 @@ template <bool TS = false>                 // TS: the stamped instantiation (DCT
 __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) {
   __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
   __shared__ int s_go;
+  // the layers' descriptors, copied once: read through the scalar cache a layer's fields arrive as several dependent scalar loads inside the layer
+  __shared__ XGroupLayer s_lay[10];
   typedef const __attribute__((address_space(4))) XGroupParams CP;
   CP& p = *(CP*)pp;
   if (p.p_blocks) {
@@ -98,6 +107,13 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       return;
     }
   }
+  // everything the first layer needs, in ONE batch of scalar loads (left alone the fields arrive lazily, a dependent scalar load at a time: ~3 us
+  // until the first row was built)
+  asm volatile("; xgroup: the first layer's parameters, one batch"
+               :: "s"(p.B), "s"(p.L), "s"(p.P0), "s"(p.p0_bs), "s"(p.stats0), "s"(p.pg1), "s"(p.pb1),
+                  "s"(p.lay[0].wp), "s"(p.lay[0].tap2), "s"(p.lay[0].xt), "s"(p.lay[0].xt_bs), "s"(p.lay[0].presum), "s"(p.lay[0].presum_bs),
+                  "s"(p.xch), "s"(p.sch), "s"(p.xch_set), "s"(p.sch_set), "s"(p.bar), "s"(p.bar_base), "s"(p.err),
+                  "s"(p.sig), "s"(p.sig_val), "s"(p.wait2), "s"(p.wait_val), "s"(p.pout), "s"(p.stats_out));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   const int grp = bq & 15, team = bx + 8 * (bq >> 4), m0 = team * 4;
@@ -148,6 +164,11 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
     }
   }
+  {
+    constexpr int NW32 = (int)(sizeof(XGroupLayer) * 10 / 4);
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(pp->lay);
+    if (tid < NW32) reinterpret_cast<uint32_t*>(s_lay)[tid] = src[tid];
+  }
   // ---- placement check, the stream signal, and the wait for the side stream (first launch of a chain piece), while those loads are in flight
   if (tid == 0) {
     int go = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
@@ -185,7 +206,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   stamp();                                                                 // first input row built (the wait for the side stream is in here)
   for (int g = 0; g < p.L; ++g) {
     const bool last = (g + 1 == p.L);
-    const bool t2 = p.lay[g].tap2 != 0;
+    const bool t2 = __builtin_amdgcn_readfirstlane(s_lay[g].tap2) != 0;
     // ---- contraction of layer g
     f32x4 acc0 = z4, acc1 = z4;
     if (t2) {
@@ -210,30 +231,32 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     f32x4 ng1[2], nb1[2], ng2[2], nb2[2];                                  // (the last layer leaves them unloaded, and leaves the loop before they are used)
     float naddv = 0.f;
     if (!last) {
-      const bool nt2 = p.lay[g + 1].tap2 != 0;
+      const XGroupLayer& Ln = s_lay[g + 1];
+      const bool nt2 = __builtin_amdgcn_readfirstlane(Ln.tap2) != 0;
       const unsigned nkg = nt2 ? 32u : 16u, kc = nt2 ? 16u : 0u;
-      const float* wb = p.lay[g + 1].wp + lane * 4;
+      const float* wb = Ln.wp + lane * 4;
       const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
+      for (int e = 0; e < 2; ++e) { vb0[e] = ldg4(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldg4(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
       if (nt2) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+        for (int e = 0; e < 2; ++e) { vtb0[e] = ldg4(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldg4(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
       }
       {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-          ng1[e] = ldv(p.lay[g].g1, ch); nb1[e] = ldv(p.lay[g].b1, ch); ng2[e] = ldv(p.lay[g].g2, ch); nb2[e] = ldv(p.lay[g].b2, ch);
-          if (nt2) vta[e] = ldv(p.lay[g + 1].xt, bb * (unsigned)p.lay[g + 1].xt_bs + ch);
+          ng1[e] = ldg4(s_lay[g].g1, ch); nb1[e] = ldg4(s_lay[g].b1, ch); ng2[e] = ldg4(s_lay[g].g2, ch); nb2[e] = ldg4(s_lay[g].b2, ch);
+          if (nt2) vta[e] = ldg4(Ln.xt, bb * (unsigned)Ln.xt_bs + ch);
         }
       }
-      if (wr) naddv = p.lay[g + 1].presum[(unsigned)(eb * p.lay[g + 1].presum_bs) + (unsigned)pcol];      // behind the wait for the side stream; never read before in this launch
+      if (wr) naddv = ldg1(Ln.presum, (unsigned)(eb * Ln.presum_bs) + (unsigned)pcol);      // behind the wait for the side stream; never read before in this launch
     }
     // this layer's input row is kept for later launches (history / residual): column group 0 stores it
-    if (p.lay[g].xm && grp == 0 && valid) {
+    if (grp == 0 && valid && s_lay[g].xm) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) *reinterpret_cast<float4*>(p.lay[g].xm + (long)b * p.lay[g].xm_bs + (8 * e + wave) * 16 + c4) = x[e];
+      for (int e = 0; e < 2; ++e)
+        *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(reinterpret_cast<uintptr_t>(s_lay[g].xm + (long)b * s_lay[g].xm_bs + (8 * e + wave) * 16 + c4)) = f32x4{x[e].x, x[e].y, x[e].z, x[e].w};
     }
     stamp();                                                               // contraction issued, partial sums written, prefetches issued
     __syncthreads();
