@@ -577,6 +577,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   typedef const __attribute__((address_space(4))) MlpRowsParams CP;
   typedef float f32x8 __attribute__((ext_vector_type(8)));
   CP& p = *(CP*)pp;
+  // what the first rows and the first layer need, in ONE batch of scalar loads (lazily they arrive as five dependent batches, ~1.5 us)
+  asm volatile("; mlp_rows: parameters, one batch"
+               :: "s"(p.B), "s"(p.frame), "s"(p.nlayers), "s"(p.mel_layer), "s"(p.par),
+                  "s"(p.nrm.P), "s"(p.nrm.np), "s"(p.nrm.g1), "s"(p.nrm.b1), "s"(p.nrm.g2), "s"(p.nrm.b2),
+                  "s"(p.nrm.res), "s"(p.nrm.res_bstride), "s"(p.nrm.res_row0), "s"(p.nrm.res_stride), "s"(p.nrm.res_set),
+                  "s"(p.L[0].w), "s"(p.L[0].bias), "s"(p.L[0].g), "s"(p.L[0].be), "s"(p.L[0].cin), "s"(p.L[0].cout), "s"(p.L[0].relu));
   __shared__ __attribute__((aligned(16))) float xs[R * 256];
   __shared__ __attribute__((aligned(16))) float red[8 * R * 256];
   __shared__ int s_desc[7 * 12];             // the layer descriptors, copied once: a scalar load from the (cold, per-frame) parameter
