@@ -84,6 +84,9 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   __shared__ int s_go;
   // the layers' descriptors, copied once: read through the scalar cache a layer's fields arrive as several dependent scalar loads inside the layer
   __shared__ XGroupLayer s_lay[10];
+  // per wave: the wave's 32 channels (k-groups w and w + 8) of the team's four rows, [row][e * 16 + c]: written in the COMPACT layout the rows are
+  // rebuilt in (lane = (row, c): two values per lane), read in the MFMA A-operand layout (lane = (row, 4-channel group): two float4 per lane)
+  __shared__ __attribute__((aligned(16))) float s_xs[8][4 * 32];
   typedef const __attribute__((address_space(4))) XGroupParams CP;
   CP& p = *(CP*)pp;
   if (p.p_blocks) {
@@ -203,6 +206,15 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     }
   }
 
+  // The rebuild of a layer's input (layer-norm of both halves, sigmoid gate, highway mix) is done in a COMPACT layout: lane (cr, cc) owns row cr and the
+  // two channels 16 w + cc and 128 + 16 w + cc.  In the A-operand layout every lane rebuilt 8 values, 6 of them for padding rows: ~165 instructions with
+  // 8 v_exp + 8 v_rcp per wave and layer, twice per SIMD, between "rows landed" and the first MFMA.  Compact: 2 values per lane and an LDS hop.
+  const int cr = lane >> 4, cc = lane & 15;
+  const unsigned crow = (m0 + cr < p.B) ? (unsigned)(m0 + cr) : 0u;
+  float* const xs = s_xs[wave];
+  float xc[2];                                                             // this layer's input at (cr, channel e) = the next rebuild's highway residual
+  if (arow < 4) { *reinterpret_cast<float4*>(&xs[arow * 32 + c4]) = x[0]; *reinterpret_cast<float4*>(&xs[arow * 32 + 16 + c4]) = x[1]; }
+  xc[0] = xs[cr * 32 + cc]; xc[1] = xs[cr * 32 + 16 + cc];
   stamp();                                                                 // first input row built (the wait for the side stream is in here)
   for (int g = 0; g < p.L; ++g) {
     const bool last = (g + 1 == p.L);
@@ -228,7 +240,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
 #pragma unroll
     for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
     // ---- requests that do not depend on the other workgroups: the next layer's weights / presum / history row, this layer's LN parameters
-    f32x4 ng1[2], nb1[2], ng2[2], nb2[2];                                  // (the last layer leaves them unloaded, and leaves the loop before they are used)
+    float ng1[2], nb1[2], ng2[2], nb2[2];                                   // compact (the last layer leaves them unloaded, and leaves the loop before they are used)
     float naddv = 0.f;
     if (!last) {
       const XGroupLayer& Ln = s_lay[g + 1];
@@ -245,18 +257,18 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       {
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-          ng1[e] = ldg4(s_lay[g].g1, ch); nb1[e] = ldg4(s_lay[g].b1, ch); ng2[e] = ldg4(s_lay[g].g2, ch); nb2[e] = ldg4(s_lay[g].b2, ch);
-          if (nt2) vta[e] = ldg4(Ln.xt, bb * (unsigned)Ln.xt_bs + ch);
+          const unsigned chc = (unsigned)((8 * e + wave) * 16 + cc);
+          ng1[e] = ldg1(s_lay[g].g1, chc); nb1[e] = ldg1(s_lay[g].b1, chc); ng2[e] = ldg1(s_lay[g].g2, chc); nb2[e] = ldg1(s_lay[g].b2, chc);
+          if (nt2) vta[e] = ldg4(Ln.xt, bb * (unsigned)Ln.xt_bs + (unsigned)((8 * e + wave) * 16 + c4));
         }
       }
       if (wr) naddv = ldg1(Ln.presum, (unsigned)(eb * Ln.presum_bs) + (unsigned)pcol);      // behind the wait for the side stream; never read before in this launch
     }
     // this layer's input row is kept for later launches (history / residual): column group 0 stores it
-    if (grp == 0 && valid && s_lay[g].xm) {
+    if (grp == 0 && m0 + cr < p.B && s_lay[g].xm) {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
-        *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(reinterpret_cast<uintptr_t>(s_lay[g].xm + (long)b * s_lay[g].xm_bs + (8 * e + wave) * 16 + c4)) = f32x4{x[e].x, x[e].y, x[e].z, x[e].w};
+        *reinterpret_cast<__attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(s_lay[g].xm + (long)(m0 + cr) * s_lay[g].xm_bs + (8 * e + wave) * 16 + cc)) = xc[e];
     }
     stamp();                                                               // contraction issued, partial sums written, prefetches issued
     __syncthreads();
@@ -303,43 +315,37 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     __syncthreads();
     stamp();                                                               // team barrier passed
     // ---- the team's rows of layer g, past the L1
-    f32x4 h1[2], h2[2], st4[4];
+    float hg[2], hi[2]; f32x4 stc;
     {
-      const float* xr = p.xch + (long)par * p.xch_set + (long)bb * 512 + wave * 16 + c4;     // channels 16 w + c4; +128 floats = the second k-group
-      const float* sr = p.sch + (long)par * p.sch_set + (long)bb * 64 + aq * 16;
-      f32x4 t0, t1, t2, t3, t4, t5, t6, t7;
+      const float* xr = p.xch + (long)par * p.xch_set + (long)crow * 512 + wave * 16 + cc;   // gate channel 16 w + cc; +128 floats = the second k-group; +256 = info
+      const float* sr = p.sch + (long)par * p.sch_set + (long)crow * 64 + cc * 4;             // column group cc's partial statistics of the row
       asm volatile(
-          "global_load_dwordx4 %0, %8, off sc1\n\t"
-          "global_load_dwordx4 %1, %8, off offset:512 sc1\n\t"
-          "global_load_dwordx4 %2, %8, off offset:1024 sc1\n\t"
-          "global_load_dwordx4 %3, %8, off offset:1536 sc1\n\t"
-          "global_load_dwordx4 %4, %9, off sc1\n\t"
-          "global_load_dwordx4 %5, %9, off offset:16 sc1\n\t"
-          "global_load_dwordx4 %6, %9, off offset:32 sc1\n\t"
-          "global_load_dwordx4 %7, %9, off offset:48 sc1\n\t"
+          "global_load_dword %0, %5, off sc1\n\t"
+          "global_load_dword %1, %5, off offset:512 sc1\n\t"
+          "global_load_dword %2, %5, off offset:1024 sc1\n\t"
+          "global_load_dword %3, %5, off offset:1536 sc1\n\t"
+          "global_load_dwordx4 %4, %6, off sc1\n\t"
           "s_waitcnt vmcnt(0)"
-          : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+          : "=&v"(hg[0]), "=&v"(hg[1]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(stc)
           : "v"(xr), "v"(sr)
           : "memory");
-      h1[0] = t0; h1[1] = t1; h2[0] = t2; h2[1] = t3; st4[0] = t4; st4[1] = t5; st4[2] = t6; st4[3] = t7;
     }
     stamp();                                                               // exchanged rows landed
-    // ---- rebuild the next layer's input: gate(LN(exchanged rows)) mixed with this layer's input (the highway residual, still in registers)
+    // ---- rebuild the next layer's input: gate(LN(exchanged rows)) mixed with this layer's input (the highway residual), compact, then through
+    //      the LDS into the A-operand layout.  Chan-combine of the 16 per-group partials (mean_g, M2_g over 16 channels each): the row's 16 lanes hold one each.
     {
-      float4 st[4] = {f4(st4[0]), f4(st4[1]), f4(st4[2]), f4(st4[3])};
-      float m1, r1, m2, r2;
-      combine_stats(st, 0, m1, r1); combine_stats(st, 1, m2, r2);
+      const float m1 = row16_sum(stc[0]) * (1.0f / 16.0f), m2 = row16_sum(stc[2]) * (1.0f / 16.0f);
+      const float d1 = stc[0] - m1, d2 = stc[2] - m2;
+      const float r1 = rsqrt_fast(row16_sum(stc[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+      const float r2 = rsqrt_fast(row16_sum(stc[3] + 16.0f * d2 * d2) * (1.0f / 256.0f) + 1e-12f);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const f32x4 a1 = h1[e], a2 = h2[e], g1 = ng1[e], b1 = nb1[e], g2 = ng2[e], b2 = nb2[e];
-        const float4 xr = x[e];
-        float4 o;
-        { const float s_ = sigmoid_fast((a1[0] - m1) * r1 * g1[0] + b1[0]); o.x = s_ * ((a2[0] - m2) * r2 * g2[0] + b2[0]) + (1.0f - s_) * xr.x; }
-        { const float s_ = sigmoid_fast((a1[1] - m1) * r1 * g1[1] + b1[1]); o.y = s_ * ((a2[1] - m2) * r2 * g2[1] + b2[1]) + (1.0f - s_) * xr.y; }
-        { const float s_ = sigmoid_fast((a1[2] - m1) * r1 * g1[2] + b1[2]); o.z = s_ * ((a2[2] - m2) * r2 * g2[2] + b2[2]) + (1.0f - s_) * xr.z; }
-        { const float s_ = sigmoid_fast((a1[3] - m1) * r1 * g1[3] + b1[3]); o.w = s_ * ((a2[3] - m2) * r2 * g2[3] + b2[3]) + (1.0f - s_) * xr.w; }
-        x[e] = o;
+        const float s_ = sigmoid_fast((hg[e] - m1) * r1 * ng1[e] + nb1[e]);
+        xc[e] = s_ * ((hi[e] - m2) * r2 * ng2[e] + nb2[e]) + (1.0f - s_) * xc[e];
+        xs[cr * 32 + e * 16 + cc] = xc[e];
       }
+      x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
+      x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
     }
     addv = naddv;
   }
