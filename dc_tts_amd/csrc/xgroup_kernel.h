@@ -89,13 +89,19 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   __shared__ __attribute__((aligned(16))) float s_xs[8][4 * 32];
   typedef const __attribute__((address_space(4))) XGroupParams CP;
   CP& p = *(CP*)pp;
+  // Block order of a launch with passengers: [the COUNTED passengers (the side stream waits for them; a multiple of 8 blocks, so the teams' blocks keep
+  // their XCDs)] [the teams] [the other passengers].  The counted ones come first because the launch usually starts while the side stream's xcone_kernel
+  // still holds half the CUs and the teams take the other half: behind the teams they would start only when xcone ends -- which is when the side stream
+  // begins to wait for them.
+  int tbid = (int)blockIdx.x;              // block index among the teams' blocks
   if (p.p_blocks) {
-    const int first = (int)gridDim.x - p.p_blocks;
-    if ((int)blockIdx.x >= first) {
+    const int nd = p.p_blocks / p.p_ipl, front = (nd - p.p_count_from) * p.p_ipl, back0 = (int)gridDim.x - (p.p_blocks - front);
+    if ((int)blockIdx.x < front || (int)blockIdx.x >= back0) {
       extern __shared__ __attribute__((aligned(16))) float pass_smem[];
       __shared__ long s_prow[2][32];
-      const int nd = p.p_blocks / p.p_ipl, q = (int)blockIdx.x - first, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
-      const int ncount = nd - p.p_count_from, layer = qd < ncount ? p.p_count_from + qd : qd - ncount;
+      const bool counted = (int)blockIdx.x < front;
+      const int q = counted ? (int)blockIdx.x : (int)blockIdx.x - back0, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
+      const int layer = counted ? p.p_count_from + qd : qd;
       ConstSplitParams& sp = *((ConstSplitParams*)p.ptab + layer);
       hbulk_body<8, ConstSplitParams>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, pass_smem, s_prow);
       if (p.pdone && layer >= p.p_count_from) {
@@ -109,6 +115,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       }
       return;
     }
+    tbid -= front;
   }
   // everything the first layer needs, in ONE batch of scalar loads (left alone the fields arrive lazily, a dependent scalar load at a time: ~3 us
   // until the first row was built)
@@ -118,7 +125,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
                   "s"(p.xch), "s"(p.sch), "s"(p.xch_set), "s"(p.sch_set), "s"(p.bar), "s"(p.bar_base), "s"(p.err),
                   "s"(p.sig), "s"(p.sig_val), "s"(p.wait2), "s"(p.wait_val), "s"(p.pout), "s"(p.stats_out));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
+  const int bx = tbid & 7, bq = tbid >> 3;
   const int grp = bq & 15, team = bx + 8 * (bq >> 4), m0 = team * 4;
   if (m0 >= p.B) return;                                                   // a team without utterances (B not a multiple of 32): uniform per workgroup
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
@@ -136,7 +143,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   unsigned* const bar = p.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
   int nts = 0;
-  auto stamp = [&]() { if constexpr (TS) { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); } };
+  auto stamp = [&]() { if constexpr (TS) { if (p.ts && tbid == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); } };
   stamp();
 
   // ---- layer 0: everything that does not come from the side stream by plain loads (the producer is an earlier launch)
@@ -175,7 +182,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   // ---- placement check, the stream signal, and the wait for the side stream (first launch of a chain piece), while those loads are in flight
   if (tid == 0) {
     int go = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
-    if (p.sig && blockIdx.x == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p.sig && tbid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p.wait2 && go) {
       bool ok = false;
       for (int i = 0; i < (1 << 20) && !ok; ++i) {                         // bounded: about a second
