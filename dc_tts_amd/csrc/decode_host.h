@@ -995,8 +995,9 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 extern "C" int dctts_decode_status(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   if (c->xg_err_host && *c->xg_err_host) {                  // reported once; a placement failure switches the kernel off for good
+    const int ew = *c->xg_err_host;
     *c->xg_err_host = 0; c->xgroup_ok = false;
-    return fail(DCTTS_ERR_STATE, "decode: a bounded wait inside xgroup_kernel gave up (a team of workgroups was not on one XCD, or the side stream never arrived): the results of that decode are invalid; further decodes run one launch per layer");
+    return fail(DCTTS_ERR_STATE, "decode: a bounded wait inside a team kernel gave up (error word " + std::to_string(ew) + ": 1 / 2 = xgroup_kernel barrier time-out / a team not on one XCD, 4 / 8 = the same in xcone_kernel, 16 = the side stream never arrived): the results of that decode are invalid; further decodes run one launch per layer");
   }
   if (c->wait_err_host && *c->wait_err_host) {              // reported once: the error word is cleared so that the next decode starts clean
     DevGuard dev_guard(c);

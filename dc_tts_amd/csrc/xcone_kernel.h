@@ -57,9 +57,9 @@ __device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned x
       for (;;) {
         const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;       // sc1 loads: past the L1, served by the L2
         const bool there = (int)((v >> 4) - target) >= 0;
-        if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(err, 3); break; }         // a split team
+        if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(err, 8); break; }         // a split team
         if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
-        if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(err, 1); break; }
+        if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(err, 4); break; }
       }
     }
   }
@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   __shared__ int s_prow[256];            // ... its pre-norm row index in pout
   typedef const __attribute__((address_space(4))) XConeParams CP;
   CP& p = *(CP*)pp;
+  // the launch's own parameters in ONE batch of scalar loads (lazily: six dependent batches before the first layer)
+  asm volatile("; xcone: parameters, one batch" :: "s"(p.B), "s"(p.L), "s"(p.frame), "s"(p.bar), "s"(p.bar_base), "s"(p.err), "s"(p.ts),
+               "s"(p.done), "s"(p.done_target), "s"(p.sig), "s"(p.sig_val), "s"(p.wait), "s"(p.wait_val), "s"(p.wait_err), "s"(p.lay[0].wp));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   const int grp = bq & 15, team = bx + 8 * (bq >> 4), b0 = team * 4;
@@ -105,6 +108,13 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   };
   load_w(0, bq0, bq1);
   for (int li = 0; li < p.L; ++li) {
+    {                                      // ... and a layer's descriptor in one batch (lazily: three dependent batches at the top of every layer, more in the row pass)
+      typedef const __attribute__((address_space(4))) XConeLayer CL;
+      CL& y = p.lay[li];
+      asm volatile("; xcone: a layer's descriptor, one batch" :: "s"(y.bias), "s"(y.g1), "s"(y.b1), "s"(y.g2), "s"(y.b2), "s"(y.xin), "s"(y.xin_bstride), "s"(y.xin_row0),
+                   "s"(y.xin_stride), "s"(y.xout), "s"(y.xout_bstride), "s"(y.xout_row0), "s"(y.xout_stride), "s"(y.pout), "s"(y.offs), "s"(y.R),
+                   "s"(y.tap_off[0]), "s"(y.tap_off[1]));
+    }
     const int R = p.lay[li].R, M = nb * R, ntile = (M + 15) >> 4;
     const float bias = p.lay[li].bias[pcol];
     const float* xin = p.lay[li].xin;

@@ -89,19 +89,17 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   __shared__ __attribute__((aligned(16))) float s_xs[8][4 * 32];
   typedef const __attribute__((address_space(4))) XGroupParams CP;
   CP& p = *(CP*)pp;
-  // Block order of a launch with passengers: [the COUNTED passengers (the side stream waits for them; a multiple of 8 blocks, so the teams' blocks keep
-  // their XCDs)] [the teams] [the other passengers].  The counted ones come first because the launch usually starts while the side stream's xcone_kernel
-  // still holds half the CUs and the teams take the other half: behind the teams they would start only when xcone ends -- which is when the side stream
-  // begins to wait for them.
-  int tbid = (int)blockIdx.x;              // block index among the teams' blocks
+  // Block order of a launch with passengers: [the teams] [the counted passengers] [the others].  The teams come FIRST: when the launch starts, the side
+  // stream's xcone_kernel holds 16 of every XCD's 32 CUs and the teams need exactly the other 16 -- with the counted passengers in front of them (they would
+  // finish ~4 us earlier, worth 0.9 us per frame) some team workgroups have to wait for a CU of THEIR XCD, and one decode in ~100 then failed a team hand-off.
+  const int tbid = (int)blockIdx.x;        // block index among the teams' blocks
   if (p.p_blocks) {
-    const int nd = p.p_blocks / p.p_ipl, front = (nd - p.p_count_from) * p.p_ipl, back0 = (int)gridDim.x - (p.p_blocks - front);
-    if ((int)blockIdx.x < front || (int)blockIdx.x >= back0) {
+    const int first = (int)gridDim.x - p.p_blocks;
+    if ((int)blockIdx.x >= first) {
       extern __shared__ __attribute__((aligned(16))) float pass_smem[];
       __shared__ long s_prow[2][32];
-      const bool counted = (int)blockIdx.x < front;
-      const int q = counted ? (int)blockIdx.x : (int)blockIdx.x - back0, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
-      const int layer = counted ? p.p_count_from + qd : qd;
+      const int nd = p.p_blocks / p.p_ipl, q = (int)blockIdx.x - first, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
+      const int ncount = nd - p.p_count_from, layer = qd < ncount ? p.p_count_from + qd : qd - ncount;
       ConstSplitParams& sp = *((ConstSplitParams*)p.ptab + layer);
       hbulk_body<8, ConstSplitParams>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, pass_smem, s_prow);
       if (p.pdone && layer >= p.p_count_from) {
@@ -115,7 +113,6 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       }
       return;
     }
-    tbid -= front;
   }
   // everything the first layer needs, in ONE batch of scalar loads (left alone the fields arrive lazily, a dependent scalar load at a time: ~3 us
   // until the first row was built)
@@ -189,7 +186,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
         ok = __hip_atomic_load(p.wait2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
         if (!ok) __builtin_amdgcn_s_sleep(16);                              // 128 pollers over the fabric: ~0.4 us apart is plenty, and spares the side stream's bandwidth
       }
-      if (!ok) atomicOr(p.err, 1);
+      if (!ok) atomicOr(p.err, 16);                                        // (bits of the error word: 1 / 2 xgroup barrier time-out / split team, 4 / 8 the same in xcone_kernel, 16 this wait)
     }
     s_go = go;
   }
@@ -313,7 +310,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
         for (;;) {
           const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : mine;   // sc1 loads: past the L1, served by the L2
           const bool there = (int)((v >> 4) - target) >= 0;
-          if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(p.err, 3); break; }      // a split team
+          if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(p.err, 2); break; }      // a split team
           if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
           if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(p.err, 1); break; }   // bounded (~20 ms), and nobody keeps waiting once anybody gave up
         }
