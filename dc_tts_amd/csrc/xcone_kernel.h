@@ -211,11 +211,11 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     // ---- layer-norm / gate / highway mix of the cone rows (offsets < 0): one wave per row, the team's 128 waves in turn
     const int Rb = R - 1;
     if (Rb > 0) {
-      RowNorm n; n.P = pout; n.np = 512; n.g1 = p.lay[li].g1; n.b1 = p.lay[li].b1; n.g2 = p.lay[li].g2; n.b2 = p.lay[li].b2; n.act = ACT_NONE; n.ngroups = 16;
-      n.res = nullptr; n.res_bstride = 0; n.res_row0 = 0; n.res_stride = 0; n.res_set = 0;
       float* xout = p.lay[li].xout;
       const long obs = p.lay[li].xout_bstride, or0 = p.lay[li].xout_row0; const int os = p.lay[li].xout_stride;
       const int c = lane * 4;
+      // the layer's layer-norm parameters once, with the first row's requests (inside norm_hc_regs they were a second round trip per row)
+      const float4 g1 = ld4(p.lay[li].g1 + c), be1 = ld4(p.lay[li].b1 + c), g2 = ld4(p.lay[li].g2 + c), be2 = ld4(p.lay[li].b2 + c);
       for (int q = grp * 8 + wave; q < nb * Rb; q += 128) {
         const int bl = q / Rb, r = q - bl * Rb;
         const int m = bl * R + r;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
         const long prow = (long)(s_prow[m] & 0x3fffffff);
         const float4 h1 = ld4(pout + prow * 512 + c), h2 = ld4(pout + prow * 512 + 256 + c);
         const float4 xr = ld4(xin + xo + c);                                   // the layer's own input row (modules.py:171,193)
-        const float4 o = norm_hc_regs(n, h1, h2, xr, lane);
+        const float4 o = norm_hc_vals(h1, h2, xr, g1, be1, g2, be2);
         const int t = (int)((long)xo / xs - ((long)(b0 + bl) * xbs + xr0));
         *reinterpret_cast<float4*>(xout + ((long)(b0 + bl) * obs + or0 + t) * os + c) = o;
       }
