@@ -32,6 +32,14 @@ __global__ void census_kernel(unsigned* out) {
   if (threadIdx.x == 0) out[blockIdx.x] = xcc_id();
 }
 
+__global__ void __launch_bounds__(512) hog_kernel(long long* sink, int ticks) {          // holds its CU for `ticks` x 10 ns
+  extern __shared__ float hog_lds[];
+  const long long t0 = wall_clock64();
+  long long t = t0;
+  while (t - t0 < ticks) { t = wall_clock64(); }
+  if (threadIdx.x == 0 && blockIdx.x == 0) { hog_lds[0] = 1.f; sink[0] = t; }
+}
+
 struct TeamParams {
   unsigned* census;      // [16] arrivals per XCD (mode 0) / [0] arrivals (mode 1)
   unsigned* bar;         // barrier counter (monotonic)
@@ -141,6 +149,28 @@ int main() {
   printf("census of 512 blocks x 512 threads: per XCD");
   for (int x = 0; x < 8; ++x) printf(" %d", per2[x]);
   printf("; b %% 8 rule holds for %d of 512\n", rr);
+
+  // ---- (1b) census under pressure: does block b of a launch still land on XCD (b + k) % 8 when another stream's workgroups hold most CUs and the
+  //      launch's workgroups have to wait for free ones?  (The team kernels' placement rule; a violation is detected there, never trusted.)
+  {
+    hipStream_t sa, sb; CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+    long long* d_t; CK(hipMalloc(&d_t, 8));
+    for (int hogs : {96, 128, 160, 200, 240, 256}) {
+      int viol = 0, launches = 0;
+      for (int rep = 0; rep < 40; ++rep) {
+        hipLaunchKernelGGL(hog_kernel, dim3(hogs), dim3(512), 60 * 1024, sa, d_t, 3000 + 500 * (rep % 5));      // 60 KB of LDS: one per CU next to a 512-thread census block
+        hipLaunchKernelGGL(census_kernel, dim3(512), dim3(512), 0, sb, d_c);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c.data(), d_c, 512 * 4, hipMemcpyDeviceToHost));
+        const int k = (int)c[0];
+        int v = 0;
+        for (int b = 0; b < 512; ++b) v += ((int)c[b] != (b + k) % 8);
+        viol += (v != 0); ++launches;
+      }
+      printf("census of 512 x 512-thread blocks next to %3d long-running workgroups on another stream: %d of %d launches broke the (b + k) %% 8 rule\n", hogs, viol, launches);
+    }
+    CK(hipStreamDestroy(sa)); CK(hipStreamDestroy(sb)); CK(hipFree(d_t));
+  }
 
   // ---- (2) team runs
   const int L = 208;
