@@ -424,21 +424,22 @@ extern "C" int dctts_train_sigmoid(dctts_train* t, const float* x, float* y, lon
 extern "C" int dctts_train_attention_forward(dctts_train* t, const float* Q, const float* K, const float* V, int B, int T, int N, int d,
                                              float* R, float* alignments, void* stream) {
   if (!t || !Q || !K || !V || !R || !alignments) TFAIL(DCTTS_ERR_ARG, "attention_forward: null argument");
-  if (B <= 0 || T <= 0 || N <= 0 || (N & 3) || d <= 0 || (d & 3)) TFAIL(DCTTS_ERR_ARG, "attention_forward: N and d multiples of 4");
+  if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || (d & 3)) TFAIL(DCTTS_ERR_ARG, "attention_forward: d must be a multiple of 4");
   DevScope ds(t->device);
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const long rows = (long)B * T;
-  if (reserve(&t->att, (size_t)2 * rows * N * 4)) return DCTTS_ERR_HIP;
+  const int Np = (N + 3) & ~3;             // leading dimension of the attention matrix (the GEMMs load 16 bytes at a time): any N, softmax over the true N
+  if (reserve(&t->att, (size_t)2 * rows * Np * 4)) return DCTTS_ERR_HIP;
   float* A = (float*)t->att.p;
   int rc;
-  if ((rc = gemm_batched<false, true>(st, B, Q, (long)T * d, K, (long)N * d, A, (long)T * N, T, N, d, d, d, N, 0))) return rc;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, rows, N, N, 1.0f / std::sqrt((float)d));
+  if ((rc = gemm_batched<false, true>(st, B, Q, (long)T * d, K, (long)N * d, A, (long)T * Np, T, N, d, d, d, Np, 0))) return rc;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, rows, N, Np, 1.0f / std::sqrt((float)d));
   THIP(hipGetLastError());
-  if ((rc = gemm_batched<false, false>(st, B, A, (long)T * N, V, (long)N * d, R, (long)T * 2 * d, T, d, N, N, d, 2 * d, 0))) return rc;
+  if ((rc = gemm_batched<false, false>(st, B, A, (long)T * Np, V, (long)N * d, R, (long)T * 2 * d, T, d, N, Np, d, 2 * d, 0))) return rc;
   hipLaunchKernelGGL(scatter_cols_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, Q, R + d, 2 * d, rows, d);
   THIP(hipGetLastError());
-  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows * N + 255) / 256)), dim3(256), 0, st, (const float*)A, alignments, B, T, N);
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((rows * N + 255) / 256)), dim3(256), 0, st, (const float*)A, alignments, B, T, N, Np);
   THIP(hipGetLastError());
   return 0;
 }
@@ -447,29 +448,30 @@ extern "C" int dctts_train_attention_forward(dctts_train* t, const float* Q, con
 extern "C" int dctts_train_attention_backward(dctts_train* t, const float* Q, const float* K, const float* V, const float* dR, const float* dAl,
                                               int B, int T, int N, int d, float* dQ, float* dK, float* dV, void* stream) {
   if (!t || !Q || !K || !V || !dR || !dAl || !dQ || !dK || !dV) TFAIL(DCTTS_ERR_ARG, "attention_backward: null argument");
-  if (B <= 0 || T <= 0 || N <= 0 || (N & 3) || d <= 0 || (d & 3)) TFAIL(DCTTS_ERR_ARG, "attention_backward: N and d multiples of 4");
+  if (B <= 0 || T <= 0 || N <= 0 || d <= 0 || (d & 3)) TFAIL(DCTTS_ERR_ARG, "attention_backward: d must be a multiple of 4");
   DevScope ds(t->device);
   if (!ds.ok) TFAIL(DCTTS_ERR_HIP, "hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
   const long rows = (long)B * T;
-  if (reserve(&t->att, (size_t)2 * rows * N * 4)) return DCTTS_ERR_HIP;
-  float* A = (float*)t->att.p; float* dA = A + rows * N;
+  const int Np = (N + 3) & ~3;             // (as in the forward pass)
+  if (reserve(&t->att, (size_t)2 * rows * Np * 4)) return DCTTS_ERR_HIP;
+  float* A = (float*)t->att.p; float* dA = A + rows * Np;
   const float scale = 1.0f / std::sqrt((float)d);
   int rc;
   // A = softmax(Q K^T * scale)
-  if ((rc = gemm_batched<false, true>(st, B, Q, (long)T * d, K, (long)N * d, A, (long)T * N, T, N, d, d, d, N, 0))) return rc;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, rows, N, N, scale);
+  if ((rc = gemm_batched<false, true>(st, B, Q, (long)T * d, K, (long)N * d, A, (long)T * Np, T, N, d, d, d, Np, 0))) return rc;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, rows, N, Np, scale);
   THIP(hipGetLastError());
   // dA = dR[:, :, :d] V^T (+ dAl^T in the row kernel);  dV = A^T dR[:, :, :d]
-  if ((rc = gemm_batched<false, true>(st, B, dR, (long)T * 2 * d, V, (long)N * d, dA, (long)T * N, T, N, d, 2 * d, d, N, 0))) return rc;
-  if ((rc = gemm_batched<true, false>(st, B, A, (long)T * N, dR, (long)T * 2 * d, dV, (long)N * d, N, d, T, N, 2 * d, d, 0))) return rc;
-  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)A, dA, dAl, B, T, N, N, scale);
+  if ((rc = gemm_batched<false, true>(st, B, dR, (long)T * 2 * d, V, (long)N * d, dA, (long)T * Np, T, N, d, 2 * d, d, Np, 0))) return rc;
+  if ((rc = gemm_batched<true, false>(st, B, A, (long)T * Np, dR, (long)T * 2 * d, dV, (long)N * d, N, d, T, Np, 2 * d, d, 0))) return rc;
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, (const float*)A, dA, dAl, B, T, N, Np, scale);
   THIP(hipGetLastError());
   // dQ = dS K + dR[:, :, d:];  dK = dS^T Q      (the 1 / sqrt(d) is folded into dS)
   hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)((rows * d + 255) / 256)), dim3(256), 0, st, dR + d, 2 * d, dQ, rows, d);
   THIP(hipGetLastError());
-  if ((rc = gemm_batched<false, false>(st, B, dA, (long)T * N, K, (long)N * d, dQ, (long)T * d, T, d, N, N, d, d, 1))) return rc;
-  if ((rc = gemm_batched<true, false>(st, B, dA, (long)T * N, Q, (long)T * d, dK, (long)N * d, N, d, T, N, d, d, 0))) return rc;
+  if ((rc = gemm_batched<false, false>(st, B, dA, (long)T * Np, K, (long)N * d, dQ, (long)T * d, T, d, N, Np, d, d, 1))) return rc;
+  if ((rc = gemm_batched<true, false>(st, B, dA, (long)T * Np, Q, (long)T * d, dK, (long)N * d, N, d, T, Np, d, d, 0))) return rc;
   return 0;
 }
 

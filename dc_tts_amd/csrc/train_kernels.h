@@ -528,11 +528,12 @@ __global__ void embed_fwd_kernel(const int* __restrict__ ids, const float* __res
 }
 
 // dst (B, C, R) <- src (B, R, C)^T per batch item (alignments = A^T, networks.py:153)
-__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int R, int C) {
+// (src rows are ld floats apart: the attention matrix keeps a leading dimension rounded up to 4 floats for the GEMMs' 16-byte loads)
+__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int R, int C, int ld) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * R * C) return;
   const int r = (int)(i % R); const long q = i / R; const int c = (int)(q % C), b = (int)(q / C);
-  dst[i] = src[((long)b * R + r) * C + c];
+  dst[i] = src[((long)b * R + r) * ld + c];
 }
 
 // dst rows (ld_dst apart) at column offset <- src rows (C wide)
@@ -558,6 +559,7 @@ __global__ void __launch_bounds__(256) softmax_rows_kernel(float* __restrict__ S
   for (int n = lane; n < N; n += 64) { const float e = expf(s[n] * scale - mx); s[n] = e; sum += e; }
   const float inv = 1.0f / t_wave_sum(sum);
   for (int n = lane; n < N; n += 64) s[n] *= inv;
+  for (int n = N + lane; n < Np; n += 64) s[n] = 0.f;             // pad columns: read (as zeros) by the 16-byte loads of the GEMMs that contract over N
 }
 
 // dS = A * (dA + dAl^T - sum_n A (dA + dAl^T)) * scale, in place in dA (rows = B * T; dAl is (B, N, T)).  Wave per row.
@@ -573,6 +575,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_rows_kernel(const float* __re
   for (int n = lane; n < N; n += 64) { const float g = d[n] + al[(long)n * T]; d[n] = g; dot += a[n] * g; }
   dot = t_wave_sum(dot);
   for (int n = lane; n < N; n += 64) d[n] = a[n] * (d[n] - dot) * scale;
+  for (int n = N + lane; n < Np; n += 64) d[n] = 0.f;
 }
 
 // dst (rows, C) <- src (rows, C) taken from a wider row (ld floats apart)

@@ -102,7 +102,8 @@ class BatchQueue:
     emitted as one batch, every tensor zero-padded to the longest member (tf.contrib.training.bucket_by_sequence_length(dynamic_pad=True)).
     Yields (texts (B, N) int32, mels (B, T / r, n_mels), mags (B, T, 1 + n_fft / 2), fnames).  Leftovers stay in their bucket for the
     next epoch, as in a queue.  The reference's 8 reader threads make its batch order nondeterministic; here it is a function of `seed`.
-    `pad_text_to`: N is rounded up to this multiple with more P (id 0) columns -- dctts_train_attention_backward needs N % 4 == 0."""
+    `pad_text_to`: N is rounded up to this multiple with more P (id 0) columns (default 1 = the reference's padding to the longest text of the batch;
+    the training attention takes any N)."""
 
     def __init__(self, hp: Hyperparams = _hp, seed: int = 0, prepro_dir: str = ".", transcript: Optional[str] = None, pad_text_to: int = 1):
         self.hp, self.prepro_dir, self.pad_text_to = hp, prepro_dir, pad_text_to

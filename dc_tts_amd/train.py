@@ -492,7 +492,7 @@ def main(argv=None, hp=None, save_every: int = 1000, batches=None, init_seed: in
     print("Training Graph loaded" + (" (resumed at global_step %d)" % g.global_step if resumed else ""), file=sys.stderr)
     if batches is None:
         from .data_load import get_batch
-        batches = get_batch(hp, seed=g.global_step, prepro_dir=args.prepro_dir, pad_text_to=4)     # attention_backward needs N % 4 == 0
+        batches = get_batch(hp, seed=g.global_step, prepro_dir=args.prepro_dir)                    # texts padded to the batch's longest, as data_load.py:152-160 does
     dev = g.ops.device
     for texts, mels, mags, _ in batches:
         if num == 1:

@@ -101,7 +101,7 @@ def test_loop_reads_the_batch_queue(fake, tmp_path):
     assert prepo.main(["--out", pre], hp=h) == 0
     assert TRN.main(["1", "--prepro-dir", pre, "--num-iterations", "2"], hp=h, save_every=50) == 0
     g = fake.made[-1]
-    assert g.global_step == 3 and all(b[0][0] == 4 and b[0][1] % 4 == 0 and b[1][2] == hp.n_mels for b in g.batches)
+    assert g.global_step == 3 and all(b[0][0] == 4 and b[0][1] >= 1 and b[1][2] == hp.n_mels for b in g.batches)     # (texts padded to the batch's longest: any N)
     assert TRN.main(["2", "--data", root, "--prepro-dir", pre, "--logdir", h.logdir, "--num-iterations", "0"], hp=hp.replace(B=4), save_every=50) == 0
     assert fake.made[-1].batches[0][1][2] == hp.n_linear and fake.made[-1].batches[0][1][1] == 4 * fake.made[-1].batches[0][0][1]
 
