@@ -362,7 +362,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     const bool prof = c->prof_id == DCTTS_PROF_XCONE && f >= 100 && (f & 15) == 8;          // full-size cones only; eager decode only (graph mode 0)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, sb)); }
-    hipLaunchKernelGGL(xcone_kernel, dim3(128 * (((B + 3) / 4 + 7) / 8)), dim3(512), 0, sb, xp);
+    hipLaunchKernelGGL(xcone_kernel, dim3(128), dim3(512), 0, sb, xp);
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < AD.size(); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
     return 0;
@@ -521,7 +521,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       p.pout = P[i1 - 1]; p.stats_out = S[i1 - 1];
       p.xch = m.xch[net]; p.sch = m.sch[net]; p.xch_set = m.bpad * 512; p.sch_set = m.bpad * 64;
       p.bar = m.bar; p.bar_base = arrivals; p.err = m.err;
-      arrivals += (unsigned)(L - 1) * 16u;
+      arrivals += (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(L - 1) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
       if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
         if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
@@ -556,8 +556,9 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
   const int pass = (net == 0 && c->ae_pass && piece >= 0 && piece + 1 < c->xg_T) ? c->aepre_layers * (((B + 31) / 32) * (c->cfg.d / 32)) : 0;     // as in the table
-  if (piece == c->trace_frame) hipLaunchKernelGGL(xgroup_kernel<true>, dim3(128 * ((teams + 7) / 8) + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);      // DCTTS_TRACE: stamped
-  else hipLaunchKernelGGL(xgroup_kernel<false>, dim3(128 * ((teams + 7) / 8) + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
+  // always 128 team workgroups (8 teams of 16, one team per XCD): more could starve the other stream of CUs while they poll for it
+  if (piece == c->trace_frame) hipLaunchKernelGGL(xgroup_kernel<true>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);      // DCTTS_TRACE: stamped
+  else hipLaunchKernelGGL(xgroup_kernel<false>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
   HIPCHK(hipGetLastError());
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }   // prof_rows counts LAYERS here
   return 0;
@@ -591,9 +592,9 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       q.offs = c->cone3_dev[i]; q.R = c->cone_len[i];
       for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = Ly.tap_off[t3];
     }
-    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(2 * L - 1) * 16u; p.err = m.err;
+    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(2 * L - 1) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
     if (insig) {                                                // the launch's last team publishes "side-stream piece f complete" itself
-      p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)((B + 3) / 4);
+      p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)(((B + 3) / 4 < 8) ? (B + 3) / 4 : 8);      // one count per team (at most 8)
       p.sig = c->wait_ctr + 32; p.sig_val = (unsigned)(f + 1);
       if (f + 1 < T) { p.wait = c->wait_ctr; p.wait_val = (unsigned)(f + 1); p.wait_err = (int*)(c->wait_ctr + 64); }      // what side-stream piece f + 1 starts from
     }

@@ -80,9 +80,9 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
                "s"(p.done), "s"(p.done_target), "s"(p.sig), "s"(p.sig_val), "s"(p.wait), "s"(p.wait_val), "s"(p.wait_err), "s"(p.lay[0].wp));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
-  const int grp = bq & 15, team = bx + 8 * (bq >> 4), b0 = team * 4;
-  if (b0 >= p.B) return;
-  const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
+  // the grid is always 128 workgroups (8 teams): a team takes the utterance groups team, team + 8, ... in turn (xgroup_kernel.h says why)
+  const int grp = bq & 15, team = bx;
+  if (team * 4 >= p.B) return;
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
   const int etile = wave >> 2, ecol = lane & 15, ej = wave & 3;
   const int pcol = etile * 256 + grp * 16 + ecol;
@@ -106,6 +106,8 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
 #pragma unroll
     for (int i = 0; i < 6; ++i) { q0[i] = ldv(wb, w0 + (unsigned)(6 * wave + i) * 256u); q1[i] = ldv(wb, w1 + (unsigned)(6 * wave + i) * 256u); }
   };
+  for (int b0 = team * 4; b0 < p.B; b0 += 32) {
+  const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
   load_w(0, bq0, bq1);
   for (int li = 0; li < p.L; ++li) {
     {                                      // ... and a layer's descriptor in one batch (lazily: three dependent batches at the top of every layer, more in the row pass)
@@ -121,6 +123,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     const long xbs = p.lay[li].xin_bstride, xr0 = p.lay[li].xin_row0; const int xs = p.lay[li].xin_stride;
     const int to0 = p.lay[li].tap_off[0] * xs, to1 = p.lay[li].tap_off[1] * xs;        // (tap 2 is the row itself: causal)
     float* pout = p.lay[li].pout;
+    const int xsafe = (int)(((long)b0 * xbs + xr0) * xs);
     // ---- row tables of the layer (the two integer divisions and the offset-table read happen once per row, not once per tile and lane)
     if (tid < 256) {
       int xo = -1, pr = 0;
@@ -143,7 +146,8 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       const int xo = s_xoff[mi];
       const bool ok = m < M && xo >= 0;
       flags = (ok ? 1 : 0) | (((s_prow[mi] >> 30) & 1) ? 2 : 0);
-      const float* xrow = xin + (ok ? xo : 0) + c4;
+      const float* xrow = xin + (ok ? xo : xsafe) + c4;                       // (a row that does not exist reads this team's first utterance, time 0: the taps reach back
+                                                                              //  into that utterance's own zero rows, never in front of the buffer)
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
         const int g = 6 * wave + i, tap = g >> 4;                              // wave-uniform
@@ -234,6 +238,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     xcone_barrier(bar, grp, xcc, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
   }
+  }                                        // next utterance group of this team (the barrier count simply runs on)
   // ---- the team's rows are in this XCD's L2 (every team-mate has passed the last barrier behind its stores): write them back, count the
   // team, and let the last team publish the piece to the chain's stream, which polls `sig` in its next launch (chain3_kernel / xgroup_kernel: wait2)
   if (p.done && grp == 0 && tid == 0) {

@@ -123,25 +123,31 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
                   "s"(p.sig), "s"(p.sig_val), "s"(p.wait2), "s"(p.wait_val), "s"(p.pout), "s"(p.stats_out));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = tbid & 7, bq = tbid >> 3;
-  const int grp = bq & 15, team = bx + 8 * (bq >> 4), m0 = team * 4;
-  if (m0 >= p.B) return;                                                   // a team without utterances (B not a multiple of 32): uniform per workgroup
+  // The grid is ALWAYS 128 team workgroups (8 teams, one per XCD), whatever the batch: a team takes the utterance groups team, team + 8, ... in turn.
+  // More team workgroups than that can starve the other stream of CUs while they poll for it (both team kernels are one workgroup per CU by registers):
+  // at B = 96 a third round of polling xgroup workgroups held the CUs xcone_kernel needed to finish -- a resource deadlock until the bounded waits gave up.
+  const int grp = bq & 15, team = bx;
+  if (team * 4 >= p.B) return;                                             // a team without utterances: uniform per workgroup
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned* const bar = p.bar + team * 32;
+  const unsigned xcc = xg_xcc_id();
+  const int erow = aq * 4 + (wave & 3), etile = wave >> 2, ecol = lane & 15;
+  const int pcol = etile * 256 + grp * 16 + ecol;
+  int nts = 0;
+  auto stamp = [&]() { if constexpr (TS) { if (p.ts && tbid == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); } };
+  stamp();
+  for (int round = 0, m0 = team * 4; m0 < p.B; ++round, m0 += 32) {
+  if (round > 0) __syncthreads();                                          // the previous round's last reads of the LDS buffers
+  const unsigned rbase = p.bar_base + (unsigned)round * (unsigned)(p.L - 1) * 16u;      // the team's barrier sequence numbers of this round
   const int b = m0 + arow;
   // Only 4 of the 16 rows of an MFMA tile are utterances.  The other lanes run the same instructions on row 0's addresses: what they compute lands in
   // output rows nobody reads (MFMA rows are independent), so nothing is masked or zeroed for them -- per layer that was ~100 v_mov / select / exec-mask
   // instructions per wave, on a path that is bound by instruction issue as much as by latency.
   const bool valid = arow < 4 && b < p.B;
   const unsigned bb = valid ? (unsigned)b : 0u;
-  const int erow = aq * 4 + (wave & 3), etile = wave >> 2, ecol = lane & 15;
   const int eb = m0 + erow;
   const bool wr = erow < 4 && eb < p.B;
-  const int pcol = etile * 256 + grp * 16 + ecol;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  unsigned* const bar = p.bar + team * 32;
-  const unsigned xcc = xg_xcc_id();
-  int nts = 0;
-  auto stamp = [&]() { if constexpr (TS) { if (p.ts && tbid == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); } };
-  stamp();
 
   // ---- layer 0: everything that does not come from the side stream by plain loads (the producer is an earlier launch)
   f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2], vg1[2], vbe1[2], vst[4];
@@ -171,13 +177,13 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
     }
   }
-  {
+  if (round == 0) {
     constexpr int NW32 = (int)(sizeof(XGroupLayer) * 10 / 4);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(pp->lay);
     if (tid < NW32) reinterpret_cast<uint32_t*>(s_lay)[tid] = src[tid];
   }
   // ---- placement check, the stream signal, and the wait for the side stream (first launch of a chain piece), while those loads are in flight
-  if (tid == 0) {
+  if (tid == 0 && round == 0) {
     int go = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
     if (p.sig && tbid == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p.wait2 && go) {
@@ -303,7 +309,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     // the pollers' reads of that word queue in between (measured: 128 arrivals per layer cost 3-5 us).
     // The word also carries the XCD the writer runs on: a word from another XCD (should its line ever get here through memory) is an error, never a pass.
     if (wave == 0) {
-      const unsigned target = p.bar_base + (unsigned)(g + 1) * 16u, mine = (target << 4) | xcc;
+      const unsigned target = rbase + (unsigned)(g + 1) * 16u, mine = (target << 4) | xcc;
       if (lane == 0) __hip_atomic_store(bar + grp, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (team_ok) {
         int spins = 0;
@@ -353,6 +359,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     }
     addv = naddv;
   }
+  }                                        // next utterance group of this team
 }
 
 }  // namespace dctts

@@ -483,6 +483,21 @@ def test_ragged_batch_sizes(weights):
     assert bool(torch.isfinite(Y33).all())
 
 
+def test_large_batch_team_rounds(weights):
+    """B = 134: 34 teams of the decode's team kernels = 640 team workgroups, more than two rounds of the 256 CUs, the last team with two utterances.
+    Every utterance's mel rows and trajectory are bitwise those of the same utterance decoded inside a batch of 32 (teams that all fit at once)."""
+    T = 100
+    eng = engine_for(weights, max_T=T)
+    L = dev(synthetic_text(hp.replace(max_T=T), B=134, seed=77))
+    Y, mx = eng.text2mel(L)
+    eng.synchronize()
+    for a in (0, 64, 102):
+        Ys, ms = eng.text2mel(L[a:a + 32].contiguous())
+        eng.synchronize()
+        assert torch.equal(Y[a:a + 32], Ys) and torch.equal(mx[a:a + 32], ms), f"utterances {a} .. {a + 31}"
+    assert bool(torch.isfinite(Y).all())
+
+
 def test_long_form_shape(weights):
     """configs[4] shape class: max_T = 1000 (one GPU's share, B = 8); cone / history indexing far beyond 210."""
     T = 1000
