@@ -67,7 +67,7 @@ __device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned x
   return true;
 }
 
-// grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads
+// grid: 128 blocks of 512 threads, whatever the batch
 __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restrict__ pp) {
   __shared__ __attribute__((aligned(16))) float red[2][2 * 8 * 2 * 4 * 64];  // split-K partial sums of two row tiles, double-buffered: one barrier per pass
   __shared__ int s_go;

@@ -12,8 +12,9 @@
 // workgroups on one XCD gets through "publish 512 B, barrier, read everybody's slice" in 0.87 us with one flag word per workgroup (1.02 us with
 // an L2 atomic counter), against 1.8 us with agent-scope operations over the fabric and ~3 us for a launch boundary + cold loads.
 //
-// So: grid = 128 workgroups for B = 32; block b belongs to team b % 8 (= its XCD) and owns column group (b / 8) % 16; a team owns FOUR
-// utterances (the newest row of each) and all 16 column groups, i.e. everything a layer's layer-norm needs.  Per layer a workgroup contracts
+// So: grid = 128 workgroups, always; block b belongs to team b % 8 (= its XCD) and owns column group (b / 8) % 16; a team owns FOUR utterances at a
+// time (the newest row of each; utterance groups team, team + 8, ... in turn when B > 32) and all 16 column groups, i.e. everything a layer's
+// layer-norm needs.  Per layer a workgroup contracts
 // K = 256 for its (gate, info) pair of 16-column tiles over 8 waves (chain3_kernel's arithmetic: 16x16x4 fp32 MFMA, fixed-order LDS reduction,
 // partial layer-norm statistics per column group), publishes 4 x 32 pre-norm values + statistics with plain stores, arrives at the team's
 // barrier (its own word of the team's 64-byte line: no read-modify-write), and reads the other 15 slices past its L1.  Everything that does not depend on the predecessor -- the next layer's
