@@ -78,7 +78,7 @@ __device__ __forceinline__ unsigned xg_xcc_id() {
   return v & 0xfu;
 }
 
-// grid: 128 * ceil(ceil(B / 4) / 8) blocks of 512 threads (+ p_blocks passengers, with hsplit_smem(32) bytes of dynamic LDS)
+// grid: 128 blocks of 512 threads, whatever the batch (+ p_blocks passengers, with hsplit_smem(32) bytes of dynamic LDS)
 template <bool TS = false>                 // TS: the stamped instantiation (DCTTS_TRACE); the production kernel carries no trace of the stamps
 __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) {
   __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
