@@ -85,6 +85,22 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in src and "from oracle" not in src and "dctts_ref" not in src and "vocoder_ref" not in src, os.path.join(dp, f)
 
 
+def test_environment_knobs_are_the_documented_ones():
+    """The library reads a handful of measurement / A-B knobs from the environment (once, when a context is created).  The set in the source and the
+    table in tools/README.md must be the same, and small: knobs are how unmeasured variants pile up."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = ""
+    for name in ("dctts_api.hip", "decode_host.h"):
+        src += open(os.path.join(root, "dc_tts_amd", "csrc", name)).read()
+    in_source = set(re.findall(r'"(DCTTS_[A-Z_0-9]+)"', src))
+    readme = open(os.path.join(root, "tools", "README.md")).read()
+    table = readme.split("## Environment knobs")[1].split("Everything else")[0]
+    documented = set(re.findall(r"`(DCTTS_[A-Z_0-9]+)`", table))
+    assert in_source == documented, (sorted(in_source), sorted(documented))
+    assert len(in_source) <= 8
+
+
 def test_weights_container(weights):
     from dc_tts_amd.hyperparams import hp
     from dc_tts_amd.weights import check_weights, load_npz, save_npz, synthetic_text
