@@ -39,9 +39,11 @@ SYMBOLS = {
                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "dctts_audiodec_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "dctts_ssrn_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "dctts_text2mel_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "dctts_synthesize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dctts_text2mel_decode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dctts_synthesize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dctts_decode_status": (c_int, [c_void_p]),
+    "dctts_set_team_kernels": (c_int, [c_void_p, c_int]),
+    "dctts_debug_inject_decode_error": (c_int, [c_void_p, c_int]),
     "dctts_set_decode_graph": (c_int, [c_void_p, c_int]),
     "dctts_set_decode_mode": (c_int, [c_void_p, c_int]),
     "dctts_device_bytes": (c_size_t, [c_void_p]),

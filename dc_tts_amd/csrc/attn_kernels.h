@@ -40,7 +40,7 @@ struct AttnFullParams {
   const float* V; int v_stride; long v_bstride;
   int T, N, d;
   int monotonic; const int* prev_max; int win;
-  float* R;          // (B,T,2d) contiguous
+  float* R;          // (B,T,2d) contiguous, may be null
   float* align;      // (B,N,T) contiguous, may be null
   long long* maxatt; // (B,T) int64, may be null
 };
@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(256) attention_full_kernel(const AttnFullParam
   __syncthreads();
   block_argmax(pmx, pam);
   if (tid == 0 && p.maxatt) p.maxatt[(long)b * p.T + t] = (long long)s_arg;
+  if (!p.R) return;                                  // alignments / arg-max only (the decode's `alignments` output)
   float* rrow = p.R + ((long)b * p.T + t) * (2 * p.d);
   for (int c = tid; c < p.d; c += 256) {
     float acc = 0.f;
@@ -192,6 +193,33 @@ __global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x 
 __global__ void traj_to_i64_kernel(const int* pm_all, long long* out, int B, int T) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * T) { const int b = i / T, t = i - b * T; out[i] = (long long)pm_all[(long)(t + 1) * B + b]; }
+}
+
+
+// The LAST kernel of every decode.  xerr / werr: this decode's error words (team kernels; in-kernel waits), inject: the debug hook's bits.
+// dstat: the context's sticky status block -- [0] OR of error bits over every decode since the last report, [1] failed decodes, [2] whether THIS
+// decode failed (rewritten by every decode; poison_if_failed_kernel reads it behind the SSRN pass of dctts_synthesize).  A failed decode's outputs
+// are overwritten with NaN / -1: whatever consumes them cannot mistake them for results (the reference's sess.run raises instead of returning).
+__global__ void __launch_bounds__(256) decode_finish_kernel(const int* xerr, const int* werr, int inject, int* dstat, float* Y, long ny,
+                                                            long long* mx, long nmx, float* al, long nal) {
+  int e = inject;
+  if (xerr) e |= *xerr;
+  if (werr && *werr) e |= 32;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    dstat[2] = e != 0;
+    if (e) { atomicOr(dstat, e); atomicAdd(dstat + 1, 1); }
+  }
+  if (e == 0) return;
+  const float qnan = __int_as_float(0x7fc00000);
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x, step = (long)gridDim.x * blockDim.x;
+  for (long i = i0; i < ny; i += step) Y[i] = qnan;
+  if (mx) for (long i = i0; i < nmx; i += step) mx[i] = -1;
+  if (al) for (long i = i0; i < nal; i += step) al[i] = qnan;
+}
+__global__ void __launch_bounds__(256) poison_if_failed_kernel(const int* dstat, float* Z, long nz) {
+  if (dstat[2] == 0) return;
+  const float qnan = __int_as_float(0x7fc00000);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nz; i += (long)gridDim.x * blockDim.x) Z[i] = qnan;
 }
 
 }  // namespace dctts

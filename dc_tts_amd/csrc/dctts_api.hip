@@ -11,6 +11,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -183,7 +184,14 @@ struct dctts_ctx {
   bool xgroup_ok = true;               // cleared for good when a decode reports that the placement assumption (block b on XCD b % 8) does not hold here
   void* xg_tab = nullptr; std::string xg_geom;   // per chain piece: [T + 1][2] XGroupParams (AudioDec run of frame j, AudioEnc run of frame j + 1)
   float* xg_mem = nullptr;             // exchange buffers (2 networks x 2 parity copies of rows + statistics), team barriers, error word: one allocation
-  int* xg_err_host = nullptr;          // pinned copy of the error word, refreshed after every decode (dctts_decode_status)
+  // Decode status (decode_host.h: decode_finish): the LAST kernel of every decode folds that decode's error words (team kernels, in-kernel waits, the
+  // debug injection) into a STICKY device block that no decode ever clears -- [0] OR of the error bits, [1] failed decodes, [2] "the decode that just
+  // ended failed" -- and poisons the decode's outputs (NaN / -1) when it failed; the block is copied to pinned host memory behind every decode and
+  // cleared only by dctts_decode_status (or by the one refusal of the next decode call).
+  int* dstat = nullptr; int* dstat_host = nullptr;
+  const int* fin_xerr = nullptr; const int* fin_werr = nullptr;   // the running decode's own error words (decode_v3 sets them, decode_finish reads them)
+  int inject_err = 0;                  // debug hook: error bits OR-ed into the NEXT decode's status (dctts_debug_inject_decode_error)
+  int team_fail_streak = 0;            // consecutive failed status reports without a split-team bit: the team kernels are switched off at 3
   // the tail of AudioDec's cone (HC_3 .. HC_7 and their row passes) as one launch per frame on the side stream (xcone_kernel.h); DCTTS_XCONE=0: nine launches
   int xcone = 1;
   void* xc_tab = nullptr; std::string xc_geom;   // per frame: XConeParams
@@ -198,7 +206,6 @@ struct dctts_ctx {
                                        // produced for it) instead of a wait-value operation in front of it (DCTTS_CHAIN_WAIT=0)
   unsigned wait2_next = 0;             // counter value the next run_chain3 launch waits for (0 = none)
   unsigned* wait_ctr = nullptr;        // device memory, polled in-kernel: [0] chain pieces done + 1, [32] bulk pieces complete (written by xcone_kernel's last team, or a write-value operation), [64] error word
-  int* wait_err_host = nullptr;        // pinned copy of the error word, refreshed after every decode (dctts_decode_status)
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
@@ -443,7 +450,8 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->ctr_chain) (void)hipFree(c->ctr_chain);
   if (c->ctr_bulk) (void)hipFree(c->ctr_bulk);
   if (c->wait_ctr) (void)hipFree(c->wait_ctr);
-  if (c->wait_err_host) (void)hipHostFree(c->wait_err_host);
+  if (c->dstat) (void)hipFree(c->dstat);
+  if (c->dstat_host) (void)hipHostFree(c->dstat_host);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   if (c->tail_ws) (void)hipFree(c->tail_ws);
@@ -457,7 +465,6 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->xg_tab) (void)hipFree(c->xg_tab);
   if (c->xc_tab) (void)hipFree(c->xc_tab);
   if (c->xg_mem) (void)hipFree(c->xg_mem);
-  if (c->xg_err_host) (void)hipHostFree(c->xg_err_host);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;

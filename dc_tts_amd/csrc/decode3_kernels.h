@@ -1,7 +1,7 @@
 // decode3_kernels.h -- row kernels of the round-2 decode ("v3") on gfx950.
 //
 // Two algebraic moves take work off the latency-critical chain of a decode step (synthesize.py:47-54) without changing what is
-// computed (tests/algo_model.incremental_decode_v3 states the data flow in numpy; test_v3_model_equals_reference_loop proves it
+// computed (oracle/incremental_ref.incremental_decode_v3 states the data flow in numpy; test_v3_model_equals_reference_loop proves it
 // against the restated reference loop in fp64):
 //
 //  1. AudioDec C_1 (networks.py:167-174) is a k = 1 conv on R = [A.V ; Q] (networks.py:150-151).  With its kernel split by rows,

@@ -484,7 +484,6 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
   if (c->xg_mem) { (void)hipFree(c->xg_mem); c->xg_mem = nullptr; }
   HIPCHK(hipMalloc((void**)&c->xg_mem, xg_mem_floats(B) * sizeof(float)));
   HIPCHK(hipMemset(c->xg_mem, 0, xg_mem_floats(B) * sizeof(float)));
-  if (!c->xg_err_host) { HIPCHK(hipHostMalloc((void**)&c->xg_err_host, sizeof(int), 0)); *c->xg_err_host = 0; }
   const XgMem m = xg_mem(c, B);
   const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
   auto rowp = [](const View& v, long par, int j) { return v.p + par * v.set + (v.row0 + j) * (long)v.stride; };
@@ -792,14 +791,6 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   if (cwait && !c->wait_ctr) {
     HIPCHK(hipMalloc((void**)&c->wait_ctr, 128 * sizeof(unsigned)));
     HIPCHK(hipMemset(c->wait_ctr, 0, 128 * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void**)&c->wait_err_host, sizeof(int), 0)); *c->wait_err_host = 0;
-  }
-  if (cwait && *c->wait_err_host) {
-    // the previous decode's in-kernel wait timed out and nobody asked (dctts_decode_status reports and clears it): refuse once, so the
-    // failure cannot go unnoticed, then start clean
-    *c->wait_err_host = 0;
-    HIPCHK(hipMemset(c->wait_ctr + 64, 0, sizeof(int)));
-    return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-kernel wait for the side stream timed out and its results were invalid (dctts_decode_status was not consulted)");
   }
   CHK(v3_mlp_table(c, w, B, T));
   c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (that timing id looks at chain3_kernel launches; so does DCTTS_TRACE with DCTTS_XGROUP=0)
@@ -817,11 +808,6 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   CHK(v3_aepre_table(c, w, B, c->c1qw_chain));
   c->sig_ptr = cwait ? c->wait_ctr : (unsigned*)c->ctr_chain;
   if (c->xg_on || c->xc_on) {
-    if (c->xg_err_host && *c->xg_err_host) {
-      // the previous decode's team hand-offs failed and nobody asked (dctts_decode_status): refuse once, and never use the kernel again if it was the placement
-      *c->xg_err_host = 0; c->xgroup_ok = false;
-      return fail(DCTTS_ERR_STATE, "decode: the PREVIOUS decode's in-launch hand-offs failed (xgroup_kernel) and its results were invalid (dctts_decode_status was not consulted)");
-    }
     CHK(v3_xgroup_table(c, w, B, T, insig, cwait));            // (also allocates the memory both kernels meet through)
     if (c->xc_on) CHK(v3_xcone_table(c, w, B, T, bsig));
     const XgMem m = xg_mem(c, B);
@@ -858,7 +844,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
       c->graphs3_geom = g;
     }
   }
-  if (cwait) HIPCHK(hipMemsetAsync(c->wait_ctr, 0, 64 * sizeof(unsigned), st));      // st is ordered after the previous decode's last piece, and that piece after all bulk work
+  if (cwait) HIPCHK(hipMemsetAsync(c->wait_ctr, 0, 65 * sizeof(unsigned), st));      // the counters and THIS decode's wait error word ([64]; the sticky copy lives in dstat); st is ordered after the previous decode's last piece (and its decode_finish), and that piece after all bulk work
   if (vs) {
     HIPCHK(hipStreamWriteValue32(st, c->ctr_chain, 0u, 0));
     HIPCHK(hipStreamWriteValue32(st, c->ctr_bulk, 0u, 0));
@@ -911,8 +897,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     }
   }
   // the chain's last piece is on `st`; the bulk stream's last piece was consumed by it, so `st` is ordered after all decode work.
-  if (cwait) HIPCHK(hipMemcpyAsync(c->wait_err_host, c->wait_ctr + 64, sizeof(int), hipMemcpyDeviceToHost, st));
-  if (c->xg_on || c->xc_on) HIPCHK(hipMemcpyAsync(c->xg_err_host, xg_mem(c, B).err, sizeof(int), hipMemcpyDeviceToHost, st));
+  c->fin_xerr = (c->xg_on || c->xc_on) ? xg_mem(c, B).err : nullptr;      // this decode's error words, folded into the sticky status by decode_finish
+  c->fin_werr = cwait ? (const int*)(c->wait_ctr + 64) : nullptr;
   if (pt0 >= 0 && pt0 + 8 < T) {
     HIPCHK(hipStreamSynchronize(st)); HIPCHK(hipStreamSynchronize(sb));
     for (int i = 0; i < 8; ++i) {
@@ -928,8 +914,41 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   return 0;
 }
 
-static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, hipStream_t st) {
+// Decodes of DIFFERENT contexts on one device must not overlap: each runs two polling team kernels sized to half the CUs, and two pairs of them starve each
+// other until the bounded waits give up (a resource deadlock).  Inside a process they are serialised here: a decode waits for the
+// completion event of the last decode another context enqueued on the device.  (Another PROCESS on the same GPU cannot be seen from here: there the bounded
+// waits, the poisoned outputs and dctts_decode_status are the protection, and dc_tts_amd.Engine repeats the decode with one launch per layer.)
+struct DeviceLease { hipEvent_t done = nullptr; const dctts_ctx* owner = nullptr; };
+static std::mutex g_lease_mu;
+static std::map<int, DeviceLease> g_lease;
+
+static int decode_status_init(dctts_ctx* c) {
+  if (c->dstat) return 0;
+  HIPCHK(hipMalloc((void**)&c->dstat, 4 * sizeof(int)));
+  HIPCHK(hipMemset(c->dstat, 0, 4 * sizeof(int)));
+  HIPCHK(hipHostMalloc((void**)&c->dstat_host, 4 * sizeof(int), 0));
+  for (int i = 0; i < 4; ++i) c->dstat_host[i] = 0;
+  return 0;
+}
+
+static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, float* alignments, hipStream_t st) {
   if (N != c->cfg.max_N) return fail(DCTTS_ERR_ARG, "decode: N must equal hp.max_N (mask built from it, networks.py:142)");
+  CHK(decode_status_init(c));
+  if (c->dstat_host[0]) {
+    // an earlier decode failed on the device and nobody asked (dctts_decode_status reports and clears): refuse ONCE, so that the failure cannot go
+    // unnoticed (its outputs were poisoned as well), then start clean
+    const int ew = c->dstat_host[0];
+    c->dstat_host[0] = 0; c->dstat_host[1] = 0;
+    HIPCHK(hipMemsetAsync(c->dstat, 0, 2 * sizeof(int), st));
+    if (ew & (2 | 8)) c->xgroup_ok = false;
+    return fail(DCTTS_ERR_STATE, "decode: an EARLIER decode on this context failed on the device (error word " + std::to_string(ew) + ") and dctts_decode_status was not consulted; its outputs were poisoned (NaN / -1)");
+  }
+  {
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    DeviceLease& ls = g_lease[c->device];
+    if (ls.done && ls.owner != c) HIPCHK(hipStreamWaitEvent(st, ls.done, 0));
+  }
+  c->fin_xerr = nullptr; c->fin_werr = nullptr;
   DecodeWs w;
   CHK(decode_ws(c, B, N, T, &w));
   const bool v3 = (c->decode_mode == 3);
@@ -975,37 +994,83 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     hipLaunchKernelGGL(traj_to_i64_kernel, dim3((B * T + 255) / 256), dim3(256), 0, st, w.pm_all, (long long*)maxatt, B, T);
     HIPCHK(hipGetLastError());
   }
+  if (alignments) {
+    // `g.alignments` as the LAST sess.run of the loop fetches it (synthesize.py:48, networks.py:153): every time row t against the window of step
+    // T - 1, (B, N, T).  Q[t] for all t is AudioEnc's last history buffer; the window of step T - 1 is row T - 1 of the trajectory table.
+    const View& q = w.ae.back();
+    const int d = c->cfg.d;
+    AttnFullParams p;
+    p.Q = q.p + q.row0 * (long)q.stride; p.q_stride = q.stride; p.q_bstride = q.bstride;
+    p.K = w.kv.p; p.k_stride = w.kv.stride; p.k_bstride = w.kv.bstride; p.V = w.kv.p + d; p.v_stride = w.kv.stride; p.v_bstride = w.kv.bstride;
+    p.T = T; p.N = N; p.d = d; p.monotonic = 1; p.prev_max = w.pm_all + (long)(T - 1) * B; p.win = c->cfg.attention_win_size;
+    p.R = nullptr; p.align = alignments; p.maxatt = nullptr;
+    hipLaunchKernelGGL(attention_full_kernel, dim3(T, B), dim3(256), (d + N) * sizeof(float), st, p);
+    HIPCHK(hipGetLastError());
+  }
+  // fold this decode's error words into the sticky status, poison the outputs if it failed, publish the status to the host
+  const int inject = c->inject_err; c->inject_err = 0;
+  hipLaunchKernelGGL(decode_finish_kernel, dim3(128), dim3(256), 0, st, c->fin_xerr, c->fin_werr, inject, c->dstat, Y, (long)B * T * nm,
+                     (long long*)maxatt, (long)B * T, alignments, (long)B * N * T);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(c->dstat_host, c->dstat, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  {
+    std::lock_guard<std::mutex> lk(g_lease_mu);
+    DeviceLease& ls = g_lease[c->device];
+    if (!ls.done) HIPCHK(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ls.done, st));
+    ls.owner = c;
+  }
   return 0;
 }
 
-extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, void* stream) {
+extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, float* alignments, void* stream) {
   DevGuard dev_guard(c);
   CHK(check_ready(c, dev_guard));
   if (!L || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "decode: bad argument");
-  return decode_impl(c, L, B, N, T, Y, maxatt, (hipStream_t)stream);
+  return decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream);
 }
 
-extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, float* Z, int64_t* maxatt, void* stream) {
+extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, float* Z, int64_t* maxatt, float* alignments, void* stream) {
   DevGuard dev_guard(c);
   CHK(check_ready(c, dev_guard));
   if (!L || !Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "synthesize: bad argument");
-  CHK(decode_impl(c, L, B, N, T, Y, maxatt, (hipStream_t)stream));
-  return dctts_ssrn_fwd(c, Y, B, T, nullptr, Z, stream);                  // synthesize.py:57
+  CHK(decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream));
+  CHK(dctts_ssrn_fwd(c, Y, B, T, nullptr, Z, stream));                    // synthesize.py:57
+  // SSRN's ReLU layers turn a poisoned (NaN) mel back into finite numbers: Z of a failed decode is poisoned explicitly
+  hipLaunchKernelGGL(poison_if_failed_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, c->dstat, Z, (long)B * 4 * T * c->cfg.n_linear);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 extern "C" int dctts_decode_status(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
-  if (c->xg_err_host && *c->xg_err_host) {                  // reported once; a placement failure switches the kernel off for good
-    const int ew = *c->xg_err_host;
-    *c->xg_err_host = 0; c->xgroup_ok = false;
-    return fail(DCTTS_ERR_STATE, "decode: a bounded wait inside a team kernel gave up (error word " + std::to_string(ew) + ": 1 / 2 = xgroup_kernel barrier time-out / a team not on one XCD, 4 / 8 = the same in xcone_kernel, 16 = the side stream never arrived): the results of that decode are invalid; further decodes run one launch per layer");
-  }
-  if (c->wait_err_host && *c->wait_err_host) {              // reported once: the error word is cleared so that the next decode starts clean
+  if (c->dstat_host && c->dstat_host[0]) {                  // reported once, then cleared on both sides so that the next decode starts clean
     DevGuard dev_guard(c);
-    *c->wait_err_host = 0;
-    (void)hipMemset(c->wait_ctr + 64, 0, sizeof(int));
-    return fail(DCTTS_ERR_STATE, "decode: the in-kernel wait for the side stream timed out (chain3_kernel): the results of that decode are invalid");
+    const int ew = c->dstat_host[0], nfail = c->dstat_host[1];
+    c->dstat_host[0] = 0; c->dstat_host[1] = 0;
+    (void)hipMemset(c->dstat, 0, 2 * sizeof(int));
+    // only a team that is not on one XCD (bits 2 / 8) says something permanent about this device; time-outs (bits 1 / 4 / 16 / 32: CUs or the side stream held
+    // up by somebody else's work) are transient -- the team kernels stay on unless three reports in a row fail
+    if (ew & (2 | 8)) c->xgroup_ok = false;
+    else if (++c->team_fail_streak >= 3) c->xgroup_ok = false;
+    return fail(DCTTS_ERR_STATE, "decode: " + std::to_string(nfail) + " decode(s) failed on the device since the last report (error word " + std::to_string(ew) +
+                ": 1 / 2 = xgroup_kernel barrier time-out / a team not on one XCD, 4 / 8 = the same in xcone_kernel, 16 = the side stream never arrived, 32 = an in-kernel stream wait timed out, "
+                "64 = injected by the debug hook): their outputs were overwritten with NaN / -1" + (c->xgroup_ok ? "" : "; further decodes run one launch per layer"));
   }
+  c->team_fail_streak = 0;
+  return 0;
+}
+
+extern "C" int dctts_set_team_kernels(dctts_ctx* c, int enable) {
+  if (!c || enable < 0 || enable > 1) return fail(DCTTS_ERR_ARG, "team kernels: 0 or 1");
+  c->xgroup = enable; c->xcone = enable;
+  if (enable) { c->xgroup_ok = true; c->team_fail_streak = 0; }
+  return 0;
+}
+
+extern "C" int dctts_debug_inject_decode_error(dctts_ctx* c, int bits) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  c->inject_err = bits ? (bits | 64) : 0;
   return 0;
 }
 

@@ -78,7 +78,7 @@ class Engine:
             pass
 
     def set_decode_graph(self, enable):
-        """False/0: eager launches; True/1: the side stream's work as one hipGraph per frame (default)."""
+        """False/0 (default): eager launches; True/1: the side stream's work as one hipGraph per frame (measured slower)."""
         self._ok(self.lib.dctts_set_decode_graph(self._h, int(bool(enable))))
 
     def set_decode_mode(self, mode: int):
@@ -185,19 +185,49 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ synthesize.py:45-57
-    def text2mel(self, L: torch.Tensor, max_T: Optional[int] = None):
-        """The autoregressive loop of synthesize.py:45-54.  Returns (Y (B,T,n_mels), max_attentions (B,T) int64)."""
+    def _decode(self, call, check: bool):
+        """Enqueue a decode; with check=True behave like the reference's `sess.run`: wait for it, and if it failed on the device (a bounded
+        in-launch wait gave up: the GPU is shared with somebody else's kernels) repeat it ONCE with one launch per layer, which cannot fail
+        that way.  Without check the call returns at once; a failed decode's outputs are NaN / -1 and `synchronize()` raises."""
+        call()
+        if not check:
+            return
+        torch.cuda.current_stream(self.device).synchronize()
+        if self.lib.dctts_decode_status(self._h) == 0:
+            return
+        first = _lib.last_error()
+        self._ok(self.lib.dctts_set_team_kernels(self._h, 0))
+        try:
+            call()
+            torch.cuda.current_stream(self.device).synchronize()
+            if self.lib.dctts_decode_status(self._h) != 0:
+                raise DcttsError(f"decode failed twice: {first} / {_lib.last_error()}")
+        finally:
+            self._ok(self.lib.dctts_set_team_kernels(self._h, 1))
+
+    def set_team_kernels(self, enable: bool):
+        """True (default): runs of dependent decode layers as one launch (xgroup / xcone kernels); False: one launch per layer."""
+        self._ok(self.lib.dctts_set_team_kernels(self._h, int(bool(enable))))
+
+    def debug_inject_decode_error(self, bits: int = 1):
+        """Test hook (dctts_hip_debug.h): the next decode reports a failure and poisons its outputs."""
+        self._ok(self.lib.dctts_debug_inject_decode_error(self._h, int(bits)))
+
+    def text2mel(self, L: torch.Tensor, max_T: Optional[int] = None, alignments: bool = False, check: bool = False):
+        """The autoregressive loop of synthesize.py:45-54.  Returns (Y (B,T,n_mels), max_attentions (B,T) int64) and, with
+        alignments=True, `g.alignments` (B,N,T) as the loop's last step fetches it (synthesize.py:48)."""
         _check(L, "L", torch.int32, 2, self.device)
         B, N = L.shape
         T = self.hp.max_T if max_T is None else int(max_T)
         if N != self.hp.max_N:
             raise ValueError(f"L must be padded to hp.max_N={self.hp.max_N} (data_load.py:83); got {N}")
         Y = self._new(B, T, self.hp.n_mels); mx = self._new(B, T, dtype=torch.int64)
-        self._ok(self.lib.dctts_text2mel_decode(self._h, _ptr(L), B, N, T, _ptr(Y), _ptr(mx), self._stream()))
-        return Y, mx
+        al = self._new(B, N, T) if alignments else None
+        self._decode(lambda: self._ok(self.lib.dctts_text2mel_decode(self._h, _ptr(L), B, N, T, _ptr(Y), _ptr(mx), _ptr(al), self._stream())), check)
+        return (Y, mx, al) if alignments else (Y, mx)
 
-    def synthesize(self, L: torch.Tensor, max_T: Optional[int] = None):
-        """synthesize.py:45-57 without the vocoder: returns (Y, Z (B,4T,1025), max_attentions)."""
+    def synthesize(self, L: torch.Tensor, max_T: Optional[int] = None, alignments: bool = False, check: bool = False):
+        """synthesize.py:45-57 without the vocoder: returns (Y, Z (B,4T,1025), max_attentions[, alignments])."""
         _check(L, "L", torch.int32, 2, self.device)
         B, N = L.shape
         T = self.hp.max_T if max_T is None else int(max_T)
@@ -205,5 +235,6 @@ class Engine:
             raise ValueError(f"L must be padded to hp.max_N={self.hp.max_N} (data_load.py:83); got {N}")
         Y = self._new(B, T, self.hp.n_mels); Z = self._new(B, self.hp.r * T, self.hp.n_linear)
         mx = self._new(B, T, dtype=torch.int64)
-        self._ok(self.lib.dctts_synthesize(self._h, _ptr(L), B, N, T, _ptr(Y), _ptr(Z), _ptr(mx), self._stream()))
-        return Y, Z, mx
+        al = self._new(B, N, T) if alignments else None
+        self._decode(lambda: self._ok(self.lib.dctts_synthesize(self._h, _ptr(L), B, N, T, _ptr(Y), _ptr(Z), _ptr(mx), _ptr(al), self._stream())), check)
+        return (Y, Z, mx, al) if alignments else (Y, Z, mx)

@@ -36,11 +36,31 @@ def _gather_rows(x: torch.Tensor, counts, group, rank: int, dst: int = 0):
     return torch.cat([b[:n] for b, n in zip(bufs, counts)], dim=0)
 
 
-def gather_to_host(Z: torch.Tensor, Zh: torch.Tensor, group, world: int, rank: int):
+def _all_ranks_ok(err: Optional[BaseException], group, world: int):
+    """A rank whose decode failed must not leave the others blocked in the gathers: every rank contributes a flag, and all of them raise."""
+    if world > 1:
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag[0]) and err is None:
+            raise RuntimeError("synthesis failed on another rank (its decode reported a device-side failure); no results were gathered")
+    if err is not None:
+        raise err
+
+
+def gather_to_host(Z: torch.Tensor, Zh: torch.Tensor, group, world: int, rank: int, engine=None):
     """SURVEY 8e's result gather for equal shards: this rank's device tensor Z -> its pinned host buffer Zh (one D2H copy), then
-    rank 0's host over `group` (gloo).  Returns the (world * B, ...) host tensor on rank 0, Zh itself when world == 1, else None."""
+    rank 0's host over `group` (gloo).  Returns the (world * B, ...) host tensor on rank 0, Zh itself when world == 1, else None.
+    With `engine`, the decode status of this rank is checked first and a failure on ANY rank raises on every rank before the gather."""
     Zh.copy_(Z, non_blocking=True)
-    torch.cuda.synchronize()
+    err = None
+    try:
+        if engine is not None:
+            engine.synchronize()
+        else:
+            torch.cuda.synchronize()
+    except Exception as e:                                             # noqa: BLE001 -- re-raised on every rank below
+        err = e
+    _all_ranks_ok(err, group, world)
     if world == 1:
         return Zh
     return _gather_rows(Zh, [Z.shape[0]] * world, group, rank)
@@ -58,7 +78,12 @@ def synthesize_sharded(L: np.ndarray, synth: Callable[[np.ndarray], Tuple[np.nda
     Bt = L.shape[0]
     bounds = [shard_bounds(Bt, world, r) for r in range(world)]
     lo, hi = bounds[rank]
-    out = synth(L[lo:hi]) if hi > lo else None
+    out, err = None, None
+    try:
+        out = synth(L[lo:hi]) if hi > lo else None
+    except Exception as e:                                             # noqa: BLE001 -- re-raised on every rank by _all_ranks_ok
+        err = e
+    _all_ranks_ok(err, group, world)
     if world == 1:
         return out
     counts = [b[1] - b[0] for b in bounds]
@@ -82,7 +107,7 @@ def gpu_synth(engine) -> Callable[[np.ndarray], Tuple[np.ndarray, np.ndarray, np
     """Adapter: host slice -> this rank's GPU -> host."""
     def run(Ls: np.ndarray):
         Ld = torch.from_numpy(np.ascontiguousarray(Ls, dtype=np.int32)).to(engine.device)
-        Y, Z, mx = engine.synthesize(Ld)
+        Y, Z, mx = engine.synthesize(Ld, check=True)                   # waits; a decode that failed on the device is repeated once, one launch per layer
         outs = []
         for t in (Y, Z, mx):                                           # one D2H copy each, into pinned host memory
             h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)

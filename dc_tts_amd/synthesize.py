@@ -15,9 +15,11 @@ from .engine import Engine
 
 
 def synthesize(L: torch.Tensor, engine: Optional[Engine] = None, max_T: Optional[int] = None):
-    """L (B, max_N) int32 on the engine's GPU -> (Y (B,T,80), Z (B,4T,1025), max_attentions (B,T))."""
+    """L (B, max_N) int32 on the engine's GPU -> (Y (B,T,80), Z (B,4T,1025), max_attentions (B,T)).
+    Like the `sess.run` calls it replaces this returns checked results: it waits for the decode and, should it have failed on the
+    device (the GPU shared with another process's kernels), repeats it once with one launch per layer (`Engine.synthesize(check=True)`)."""
     eng = engine or networks.bound_engine()
-    return eng.synthesize(L, max_T)
+    return eng.synthesize(L, max_T, check=True)
 
 
 def synthesize_reference_loop(L: torch.Tensor, engine: Optional[Engine] = None):
@@ -69,8 +71,7 @@ def main(argv=None):
         W = synthetic_weights(hp, seed=1234, perturb=True)
     eng = Engine(W, hp)
     L = load_data("synthesize", args.text, hp)
-    Y, Z, _ = eng.synthesize(torch.from_numpy(L).to(eng.device))
-    eng.synchronize()                                                   # results are only trusted once the decode reported no time-out
+    Y, Z, _ = eng.synthesize(torch.from_numpy(L).to(eng.device), check=True)     # waits, checks the decode's status, repeats it once if it failed
     os.makedirs(args.out, exist_ok=True)
     if args.save_spectrograms or args.no_wav:
         for i in range(L.shape[0]):

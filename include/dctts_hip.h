@@ -79,21 +79,35 @@ int dctts_ssrn_fwd(dctts_ctx* ctx, const float* Y, int B, int T, float* logits, 
  * decoder that is arithmetically the reference's full-recompute loop (TextEnc once, AudioEnc
  * incrementally, windowed attention + the 85-row AudioDec dependency cone re-evaluated with the
  * current window at every step).  L (B,N) int32, N == max_N.  Y (B,T,n_mels) out;
- * max_attentions (B,T) int64 out or NULL (column j = the value fed back as prev_max at step j+1). */
+ * max_attentions (B,T) int64 out or NULL (column j = the value fed back as prev_max at step j+1);
+ * alignments (B,N,T) out or NULL = `g.alignments` as the loop's LAST sess.run fetches it (synthesize.py:48,
+ * networks.py:153): every time row against the window of step T-1.
+ * A decode that fails on the device (see dctts_decode_status) overwrites Y / alignments with NaN and
+ * max_attentions with -1 before the call's work on `stream` ends. */
 int dctts_text2mel_decode(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y,
-                          int64_t* max_attentions, void* stream);
-/* synthesize.py:45-57: decode + one SSRN pass.  Z (B,4T,n_linear). */
+                          int64_t* max_attentions, float* alignments, void* stream);
+/* synthesize.py:45-57: decode + one SSRN pass.  Z (B,4T,n_linear) (NaN as well after a failed decode). */
 int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, float* Y, float* Z,
-                     int64_t* max_attentions, void* stream);
+                     int64_t* max_attentions, float* alignments, void* stream);
 
-/* Status of the decodes issued so far on this context; call after synchronising their stream.  0, or DCTTS_ERR_STATE when the
- * first launch of a chain piece gave up waiting for the side stream's counter (the wait is bounded at about a second: a stalled side
- * stream must not hang the queue): the outputs of that decode are invalid.  Reports once and clears; a failure that nobody asked
- * about makes the NEXT decode call on the context fail instead of running.  dc_tts_amd.Engine.synchronize() calls this. */
+/* Status of the decodes issued so far on this context; call after synchronising their stream.  The default decode form runs two
+ * kernels per frame whose workgroups wait for each other inside the launch (bounded waits, about a second at most: a stalled
+ * stream must not hang the queue).  When a wait gives up -- the GPU is shared with another process's kernels, or a team of
+ * workgroups was not placed on one XCD -- that decode is INVALID: its last kernel overwrites its outputs with NaN / -1 and raises a
+ * sticky status word on the device that no later decode clears.  This call returns DCTTS_ERR_STATE once for all decodes that
+ * failed since the previous call (the message has the count and the error bits) and clears the word; a failure nobody asked
+ * about makes the next decode call on the context fail instead of running.  Time-outs leave the team kernels on (three failed
+ * reports in a row switch them off); a misplaced team switches them off for good.  dc_tts_amd.Engine.synchronize() calls this;
+ * Engine.text2mel / synthesize(check=True) also repeat a failed decode once with one launch per layer. */
 int dctts_decode_status(dctts_ctx* ctx);
 
-/* Decode launch mode: 0 = every launch eager; 1 (default) = the side-stream (bulk) work of each frame is one hipGraph launch,
- * the latency-critical chain launches stay eager (a graph launch per chain piece was measured: ~10 us more per frame). */
+/* 1 (default): runs of dependent layers of a decode frame are ONE launch whose workgroups meet inside an XCD's L2
+ * (csrc/xgroup_kernel.h, xcone_kernel.h); 0: one launch per layer (no hand-offs between the workgroups of a launch; ~1.3x the frame time). */
+int dctts_set_team_kernels(dctts_ctx* ctx, int enable);
+
+/* Decode launch mode: 0 (default) = every launch eager; 1 = the side-stream (bulk) work of each frame is one hipGraph launch,
+ * the latency-critical chain launches stay eager.  Measured on MI355X: a graph launch costs ~10 us of start-up on a path that is
+ * ~100 us per frame, so the eager form is the faster one and the default. */
 int dctts_set_decode_graph(dctts_ctx* ctx, int enable);
 
 /* Decode algorithm form (results agree to fp32 re-association; both are the exact-parity incremental decode):

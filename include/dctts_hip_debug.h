@@ -23,6 +23,10 @@ int dctts_debug_layer(dctts_ctx* ctx, const char* net, int index, const float* X
  * production geometry (networks.py:142-147: the window clipped to 2, then 1 keys; the cached V.W / V.W.W tables read at their last rows). */
 int dctts_debug_seed_prev_max(dctts_ctx* ctx, const int32_t* prev_max, int B);
 
+/* Test hook: the NEXT decode on this context behaves as if a bounded in-kernel wait had given up (`bits` of the error word, | 64): its outputs are
+ * poisoned and the sticky status is raised exactly as for a real time-out; the decode itself runs normally.  bits = 0 withdraws the injection. */
+int dctts_debug_inject_decode_error(dctts_ctx* ctx, int bits);
+
 /* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
 int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
 

@@ -147,7 +147,7 @@ def test_deconv_vs_torch():
 def test_incremental_model_equals_reference_loop(weights):
     """The decode the HIP path implements (cached AudioEnc + 85-row cone with the current window) reproduces the
     restated full-recompute loop; the frozen-R cache does not (SURVEY B.7 regression guard).  T=100 > 85."""
-    from algo_model import incremental_decode
+    from oracle.incremental_ref import incremental_decode
     from dc_tts_amd.weights import synthetic_text
     h = hp.replace(max_T=100)
     L = synthetic_text(h, B=2, seed=7)
@@ -169,10 +169,10 @@ def short_text(h, B, seed):
 
 
 def test_v3_model_equals_reference_loop(weights):
-    """Round-2 decode data flow (tests/algo_model.incremental_decode_v3: AudioDec C_1 as a row operation on V.W_top / Q.W_bot,
+    """Round-2 decode data flow (oracle/incremental_ref.incremental_decode_v3: AudioDec C_1 as a row operation on V.W_top / Q.W_bot,
     the two older taps of every causal k=3 layer as presums) == the restated synthesize.py loop, fp64: the reorganisation is
     exact algebra, not an approximation."""
-    from algo_model import incremental_decode_v3
+    from oracle.incremental_ref import incremental_decode_v3
     from dc_tts_amd.weights import synthetic_text
     h = hp.replace(max_T=100)
     L = synthetic_text(h, B=2, seed=7)
@@ -188,7 +188,7 @@ def test_end_of_text_window_clipping_models(weights):
     """networks.py:142-147 once prev_max >= max_N - 2: the window is clipped to 2, then 1 key.  A 10-character text saturates
     within ~40 frames; both incremental models must follow the restated loop through and beyond saturation (fp32, trajectory
     integer-exact)."""
-    from algo_model import incremental_decode, incremental_decode_v3
+    from oracle.incremental_ref import incremental_decode, incremental_decode_v3
     h = hp.replace(max_N=10, max_T=90)
     L = short_text(h, 2, 11)
     Y, _, traj = O.synthesize(L, weights, h, np.float32, run_ssrn=False)
