@@ -3,8 +3,9 @@ TensorFlow -- so the reference's trained weights (`synthesize.py:32-40` restores
 from `logdir-2`) can feed `dc_tts_amd.engine.Engine` directly.
 
 Formats implemented from their public specifications.  UNPINNED: TensorFlow is not installable here and no TF-written bundle is
-reachable (no network), so this reader is exercised only against bundles produced by the spec-following writer in
-tests/test_tf_checkpoint.py.  What it does not implement fails with a named CheckpointError instead of mis-reading: compressed
+reachable (no network), so this reader is exercised against bundles assembled by an independent encoder in tests/test_tf_checkpoint.py
+(own CRC pinned to RFC 3720, shortened separator keys, restart arrays, several shards; a committed byte-exact fixture under
+tests/golden/tf_bundle/) and, on the GPU, end to end: checkpoint directories -> load_reference_weights -> Engine -> synthesize.  What it does not implement fails with a named CheckpointError instead of mis-reading: compressed
 (snappy) table blocks, partitioned (sliced) variables, big-endian bundles, missing shard files; multi-shard bundles are read.
   * `.index` is a LevelDB-style sorted string table (tensorflow/core/lib/io/table): 48-byte footer = metaindex BlockHandle,
     index BlockHandle (varint64 offset + size each), zero padding, magic 0xdb4775248b80fb57; every block is followed by a
@@ -387,9 +388,11 @@ def save_checkpoint(logdir: str, variables: Dict[str, np.ndarray], global_step: 
     for suffix, d in (slots or {}).items():
         for n, v in d.items():
             t[n + "/" + suffix] = np.asarray(v)
-    if slots:                                               # tf.train.AdamOptimizer's two non-slot variables (beta^t after t = global_step updates)
-        t["beta1_power"] = np.asarray(0.9 ** global_step, dtype=np.float32)
-        t["beta2_power"] = np.asarray(0.999 ** global_step, dtype=np.float32)
+    if slots:
+        # tf.train.AdamOptimizer's two non-slot variables: created as beta (not 1) and multiplied by beta once per update, so after
+        # t = global_step updates they hold beta ** (t + 1) -- what a TF process that restores this file uses for the NEXT step's bias correction
+        t["beta1_power"] = np.asarray(0.9 ** (global_step + 1), dtype=np.float32)
+        t["beta2_power"] = np.asarray(0.999 ** (global_step + 1), dtype=np.float32)
     write_checkpoint(prefix, t)
     with open(os.path.join(logdir, "checkpoint"), "w") as f:
         f.write('model_checkpoint_path: "{0}"\nall_model_checkpoint_paths: "{0}"\n'.format(os.path.basename(prefix)))

@@ -1,5 +1,8 @@
-"""TF V2 checkpoint (tensor bundle) reader, exercised against bundles written by the spec-following writer below
-(TensorFlow itself cannot be installed here; see dc_tts_amd/tf_checkpoint.py for the format references)."""
+"""TF V2 checkpoint (tensor bundle) reader, exercised against bundles assembled by the INDEPENDENT encoder below: it shares no code with
+dc_tts_amd/tf_checkpoint.py (own varints, own protobuf fields, own table blocks with prefix-compressed keys and restart arrays, own bit-serial
+CRC-32C pinned to the RFC 3720 vectors, LevelDB-style SHORTENED separator keys in the index block, any number of shards).  A tiny bundle it
+produced is committed under tests/golden/tf_bundle/ and must be reproduced byte for byte.  TensorFlow itself cannot be installed here, so no
+TF-written file exists: see dc_tts_amd/tf_checkpoint.py for the format references."""
 import os
 import struct
 
@@ -7,6 +10,35 @@ import numpy as np
 import pytest
 
 from dc_tts_amd import tf_checkpoint as C
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_bundle")
+MAGIC = 0xDB4775248B80FB57
+
+
+def crc32c_bits(data, crc=0):
+    """CRC-32C (Castagnoli) bit by bit from the polynomial -- no table, nothing shared with the product's implementation."""
+    c = crc ^ 0xFFFFFFFF
+    for b in bytes(data):
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 & -(c & 1))
+    return c ^ 0xFFFFFFFF
+
+
+def masked(c):
+    """tensorflow/core/lib/hash/crc32c.h Mask(): rotate right by 15, add a constant."""
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def shortest_separator(a, b):
+    """leveldb BytewiseComparator::FindShortestSeparator(a, b): a key k with a <= k < b, as short as the rule allows (what a real table
+    builder stores in the index block instead of the block's last key)."""
+    n = min(len(a), len(b)); i = 0
+    while i < n and a[i] == b[i]:
+        i += 1
+    if i < n and a[i] < 0xFF and a[i] + 1 < b[i]:
+        return a[:i] + bytes([a[i] + 1])
+    return a
 
 
 def _vint(n):
@@ -41,20 +73,20 @@ def _block(entries, restart_interval=4):
     return bytes(buf)
 
 
-def write_bundle(prefix, tensors, keys_per_block=5, with_crc=True, num_shards=1, sliced=(), block_ctype=0):
+def write_bundle(prefix, tensors, keys_per_block=5, with_crc=True, num_shards=1, sliced=(), block_ctype=0, restart_interval=4, tensor_crc=None):
     """Minimal TF tensor-bundle writer: uncompressed table blocks, masked crc32c everywhere.  num_shards > 1 deals the tensors
     round-robin over shard files; `sliced` names get a BundleEntryProto.slices field; block_ctype != 0 marks the data blocks as
     compressed (the bytes stay raw: only the reader's diagnostic is exercised)."""
     datas = [bytearray() for _ in range(num_shards)]; entries = []
     dt_enum = {np.dtype(np.float32): 1, np.dtype(np.int32): 3, np.dtype(np.int64): 9}
     for i, name in enumerate(sorted(tensors)):
-        a = np.ascontiguousarray(tensors[name]); raw = a.tobytes()
+        a = np.asarray(tensors[name]); raw = a.tobytes()                  # (tobytes is C order; ascontiguousarray would make a scalar 1-d)
         sid = i % num_shards; data = datas[sid]
         shape = b"".join(_field(2, 2, _vint(len(d)) + d) for d in (_field(1, 0, _vint(s)) for s in a.shape))
         e = _field(1, 0, _vint(dt_enum[a.dtype])) + _field(2, 2, _vint(len(shape)) + shape) + _field(3, 0, _vint(sid)) + \
             _field(4, 0, _vint(len(data))) + _field(5, 0, _vint(len(raw)))
         if with_crc:
-            e += _field(6, 5, struct.pack("<I", C.mask_crc(C.crc32c(raw))))
+            e += _field(6, 5, struct.pack("<I", masked((tensor_crc or crc32c_bits)(raw))))
         if name in sliced:
             e += _field(7, 2, _vint(0))                     # repeated TensorSliceProto slices = 7 (an empty message is enough)
         entries.append((name.encode(), e)); data += raw
@@ -63,23 +95,78 @@ def write_bundle(prefix, tensors, keys_per_block=5, with_crc=True, num_shards=1,
     out = bytearray(); index = []
     def emit(block, ctype=0):
         off = len(out); out.extend(block); trailer = bytes([ctype])
-        out.extend(trailer + struct.pack("<I", C.mask_crc(C.crc32c(block + trailer))))
+        out.extend(trailer + struct.pack("<I", masked(crc32c_bits(block + trailer))))
         return _vint(off) + _vint(len(block))
     for i in range(0, len(entries), keys_per_block):
         chunk = entries[i:i + keys_per_block]
-        index.append((chunk[-1][0] + b"\xff", emit(_block(chunk), block_ctype)))
+        nxt = entries[i + keys_per_block][0] if i + keys_per_block < len(entries) else None
+        sep = shortest_separator(chunk[-1][0], nxt) if nxt is not None else chunk[-1][0] + b"\xff"     # (last block: FindShortSuccessor-like)
+        index.append((sep, emit(_block(chunk, restart_interval), block_ctype)))
     meta = emit(_block([]))
     idx = emit(_block(index, restart_interval=1))
     footer = meta + idx
-    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", C.TABLE_MAGIC)
+    out += footer + b"\x00" * (40 - len(footer)) + struct.pack("<Q", MAGIC)
     open(prefix + ".index", "wb").write(bytes(out))
     for sid, data in enumerate(datas):
         open("%s.data-%05d-of-%05d" % (prefix, sid, num_shards), "wb").write(bytes(data))
 
 
 def test_crc32c_known_answers():
-    assert C.crc32c(b"123456789") == 0xE3069283            # the standard CRC-32C check value
-    assert C.crc32c(b"\x00" * 32) == 0x8A9136AA             # RFC 3720 B.4
+    """RFC 3720 B.4 test vectors + the standard check value, for the product's CRC and for the test's own bit-serial one."""
+    inc, dec = bytes(range(32)), bytes(range(31, -1, -1))
+    for f in (C.crc32c, crc32c_bits):
+        assert f(b"123456789") == 0xE3069283
+        assert f(b"\x00" * 32) == 0x8A9136AA
+        assert f(b"\xff" * 32) == 0x62A8AB43
+        assert f(inc) == 0x46DD794E
+        assert f(dec) == 0x113FDB5C
+    assert masked(0) == C.mask_crc(0) == 0xA282EAD8 and masked(0xFFFFFFFF) == C.mask_crc(0xFFFFFFFF)
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 64, 1000):
+        a = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert C.crc32c(a) == crc32c_bits(a) and C.mask_crc(C.crc32c(a)) == masked(crc32c_bits(a))
+
+
+def _fixture_tensors():
+    """A miniature of the two-directory layout (synthesize.py:32-40) in ONE bundle: scoped names with shared prefixes that straddle block
+    boundaries, optimizer slots that must be ignored by a name-restricted restore, a scalar, an int32 step, four dtypes, two shards."""
+    rng = np.random.default_rng(2024)
+    t = {}
+    for i in (1, 2, 3, 10, 11):
+        t[f"Text2Mel/AudioEnc/HC_{i}/conv1d/kernel"] = rng.standard_normal((3, 4, 8)).astype(np.float32)
+        t[f"Text2Mel/AudioEnc/HC_{i}/conv1d/kernel/Adam"] = rng.standard_normal((3, 4, 8)).astype(np.float32)
+        t[f"Text2Mel/AudioEnc/HC_{i}/conv1d/kernel/Adam_1"] = rng.standard_normal((3, 4, 8)).astype(np.float32)
+        t[f"Text2Mel/AudioEnc/HC_{i}/H1/gamma"] = rng.standard_normal(4).astype(np.float32)
+    t["SSRN/D_4/conv2d_transpose/kernel"] = rng.standard_normal((1, 3, 5, 5)).astype(np.float32)
+    t["SSRN/C_16/normalize/beta"] = rng.standard_normal(1025).astype(np.float32)
+    t["beta1_power"] = np.asarray(0.9 ** 3, np.float32)
+    t["gs/global_step"] = np.asarray(2, np.int32)
+    t["aux/int64"] = np.arange(-3, 4, dtype=np.int64)
+    return t
+
+
+def test_committed_bundle_fixture(tmp_path):
+    """tests/golden/tf_bundle/model.{index,data-0000?-of-00002}: assembled by the independent encoder above (3 keys per block -> an eight-block
+    index with shortened separator keys, restart interval 2, two shards, bit-serial CRCs), committed, reproduced here byte for byte, and read by
+    the product's reader -- every tensor, every checksum."""
+    t = _fixture_tensors()
+    p = str(tmp_path / "model")
+    write_bundle(p, t, keys_per_block=3, num_shards=2, restart_interval=2)
+    names = ["model.index", "model.data-00000-of-00002", "model.data-00001-of-00002"]
+    if os.environ.get("DCTTS_WRITE_FIXTURES"):
+        os.makedirs(GOLD, exist_ok=True)
+        for n in names:
+            open(os.path.join(GOLD, n), "wb").write(open(os.path.join(str(tmp_path), n), "rb").read())
+    for n in names:
+        assert open(os.path.join(GOLD, n), "rb").read() == open(os.path.join(str(tmp_path), n), "rb").read(), n
+    header, entries = C.read_index(os.path.join(GOLD, "model.index"))
+    assert header["num_shards"] == 2 and set(entries) == set(t) and {e["shard_id"] for e in entries.values()} == {0, 1}
+    got = C.read_checkpoint(os.path.join(GOLD, "model"), verify=True, verify_tensors=True)
+    assert set(got) == set(t)
+    for k in t:
+        assert got[k].dtype == t[k].dtype and got[k].shape == t[k].shape and np.array_equal(got[k], t[k]), k
+    only = C.read_checkpoint(os.path.join(GOLD, "model"), [k for k in t if k.startswith("Text2Mel/") and "Adam" not in k])
+    assert len(only) == 10
 
 
 def test_round_trip_and_errors(tmp_path):
@@ -189,7 +276,7 @@ def test_crc32c_vector_path_equals_byte_loop():
 def test_index_keys_bound_their_blocks_for_a_seeking_reader(tmp_path):
     """Table format: the index key of a data block is >= the block's last key and < the next block's first key, so that a reader that SEEKS
     (TensorFlow's BundleReader) lands in the right block.  With Adam slots the keys 'X' < 'X/Adam' < 'X/Adam_1' straddle block boundaries,
-    where 'last key + 0xff' would overshoot ('X\\xff' > 'X/Adam'); the writer must stay legal there, and store beta1_power / beta2_power."""
+    where 'last key + 0xff' would overshoot ('X\\xff' > 'X/Adam'); the writer must stay legal there, and store beta1_power / beta2_power = beta ** (step + 1)."""
     import struct
     from dc_tts_amd import tf_checkpoint as C
     rng = np.random.default_rng(0)
@@ -223,5 +310,6 @@ def test_index_keys_bound_their_blocks_for_a_seeking_reader(tmp_path):
         if i + 1 < len(blocks) and blocks[i + 1][1][0] > keys[-1]:          # same file: the next block's first key
             assert ikey < blocks[i + 1][1][0], (ikey, blocks[i + 1][1][0])
     t = C.read_checkpoint(prefix)
-    assert abs(float(t["beta1_power"]) - 0.9 ** 2000) < 1e-12 and abs(float(t["beta2_power"]) - 0.999 ** 2000) < 1e-6
+    # tf.train.AdamOptimizer creates beta1_power = beta1 and multiplies it once per update: after t updates it holds beta1 ** (t + 1)
+    assert abs(float(t["beta1_power"]) - 0.9 ** 2001) < 1e-12 and abs(float(t["beta2_power"]) - 0.999 ** 2001) < 1e-6
     assert int(t["gs/global_step"]) == 2000
