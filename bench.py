@@ -61,7 +61,7 @@ def cpu_baseline(hp, W):
     from oracle import torch_ref as TR
     from oracle.incremental_ref import incremental_decode_v3
     ncpu = os.cpu_count() or 1
-    Bt = 2
+    Bt, STEPS_T = 8, 4                                        # 4 timed loop steps at B = 8 (after one untimed warm-up step) per thread count
     Lt = synthetic_text(hp, B=Bt, seed=99)
     Pt = TR.params(W)
     def torch_leg(threads, steps_t):
@@ -97,11 +97,11 @@ def cpu_baseline(hp, W):
     for th in sorted({min(16, navail), min(64, navail), navail}):
         if tried and (time.perf_counter() - t_leg0 > 30.0 or tried[max(tried)] > 1.5 * min(tried.values())):
             break
-        tried[th] = torch_leg(th, 1)
+        tried[th] = torch_leg(th, STEPS_T)
     best_th = min(tried, key=tried.get)
     per_frame_t = tried[best_th]
     _torch.set_num_threads(best_th)
-    steps_t = 1
+    steps_t = STEPS_T
     # ---- the numpy oracle on the same kind of sample
     Bs, steps = 2, 3
     L = synthetic_text(hp, B=Bs, seed=99)
@@ -129,7 +129,7 @@ def cpu_baseline(hp, W):
     except Exception:
         cores_np = ncpu
     return {"value": 1.0 / per_frame_t, "unit": "mel frames/s", "cores": best_th, "host_cores": ncpu, "usable_cores": navail, "cgroup_cpu_quota_cores": quota, "kind": "port",
-            "sample": f"{steps_t} step of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, B={Bt}, N={hp.max_N}, "
+            "sample": f"{steps_t} timed steps of the restated synthesize.py loop (full Text2Mel graph incl. TextEnc per step, B={Bt}, N={hp.max_N}, "
                       f"T={hp.max_T}) + 1 SSRN pass (B={Bt}), torch-CPU fp32 (oracle/torch_ref.py) at torch.set_num_threads({best_th}) = the fastest of the "
                       f"thread counts tried, one untimed warm-up step each, prorated per mel frame",
             "rtf": per_frame_t / hp.seconds_per_mel_frame,

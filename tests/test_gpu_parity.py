@@ -756,3 +756,46 @@ def test_two_contexts_on_one_gpu_take_turns(weights):
         Ys, ms = (Y1s, m1s) if tag == "a" else (Y2s, m2s)
         assert torch.equal(Y, Ys) and torch.equal(m, ms)
     e2.close()
+
+
+# ---------------------------------------------------------------- the restore path end to end (synthesize.py:32-40)
+def test_checkpoint_directories_to_spectrograms(weights, tmp_path):
+    """`python -m dc_tts_amd.synthesize --logdir <prefix>`: two checkpoint directories laid out like hp.logdir-1 / hp.logdir-2 -- written by the
+    INDEPENDENT bundle encoder of tests/test_tf_checkpoint.py (two shards each, shortened index keys, optimizer slots and gs/global_step beside the
+    variables) -> tf.train.latest_checkpoint -> the two name-restricted restores -> Engine -> decode + SSRN; the spectrograms on disk are bitwise
+    those of an Engine fed the weight dict directly."""
+    import importlib.util
+    from dc_tts_amd import tf_checkpoint as C
+    from dc_tts_amd.synthesize import main as synth_main
+    spec = importlib.util.spec_from_file_location("ttc", os.path.join(os.path.dirname(__file__), "test_tf_checkpoint.py"))
+    ttc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ttc)
+    logdir = str(tmp_path / "logdir" / "LJ01")
+    rng = np.random.default_rng(0)
+    for suffix, scope, step in (("-1", "Text2Mel/", 800), ("-2", "SSRN/", 310)):
+        d = logdir + suffix
+        os.makedirs(d)
+        t = {k: v for k, v in weights.items() if k.startswith(scope)}
+        for k in list(t)[:40]:                                            # Adam slots of some variables: never restored (TRAINABLE_VARIABLES only)
+            t[k + "/Adam"] = rng.standard_normal(t[k].shape).astype(np.float32)
+            t[k + "/Adam_1"] = rng.standard_normal(t[k].shape).astype(np.float32)
+        t["gs/global_step"] = np.asarray(step * 1000, np.int32)
+        t["beta1_power"] = np.asarray(0.5, np.float32)
+        ttc.write_bundle(os.path.join(d, f"model_gs_{step}k"), t, keys_per_block=7, num_shards=2, restart_interval=16, tensor_crc=C.crc32c)
+        ttc.write_bundle(os.path.join(d, "model_gs_001k"), {k: np.zeros_like(v) for k, v in t.items()}, keys_per_block=50, with_crc=False)   # an older checkpoint that must NOT be picked
+        with open(os.path.join(d, "checkpoint"), "w") as f:
+            f.write(f'model_checkpoint_path: "model_gs_{step}k"\nall_model_checkpoint_paths: "model_gs_001k"\nall_model_checkpoint_paths: "model_gs_{step}k"\n')
+    text = tmp_path / "sents.txt"
+    text.write_text("header\n1. The birch canoe slid on the smooth planks.\n2. Glue the sheet to the dark blue background.\n3. It's easy to tell the depth of a well.\n", encoding="utf-8")
+    out = str(tmp_path / "samples")
+    synth_main(["--text", str(text), "--logdir", logdir, "--out", out, "--no-wav"])
+    from dc_tts_amd.data_load import load_data
+    L = load_data("synthesize", str(text), hp)
+    eng = engine_for(weights)
+    Y, Z, _ = eng.synthesize(dev(L), check=True)
+    for i in range(3):
+        assert np.array_equal(np.load(os.path.join(out, f"{i + 1}.mel.npy")), Y[i].cpu().numpy())
+        assert np.array_equal(np.load(os.path.join(out, f"{i + 1}.mag.npy")), Z[i].cpu().numpy())
+    g = np.load(os.path.join(GOLD, "harvard20_ref.npz"))                  # ... and these three sentences are rows 0-2 of the reference's own run
+    assert np.array_equal(L, g["L"][:3])
+    assert maxabs(Y.cpu().numpy(), g["Y"][:3]) < TOL
