@@ -9,10 +9,11 @@ Multi-GPU: utterances shard embarrassingly, 32 per GPU, no collective on the dat
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 What the JSON line holds besides the contract's fields (everything is measured in this run unless it says otherwise):
-  roofline            the kernel that dominates the step by TIME: xgroup_kernel (runs of newest-row highway layers of the decode as one
-                      launch), HIP-event timed on its stream inside the timed region (the AudioEnc run of every 16th frame), both roof fractions
-  kernels             the same figures for the FLOP-dominant kernel (SSRN HC_11/12 + its tail launch), SSRN's 1025-column layers and the
-                      decode's side-stream kernel xcone_kernel (untimed extra passes)
+  roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r04_kernel_stats.md): xcone_kernel, the re-evaluation of
+                      AudioDec's dependency cone on the decode's side stream; HIP-event timed on ITS stream inside the timed region (every 16th
+                      frame from frame 100 on), fp32-MFMA bound; `traffic` = PMC bytes per launch (profiles/r04_pmc_decode.json, separate passes)
+  kernels             the same figures for xgroup_kernel (the chain's runs of highway layers), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
+                      launch) and SSRN's 1025-column layers (event-timed in untimed extra passes)
   phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
   other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share)
   cpu_baseline        the reference's loop restated on torch-CPU fp32 (oracle/torch_ref.py) on the host cores, bounded sample; + the numpy
@@ -306,7 +307,7 @@ def main():
     chain_prof = args.decode_mode == 3
 
     def timed_region():
-        eng.prof_enable(PROF_XGROUP if chain_prof else -1)   # HIP events on the launch stream around the xgroup_kernel launches of every 16th frame
+        eng.prof_enable(PROF_XCONE if chain_prof else -1)    # HIP events on the side stream around the xcone_kernel launch of every 16th frame (frames >= 100: full cones)
         t0 = time.perf_counter()
         out = None
         for _ in range(args.steps):
@@ -364,31 +365,33 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         d = hp.d
-        # ---- roofline: the kernel that dominates the step by time on the critical stream: xgroup_kernel, a run of newest-row highway
-        #      layers of the decode chain (6 layers of AudioDec or 10 of AudioEnc per launch, 2 launches per frame).  Algorithmic work of
-        #      ONE LAYER of one launch (B rows, 256 -> 2 x 256, fp32): weights 256 x 512; presum rows in, pre-norm rows out, pre-norm rows in
-        #      (B x 512 each); partial statistics out + in (B x 64 each); the kept input row out (B x 256); LN parameters (4 x 256)
-        lay_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + B * d + 4 * d)
-        lay_flop = 2.0 * B * d * 2 * d
-        roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "xgroup_kernel: a run of newest-row highway layers of the decode chain as ONE launch (AudioDec HC_2..HC_7 = 6 layers, AudioEnc "
-                          "HC_4..HC_13 = 10 layers): per layer a 32 x 256 x 512 contraction on 16x16x4 fp32 MFMA split over 16 workgroups of a 4-utterance "
-                          "team, layer-norm statistics and pre-norm rows exchanged through the L2 of the ONE XCD the team runs on; 2 launches per frame "
-                          "(timed: the AudioEnc run, ten layers and nothing else in the launch; the AudioDec run's launch also carries passenger workgroups)",
-                "launches": n_chain, "sampled": "the AudioEnc run of every 16th frame of the timed region", "avg_launch_ms": None,
-                "layers_per_launch": None, "algorithmic_bytes_per_layer": lay_bytes, "flop_per_layer": lay_flop,
-                "note": "latency-bound: 16 dependent all-to-all layers per frame; a layer costs one L2 round trip for the exchanged rows, an 8-wave "
-                        "reduction and a team barrier (sixteen flag words in one L2 line), not a memory stream (DESIGN.md section 2c)"}
+        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r04_kernel_stats.md): xcone_kernel, AudioDec HC_3 .. HC_7
+        #      over the rows of a frame's dependency cone (cone_len rows per utterance and layer incl. the presum row) + their layer-norm / gate passes,
+        #      one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one layer: a (3 x 256) x 512 fp32 contraction =
+        #      2 * 768 * 512 FLOP; algorithmic bytes of a launch = the rows in and out (256 channels each) + the five layers' weights once.
+        row_flop = 2.0 * 3 * d * 2 * d
+        roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
+                "kernel": "xcone_kernel: AudioDec HC_3 .. HC_7 (256 ch, k = 3, dilations 3 / 9 / 27 / 1 / 1) over the rows of a frame's dependency cone "
+                          "(45 / 15 / 5 / 3 / 1 rows per utterance) + the layer-norm / gate row passes between them, ONE launch per frame on the decode's side "
+                          "stream: 16x16x4 fp32 MFMA, a 16-workgroup team per four utterances inside one XCD, each workgroup keeps its 96 KB weight slice in registers",
+                "launches": n_chain, "sampled": "every 16th frame from frame 100 on (full-size cones) of the timed region, HIP events on the side stream",
+                "avg_launch_ms": None, "rows_per_launch": None, "flop_per_row": row_flop,
+                "note": "runs concurrently with the chain's kernels on the other half of the CUs; bounded by per-layer latencies (barrier + row pass + cold "
+                        "start of every layer's first tile: DESIGN.md section 2c / 2d), not by the matrix pipe: 128 of 256 CUs give at most 0.5"}
         if n_chain > 0 and chain_layers > 0:
             avg = chain_ms / n_chain
-            lpl = chain_layers / n_chain
-            roof.update(avg_launch_ms=round(avg, 5), layers_per_launch=round(lpl, 2), algorithmic_bytes_per_launch=lay_bytes * lpl,
-                        achieved=round(lay_bytes * lpl / (avg * 1e-3) / 1e9, 1),
-                        frac=round(lay_bytes * lpl / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), frac_mfma=round(lay_flop * lpl / (avg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4))
-        tj = os.path.join(ROOT, "profiles", "r03_pmc_xgroup.json")
+            rpl = chain_layers / n_chain
+            alg_bytes = 4.0 * (rpl * (d + d) + 5 * 3 * d * 2 * d)
+            tf = row_flop * rpl / (avg * 1e-3) / 1e12
+            roof.update(avg_launch_ms=round(avg, 5), rows_per_launch=round(rpl, 1), flop_per_launch=row_flop * rpl, algorithmic_bytes_per_launch=alg_bytes,
+                        achieved=round(tf, 3), frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                        frac_hbm=round(alg_bytes / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5))
+        tj = os.path.join(ROOT, "profiles", "r04_pmc_decode.json")
         if os.path.exists(tj):
-            roof["traffic"] = json.load(open(tj)).get("hbm_bytes_per_launch")
-            roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: profiles/r03_pmc_xgroup.json)"
+            pj = json.load(open(tj))
+            if "xcone_kernel" in pj:
+                roof["traffic"] = pj["xcone_kernel"]["hbm_bytes_per_launch"]
+                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes on this tree: profiles/r04_pmc_decode.json; includes Infinity-Cache hits)"
         flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6      # SURVEY 8d, per mel frame and utterance
         out = {
             "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
@@ -471,17 +474,24 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
             kern.append(dict(kernel=what, bound="mfma", launches=n, avg_launch_ms=round(ms / n, 4), rows_per_launch=rpl, layer_rows=B * 4 * T,
                              **both_roofs(2.0 * rpl * Kk * N_, 4.0 * (rpl * (Kk + N_ / (2 if K_ else 1)) + Kk * N_), ms / n)))
     if args.decode_mode == 3:
-        eng.set_decode_graph(0); eng.text2mel(L); torch.cuda.synchronize()
-        eng.prof_enable(PROF_XCONE); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
-        n, ms = eng.prof_collect(); rows = eng.prof_rows()
-        eng.set_decode_graph(gm)
+        eng.text2mel(L); torch.cuda.synchronize()
+        eng.prof_enable(PROF_XGROUP); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
+        n, ms = eng.prof_collect(); layers = eng.prof_rows()
         if n:
-            rpl = rows / n
-            kern.append(dict(kernel="xcone_kernel (decode side stream: AudioDec HC_3 .. HC_7 over the cone rows of a frame + their layer-norm / gate row passes, "
-                                    "256 ch, k=3; one launch, 16-workgroup teams inside one XCD)",
-                             bound="mfma", launches=n, avg_launch_ms=round(ms / n, 5), rows_per_launch=rpl,
-                             **both_roofs(2.0 * rpl * 3 * d * 2 * d, 4.0 * (rpl * (d + 2 * d + d) + 5 * 3 * d * 2 * d), ms / n),
-                             note="eager decode pass (graph mode 0) so that events can bracket the launches; frames >= 100 (full-size cones); runs concurrently with the chain"))
+            lpl = layers / n
+            lay_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + B * d + 4 * d)      # one layer: weights 256 x 512, presum / rows out / rows in, statistics, kept row, LN parameters
+            lay_flop = 2.0 * B * d * 2 * d
+            e = dict(kernel="xgroup_kernel (decode chain: a run of newest-row highway layers as ONE launch -- timed: the AudioEnc run, HC_4 .. HC_13 = ten layers; per layer "
+                            "a 32 x 256 x 512 contraction split over the 16 workgroups of a 4-utterance team, rows and statistics exchanged through the L2 of the team's XCD)",
+                     bound="latency (16 dependent all-to-all layers per frame)", launches=n, avg_launch_ms=round(ms / n, 5), layers_per_launch=lpl,
+                     algorithmic_bytes_per_layer=lay_bytes, flop_per_layer=lay_flop, **both_roofs(lay_flop * lpl, lay_bytes * lpl, ms / n))
+            tj = os.path.join(ROOT, "profiles", "r04_pmc_decode.json")
+            if os.path.exists(tj):
+                pj = json.load(open(tj))
+                if "xgroup_kernel" in pj:
+                    e["traffic"] = pj["xgroup_kernel"]["hbm_bytes_per_launch"]
+                    e["traffic_note"] = "PMC bytes per launch, mean over BOTH runs of a frame (6 and 10 layers): eight XCD-local copies of every layer's weights, served by the Infinity Cache"
+            kern.append(e)
     res["kernels"] = kern
     # ---- host transfer (PCIe-inclusive figure, reported beside `value`, never as it)
     Lh = L.cpu().pin_memory()

@@ -25,6 +25,7 @@
 #include "hconv16_kernel.h"
 #include "xgroup_kernel.h"
 #include "xcone_kernel.h"
+#include "xmlp_kernel.h"
 
 using namespace dctts;
 
@@ -176,6 +177,8 @@ struct dctts_ctx {
   std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;   // one small linear graph per frame for the side stream, frame index baked into every launch
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
   void* mlp_tab = nullptr; std::string mlp_geom;
+  // the seven k = 1 layers around the mel frame in team form (xmlp_kernel.h) instead of the row-split mlp_rows_kernel; DCTTS_XMLP=0: the row-split form
+  int xmlp = 1; void* xmlp_tab = nullptr; std::string xmlp_geom;
   // runs of chain highway layers as one launch whose workgroups meet inside one XCD (xgroup_kernel.h); DCTTS_XGROUP=0: one launch per layer
   int xgroup = 1;
   bool ae_pass = false; int xg_T = 0;  // AudioEnc's presums and the C1Q . W2 row ride in the AudioDec run's xgroup_kernel launch (passengers); frames of the xgroup table
@@ -405,7 +408,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 // Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
-  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone);
+  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_XMLP", &c->xmlp);
   geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
@@ -462,6 +465,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->iota_dev) (void)hipFree(c->iota_dev);
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
   if (c->mlp_tab) (void)hipFree(c->mlp_tab);
+  if (c->xmlp_tab) (void)hipFree(c->xmlp_tab);
   if (c->xg_tab) (void)hipFree(c->xg_tab);
   if (c->xc_tab) (void)hipFree(c->xc_tab);
   if (c->xg_mem) (void)hipFree(c->xg_mem);

@@ -459,15 +459,17 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
 
 
 // ---- xgroup_kernel plumbing: one XGroupParams per (chain piece, network) in device memory; exchange buffers + team barriers + error word
-struct XgMem { float* xch[2]; float* sch[2]; unsigned* bar; unsigned* bar_cone; int* err; int bpad; size_t bar_words; };
-static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
+struct XgMem { float* xch[2]; float* sch[2]; float* xch_m; float* sch_m; unsigned* bar; unsigned* bar_cone; unsigned* bar_mlp; int* err; int bpad; size_t bar_words; };
+static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 256 + 2 * bpad * 32) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
 static XgMem xg_mem(dctts_ctx* c, int B) {
   XgMem m; m.bpad = (B + 3) / 4 * 4;
   float* q = c->xg_mem;
   for (int n = 0; n < 2; ++n) { m.xch[n] = q; q += (size_t)2 * m.bpad * 512; m.sch[n] = q; q += (size_t)2 * m.bpad * 64; }
+  m.xch_m = q; q += (size_t)2 * m.bpad * 256; m.sch_m = q; q += (size_t)2 * m.bpad * 32;      // xmlp_kernel's exchange: [2][bpad][256] rows, [2][bpad][16][2] statistics
   m.bar_words = (size_t)((m.bpad / 4 + 7) / 8 * 8) * 32;
   m.bar = (unsigned*)q; q += m.bar_words;                     // the chain's teams (xgroup_kernel)
   m.bar_cone = (unsigned*)q; q += m.bar_words;                // the side stream's teams (xcone_kernel): the two run concurrently
+  m.bar_mlp = (unsigned*)q; q += m.bar_words;                 // the chain's teams between the two xgroup runs (xmlp_kernel)
   m.err = (int*)q;
   return m;
 }
@@ -646,8 +648,58 @@ static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   return 0;
 }
 
+// xmlp_kernel's per-frame parameters: the same seven layers as v3_mlp_table, column-split over the teams (needs xg_mem: call after v3_xgroup_table)
+static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
+  const std::string g = geom("xmlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem);
+  if (c->xmlp_tab && c->xmlp_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->xmlp_tab) { (void)hipFree(c->xmlp_tab); c->xmlp_tab = nullptr; }
+  const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
+  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
+  size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
+  const int ntail = (int)(AD.size() - lh - 1), nhead = (int)nh;
+  if (lh < 1 || ntail < 1 || ntail + nhead > 7 || nhead < 1 || AD[lh].cout != 256) return fail(DCTTS_ERR_STATE, "xmlp: unexpected layer structure");
+  const XgMem m = xg_mem(c, B);
+  auto fill = [&](const DevLayer& L, XMlpLayer* x, bool mel) -> int {
+    if (!L.wp16 || L.hc || L.ntaps != 1 || (L.cin_p & 15) || (L.cout & 15) || L.cin_p > 256 || L.cout > 256) return fail(DCTTS_ERR_STATE, "xmlp: unsupported layer shape");
+    x->wp = L.wp16; x->bias = L.bias; x->g = L.g1; x->be = L.b1; x->nkg = L.cin_p / 16; x->cout = L.cout; x->act = mel ? ACT_SIGMOID : L.act; x->pad_ = 0;
+    return 0;
+  };
+  const int rounds = ((B + 3) / 4 + 7) / 8;
+  std::vector<XMlpParams> tab((size_t)T);
+  for (int j = 0; j < T; ++j) {
+    XMlpParams p; memset(&p, 0, sizeof(p));
+    const long par = j & 1;
+    p.B = B;
+    p.P0 = w.pd[lh]; p.p0_bs = 2 * AD[lh].cout; p.stats0 = w.sd[lh];
+    p.g1 = AD[lh].g1; p.b1 = AD[lh].b1; p.g2 = AD[lh].g2; p.b2 = AD[lh].b2;
+    const View& rv = w.ad[lh - 1];
+    p.res = rv.p + par * rv.set + (rv.row0 + j) * (long)rv.stride; p.res_bs = (int)(rv.bstride * rv.stride);
+    int n = 0;
+    for (size_t i = lh + 1; i < AD.size(); ++i) { CHK(fill(AD[i], &p.lay[n], i + 1 == AD.size())); ++n; }
+    p.mel_layer = n - 1;
+    if (j + 1 < T) for (size_t i = 0; i < nh; ++i) { CHK(fill(AE[i], &p.lay[n], false)); ++n; }     // the last frame has no next frame to encode
+    p.nl = n;
+    p.ymel = w.ypad.p + (w.ypad.row0 + 1 + j) * (long)w.ypad.stride; p.y_bs = (int)(w.ypad.bstride * w.ypad.stride);      // the +1 shift of train.py:51
+    p.logits = w.logits.p + (w.logits.row0 + j) * (long)w.logits.stride; p.l_bs = (int)(w.logits.bstride * w.logits.stride);
+    p.pout = w.pe[nh - 1]; p.stats_out = w.se[nh - 1];
+    p.xch = m.xch_m; p.sch = m.sch_m; p.xch_set = m.bpad * 256; p.sch_set = m.bpad * 32;
+    p.bar = m.bar_mlp; p.bar_base = (unsigned)j * (unsigned)rounds * 7u * 16u; p.err = m.err;
+    tab[j] = p;
+  }
+  HIPCHK(hipMalloc(&c->xmlp_tab, tab.size() * sizeof(XMlpParams)));
+  HIPCHK(hipMemcpy(c->xmlp_tab, tab.data(), tab.size() * sizeof(XMlpParams), hipMemcpyHostToDevice));
+  c->xmlp_geom = g;
+  return 0;
+}
+
 static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
   CHK(prof_close_run(c, st));
+  if (c->xg_on && c->xmlp && c->xmlp_tab) {
+    hipLaunchKernelGGL(xmlp_kernel, dim3(128), dim3(512), 0, st, (const XMlpParams*)c->xmlp_tab + j);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   const MlpRowsParams* pm = (const MlpRowsParams*)c->mlp_tab + j;
   if (c->trace_on) {                                              // DCTTS_TRACE: stamped instantiation, stamps at the end of the trace buffer
     hipLaunchKernelGGL((mlp_rows_kernel<2, true>), dim3((B + 1) / 2), dim3(512), 0, st, pm, c->trace_buf + 64 * 64 * 32 - 64);
@@ -811,7 +863,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     CHK(v3_xgroup_table(c, w, B, T, insig, cwait));            // (also allocates the memory both kernels meet through)
     if (c->xc_on) CHK(v3_xcone_table(c, w, B, T, bsig));
     const XgMem m = xg_mem(c, B);
-    HIPCHK(hipMemsetAsync(m.bar, 0, (2 * m.bar_words + 64) * sizeof(unsigned), st));      // both sets of team barriers and the error word
+    HIPCHK(hipMemsetAsync(m.bar, 0, (3 * m.bar_words + 64) * sizeof(unsigned), st));      // the three sets of team barriers and the error word
+    if (c->xg_on && c->xmlp) CHK(v3_xmlp_table(c, w, B, T));
   }
   hipStream_t sb = c->s_bulk;
   // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch (the chain launches stay eager: a graph

@@ -1,20 +1,20 @@
 #!/bin/bash
-# Reproduces everything under profiles/ (round 3) on a 1x MI355X box (run from the repo root; ~5 minutes of GPU time).
+# Reproduces everything under profiles/ (round 4) on a 1x MI355X box (run from the repo root; ~5 minutes of GPU time).
 # Every profiler command is wrapped in `timeout`; --pmc passes are separate runs with --kernel-trace only.
 set -u
 R=$PWD
-OUT=${1:-$R/gpurun_out/profile_r03}
+OUT=${1:-$R/gpurun_out/profile_r04}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 STEPS=${STEPS:-123457}           # e.g. STEPS=127 bash tools/profile_all.sh: only the bench line, the kernel trace and the layer table
 want() { case "$STEPS" in *$1*) return 0;; *) return 1;; esac; }
-# 1. the bench line (metric, roofline of the time-dominant kernel, kernels, other configs, cpu_baseline, vocoder)  -> profiles/r03_bench.json
+# 1. the bench line (metric, roofline of the time-dominant kernel, kernels, other configs, cpu_baseline, vocoder)  -> profiles/r04_bench.json
 want 1 && timeout 600 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
-# 2. per-kernel time of the same workload                                               -> profiles/r03_kernel_stats.{csv,md}
+# 2. per-kernel time of the same workload                                               -> profiles/r04_kernel_stats.{csv,md}
 want 2 && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_stats" -- \
     python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-extras > "$OUT/kernel_stats.log" 2>&1
-# 3. HBM traffic of the decode kernels (FETCH_SIZE x2 per the gfx950 correction; WRITE_SIZE exact)   -> profiles/r03_pmc.{md,json}
+# 3. HBM traffic of the decode kernels (FETCH_SIZE x2 per the gfx950 correction; WRITE_SIZE exact)   -> profiles/r04_pmc.{md,json}
 #    Counter collection serialises dispatches ACROSS queues, so a launch that waits for the other stream's counter (stream memory
 #    operations, in-kernel signals) would wait for ever: the counter passes let the two streams meet through events (DCTTS_SYNC_VALUES=0).
 export DCTTS_SYNC_VALUES=0
@@ -27,7 +27,7 @@ unset DCTTS_SYNC_VALUES
 cd "$R"
 want 3 && python tools/pmc_summary.py "$OUT/pmc_fetch" FETCH_SIZE > "$OUT/pmc_fetch.txt"
 want 3 && python tools/pmc_summary.py "$OUT/pmc_write" WRITE_SIZE > "$OUT/pmc_write.txt"
-want 3 && python tools/pmc_json.py "$OUT/pmc_fetch.txt" "$OUT/pmc_write.txt" "$OUT/pmc_xgroup.json" > /dev/null
+want 3 && python tools/pmc_json.py "$OUT/pmc_fetch.txt" "$OUT/pmc_write.txt" "$OUT/pmc_decode.json" > /dev/null
 want 4 && for ctr in SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE; do
   echo "== $ctr"; python tools/pmc_summary.py "$OUT/pmc_sq" $ctr | head -12; done > "$OUT/pmc_sq.txt"
 # 5. where the team kernels / mlp_rows_kernel spend their time (in-kernel wall-clock stamps) and how long the two streams' pieces take
