@@ -26,6 +26,7 @@
 #include "xgroup_kernel.h"
 #include "xcone_kernel.h"
 #include "xmlp_kernel.h"
+#include "xtail_kernel.h"
 
 using namespace dctts;
 
@@ -177,8 +178,13 @@ struct dctts_ctx {
   std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;   // one small linear graph per frame for the side stream, frame index baked into every launch
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
   void* mlp_tab = nullptr; std::string mlp_geom;
-  // the seven k = 1 layers around the mel frame in team form (xmlp_kernel.h) instead of the row-split mlp_rows_kernel; DCTTS_XMLP=0: the row-split form
-  int xmlp = 1; void* xmlp_tab = nullptr; std::string xmlp_geom;
+  // What follows the chain's AudioDec run (DCTTS_CHAIN_TAIL): 2 (default) = xtail_kernel: AudioDec HC_5 .. HC_7 over the few cone rows they need + the seven
+  // k = 1 layers around the mel frame, one launch in team form (the side stream then stops behind HC_4); 1 = xmlp_kernel: the seven k = 1 layers in team form
+  // (HC_5 .. HC_7 stay split between the chain's run and the side stream); 0 = mlp_rows_kernel (round 2: split by rows)
+  int chain_tail = 2; bool tail_on = false, xmlp_on = false;
+  bool attn_fold = false;              // the newest row's attention + AudioDec C_1 run behind the AudioEnc run's last layer inside xgroup_kernel (chain_tail >= 1) instead of as two more launches
+  void* xmlp_tab = nullptr; std::string xmlp_geom;
+  void* xtail_tab = nullptr; std::string xtail_geom;
   // runs of chain highway layers as one launch whose workgroups meet inside one XCD (xgroup_kernel.h); DCTTS_XGROUP=0: one launch per layer
   int xgroup = 1;
   bool ae_pass = false; int xg_T = 0;  // AudioEnc's presums and the C1Q . W2 row ride in the AudioDec run's xgroup_kernel launch (passengers); frames of the xgroup table
@@ -408,7 +414,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 // Measurement / A-B knobs (tools/README.md).  Read once per context: the decode path itself never calls getenv.
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
-  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_XMLP", &c->xmlp);
+  geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_CHAIN_TAIL", &c->chain_tail);
   geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
@@ -466,6 +472,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->aepre_tab) (void)hipFree(c->aepre_tab);
   if (c->mlp_tab) (void)hipFree(c->mlp_tab);
   if (c->xmlp_tab) (void)hipFree(c->xmlp_tab);
+  if (c->xtail_tab) (void)hipFree(c->xtail_tab);
   if (c->xg_tab) (void)hipFree(c->xg_tab);
   if (c->xc_tab) (void)hipFree(c->xc_tab);
   if (c->xg_mem) (void)hipFree(c->xg_mem);

@@ -364,7 +364,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, sb)); }
     hipLaunchKernelGGL(xcone_kernel, dim3(128), dim3(512), 0, sb, xp);
     HIPCHK(hipGetLastError());
-    if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < AD.size(); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
+    if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < (c->tail_on ? (size_t)4 : AD.size()); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
     return 0;
   }
   for (size_t i = first_gemm; i < AD.size(); ++i) {
@@ -459,13 +459,14 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
 
 
 // ---- xgroup_kernel plumbing: one XGroupParams per (chain piece, network) in device memory; exchange buffers + team barriers + error word
-struct XgMem { float* xch[2]; float* sch[2]; float* xch_m; float* sch_m; unsigned* bar; unsigned* bar_cone; unsigned* bar_mlp; int* err; int bpad; size_t bar_words; };
-static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 256 + 2 * bpad * 32) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
+struct XgMem { float* xch[2]; float* sch[2]; float* xch_m; float* sch_m; float* xch_h; float* sch_h; unsigned* bar; unsigned* bar_cone; unsigned* bar_mlp; int* err; int bpad; size_t bar_words; };
+static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 256 + 2 * bpad * 32) + (size_t)2 * (bpad / 4) * XT_MAXM * (512 + 64) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
 static XgMem xg_mem(dctts_ctx* c, int B) {
   XgMem m; m.bpad = (B + 3) / 4 * 4;
   float* q = c->xg_mem;
   for (int n = 0; n < 2; ++n) { m.xch[n] = q; q += (size_t)2 * m.bpad * 512; m.sch[n] = q; q += (size_t)2 * m.bpad * 64; }
   m.xch_m = q; q += (size_t)2 * m.bpad * 256; m.sch_m = q; q += (size_t)2 * m.bpad * 32;      // xmlp_kernel's exchange: [2][bpad][256] rows, [2][bpad][16][2] statistics
+  m.xch_h = q; q += (size_t)2 * (m.bpad / 4) * XT_MAXM * 512; m.sch_h = q; q += (size_t)2 * (m.bpad / 4) * XT_MAXM * 64;   // xtail_kernel's highway layers: [2][groups][20][512], [2][groups][20][16][4]
   m.bar_words = (size_t)((m.bpad / 4 + 7) / 8 * 8) * 32;
   m.bar = (unsigned*)q; q += m.bar_words;                     // the chain's teams (xgroup_kernel)
   m.bar_cone = (unsigned*)q; q += m.bar_words;                // the side stream's teams (xcone_kernel): the two run concurrently
@@ -479,7 +480,8 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
                         std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
-                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string(c->trace_frame);
+                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string(c->trace_frame) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string((int)c->attn_fold) + ":" +
+                        std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all);
   if (c->xg_tab && c->xg_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xg_tab) { (void)hipFree(c->xg_tab); c->xg_tab = nullptr; }
@@ -500,6 +502,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       const std::vector<DevLayer>& Lr = net ? AE : AD;
       size_t i0 = 0; while (i0 < Lr.size() && !Lr[i0].hc) ++i0;
       size_t i1 = i0; while (i1 < Lr.size() && Lr[i1].hc) ++i1;
+      if (net == 0 && c->tail_on) i1 = i0 + 3;                 // AudioDec HC_2 .. HC_4 only: HC_5 .. HC_7 run in xtail_kernel, the launch behind this one
       const int L = (int)(i1 - i0);
       if (i0 == 0 || L < 2 || L > 10 || Lr[i0 - 1].cout != 256 || Lr[i0 - 1].act != ACT_NONE) return fail(DCTTS_ERR_STATE, "xgroup: a run of 2..10 highway layers after a linear 256-channel layer");
       p.B = B; p.L = L;
@@ -522,7 +525,19 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       p.pout = P[i1 - 1]; p.stats_out = S[i1 - 1];
       p.xch = m.xch[net]; p.sch = m.sch[net]; p.xch_set = m.bpad * 512; p.sch_set = m.bpad * 64;
       p.bar = m.bar; p.bar_base = arrivals; p.err = m.err;
-      arrivals += (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(L - 1) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
+      if (net == 1 && c->attn_fold) {
+        // the attention row of frame j and AudioDec C_1 of frame j behind the run's last layer (what attnq_kernel + chain3_kernel<RAW> compute, v3_chain_enc)
+        const size_t la = AE.size() - 1;
+        const int d = c->cfg.d;
+        p.attn = 1; p.N = c->cfg.max_N; p.win = c->cfg.attention_win_size;
+        p.pm = w.pm_all + (long)j * B; p.pm_next = w.pm_all + (long)(j + 1) * B;
+        p.K = w.kv.p; p.k_stride = 2 * d; p.VW = w.vw; p.vw_stride = d; p.kv_bs = c->cfg.max_N;
+        p.qhist = w.ae[la].p + (w.ae[la].row0 + j) * (long)w.ae[la].stride; p.q_bs = (int)(w.ae[la].bstride * w.ae[la].stride);
+        p.c1_wp = c->ad_c1q.wp16; p.c1_bias = c->audiodec[0].bias;
+        p.c1_raw = w.c1q.p + (w.c1q.row0 + j) * (long)w.c1q.stride; p.raw_bs = (int)(w.c1q.bstride * w.c1q.stride);
+        p.c1_pout = w.pd[0]; p.c1_stats = w.sd[0];
+      }
+      arrivals += (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(L - 1 + p.attn) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
       if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
         if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
@@ -567,20 +582,22 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
 
 // ---- xcone_kernel plumbing: one XConeParams per frame in device memory (layers HC_3 .. HC_7 of AudioDec's cone, parity copies folded in)
 static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig) {
-  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr);
+  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on);
   if (c->xc_tab && c->xc_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xc_tab) { (void)hipFree(c->xc_tab); c->xc_tab = nullptr; }
   const std::vector<DevLayer>& AD = c->audiodec;
   const XgMem m = xg_mem(c, B);
   size_t i0 = 2, i1 = i0; while (i1 < AD.size() && AD[i1].hc) ++i1;     // HC_3 .. the last highway layer
+  const int tail = c->tail_on ? 1 : 0;
+  if (tail) i1 = i0 + 2;                                                 // HC_3, HC_4 and HC_4's cone rows: the chain's xtail_kernel takes it from there
   const int L = (int)(i1 - i0);
   if (L < 1 || L > 5) return fail(DCTTS_ERR_STATE, "xcone: 1..5 highway layers behind HC_2");
   std::vector<XConeParams> tab((size_t)T);
   for (int f = 0; f < T; ++f) {
     const long par = f & 1;
     XConeParams p; memset(&p, 0, sizeof(p));
-    p.B = B; p.L = L; p.frame = f;
+    p.B = B; p.L = L; p.frame = f; p.tail_rows = tail;
     for (int k = 0; k < L; ++k) {
       const size_t i = i0 + k; const DevLayer& Ly = AD[i];
       if (Ly.cout != 256 || Ly.cin != 256 || Ly.cin_p != 256 || Ly.ntaps != 3 || Ly.tap_off[2] != 0 || !Ly.wp16 || c->cone_len[i] > 64) return fail(DCTTS_ERR_STATE, "xcone: causal k=3 highway layers over 256 channels, <= 64 cone rows");
@@ -593,7 +610,7 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       q.offs = c->cone3_dev[i]; q.R = c->cone_len[i];
       for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = Ly.tap_off[t3];
     }
-    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(2 * L - 1) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
+    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(2 * L - 1 + tail) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
     if (insig) {                                                // the launch's last team publishes "side-stream piece f complete" itself
       p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)(((B + 3) / 4 < 8) ? (B + 3) / 4 : 8);      // one count per team (at most 8)
       p.sig = c->wait_ctr + 32; p.sig_val = (unsigned)(f + 1);
@@ -648,54 +665,121 @@ static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   return 0;
 }
 
-// xmlp_kernel's per-frame parameters: the same seven layers as v3_mlp_table, column-split over the teams (needs xg_mem: call after v3_xgroup_table)
-static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
-  const std::string g = geom("xmlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem);
-  if (c->xmlp_tab && c->xmlp_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->xmlp_tab) { (void)hipFree(c->xmlp_tab); c->xmlp_tab = nullptr; }
+// The k = 1 layers around the mel frame for frame j as XMlpParams (shared by xmlp_kernel and xtail_kernel); `prod` = index of the AudioDec highway layer whose
+// pre-norm rows / statistics / input rows the launch starts from.
+static int fill_xmlp(dctts_ctx* c, const DecodeWs& w, int B, int T, int j, size_t prod, const XgMem& m, int slots, XMlpParams* out) {
   const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
   size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
   size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
   const int ntail = (int)(AD.size() - lh - 1), nhead = (int)nh;
-  if (lh < 1 || ntail < 1 || ntail + nhead > 7 || nhead < 1 || AD[lh].cout != 256) return fail(DCTTS_ERR_STATE, "xmlp: unexpected layer structure");
-  const XgMem m = xg_mem(c, B);
+  if (lh < 1 || ntail < 1 || ntail + nhead > 7 || nhead < 1 || AD[prod].cout != 256 || !AD[prod].hc || prod < 1) return fail(DCTTS_ERR_STATE, "xmlp: unexpected layer structure");
   auto fill = [&](const DevLayer& L, XMlpLayer* x, bool mel) -> int {
     if (!L.wp16 || L.hc || L.ntaps != 1 || (L.cin_p & 15) || (L.cout & 15) || L.cin_p > 256 || L.cout > 256) return fail(DCTTS_ERR_STATE, "xmlp: unsupported layer shape");
     x->wp = L.wp16; x->bias = L.bias; x->g = L.g1; x->be = L.b1; x->nkg = L.cin_p / 16; x->cout = L.cout; x->act = mel ? ACT_SIGMOID : L.act; x->pad_ = 0;
     return 0;
   };
   const int rounds = ((B + 3) / 4 + 7) / 8;
+  XMlpParams p; memset(&p, 0, sizeof(p));
+  const long par = j & 1;
+  p.B = B;
+  p.P0 = w.pd[prod]; p.p0_bs = 2 * AD[prod].cout; p.stats0 = w.sd[prod];
+  p.g1 = AD[prod].g1; p.b1 = AD[prod].b1; p.g2 = AD[prod].g2; p.b2 = AD[prod].b2;
+  const View& rv = w.ad[prod - 1];
+  p.res = rv.p + par * rv.set + (rv.row0 + j) * (long)rv.stride; p.res_bs = (int)(rv.bstride * rv.stride);
+  int n = 0;
+  for (size_t i = lh + 1; i < AD.size(); ++i) { CHK(fill(AD[i], &p.lay[n], i + 1 == AD.size())); ++n; }
+  p.mel_layer = n - 1;
+  if (j + 1 < T) for (size_t i = 0; i < nh; ++i) { CHK(fill(AE[i], &p.lay[n], false)); ++n; }     // the last frame has no next frame to encode
+  p.nl = n;
+  p.ymel = w.ypad.p + (w.ypad.row0 + 1 + j) * (long)w.ypad.stride; p.y_bs = (int)(w.ypad.bstride * w.ypad.stride);      // the +1 shift of train.py:51
+  p.logits = w.logits.p + (w.logits.row0 + j) * (long)w.logits.stride; p.l_bs = (int)(w.logits.bstride * w.logits.stride);
+  p.pout = w.pe[nh - 1]; p.stats_out = w.se[nh - 1];
+  p.xch = m.xch_m; p.sch = m.sch_m; p.xch_set = m.bpad * 256; p.sch_set = m.bpad * 32;
+  p.bar = m.bar_mlp; p.bar_base = (unsigned)j * (unsigned)rounds * (unsigned)slots * 16u; p.err = m.err;
+  *out = p;
+  return 0;
+}
+
+// xmlp_kernel's per-frame parameters: the same seven layers as v3_mlp_table, column-split over the teams (needs xg_mem: call after v3_xgroup_table)
+static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
+  const std::string g = geom("xmlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem);
+  if (c->xmlp_tab && c->xmlp_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->xmlp_tab) { (void)hipFree(c->xmlp_tab); c->xmlp_tab = nullptr; }
+  const std::vector<DevLayer>& AD = c->ad_c;
+  size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;
+  const XgMem m = xg_mem(c, B);
   std::vector<XMlpParams> tab((size_t)T);
-  for (int j = 0; j < T; ++j) {
-    XMlpParams p; memset(&p, 0, sizeof(p));
-    const long par = j & 1;
-    p.B = B;
-    p.P0 = w.pd[lh]; p.p0_bs = 2 * AD[lh].cout; p.stats0 = w.sd[lh];
-    p.g1 = AD[lh].g1; p.b1 = AD[lh].b1; p.g2 = AD[lh].g2; p.b2 = AD[lh].b2;
-    const View& rv = w.ad[lh - 1];
-    p.res = rv.p + par * rv.set + (rv.row0 + j) * (long)rv.stride; p.res_bs = (int)(rv.bstride * rv.stride);
-    int n = 0;
-    for (size_t i = lh + 1; i < AD.size(); ++i) { CHK(fill(AD[i], &p.lay[n], i + 1 == AD.size())); ++n; }
-    p.mel_layer = n - 1;
-    if (j + 1 < T) for (size_t i = 0; i < nh; ++i) { CHK(fill(AE[i], &p.lay[n], false)); ++n; }     // the last frame has no next frame to encode
-    p.nl = n;
-    p.ymel = w.ypad.p + (w.ypad.row0 + 1 + j) * (long)w.ypad.stride; p.y_bs = (int)(w.ypad.bstride * w.ypad.stride);      // the +1 shift of train.py:51
-    p.logits = w.logits.p + (w.logits.row0 + j) * (long)w.logits.stride; p.l_bs = (int)(w.logits.bstride * w.logits.stride);
-    p.pout = w.pe[nh - 1]; p.stats_out = w.se[nh - 1];
-    p.xch = m.xch_m; p.sch = m.sch_m; p.xch_set = m.bpad * 256; p.sch_set = m.bpad * 32;
-    p.bar = m.bar_mlp; p.bar_base = (unsigned)j * (unsigned)rounds * 7u * 16u; p.err = m.err;
-    tab[j] = p;
-  }
+  for (int j = 0; j < T; ++j) CHK(fill_xmlp(c, w, B, T, j, lh, m, 7, &tab[j]));
   HIPCHK(hipMalloc(&c->xmlp_tab, tab.size() * sizeof(XMlpParams)));
   HIPCHK(hipMemcpy(c->xmlp_tab, tab.data(), tab.size() * sizeof(XMlpParams), hipMemcpyHostToDevice));
   c->xmlp_geom = g;
   return 0;
 }
 
+// xtail_kernel's per-frame parameters: AudioDec's last three highway layers (HC_5 .. HC_7 over 5 / 3 / 1 rows per utterance) + the k = 1 layers
+static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
+  const std::string g = geom("xtail", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string(c->trace_frame);
+  if (c->xtail_tab && c->xtail_geom == g) return 0;
+  (void)hipDeviceSynchronize();
+  if (c->xtail_tab) { (void)hipFree(c->xtail_tab); c->xtail_tab = nullptr; }
+  const std::vector<DevLayer>& AD = c->audiodec;                         // (the full layers: all three taps in wp16)
+  const size_t h0 = 4;                                                   // C_1, HC_2, HC_3, HC_4 | HC_5, HC_6, HC_7 | C_8 ..
+  for (size_t k = 0; k < 3; ++k) {
+    const DevLayer& Ly = AD[h0 + k];
+    if (!Ly.hc || Ly.cout != 256 || Ly.cin != 256 || Ly.cin_p != 256 || Ly.ntaps != 3 || Ly.tap_off[2] != 0 || !Ly.wp16) return fail(DCTTS_ERR_STATE, "xtail: causal k=3 highway layers over 256 channels");
+    if (k > 0 && (Ly.tap_off[0] != -2 || Ly.tap_off[1] != -1)) return fail(DCTTS_ERR_STATE, "xtail: the layers behind the first one have dilation 1");
+  }
+  const int nout[3] = {c->cone_len[h0], c->cone_len[h0 + 1], c->cone_len[h0 + 2]};
+  if (nout[0] != 5 || nout[1] != 3 || nout[2] != 1 || 3 * nout[0] != c->cone_len[h0 - 1] || 4 * nout[0] > XT_MAXM) return fail(DCTTS_ERR_STATE, "xtail: cone 15 / 5 / 3 / 1");
+  const XgMem m = xg_mem(c, B);
+  const int groups = m.bpad / 4;
+  const View& xv = w.ad[h0 - 1];                                         // HC_4's output rows: the side stream's xcone_kernel writes its cone rows (parity copy of the frame)
+  std::vector<XTailParams> tab((size_t)T);
+  for (int j = 0; j < T; ++j) {
+    XTailParams p; memset(&p, 0, sizeof(p));
+    CHK(fill_xmlp(c, w, B, T, j, h0 - 1, m, 10, &p.m));
+    const long par = j & 1;
+    p.nh = 3; p.nin0 = 3 * nout[0]; p.frame = j;
+    for (int k = 0; k < 3; ++k) {
+      const DevLayer& Ly = AD[h0 + k];
+      XTailHc& q = p.hc[k];
+      q.wp = Ly.wp16; q.bias = Ly.bias; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2;
+      q.nout = nout[k]; q.nin = k == 0 ? 3 * nout[0] : nout[k - 1]; q.ts = k == 0 ? nout[0] : 1;
+    }
+    p.xin = xv.p + par * xv.set + (xv.row0 + j) * (long)xv.stride; p.xin_bs = xv.bstride * (long)xv.stride; p.xin_stride = xv.stride;
+    for (int kk = 0; kk < 3; ++kk)
+      for (int r = 0; r < nout[0]; ++r) p.in_off[kk * nout[0] + r] = AD[h0].tap_off[2 - kk] - r;      // input row q = kk * 5 + r: time t - r + tap offset
+    p.xch = m.xch_h; p.sch = m.sch_h; p.xch_set = groups * XT_MAXM * 512; p.sch_set = groups * XT_MAXM * 64;
+    if (j == c->trace_frame) {
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
+      p.ts = c->trace_buf + 64 * 64 * 32 - 64;      // (the slot mlp_rows_kernel's stamps use in the row-split form)
+    }
+    tab[j] = p;
+  }
+  // every input row the first layer stages (but the newest) must be a cone row the side stream produces
+  for (int q = 1; q < 3 * nout[0]; ++q) {
+    bool found = false;
+    std::vector<int> offs((size_t)c->cone_len[h0 - 1]);
+    HIPCHK(hipMemcpy(offs.data(), c->cone3_dev[h0 - 1], offs.size() * sizeof(int), hipMemcpyDeviceToHost));
+    for (int o : offs) if (o == tab[0].in_off[q]) found = true;
+    if (!found) return fail(DCTTS_ERR_STATE, "xtail: an input row of HC_5 is not in HC_4's cone");
+  }
+  HIPCHK(hipMalloc(&c->xtail_tab, tab.size() * sizeof(XTailParams)));
+  HIPCHK(hipMemcpy(c->xtail_tab, tab.data(), tab.size() * sizeof(XTailParams), hipMemcpyHostToDevice));
+  c->xtail_geom = g;
+  return 0;
+}
+
 static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
   CHK(prof_close_run(c, st));
-  if (c->xg_on && c->xmlp && c->xmlp_tab) {
+  if (c->tail_on && c->xtail_tab) {
+    if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
+    else hipLaunchKernelGGL(xtail_kernel<false>, dim3(128), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  if (c->xmlp_on && c->xmlp_tab) {
     hipLaunchKernelGGL(xmlp_kernel, dim3(128), dim3(512), 0, st, (const XMlpParams*)c->xmlp_tab + j);
     HIPCHK(hipGetLastError());
     return 0;
@@ -743,6 +827,7 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
                      w.pe[i], w.se[i], &ex, sm));
     }
   }
+  if (c->attn_fold) return 0;                                   // the AudioEnc run's launch carried the attention row and AudioDec C_1 (xgroup_kernel.h)
   const size_t la = AE.size() - 1;
   AttnQParams a; memset(&a, 0, sizeof(a));
   a.B = B; a.frame = j;
@@ -808,7 +893,12 @@ static int write_trace3(dctts_ctx* c, int j) {
   }
   {
     const long long* o = &h[64 * 64 * 32 - 64];
-    if (o[0]) {
+    if (o[0] && c->tail_on) {
+      fprintf(f, "# xtail_kernel (workgroup 0, thread 0), microseconds since its entry: rows staged + newest row rebuilt | per highway layer: MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
+      fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
+      for (int i = 2; i < 60 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i <= 16 && (i - 2) % 5 == 4) ? " |" : "");
+      fprintf(f, "\n");
+    } else if (o[0]) {
       fprintf(f, "# mlp_rows_kernel (workgroup 0, thread 0), microseconds since its entry: rows rebuilt | per layer: loads landed, FMAs done, partial sums exchanged, row finished\n");
       fprintf(f, "  %6.2f |", (o[1] - o[0]) / 100.0);
       for (int i = 2; i + 3 < 32 && o[i + 3]; i += 4) fprintf(f, "  %6.2f %6.2f %6.2f %6.2f |", (o[i] - o[0]) / 100.0, (o[i + 1] - o[0]) / 100.0, (o[i + 2] - o[0]) / 100.0, (o[i + 3] - o[0]) / 100.0);
@@ -848,6 +938,9 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (that timing id looks at chain3_kernel launches; so does DCTTS_TRACE with DCTTS_XGROUP=0)
   c->xc_on = c->xcone != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_BULK_GEMM &&
              c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;      // (behind rowhc2_kernel)
+  c->tail_on = c->xg_on && c->xc_on && c->chain_tail == 2 && c->audiodec.size() == 11 && c->cone_len.size() > 6 && c->cone_len[4] == 5 && c->cone_len[5] == 3 && c->cone_len[6] == 1;
+  c->xmlp_on = c->xg_on && c->chain_tail >= 1 && !c->tail_on;
+  c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's
   // counter, and xcone_kernel's last team writes the side stream's
   const bool bsig = cwait && c->xc_on;
@@ -864,7 +957,8 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     if (c->xc_on) CHK(v3_xcone_table(c, w, B, T, bsig));
     const XgMem m = xg_mem(c, B);
     HIPCHK(hipMemsetAsync(m.bar, 0, (3 * m.bar_words + 64) * sizeof(unsigned), st));      // the three sets of team barriers and the error word
-    if (c->xg_on && c->xmlp) CHK(v3_xmlp_table(c, w, B, T));
+    if (c->xmlp_on) CHK(v3_xmlp_table(c, w, B, T));
+    if (c->tail_on) CHK(v3_xtail_table(c, w, B, T));
   }
   hipStream_t sb = c->s_bulk;
   // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch (the chain launches stay eager: a graph

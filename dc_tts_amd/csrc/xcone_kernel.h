@@ -33,6 +33,7 @@ struct XConeLayer {
 };
 struct XConeParams {
   int B, L, frame;
+  int tail_rows;                         // 1: the LAST layer's cone rows are normalised / gated / stored as well (round 4: the layers behind it run on the chain, xtail_kernel.h)
   XConeLayer lay[5];
   unsigned* bar; unsigned bar_base;      // team barriers: bar[team * 32] counts arrivals since the decode started; value before this launch
   int* err;
@@ -210,8 +211,9 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     arrived += 16u;
     xcone_barrier(bar, grp, xcc, arrived, p.err, s_go != 0);
     stamp();                                                                   // barrier passed
-    if (li + 1 == p.L) break;                                                  // the last layer only leaves its presum rows
-    load_w(li + 1, bq0, bq1);                                                  // the next layer's slice lands while this layer's rows are normalised
+    const bool lastl = li + 1 == p.L;
+    if (lastl && !p.tail_rows) break;                                          // the last layer only leaves its presum rows (unless its cone rows are somebody's input)
+    if (!lastl) load_w(li + 1, bq0, bq1);                                      // the next layer's slice lands while this layer's rows are normalised
     // ---- layer-norm / gate / highway mix of the cone rows (offsets < 0): one wave per row, the team's 128 waves in turn
     const int Rb = R - 1;
     if (Rb > 0) {

@@ -1,0 +1,420 @@
+// xtail_kernel.h -- the TAIL of AudioDec for one decode frame on the chain's stream (round 4): the last three highway layers HC_5 .. HC_7
+// (networks.py:175-191) over the FEW rows of the dependency cone they need, then the seven k = 1 layers of xmlp_kernel.h, as one launch in team form.
+//
+// Why.  Exact parity with synthesize.py:47-54 makes every frame re-evaluate AudioDec's dependency cone with the frame's attention window
+// (85 / 83 / 45 / 15 / 5 / 3 / 1 rows per utterance for C_1 .. HC_7).  Rounds 2-3 put ALL cone rows at offsets < 0 on the side stream and only the
+// newest row of every layer on the chain; with the team kernels the side stream became the longer one (99 against ~72 us of chain work per frame once
+// the k = 1 layers ran in team form), and 23 of its 99 us were the three LAST layers, whose cone is 5, 3 and 1 rows per utterance: latency
+// (barrier + row pass + a cold start per layer), not arithmetic.  Those rows fit the chain's MFMA tiles for free -- a team owns four utterances,
+// i.e. 4 of the 16 rows of a tile -- so here the chain computes them itself:
+//     HC_5 (dilation 27):  rows t .. t-4 of every utterance, K = 768 (all three taps): inputs are HC_4's rows at (t - r) - {0, 27, 54}:
+//                          the 14 cone rows the side stream's xcone_kernel leaves (its LAST layer now) + the chain's own newest row
+//     HC_6 (dilation 1):   rows t .. t-2, inputs = the five HC_5 rows above
+//     HC_7 (dilation 1):   row t, inputs = the three HC_6 rows above
+// and the side stream stops behind HC_4.  Nothing about the arithmetic changes: every row is the same contraction, two layer-norms, gate and
+// highway mix (modules.py:183-193) as in xcone_kernel / xgroup_kernel; rows that were "presum + centre tap" are now one K = 768 contraction.
+//
+// Team form exactly as xgroup_kernel.h / xmlp_kernel.h: 16 workgroups on one XCD own four utterances, workgroup `grp` owns a (gate, info) pair of
+// 16-column tiles, K is split over the 8 waves (six consecutive k-groups of 16 each), partial sums meet in LDS in a fixed order, pre-norm slices +
+// partial layer-norm statistics are published with plain stores, the team passes its flag-word barrier, and EVERY workgroup rebuilds all rows of
+// the layer's output (M <= 20 rows x 256 channels) into its own LDS, where the next layer's A operand is read from.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "xmlp_kernel.h"
+
+namespace dctts {
+
+struct XTailHc {
+  const float* wp;                       // 16-column tiles, all three taps: [tile = 2 grp + h][48 k-groups][lane][4]
+  const float* bias;                     // [512]
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  int nin, nout, ts, pad_;               // rows per utterance in / out; the input row of (output row r, tap) is r + (2 - tap) * ts
+};
+struct XTailParams {
+  XMlpParams m;                          // the k = 1 layers; m.P0 / stats0 / g1 .. b2 / res describe the producer of the FIRST highway layer's newest input row (HC_4)
+  XTailHc hc[3]; int nh; int nin0;       // highway layers; input rows per utterance of the first one
+  int frame; int pad1;                   // the frame t of the newest row: output row r of a layer is time t - r, and rows in front of t = 0 do not exist -- they are the ZERO padding
+                                         // of the next layer's input (modules.py:173-177 pads every layer's input), not a layer evaluated on padding
+  const float* xin; long xin_bs; int xin_stride; int pad0;   // the first layer's other input rows come from the side stream's buffer: row of time t of utterance b at xin + b * xin_bs
+  int in_off[16];                        // ... + in_off[q] * xin_stride for input row q (in_off[0] == 0: the newest row, rebuilt here)
+  float* xch; float* sch;                // exchange for the highway layers: [2][groups][20][512] pre-norm rows, [2][groups][20][16][4] statistics
+  int xch_set, sch_set;
+  long long* ts;                         // measurement (DCTTS_TRACE, TS instantiation): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
+};
+
+__device__ __forceinline__ void team_barrier(unsigned* bar, int grp, unsigned xcc, unsigned target, int* err, bool go) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this thread's stores are in the L2
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    const unsigned me = (target << 4) | xcc;
+    if (lane == 0) __hip_atomic_store(bar + grp, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (go) {
+      int spins = 0;
+      for (;;) {
+        const unsigned v = lane < 16 ? __hip_atomic_load(bar + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : me;
+        const bool there = (int)((v >> 4) - target) >= 0;
+        if (__builtin_amdgcn_ballot_w64(there && (v & 15u) != xcc) != 0ull) { if (lane == 0) atomicOr(err, 2); break; }         // a split team
+        if (__builtin_amdgcn_ballot_w64(!there) == 0ull) break;
+        if (++spins > (1 << 16) || ((spins & 255) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(err, 1); break; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ f32x4 ld4_sc1(const float* p) {                  // past the L1, served by this XCD's L2 (the team-mates' plain stores)
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+  return v;
+}
+
+constexpr int XT_LDR = 260;              // LDS row stride (floats) of the activation rows
+constexpr int XT_MAXM = 20;              // rows a team's layer can have (5 per utterance)
+
+// grid: 128 blocks of 512 threads, whatever the batch
+template <bool TS = false>
+__global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restrict__ pp) {
+  __shared__ __attribute__((aligned(16))) float bufA[60 * XT_LDR];           // the first layer's input rows (4 x 15), later the second layer's output (4 x 3)
+  __shared__ __attribute__((aligned(16))) float bufB[XT_MAXM * XT_LDR];      // the first layer's output (4 x 5), later the third layer's (4 x 1)
+  __shared__ __attribute__((aligned(16))) float red[2 * 4096];               // split-K partial sums of two row tiles: [tile][wave][h][j][lane]
+  __shared__ __attribute__((aligned(16))) float sstat[XT_MAXM * 4];          // per row: mean / rstd of the gate half, of the info half
+  __shared__ int s_go;
+  __shared__ XMlpLayer s_lay[7];
+  __shared__ __attribute__((aligned(16))) float s_xs[8][4 * 32];
+  typedef const __attribute__((address_space(4))) XTailParams CP;
+  CP& p = *(CP*)pp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
+  const int B = p.m.B;
+  if (team * 4 >= B) return;
+  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+  const int cr = lane >> 4, cc = lane & 15;
+  const int etile = wave >> 2, ej = wave & 3, ecol = lane & 15;
+  const int pcol = etile * 256 + grp * 16 + ecol;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  unsigned* const bar = p.m.bar + team * 32;
+  const unsigned xcc = xg_xcc_id();
+  const int nl = p.m.nl, nh = p.nh;
+  if (tid < (int)(sizeof(XMlpLayer) * 7 / 4)) reinterpret_cast<uint32_t*>(s_lay)[tid] = reinterpret_cast<const uint32_t*>(pp->m.lay)[tid];
+  if (tid == 0) s_go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+  float* const xs = s_xs[wave];
+  const unsigned ch0 = (unsigned)(16 * wave + cc), ch1 = ch0 + 128u;
+  // (stamps go to LDS and are copied out at the end: a global store that may be pending makes every later vector-memory wait a full drain)
+  __shared__ long long s_ts[TS ? 64 : 1];
+  int nts = 0;
+  auto stamp = [&]() { if constexpr (TS) { if (blockIdx.x == 0 && tid == 0 && nts < 60) s_ts[nts++] = wall_clock64(); } };
+  stamp();
+
+  for (int round = 0, m0 = team * 4; m0 < B; ++round, m0 += 32) {
+    __syncthreads();                                     // (round 0: s_lay / s_go; later rounds: the previous round's last LDS reads)
+    const bool team_ok = s_go != 0;
+    const unsigned rbase = p.m.bar_base + (unsigned)round * (unsigned)(nh + nl) * 16u;
+    const int gi = m0 >> 2;                              // utterance group: its rows of the exchange buffers
+    auto bof = [&](int u) { return (m0 + u < B) ? m0 + u : m0; };      // an utterance slot past the batch repeats the group's first utterance (never stored)
+
+    // ---- request order matters: a wave's loads return in order.  First what is consumed first -- the producer's pre-norm rows / statistics / residual of the
+    //      newest input row, then the 59 staged input rows (60 KB per workgroup) -- and only then the weights: the first layer's slice (96 KB per workgroup:
+    //      12 KB per wave = six k-groups x two column tiles) lands while the rows are written to LDS and the newest row is rebuilt; the second layer's slice is
+    //      requested behind it; the third layer's goes into the first layer's registers once that layer's exchanged rows have landed (a request issued earlier
+    //      would sit in front of every later load of the wave and be waited for with it).
+    f32x4 wA0[6], wA1[6], wB0[6], wB1[6];
+    unsigned wl = ((unsigned)(grp * 2) * 48u + (unsigned)(6 * wave)) * 256u + (unsigned)lane * 4u;      // uniform base + ONE 32-bit offset per lane (+ immediates)
+    asm volatile("" : "+v"(wl));                          // opaque per round: hoisted out of the round loop, the 36 request addresses derived from it lived in registers (and spilled) for the whole kernel
+    auto load_w = [&](const float* wp, f32x4 (&q0)[6], f32x4 (&q1)[6]) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) { q0[i] = ldv(wp, wl + (unsigned)i * 256u); q1[i] = ldv(wp, wl + (48u + (unsigned)i) * 256u); }
+    };
+    // the newest input row of every utterance: producer's pre-norm row + partial statistics + residual (an earlier launch: plain loads)
+    f32x4 nst = z4, nhg = z4, nhi = z4, nxr = z4, ng1 = z4, nb1 = z4, ng2 = z4, nb2 = z4;
+    const int nu = (tid >> 6) & 3;
+    const unsigned ncme = (unsigned)(tid & 63) * 4u;
+    {
+      const int su = (tid >> 4) & 3, sg = tid & 15;
+      nst = ldv(p.m.stats0, (unsigned)bof(su) * 64u + (unsigned)sg * 4u);                        // (threads 0 .. 63 use it)
+      const float* pr = p.m.P0 + (long)bof(nu) * p.m.p0_bs;
+      nhg = ldv(pr, ncme); nhi = ldv(pr, 256u + ncme); nxr = ldv(p.m.res + (long)bof(nu) * p.m.res_bs, ncme);      // (threads 0 .. 255 use them)
+    }
+    // ---- stage the first layer's input rows from the side stream's buffer (cone rows of the producing layer at offsets < 0; rows in front of t = 0 are the
+    //      buffer's zero rows = the causal padding, modules.py:173-177); row 0 of every utterance is the newest row, rebuilt below
+    {
+      const int nin = p.nin0;
+      const float* xbase = p.xin - 64 * p.xin_stride;       // (64 zero rows sit in front of every utterance: uniform base + a non-negative 32-bit offset per lane)
+      f32x4 sv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = tid + 512 * k;
+        const int rowi = (it >> 6) < 4 * nin ? (it >> 6) : 0;
+        const int u = rowi / nin, q = rowi - u * nin;
+        sv[k] = ldv(xbase, (unsigned)((long)bof(u) * p.xin_bs + (long)(p.in_off[q] + 64) * p.xin_stride) + ncme);      // (q == 0: any readable row; overwritten below)
+      }
+      load_w(p.hc[0].wp, wA0, wA1);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int it = tid + 512 * k;
+        if ((it >> 6) < 4 * nin) *reinterpret_cast<f32x4*>(&bufA[(it >> 6) * XT_LDR + ncme]) = sv[k];
+      }
+    }
+    ng1 = ldv(p.m.g1, ncme); nb1 = ldv(p.m.b1, ncme); ng2 = ldv(p.m.g2, ncme); nb2 = ldv(p.m.b2, ncme);
+    f32x4 vb[2] = {z4, z4};
+    float cbias = 0.f;
+    auto load_c0 = [&]() {                               // the first k = 1 layer's slice and bias: requested once the last highway layer's exchanged rows have landed
+      const int nkg = p.m.lay[0].nkg;
+      const float* wb = p.m.lay[0].wp + lane * 4;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) { const int kg = wave + 8 * e; vb[e] = ldv(wb, (unsigned)(grp * nkg + (kg < nkg ? kg : nkg - 1)) * 256u); }
+      cbias = p.m.lay[0].bias[grp * 16 + (lane & 15)];
+    };
+    if (tid < 64) {
+      const int u = tid >> 4, g = tid & 15;
+      const float m1 = row16_sum(nst[0]) * (1.0f / 16.0f), m2 = row16_sum(nst[2]) * (1.0f / 16.0f);
+      const float d1 = nst[0] - m1, d2 = nst[2] - m2;
+      const float r1 = rsqrt_fast(row16_sum(nst[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+      const float r2 = rsqrt_fast(row16_sum(nst[3] + 16.0f * d2 * d2) * (1.0f / 256.0f) + 1e-12f);
+      if (g == 0) { sstat[u * 4 + 0] = m1; sstat[u * 4 + 1] = r1; sstat[u * 4 + 2] = m2; sstat[u * 4 + 3] = r2; }
+    }
+    __syncthreads();                                     // (also: the staged rows are in LDS, so the rebuilt rows below overwrite row 0's placeholders)
+    if (tid < 256) {
+      const float m1 = sstat[nu * 4 + 0], r1 = sstat[nu * 4 + 1], m2 = sstat[nu * 4 + 2], r2 = sstat[nu * 4 + 3];
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float s_ = sigmoid_fast((nhg[e] - m1) * r1 * ng1[e] + nb1[e]); o[e] = s_ * ((nhi[e] - m2) * r2 * ng2[e] + nb2[e]) + (1.0f - s_) * nxr[e]; }
+      *reinterpret_cast<f32x4*>(&bufA[(nu * p.nin0) * XT_LDR + ncme]) = o;
+    }
+    __syncthreads();
+
+    stamp();                                               // input rows staged, newest row rebuilt
+    // ---- one highway layer: A from `bin` (LDS), B from the registers passed in; out rows rebuilt into `bout`
+    auto hlayer = [&](auto NITC, const int h, const float* bin, float* bout, const f32x4 (&bq0)[6], const f32x4 (&bq1)[6], auto&& after_landed) {
+      constexpr int NIT = decltype(NITC)::value;           // 512-thread sweeps over the layer's M x 64 four-channel items: 3 for M = 20 (two row tiles), 2 for M = 12, 1 for M = 4
+      typedef const __attribute__((address_space(4))) XTailHc CH;
+      CH& y = p.hc[h];
+      const int nin = y.nin, nout = y.nout, ts = y.ts, M = 4 * nout;
+      constexpr bool two = NIT > 2;
+      const float bias = y.bias[pcol];
+      const unsigned cme = (unsigned)(tid & 63) * 4u;       // the four channels of the rows this thread rebuilds (the same for each of them: 512 is a multiple of 64)
+      // A fragments: lane (arow, aq) holds row tile * 16 + arow, channels 4 aq .. 4 aq + 3 of k-group 6 w + i
+      f32x4 a0[6], a1[6];
+      {
+        const int ma = arow < M ? arow : 0, mb = (16 + arow < M) ? 16 + arow : 0;
+        const int ua = ma / nout, ra = ma - ua * nout, ub = mb / nout, rb_ = mb - ub * nout;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const int g = 6 * wave + i, tap = g >> 4, cg = g & 15;
+          a0[i] = *reinterpret_cast<const f32x4*>(&bin[(ua * nin + ra + (2 - tap) * ts) * XT_LDR + cg * 16 + c4]);
+          if constexpr (two) a1[i] = *reinterpret_cast<const f32x4*>(&bin[(ub * nin + rb_ + (2 - tap) * ts) * XT_LDR + cg * 16 + c4]);
+        }
+      }
+      f32x4 acc0 = z4, acc1 = z4, acc2 = z4, acc3 = z4;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq0[i][e], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq1[i][e], acc1, 0, 0, 0);
+        }
+      }
+      if constexpr (two) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bq0[i][e], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bq1[i][e], acc3, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j];
+        if constexpr (two) { red[4096 + ((wave * 2 + 0) * 4 + j) * 64 + lane] = acc2[j]; red[4096 + ((wave * 2 + 1) * 4 + j) * 64 + lane] = acc3[j]; }
+      }
+      stamp();                                             // A fragments read, MFMAs issued, partial sums written
+      // the layer's layer-norm parameters for this thread's channels: requested now (they land during the reduction and the hand-off), used behind it
+      const f32x4 g1 = ldv(y.g1, cme), b1 = ldv(y.b1, cme), g2 = ldv(y.g2, cme), b2 = ldv(y.b2, cme);
+      __syncthreads();
+      float v0 = bias, v1 = bias;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { v0 += red[((w * 2 + etile) * 4 + ej) * 64 + lane]; if constexpr (two) v1 += red[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
+      const int par = h & 1;
+      float* const xr_ = p.xch + (long)par * p.xch_set + (long)gi * (XT_MAXM * 512);
+      float* const sr_ = p.sch + (long)par * p.sch_set + (long)gi * (XT_MAXM * 64);
+      {
+        const int me = aq * 4 + ej;                          // the row of tile 0 this lane finishes; tile 1: me + 16
+        const float mg0 = row16_sum(v0) * (1.0f / 16.0f), dv0 = v0 - mg0, q0 = row16_sum(dv0 * dv0);
+        const float mg1 = row16_sum(v1) * (1.0f / 16.0f), dv1 = v1 - mg1, q1 = row16_sum(dv1 * dv1);
+        if (me < M) {
+          xr_[me * 512 + pcol] = v0;
+          if (ecol == 0) { float* so = sr_ + (me * 16 + grp) * 4 + etile * 2; so[0] = mg0; so[1] = q0; }
+        }
+        if (two && me + 16 < M) {
+          xr_[(me + 16) * 512 + pcol] = v1;
+          if (ecol == 0) { float* so = sr_ + ((me + 16) * 16 + grp) * 4 + etile * 2; so[0] = mg1; so[1] = q1; }
+        }
+      }
+      stamp();                                             // slice reduced, statistics, published
+      team_barrier(bar, grp, xcc, rbase + (unsigned)(h + 1) * 16u, p.m.err, team_ok);
+      stamp();                                             // team barrier passed
+      // ---- every workgroup rebuilds the layer's M output rows.  ALL requests of the phase in one batch, past the L1: column group (tid & 15)'s partial
+      //      statistics of row tid >> 4, and the (gate, info) values of up to three (row, 4-channel) items per thread: item k = tid + 512 k.
+      constexpr int nit = NIT;
+      f32x4 st, hg0, hi0, hg1 = z4, hi1 = z4, hg2 = z4, hi2 = z4;
+      {
+        const int ms = (tid >> 4) < M ? (tid >> 4) : M - 1;
+        const float* sp = sr_ + (ms * 16 + (tid & 15)) * 4;
+        auto ip = [&](int k) { const int it = tid + 512 * k; const int m = (it >> 6) < M ? (it >> 6) : M - 1; return (const float*)(xr_ + m * 512 + cme); };
+        const float* q0 = ip(0); const float* q1 = ip(1); const float* q2 = ip(2);
+        asm volatile("global_load_dwordx4 %0, %3, off sc1\n\tglobal_load_dwordx4 %1, %4, off sc1\n\tglobal_load_dwordx4 %2, %4, off offset:1024 sc1"
+                     : "=&v"(st), "=&v"(hg0), "=&v"(hi0) : "v"(sp), "v"(q0) : "memory");
+        if constexpr (nit > 1) asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1" : "=&v"(hg1), "=&v"(hi1) : "v"(q1) : "memory");
+        if constexpr (nit > 2) asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1" : "=&v"(hg2), "=&v"(hi2) : "v"(q2) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(st), "+v"(hg0), "+v"(hi0), "+v"(hg1), "+v"(hi1), "+v"(hg2), "+v"(hi2) :: "memory");
+      }
+      stamp();                                             // exchanged rows + statistics landed
+      after_landed();                                      // (the slot for requests that must not sit in front of the loads above)
+      if (tid < 16 * M) {
+        const int m = tid >> 4, g = tid & 15;
+        const float m1 = row16_sum(st[0]) * (1.0f / 16.0f), m2 = row16_sum(st[2]) * (1.0f / 16.0f);
+        const float d1 = st[0] - m1, d2 = st[2] - m2;
+        const float r1 = rsqrt_fast(row16_sum(st[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+        const float r2 = rsqrt_fast(row16_sum(st[3] + 16.0f * d2 * d2) * (1.0f / 256.0f) + 1e-12f);
+        if (g == 0) { sstat[m * 4 + 0] = m1; sstat[m * 4 + 1] = r1; sstat[m * 4 + 2] = m2; sstat[m * 4 + 3] = r2; }
+      }
+      __syncthreads();
+      auto finish = [&](int k, const f32x4 hg, const f32x4 hi) {
+        const int it = tid + 512 * k;
+        if (it >= M * 64) return;
+        const int m = it >> 6;
+        const int u = m / nout, r = m - u * nout;
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(&bin[(u * nin + r) * XT_LDR + cme]);
+        const float m1 = sstat[m * 4 + 0], r1 = sstat[m * 4 + 1], m2 = sstat[m * 4 + 2], r2 = sstat[m * 4 + 3];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float s_ = sigmoid_fast((hg[e] - m1) * r1 * g1[e] + b1[e]); o[e] = s_ * ((hi[e] - m2) * r2 * g2[e] + b2[e]) + (1.0f - s_) * xr[e]; }
+        if (r > p.frame) o = z4;                           // time t - r < 0: causal padding
+        *reinterpret_cast<f32x4*>(&bout[m * XT_LDR + cme]) = o;
+      };
+      finish(0, hg0, hi0);
+      if constexpr (nit > 1) finish(1, hg1, hi1);
+      if constexpr (nit > 2) finish(2, hg2, hi2);
+      __syncthreads();
+      stamp();                                             // output rows rebuilt
+    };
+    // (the host checks the shape this is unrolled for: 5 / 3 / 1 rows per utterance)
+    hlayer(std::integral_constant<int, 3>{}, 0, bufA, bufB, wA0, wA1, [&]() { load_w(p.hc[1].wp, wB0, wB1); });
+    hlayer(std::integral_constant<int, 2>{}, 1, bufB, bufA, wB0, wB1, [&]() { load_w(p.hc[2].wp, wA0, wA1); });
+    hlayer(std::integral_constant<int, 1>{}, 2, bufA, bufB, wA0, wA1, [&]() { load_c0(); });
+    const float* const bin = bufB;
+    // `bin` now holds one row per utterance (row u): the input of the first k = 1 layer
+
+    // ---- the k = 1 layers (xmlp_kernel.h's loop)
+    const unsigned crow = (m0 + cr < B) ? (unsigned)(m0 + cr) : 0u;
+    const bool crow_ok = m0 + cr < B;
+    const int erow = aq * 4 + wave;
+    const int eb = m0 + erow;
+    const bool wr = wave < 4 && erow < 4 && eb < B;
+    float4 x[2];
+    x[0] = *reinterpret_cast<const float4*>(&bin[(arow & 3) * XT_LDR + wave * 16 + c4]);
+    x[1] = *reinterpret_cast<const float4*>(&bin[(arow & 3) * XT_LDR + (8 + wave) * 16 + c4]);
+    const unsigned cbase = rbase + (unsigned)nh * 16u;
+    for (int l = 0; l < nl; ++l) {
+      const int nkg = __builtin_amdgcn_readfirstlane(s_lay[l].nkg), cout = __builtin_amdgcn_readfirstlane(s_lay[l].cout), act = __builtin_amdgcn_readfirstlane(s_lay[l].act);
+      const bool last = (l + 1 == nl);
+      const bool mine = grp * 16 < cout;
+      f32x4 acc = z4;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const f32x4 b = (mine && wave + 8 * e < nkg) ? vb[e] : z4;
+        const float4 a = x[e];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[3], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[(wave * 4 + j) * 64 + lane] = acc[j];
+      float lg[2], lb[2], nbias = 0.f;
+      {
+        const unsigned i0 = ch0 < (unsigned)cout ? ch0 : 0u, i1 = ch1 < (unsigned)cout ? ch1 : 0u;
+        lg[0] = ldg1(s_lay[l].g, i0); lg[1] = ldg1(s_lay[l].g, i1); lb[0] = ldg1(s_lay[l].be, i0); lb[1] = ldg1(s_lay[l].be, i1);
+      }
+      if (!last) {
+        const int nkg2 = __builtin_amdgcn_readfirstlane(s_lay[l + 1].nkg), cout2 = __builtin_amdgcn_readfirstlane(s_lay[l + 1].cout);
+        const int tile2 = (grp * 16 < cout2) ? grp : 0;
+        const float* wb = s_lay[l + 1].wp + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int kg = wave + 8 * e; vb[e] = ldg4(wb, (unsigned)(tile2 * nkg2 + (kg < nkg2 ? kg : nkg2 - 1)) * 256u); }
+        nbias = ldg1(s_lay[l + 1].bias, (unsigned)(tile2 * 16 + (lane & 15)));
+      }
+      __syncthreads();
+      float v_ = 0.f, mg = 0.f, m2g = 0.f;
+      if (wave < 4) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v_ += red[(w * 4 + wave) * 64 + lane];
+        v_ += cbias;
+        mg = row16_sum(v_) * (1.0f / 16.0f);
+        const float dv = v_ - mg;
+        m2g = row16_sum(dv * dv);
+      }
+      const int pc = grp * 16 + (lane & 15);
+      if (last && l != p.m.mel_layer) {
+        if (wr && mine) {
+          p.m.pout[(long)eb * 256 + pc] = v_;
+          if ((lane & 15) == 0) { float* so = p.m.stats_out + ((long)eb * 16 + grp) * 4; so[0] = mg; so[1] = m2g; }
+        }
+        break;
+      }
+      const int par = l & 1;
+      if (wr && mine) {
+        p.m.xch[(long)par * p.m.xch_set + (long)eb * 256 + pc] = v_;
+        if ((lane & 15) == 0) { float* so = p.m.sch + (long)par * p.m.sch_set + ((long)eb * 16 + grp) * 2; so[0] = mg; so[1] = m2g; }
+      }
+      team_barrier(bar, grp, xcc, cbase + (unsigned)(l + 1) * 16u, p.m.err, team_ok);
+      const int ng = cout >> 4;
+      float h0, h1, s0, s1;
+      {
+        const float* xr = p.m.xch + (long)par * p.m.xch_set + (long)crow * 256 + (ch0 < (unsigned)cout ? ch0 : 0u);
+        const float* sr = p.m.sch + (long)par * p.m.sch_set + ((long)crow * 16 + (cc < ng ? cc : 0)) * 2;
+        asm volatile(
+            "global_load_dword %0, %4, off sc1\n\t"
+            "global_load_dword %1, %4, off offset:512 sc1\n\t"
+            "global_load_dword %2, %5, off sc1\n\t"
+            "global_load_dword %3, %5, off offset:4 sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(h0), "=&v"(h1), "=&v"(s0), "=&v"(s1)
+            : "v"(xr), "v"(sr)
+            : "memory");
+      }
+      {
+        const bool gok = cc < ng;
+        const float inv_g = 1.0f / (float)ng;
+        const float m1 = row16_sum(gok ? s0 : 0.f) * inv_g;
+        const float d1 = s0 - m1;
+        const float r1 = rsqrt_fast(row16_sum(gok ? s1 + 16.0f * d1 * d1 : 0.f) * (inv_g * (1.0f / 16.0f)) + 1e-12f);
+        float y0 = (h0 - m1) * r1 * lg[0] + lb[0], y1 = (h1 - m1) * r1 * lg[1] + lb[1];
+        if (l == p.m.mel_layer) {
+          const float q0 = sigmoid_fast(y0), q1 = sigmoid_fast(y1);
+          if (grp == 0 && crow_ok) {
+            if (ch0 < (unsigned)cout) { p.m.logits[(long)crow * p.m.l_bs + ch0] = y0; p.m.ymel[(long)crow * p.m.y_bs + ch0] = q0; }
+            if (ch1 < (unsigned)cout) { p.m.logits[(long)crow * p.m.l_bs + ch1] = y1; p.m.ymel[(long)crow * p.m.y_bs + ch1] = q1; }
+          }
+          y0 = q0; y1 = q1;
+        } else if (act == ACT_RELU) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); }
+        xs[cr * 32 + cc] = ch0 < (unsigned)cout ? y0 : 0.f;
+        xs[cr * 32 + 16 + cc] = ch1 < (unsigned)cout ? y1 : 0.f;
+        x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
+        x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
+      }
+      cbias = nbias;
+      stamp();                                             // k = 1 layer done
+      if (last) break;
+    }
+  }
+  if constexpr (TS) { if (p.ts && blockIdx.x == 0 && tid == 0) for (int i = 0; i < nts; ++i) p.ts[i] = s_ts[i]; }
+}
+
+}  // namespace dctts
