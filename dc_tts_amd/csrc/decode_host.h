@@ -460,12 +460,12 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
 
 // ---- xgroup_kernel plumbing: one XGroupParams per (chain piece, network) in device memory; exchange buffers + team barriers + error word
 struct XgMem { float* xch[2]; float* sch[2]; float* xch_m; float* sch_m; float* xch_h; float* sch_h; unsigned* bar; unsigned* bar_cone; unsigned* bar_mlp; int* err; int bpad; size_t bar_words; };
-static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 256 + 2 * bpad * 32) + (size_t)2 * (bpad / 4) * XT_MAXM * (512 + 64) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
+static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * (bpad / 4) * XT_MAXM * (512 + 64) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
 static XgMem xg_mem(dctts_ctx* c, int B) {
   XgMem m; m.bpad = (B + 3) / 4 * 4;
   float* q = c->xg_mem;
   for (int n = 0; n < 2; ++n) { m.xch[n] = q; q += (size_t)2 * m.bpad * 512; m.sch[n] = q; q += (size_t)2 * m.bpad * 64; }
-  m.xch_m = q; q += (size_t)2 * m.bpad * 256; m.sch_m = q; q += (size_t)2 * m.bpad * 32;      // xmlp_kernel's exchange: [2][bpad][256] rows, [2][bpad][16][2] statistics
+  m.xch_m = q; q += (size_t)2 * m.bpad * 512; m.sch_m = q; q += (size_t)2 * m.bpad * 64;      // the k = 1 layers' exchange: xmlp_kernel [2][bpad][256] rows + [2][bpad][16][2] statistics; xtail_kernel the same with a tag beside every value: [2][bpad][256][2], [2][bpad][16][4]
   m.xch_h = q; q += (size_t)2 * (m.bpad / 4) * XT_MAXM * 512; m.sch_h = q; q += (size_t)2 * (m.bpad / 4) * XT_MAXM * 64;   // xtail_kernel's highway layers: [2][groups][20][512], [2][groups][20][16][4]
   m.bar_words = (size_t)((m.bpad / 4 + 7) / 8 * 8) * 32;
   m.bar = (unsigned*)q; q += m.bar_words;                     // the chain's teams (xgroup_kernel)
@@ -739,6 +739,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   for (int j = 0; j < T; ++j) {
     XTailParams p; memset(&p, 0, sizeof(p));
     CHK(fill_xmlp(c, w, B, T, j, h0 - 1, m, 10, &p.m));
+    p.m.xch_set = m.bpad * 512; p.m.sch_set = m.bpad * 64;      // (value, tag) pairs
     const long par = j & 1;
     p.nh = 3; p.nin0 = 3 * nout[0]; p.frame = j;
     for (int k = 0; k < 3; ++k) {
@@ -958,7 +959,10 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     const XgMem m = xg_mem(c, B);
     HIPCHK(hipMemsetAsync(m.bar, 0, (3 * m.bar_words + 64) * sizeof(unsigned), st));      // the three sets of team barriers and the error word
     if (c->xmlp_on) CHK(v3_xmlp_table(c, w, B, T));
-    if (c->tail_on) CHK(v3_xtail_table(c, w, B, T));
+    if (c->tail_on) {
+      CHK(v3_xtail_table(c, w, B, T));
+      HIPCHK(hipMemsetAsync(m.xch_m, 0, (size_t)(2 * m.bpad * 512 + 2 * m.bpad * 64) * sizeof(float), st));      // the tagged exchange: a tag of the previous decode must not look current
+    }
   }
   hipStream_t sb = c->s_bulk;
   // use_graph: 0 = every launch eager; 1 = the bulk piece of each frame is one hipGraph launch (the chain launches stay eager: a graph

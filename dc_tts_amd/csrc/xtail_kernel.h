@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
     // `bin` now holds one row per utterance (row u): the input of the first k = 1 layer
 
     // ---- the k = 1 layers (xmlp_kernel.h's loop)
-    const unsigned crow = (m0 + cr < B) ? (unsigned)(m0 + cr) : 0u;
+    const unsigned crow = (m0 + cr < B) ? (unsigned)(m0 + cr) : (unsigned)m0;      // (a row slot past the batch repeats the TEAM'S first row: its tags are this team's)
     const bool crow_ok = m0 + cr < B;
     const int erow = aq * 4 + wave;
     const int eb = m0 + erow;
@@ -368,26 +368,42 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
         }
         break;
       }
+      // ---- hand-off WITHOUT a barrier: every published word travels with the layer's sequence number -- (value, tag) as one 8-byte store, a column group's
+      //      statistics as (mean, M2, tag, tag) in one 16-byte store -- and the consumers poll the DATA itself past their L1 until every tag they need is
+      //      this layer's.  One L2 round trip instead of "drain the stores, workgroup barrier, flag word, poll, workgroup barrier, load" (0.7 us per layer
+      //      less, stamps).  No write-after-read hazard with two parity copies: a workgroup publishes layer l + 2 only behind its reads of layer l + 1,
+      //      which exists only once EVERY workgroup has published it, i.e. has finished reading layer l.  The buffers are cleared at the start of a decode
+      //      (tags of an earlier decode would repeat).  A team that is not on one XCD never sees its mates' stores: the bounded spin raises the error word.
       const int par = l & 1;
+      const unsigned seq = cbase + (unsigned)(l + 1) * 16u;
+      const float seqf = __uint_as_float(seq);
       if (wr && mine) {
-        p.m.xch[(long)par * p.m.xch_set + (long)eb * 256 + pc] = v_;
-        if ((lane & 15) == 0) { float* so = p.m.sch + (long)par * p.m.sch_set + ((long)eb * 16 + grp) * 2; so[0] = mg; so[1] = m2g; }
+        *reinterpret_cast<float2*>(&p.m.xch[(long)par * p.m.xch_set + ((long)eb * 256 + pc) * 2]) = make_float2(v_, seqf);
+        if ((lane & 15) == 0) *reinterpret_cast<float4*>(&p.m.sch[(long)par * p.m.sch_set + ((long)eb * 16 + grp) * 4]) = make_float4(mg, m2g, seqf, seqf);
       }
-      team_barrier(bar, grp, xcc, cbase + (unsigned)(l + 1) * 16u, p.m.err, team_ok);
       const int ng = cout >> 4;
       float h0, h1, s0, s1;
       {
-        const float* xr = p.m.xch + (long)par * p.m.xch_set + (long)crow * 256 + (ch0 < (unsigned)cout ? ch0 : 0u);
-        const float* sr = p.m.sch + (long)par * p.m.sch_set + ((long)crow * 16 + (cc < ng ? cc : 0)) * 2;
-        asm volatile(
-            "global_load_dword %0, %4, off sc1\n\t"
-            "global_load_dword %1, %4, off offset:512 sc1\n\t"
-            "global_load_dword %2, %5, off sc1\n\t"
-            "global_load_dword %3, %5, off offset:4 sc1\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(h0), "=&v"(h1), "=&v"(s0), "=&v"(s1)
-            : "v"(xr), "v"(sr)
-            : "memory");
+        const float* xr0 = p.m.xch + (long)par * p.m.xch_set + ((long)crow * 256 + (ch0 < (unsigned)cout ? ch0 : 0u)) * 2;
+        const float* xr1 = p.m.xch + (long)par * p.m.xch_set + ((long)crow * 256 + (ch1 < (unsigned)cout ? ch1 : 0u)) * 2;
+        const float* sr = p.m.sch + (long)par * p.m.sch_set + ((long)crow * 16 + (cc < ng ? cc : 0)) * 4;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 q0, q1; f32x4 qs;
+        int spins = 0;
+        for (;;) {
+          asm volatile(
+              "global_load_dwordx2 %0, %3, off sc1\n\t"
+              "global_load_dwordx2 %1, %4, off sc1\n\t"
+              "global_load_dwordx4 %2, %5, off sc1\n\t"
+              "s_waitcnt vmcnt(0)"
+              : "=&v"(q0), "=&v"(q1), "=&v"(qs)
+              : "v"(xr0), "v"(xr1), "v"(sr)
+              : "memory");
+          const bool ok = __float_as_uint(q0[1]) == seq && __float_as_uint(q1[1]) == seq && __float_as_uint(qs[2]) == seq;
+          if (__builtin_amdgcn_ballot_w64(!ok) == 0ull || !team_ok) break;
+          if (++spins > (1 << 15) || ((spins & 255) == 0 && __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { if (lane == 0) atomicOr(p.m.err, 1); break; }
+        }
+        h0 = q0[0]; h1 = q1[0]; s0 = qs[0]; s1 = qs[1];
       }
       {
         const bool gok = cc < ng;
