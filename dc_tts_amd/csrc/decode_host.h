@@ -357,6 +357,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     HIPCHK(hipGetLastError());
     first_gemm = 2;
   }
+  if (c->side_pre && f + 1 < T) CHK(v3_aepre(c, B, f + 1, sb, 1));      // AudioEnc's presums of row f + 1 (inputs: rows <= f - 1): consumed by the AudioEnc run of chain piece f, which starts behind this piece
   if (c->xc_on) {                                        // HC_3 .. HC_7 and their row passes: one launch, teams inside one XCD (xcone_kernel.h)
     const XConeParams* xp = (const XConeParams*)c->xc_tab + f;
     const bool prof = c->prof_id == DCTTS_PROF_XCONE && f >= 100 && (f & 15) == 8;          // full-size cones only; eager decode only (graph mode 0)
@@ -947,10 +948,15 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   const bool bsig = cwait && c->xc_on;
   // ... and the one small GEMM in front of the cone work (the newest row of the C1Q . W2 cache) rides in the chain's AudioEnc presum launch one piece
   // earlier: its input is the chain's own newest row, and the counter the side stream waits for is written by the launch behind it
-  c->c1qw_chain = vs && c->xc_on;
+  // (round 4, measured and switched off: the presum GEMMs as launches of their own on the SIDE stream -- the newest C1Q . W2 row in front of the row kernels,
+  //  AudioEnc's presums between rowhc2_kernel and xcone_kernel -- instead of as passenger workgroups of the chain's AudioDec launch, where they only find CUs
+  //  once that launch's teams have finished (~4 us): the two hbulk_group_kernel launches take 11 + 10.7 us on the side stream, which then bounds the frame at
+  //  99.5 us against 89.3)
+  c->side_pre = false;
+  c->c1qw_chain = vs && c->xc_on && !c->side_pre;
   // ... or, with both team kernels, in no launch of its own at all: the AudioEnc presums and that row are passengers of the chain's AudioDec launch
   // (xgroup_kernel.h); the side stream's first launch (rowc1_kernel) polls the row's own counter before it ends
-  c->ae_pass = bsig && c->xg_on && c->cone_len[0] > 1;
+  c->ae_pass = bsig && c->xg_on && c->cone_len[0] > 1 && !c->side_pre;
   CHK(v3_aepre_table(c, w, B, c->c1qw_chain));
   c->sig_ptr = cwait ? c->wait_ctr : (unsigned*)c->ctr_chain;
   if (c->xg_on || c->xc_on) {
@@ -973,13 +979,13 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     c->wait2_next = (cwait && j >= 0) ? (unsigned)(j + 1) : 0u;        // ... which also waits for bulk piece j
     // AudioEnc's presums of row j+1 (inputs: rows <= j-1, final since piece j-2): when the side stream is the longer one they run here, while this
     // piece would otherwise wait for it, instead of in front of the cone work
-    if (j >= 0 && c->xc_on && !c->ae_pass && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, c->c1qw_chain ? 0 : 1));
+    if (j >= 0 && c->xc_on && !c->ae_pass && !c->side_pre && j + 1 < T) CHK(v3_aepre(c, B, j + 1, s, c->c1qw_chain ? 0 : 1));
     if (j >= 0) { CHK(v3_chain_dec(c, w, B, j, s)); CHK(v3_mlp_launch(c, B, j, s)); }   // AudioDec HC_2 .. HC_7; C_8 .. C_11, mel frame j, AudioEnc C_1 .. C_3 of frame j+1
     if (j + 1 < T) return v3_chain_enc(c, w, B, N, j + 1, s);
     return 0;
   };
   if (gr) {
-    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)c->xc_tab) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
+    const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((int)c->side_pre) + ":" + std::to_string((size_t)c->xc_tab) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
                           std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
       destroy_graphs(c);
