@@ -940,9 +940,9 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (that timing id looks at chain3_kernel launches; so does DCTTS_TRACE with DCTTS_XGROUP=0)
   c->xc_on = c->xcone != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_BULK_GEMM &&
              c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;      // (behind rowhc2_kernel)
-  c->tail_on = c->xg_on && c->xc_on && c->chain_tail == 2 && c->audiodec.size() == 11 && c->cone_len.size() > 6 && c->cone_len[4] == 5 && c->cone_len[5] == 3 && c->cone_len[6] == 1;
+  c->tail_on = c->xg_on && c->xc_on && c->chain_tail >= 2 && c->audiodec.size() == 11 && c->cone_len.size() > 6 && c->cone_len[4] == 5 && c->cone_len[5] == 3 && c->cone_len[6] == 1;
   c->xmlp_on = c->xg_on && c->chain_tail >= 1 && !c->tail_on;
-  c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;
+  c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->chain_tail != 3 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;      // (3: xtail_kernel without the fold -- A/B)
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's
   // counter, and xcone_kernel's last team writes the side stream's
   const bool bsig = cwait && c->xc_on;

@@ -264,8 +264,6 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     // ---- requests that do not depend on the other workgroups: the next layer's weights / presum / history row, this layer's LN parameters
     float ng1[2], nb1[2], ng2[2], nb2[2];                                   // compact (a last layer without the attention tail leaves them unloaded, and leaves the loop before they are used)
     float naddv = 0.f;
-    float kk[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, vwv[3] = {0.f, 0.f, 0.f}, c1b = 0.f;
-    int pm_e = 0;
     if (!last || tail) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
@@ -288,23 +286,6 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
         for (int e = 0; e < 2; ++e) vta[e] = ldg4(Ln.xt, bb * (unsigned)Ln.xt_bs + (unsigned)((8 * e + wave) * 16 + c4));
       }
       if (wr) naddv = ldg1(Ln.presum, (unsigned)(eb * Ln.presum_bs) + (unsigned)pcol);      // behind the wait for the side stream; never read before in this launch
-    } else if (tail) {
-      // the attention tail's operands: none of them depends on this run -- C_1's 16-column tile, the window's K rows for this lane's row and channels,
-      // V . W_top of the window for the (row, column) this lane finishes, the window position itself
-      const float* wb = p.c1_wp + lane * 4;
-#pragma unroll
-      for (int e = 0; e < 2; ++e) vb0[e] = ldv(wb, (unsigned)(grp * 16 + wave + 8 * e) * 256u);
-      const int pm_c = p.pm[crow];
-      pm_e = p.pm[(wr || (erow < 4 && eb < p.B)) ? eb : (int)crow];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        int nc = pm_c + k; if (nc > p.N - 1) nc = p.N - 1;                 // beyond the window: clamped into the utterance, weight exactly 0
-        const float* kr = p.K + ((long)crow * p.kv_bs + nc) * p.k_stride;
-        kk[k][0] = kr[wave * 16 + cc]; kk[k][1] = kr[128 + wave * 16 + cc];
-        int ne = pm_e + k; if (ne > p.N - 1) ne = p.N - 1;
-        vwv[k] = p.VW[(((erow < 4 && eb < p.B) ? (long)eb : (long)crow) * p.kv_bs + ne) * p.vw_stride + grp * 16 + ecol];
-      }
-      c1b = p.c1_bias[grp * 16 + ecol];
     }
     // this layer's input row is kept for later launches (history / residual): column group 0 stores it
     if (grp == 0 && m0 + cr < p.B && s_lay[g].xm) {
@@ -390,72 +371,95 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
       x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
     }
     addv = naddv;
-    if (tail) {
-      // ---- x / xc hold Q[j] of the team's four utterances.  Keep the row (column group 0), attend, and run C_1 on it.
-      if (grp == 0 && m0 + cr < p.B) {
+    if (tail) break;
+  }
+  if (p.attn) {
+    // ---- the attention tail, OUTSIDE the layer loop: with its operands requested in the loop's prefetch slot the loop carried 47 more registers and
+    //      every layer got ~0.3 us slower (stamps).  None of the operands depends on this run -- C_1's 16-column tile, the window's K rows for this lane's
+    //      row and channels, V . W_top of the window for the (row, column) this lane finishes, the window position itself -- so they are one batch here.
+    float kk[3][2], vwv[3], c1b;
+    int pm_e;
+    {
+    // the attention tail's operands: none of them depends on this run -- C_1's 16-column tile, the window's K rows for this lane's row and channels,
+    // V . W_top of the window for the (row, column) this lane finishes, the window position itself
+    const float* wb = p.c1_wp + lane * 4;
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-          *reinterpret_cast<__attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(p.qhist + (long)(m0 + cr) * p.q_bs + (8 * e + wave) * 16 + cc)) = xc[e];
-      }
-      // logits of the window's keys (networks.py:140): this wave's 32 channels of row cr, summed over the 16 lanes of the row, then over the waves through LDS
+    for (int e = 0; e < 2; ++e) vb0[e] = ldv(wb, (unsigned)(grp * 16 + wave + 8 * e) * 256u);
+    const int pm_c = p.pm[crow];
+    pm_e = p.pm[(wr || (erow < 4 && eb < p.B)) ? eb : (int)crow];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int nc = pm_c + k; if (nc > p.N - 1) nc = p.N - 1;                 // beyond the window: clamped into the utterance, weight exactly 0
+      const float* kr = p.K + ((long)crow * p.kv_bs + nc) * p.k_stride;
+      kk[k][0] = kr[wave * 16 + cc]; kk[k][1] = kr[128 + wave * 16 + cc];
+      int ne = pm_e + k; if (ne > p.N - 1) ne = p.N - 1;
+      vwv[k] = p.VW[(((erow < 4 && eb < p.B) ? (long)eb : (long)crow) * p.kv_bs + ne) * p.vw_stride + grp * 16 + ecol];
+    }
+    c1b = p.c1_bias[grp * 16 + ecol];
+    }
+    // ---- x / xc hold Q[j] of the team's four utterances.  Keep the row (column group 0), attend, and run C_1 on it.
+    if (grp == 0 && m0 + cr < p.B) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+        *reinterpret_cast<__attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(p.qhist + (long)(m0 + cr) * p.q_bs + (8 * e + wave) * 16 + cc)) = xc[e];
+    }
+    // logits of the window's keys (networks.py:140): this wave's 32 channels of row cr, summed over the 16 lanes of the row, then over the waves through LDS
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float pr = row16_sum(fmaf(xc[1], kk[k][1], xc[0] * kk[k][0]));
+      if (cc == 0) s_att[(wave * 4 + cr) * 4 + k] = pr;
+    }
+    // C_1's contraction on the Q row does not depend on the attention result: Q[j] . W_bot, one 16-column tile per workgroup
+    f32x4 accc = z4;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const float4 a = x[e]; const f32x4 b0 = vb0[e];
+      accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], accc, 0, 0, 0); accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], accc, 0, 0, 0);
+      accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], accc, 0, 0, 0); accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], accc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[((wave * 2 + 0) * 4 + j) * 64 + lane] = accc[j];
+    __syncthreads();
+    if (wave < 4) {
+      // wave w finishes row w of the team (lanes 0 .. 15: the tile's 16 columns): masked softmax over <= 3 keys, arg-max of the post-softmax row with the
+      // first index on ties (networks.py:142-149), exactly attnq_kernel's arithmetic behind the dot products
+      const int rw = wave;
+      int nk = p.N - pm_e; if (nk > p.win) nk = p.win;
+      float lg[3], a[3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        const float pr = row16_sum(fmaf(xc[1], kk[k][1], xc[0] * kk[k][0]));
-        if (cc == 0) s_att[(wave * 4 + cr) * 4 + k] = pr;
+        float t_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) t_ += s_att[(w * 4 + rw) * 4 + k];
+        lg[k] = (k < nk) ? t_ * 0.0625f : -INFINITY;                    // tf.rsqrt(256) = 1 / 16
       }
-      // C_1's contraction on the Q row does not depend on the attention result: Q[j] . W_bot, one 16-column tile per workgroup
-      f32x4 accc = z4;
+      const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
+      float se = 0.f;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const float4 a = x[e]; const f32x4 b0 = vb0[e];
-        accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], accc, 0, 0, 0); accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], accc, 0, 0, 0);
-        accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], accc, 0, 0, 0); accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], accc, 0, 0, 0);
+      for (int k = 0; k < 3; ++k) { a[k] = (k < nk) ? expf(lg[k] - mx) : 0.f; se += a[k]; }
+      const float inv = 1.0f / se;
+      int am = 0;
+      float best = a[0] * inv; a[0] = best;
+#pragma unroll
+      for (int k = 1; k < 3; ++k) { a[k] *= inv; if (a[k] > best) { best = a[k]; am = k; } }
+      float v_ = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + 0) * 4 + rw) * 64 + lane];
+      float ps = c1b;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ps = fmaf(a[k], vwv[k], ps);          // bias + sum_k a_k (V . W_top)[p + k]   (a_k == 0 beyond the window)
+      const float vt = v_ + ps;
+      const float mg = row16_sum(vt) * (1.0f / 16.0f);
+      const float dv = vt - mg;
+      const float m2g = row16_sum(dv * dv);
+      const bool ok = aq == 0 && m0 + rw < p.B;                         // (lanes 16 .. 63 hold the tile's padding rows)
+      if (ok) {
+        const long b_ = m0 + rw; const int col = grp * 16 + ecol;
+        p.c1_raw[b_ * p.raw_bs + col] = v_;
+        p.c1_pout[b_ * 256 + col] = vt;
+        if (ecol == 0) { float* so = p.c1_stats + (b_ * 16 + grp) * 4; so[0] = mg; so[1] = m2g; }
+        if (grp == 0 && ecol == 0) p.pm_next[b_] = pm_e + am;           // max_attentions[:, j] (synthesize.py:54)
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) red[((wave * 2 + 0) * 4 + j) * 64 + lane] = accc[j];
-      __syncthreads();
-      if (wave < 4) {
-        // wave w finishes row w of the team (lanes 0 .. 15: the tile's 16 columns): masked softmax over <= 3 keys, arg-max of the post-softmax row with the
-        // first index on ties (networks.py:142-149), exactly attnq_kernel's arithmetic behind the dot products
-        const int rw = wave;
-        int nk = p.N - pm_e; if (nk > p.win) nk = p.win;
-        float lg[3], a[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float t_ = 0.f;
-#pragma unroll
-          for (int w = 0; w < 8; ++w) t_ += s_att[(w * 4 + rw) * 4 + k];
-          lg[k] = (k < nk) ? t_ * 0.0625f : -INFINITY;                    // tf.rsqrt(256) = 1 / 16
-        }
-        const float mx = fmaxf(lg[0], fmaxf(lg[1], lg[2]));
-        float se = 0.f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { a[k] = (k < nk) ? expf(lg[k] - mx) : 0.f; se += a[k]; }
-        const float inv = 1.0f / se;
-        int am = 0;
-        float best = a[0] * inv; a[0] = best;
-#pragma unroll
-        for (int k = 1; k < 3; ++k) { a[k] *= inv; if (a[k] > best) { best = a[k]; am = k; } }
-        float v_ = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + 0) * 4 + rw) * 64 + lane];
-        float ps = c1b;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) ps = fmaf(a[k], vwv[k], ps);          // bias + sum_k a_k (V . W_top)[p + k]   (a_k == 0 beyond the window)
-        const float vt = v_ + ps;
-        const float mg = row16_sum(vt) * (1.0f / 16.0f);
-        const float dv = vt - mg;
-        const float m2g = row16_sum(dv * dv);
-        const bool ok = aq == 0 && m0 + rw < p.B;                         // (lanes 16 .. 63 hold the tile's padding rows)
-        if (ok) {
-          const long b_ = m0 + rw; const int col = grp * 16 + ecol;
-          p.c1_raw[b_ * p.raw_bs + col] = v_;
-          p.c1_pout[b_ * 256 + col] = vt;
-          if (ecol == 0) { float* so = p.c1_stats + (b_ * 16 + grp) * 4; so[0] = mg; so[1] = m2g; }
-          if (grp == 0 && ecol == 0) p.pm_next[b_] = pm_e + am;           // max_attentions[:, j] (synthesize.py:54)
-        }
-      }
-      break;
     }
   }
   }                                        // next utterance group of this team
