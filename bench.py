@@ -12,7 +12,7 @@ What the JSON line holds besides the contract's fields (everything is measured i
   roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r04_kernel_stats.md): xcone_kernel, the re-evaluation of
                       AudioDec's dependency cone on the decode's side stream; HIP-event timed on ITS stream inside the timed region (every 16th
                       frame from frame 100 on), fp32-MFMA bound; `traffic` = PMC bytes per launch (profiles/r04_pmc_decode.json, separate passes)
-  kernels             the same figures for xgroup_kernel (the chain's runs of highway layers), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
+  kernels             the same figures for xgroup_kernel and xtail_kernel (the chain's launches), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
                       launch) and SSRN's 1025-column layers (event-timed in untimed extra passes)
   phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
   other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share)
@@ -40,6 +40,7 @@ PROF_SSRN_HC_TAIL = 50000 + 1 * 10000 + 16 * 100 + 8     # the row-tail launches
 PROF_SSRN_C1025 = 0 * 10000 + 3 * 100 + 11               # hconv_kernel<EPI_C, NT=3, NW=11>: SSRN C_13 .. C_16 (1025 columns)
 PROF_XGROUP = 30002               # include/dctts_hip_debug.h: xgroup_kernel, sampled every 16th frame (prof_rows counts layers)
 PROF_XCONE = 30003                # xcone_kernel (eager decode only)
+PROF_XTAIL = 30004                # xtail_kernel, sampled every 16th frame (prof_rows counts layers: 10 per launch)
 
 
 def both_roofs(flop, nbytes, ms):
@@ -365,23 +366,26 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         d = hp.d
-        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r04_kernel_stats.md): xcone_kernel, AudioDec HC_3 .. HC_7
-        #      over the rows of a frame's dependency cone (cone_len rows per utterance and layer incl. the presum row) + their layer-norm / gate passes,
-        #      one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one layer: a (3 x 256) x 512 fp32 contraction =
-        #      2 * 768 * 512 FLOP; algorithmic bytes of a launch = the rows in and out (256 channels each) + the five layers' weights once.
+        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r04_kernel_stats.md): xcone_kernel, AudioDec HC_3 and HC_4
+        #      over the rows of a frame's dependency cone (45 and 15 rows per utterance incl. the presum row) + their layer-norm / gate passes (round 4:
+        #      HC_5 .. HC_7 moved to the chain's xtail_kernel), one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one
+        #      layer: a (3 x 256) x 512 fp32 contraction = 2 * 768 * 512 FLOP; algorithmic bytes of a launch = the rows in and out (256 channels each) +
+        #      the two layers' weights once.
         row_flop = 2.0 * 3 * d * 2 * d
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                "kernel": "xcone_kernel: AudioDec HC_3 .. HC_7 (256 ch, k = 3, dilations 3 / 9 / 27 / 1 / 1) over the rows of a frame's dependency cone "
-                          "(45 / 15 / 5 / 3 / 1 rows per utterance) + the layer-norm / gate row passes between them, ONE launch per frame on the decode's side "
-                          "stream: 16x16x4 fp32 MFMA, a 16-workgroup team per four utterances inside one XCD, each workgroup keeps its 96 KB weight slice in registers",
+                "kernel": "xcone_kernel: AudioDec HC_3 and HC_4 (256 ch, k = 3, dilations 3 / 9) over the rows of a frame's dependency cone "
+                          "(45 / 15 rows per utterance) + their layer-norm / gate row passes, ONE launch per frame on the decode's side stream: 16x16x4 fp32 "
+                          "MFMA, a 16-workgroup team per four utterances inside one XCD, each workgroup keeps its 96 KB weight slice in registers "
+                          "(the cone's last three layers, 5 / 3 / 1 rows per utterance, run on the chain since round 4: kernels[] has xtail_kernel)",
                 "launches": n_chain, "sampled": "every 16th frame from frame 100 on (full-size cones) of the timed region, HIP events on the side stream",
                 "avg_launch_ms": None, "rows_per_launch": None, "flop_per_row": row_flop,
-                "note": "runs concurrently with the chain's kernels on the other half of the CUs; bounded by per-layer latencies (barrier + row pass + cold "
-                        "start of every layer's first tile: DESIGN.md section 2c / 2d), not by the matrix pipe: 128 of 256 CUs give at most 0.5"}
+                "note": "runs concurrently with the chain's kernels on the other half of the CUs (128 of 256: at most 0.5 of the roof); its launch ends with "
+                        "the team leaders polling the chain's counter, so the event-timed duration includes that wait whenever the chain is the longer stream "
+                        "(it is since round 4: DESIGN.md section 2d); the work itself is ~53 us (in-kernel stamps, profiles/r04_decode_trace.txt)"}
         if n_chain > 0 and chain_layers > 0:
             avg = chain_ms / n_chain
             rpl = chain_layers / n_chain
-            alg_bytes = 4.0 * (rpl * (d + d) + 5 * 3 * d * 2 * d)
+            alg_bytes = 4.0 * (rpl * (d + d) + 2 * 3 * d * 2 * d)
             tf = row_flop * rpl / (avg * 1e-3) / 1e12
             roof.update(avg_launch_ms=round(avg, 5), rows_per_launch=round(rpl, 1), flop_per_launch=row_flop * rpl, algorithmic_bytes_per_launch=alg_bytes,
                         achieved=round(tf, 3), frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
@@ -477,12 +481,23 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
         eng.text2mel(L); torch.cuda.synchronize()
         eng.prof_enable(PROF_XGROUP); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
         n, ms = eng.prof_collect(); layers = eng.prof_rows()
+        eng.prof_enable(PROF_XTAIL); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
+        nt, mst = eng.prof_collect()
+        if nt:
+            # per utterance and frame: HC_5 / HC_6 / HC_7 over 5 / 3 / 1 rows (K = 768 -> 512 columns) + C_8 .. C_10, C_11 (256 -> 80), AudioEnc C_1 (80 -> 256), C_2, C_3
+            fl = 2.0 * (9 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)
+            by = 4.0 * (3 * 3 * d * 2 * d + 5 * d * d + 2 * d * hp.n_mels) + 4.0 * B * (14 * d + d + hp.n_mels)      # the ten layers' weights once + per utterance the 14 staged rows, the mel frame, the output row
+            kern.append(dict(kernel="xtail_kernel (decode chain, round 4: AudioDec HC_5 .. HC_7 over the 5 / 3 / 1 cone rows they need + the seven k = 1 layers around the mel "
+                                    "frame, ONE launch per frame in team form; the k = 1 layers hand their rows over without a barrier: every value travels with a sequence tag)",
+                             bound="latency (ten dependent all-to-all layers)", launches=nt, avg_launch_ms=round(mst / nt, 5), layers_per_launch=10,
+                             **both_roofs(fl * B, by, mst / nt)))
         if n:
             lpl = layers / n
             lay_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + B * d + 4 * d)      # one layer: weights 256 x 512, presum / rows out / rows in, statistics, kept row, LN parameters
             lay_flop = 2.0 * B * d * 2 * d
-            e = dict(kernel="xgroup_kernel (decode chain: a run of newest-row highway layers as ONE launch -- timed: the AudioEnc run, HC_4 .. HC_13 = ten layers; per layer "
-                            "a 32 x 256 x 512 contraction split over the 16 workgroups of a 4-utterance team, rows and statistics exchanged through the L2 of the team's XCD)",
+            e = dict(kernel="xgroup_kernel (decode chain: a run of newest-row highway layers as ONE launch -- timed: the AudioEnc run, HC_4 .. HC_13 = ten layers + since round 4 "
+                            "the attention row of the frame and AudioDec C_1 behind them; per layer a 32 x 256 x 512 contraction split over the 16 workgroups of a "
+                            "4-utterance team, rows and statistics exchanged through the L2 of the team's XCD)",
                      bound="latency (16 dependent all-to-all layers per frame)", launches=n, avg_launch_ms=round(ms / n, 5), layers_per_launch=lpl,
                      algorithmic_bytes_per_layer=lay_bytes, flop_per_layer=lay_flop, **both_roofs(lay_flop * lpl, lay_bytes * lpl, ms / n))
             tj = os.path.join(ROOT, "profiles", "r04_pmc_decode.json")

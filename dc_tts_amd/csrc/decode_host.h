@@ -776,9 +776,13 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
 static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
   CHK(prof_close_run(c, st));
   if (c->tail_on && c->xtail_tab) {
+    const bool prof = c->prof_id == DCTTS_PROF_XTAIL && c->prof_frame;      // measurement (dctts_hip_debug.h): HIP events around the launch of every 16th frame
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
     else hipLaunchKernelGGL(xtail_kernel<false>, dim3(128), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
     HIPCHK(hipGetLastError());
+    if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }
     return 0;
   }
   if (c->xmlp_on && c->xmlp_tab) {

@@ -39,12 +39,13 @@ class Engine:
     """Owns the device-resident packed weights and workspaces for one GPU."""
 
     def __init__(self, weights: Dict[str, np.ndarray], hp: Hyperparams = _hp, device: Optional[int] = None,
-                 decode_graph: bool = False):
+                 decode_graph: bool = False, keep_weights: bool = True):
         if not torch.cuda.is_available():
             raise DcttsError("dc_tts_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
         self.hp = hp
         check_weights(weights, hp)
+        self.weights = weights if keep_weights else None      # host dict (by reference): the training=True forward of networks.py uploads it in TF layout on first use
         self.device_index = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", self.device_index)
         cfg = _lib.Config(len(hp.vocab), hp.e, hp.d, hp.c, hp.n_mels, hp.n_linear, hp.max_N, hp.attention_win_size)

@@ -38,6 +38,8 @@ int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream)
  *   DCTTS_PROF_XGROUP         xgroup_kernel (a run of newest-row highway layers of the decode chain as one launch), on every 16th frame only;
  *                             prof_rows then counts LAYERS (6 for the AudioDec run, 10 for the AudioEnc run);
  *   DCTTS_PROF_XCONE          xcone_kernel (the tail of AudioDec's cone on the side stream), frames >= 100, every 16th; eager decode only (graph mode 0);
+ *   DCTTS_PROF_XTAIL          xtail_kernel (AudioDec HC_5 .. HC_7 over their cone rows + the seven k = 1 layers around the mel frame, one launch per frame on the chain's
+ *                             stream), every 16th frame; prof_rows counts LAYERS (10 per launch);
  *   DCTTS_PROF_CHAIN_HC       chain3_kernel<LN_HC, HC> (one newest-row highway layer per launch: the form used when DCTTS_XGROUP=0), every 16th frame;
  *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (the cone GEMM of HC_3 when DCTTS_XCONE=0); eager decode only.  Enabling either of the last two
  *                             switches the corresponding team kernel off for the decodes that follow. */
@@ -45,6 +47,7 @@ int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream)
 #define DCTTS_PROF_BULK_GEMM 30001
 #define DCTTS_PROF_XGROUP 30002
 #define DCTTS_PROF_XCONE 30003
+#define DCTTS_PROF_XTAIL 30004
 int dctts_prof_enable(dctts_ctx* ctx, int kernel_id);
 int dctts_prof_collect(dctts_ctx* ctx, int* launches, double* total_ms);
 /* Output rows those launches covered, summed since the last prof_enable (a layer's rows may be split between the

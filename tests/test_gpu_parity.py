@@ -230,10 +230,35 @@ def test_attention_errors(weights):
         eng.attention(Q, K, K, True, torch.zeros(1, dtype=torch.int32, device="cuda"))
     with pytest.raises(ValueError):
         eng.attention(Q, K, K, True, None)
+
+
+def test_networks_training_true_is_the_reference_default(weights):
+    """networks.py:14,73,157,214 default to training=True (dropout behind every block, modules.py:139,195,245).  The boundary functions honour it with
+    the training forward of include/dctts_train.h: the result is the oracle's forward pass with the restated dropout masks (oracle/train_ref.py:
+    TensorFlow's random stream cannot be reproduced), differs from the training=False result, and hp.dropout_rate = 0 makes the two forms agree."""
     from dc_tts_amd import networks
+    from dc_tts_amd.layers import audiodec_layers, audioenc_layers
+    from oracle import train_ref as TR
+    T = 12
+    eng = engine_for(weights, max_T=T)
     networks.bind(eng)
-    with pytest.raises(NotImplementedError):
-        networks.AudioEnc(torch.zeros(1, 4, hp.n_mels, device="cuda"))          # training=True default
+    rng = np.random.default_rng(3)
+    S = rng.random((2, T, hp.n_mels), dtype=np.float32)
+    networks.set_training_seed(7)
+    Qt = networks.AudioEnc(dev(S))                                                      # the reference's default: training=True (call number 0)
+    Qi = networks.AudioEnc(dev(S), training=False)
+    W64 = {n: v.astype(np.float64) for n, v in weights.items() if n.startswith("Text2Mel/AudioEnc")}
+    Qr, _ = TR.network_forward(audioenc_layers(hp), W64, "Text2Mel/AudioEnc", S.astype(np.float64), "causal", (hp.dropout_rate, 7, 0))
+    assert maxabs(Qt.cpu().numpy(), Qr) < TOL_INNER
+    assert float((Qt - Qi).abs().max()) > 1e-2                                          # dropout really happened
+    R = rng.standard_normal((2, T, 2 * hp.d)).astype(np.float32)
+    lg, Y = networks.AudioDec(dev(R))                                                   # call number 1
+    Wd = {n: v.astype(np.float64) for n, v in weights.items() if n.startswith("Text2Mel/AudioDec")}
+    lr, _ = TR.network_forward(audiodec_layers(hp), Wd, "Text2Mel/AudioDec", R.astype(np.float64), "causal", (hp.dropout_rate, 7, 1))
+    assert maxabs(lg.cpu().numpy(), lr) < TOL_INNER and maxabs(Y.cpu().numpy(), 1.0 / (1.0 + np.exp(-lr))) < TOL
+    K, V = networks.TextEnc(dev(synthetic_text(hp, B=2, seed=5)))
+    _, Z = networks.SSRN(Y[:, :4].contiguous())
+    assert tuple(K.shape) == (2, hp.max_N, hp.d) == tuple(V.shape) and tuple(Z.shape) == (2, 16, hp.n_linear) and bool(torch.isfinite(Z).all())
 
 
 def test_audiodec(weights):
