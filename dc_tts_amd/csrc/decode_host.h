@@ -481,7 +481,7 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
                         std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
-                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string(c->trace_frame) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string((int)c->attn_fold) + ":" +
+                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((int)c->ae_pass_split) + ":" + std::to_string(c->trace_frame) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string((int)c->attn_fold) + ":" +
                         std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all);
   if (c->xg_tab && c->xg_geom == g) return 0;
   (void)hipDeviceSynchronize();
@@ -544,12 +544,22 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
         if (c->ae_pass && j + 1 < T) {
           // passengers: AudioEnc's presums of row j + 1 (inputs: rows <= j - 1; the AudioEnc run of frame j + 1 follows on this stream) and row j of
-          // the C1Q . W2 cache (the table's last three descriptors), which side-stream piece j + 1 needs behind its first launch
+          // the C1Q . W2 cache (the table's last three descriptors), which side-stream piece j + 1 needs behind its first launch.
+          // Round 4 (ae_pass_split): only those three descriptors ride here -- 24 workgroups find CUs between the side stream's row kernels at once, 104
+          // found them only when this launch's teams had finished (~4 us on the chain); AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch.
           const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
-          p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers;
-          p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;
+          const int first = c->ae_pass_split ? c->aepre_layers - 3 : 0;
+          p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers + first;
+          p.p_ipl = ipl; p.p_blocks = (c->aepre_layers - first) * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3 - first;
           p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
         }
+      } else if (c->ae_pass && c->ae_pass_split && j + 1 < T) {
+        // the AudioEnc run of frame j (launched in chain piece j - 1) carries AudioEnc's presums of row j + 1: their inputs are rows <= j - 1, final since chain
+        // piece j - 2, and their consumer is the AudioEnc run of frame j + 1, a later launch on this stream.  They start when the side stream's xcone_kernel
+        // lets go of its CUs (~15 us before this launch ends) and are done before it.
+        const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
+        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers;
+        p.p_ipl = ipl; p.p_blocks = (c->aepre_layers - 3) * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;      // (none of them is counted)
       }
       if (piece == c->trace_frame) {                            // DCTTS_TRACE: this piece's two launches record their phase boundaries
         if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
@@ -572,7 +582,10 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
   const bool prof = c->prof_id == DCTTS_PROF_XGROUP && c->prof_frame && net == 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-  const int pass = (net == 0 && c->ae_pass && piece >= 0 && piece + 1 < c->xg_T) ? c->aepre_layers * (((B + 31) / 32) * (c->cfg.d / 32)) : 0;     // as in the table
+  const int ipl_ = ((B + 31) / 32) * (c->cfg.d / 32);
+  int pass = 0;                                                                                                     // passenger workgroups, as in the table
+  if (net == 0 && c->ae_pass && piece >= 0 && piece + 1 < c->xg_T) pass = (c->ae_pass_split ? 3 : c->aepre_layers) * ipl_;
+  if (net == 1 && c->ae_pass && c->ae_pass_split && piece + 1 >= 0 && piece + 2 < c->xg_T) pass = (c->aepre_layers - 3) * ipl_;
   // always 128 team workgroups (8 teams of 16, one team per XCD): more could starve the other stream of CUs while they poll for it
   if (piece == c->trace_frame) hipLaunchKernelGGL(xgroup_kernel<true>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);      // DCTTS_TRACE: stamped
   else hipLaunchKernelGGL(xgroup_kernel<false>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
@@ -961,6 +974,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   // ... or, with both team kernels, in no launch of its own at all: the AudioEnc presums and that row are passengers of the chain's AudioDec launch
   // (xgroup_kernel.h); the side stream's first launch (rowc1_kernel) polls the row's own counter before it ends
   c->ae_pass = bsig && c->xg_on && c->cone_len[0] > 1 && !c->side_pre;
+  c->ae_pass_split = c->ae_pass && c->chain_tail == 4;      // (4: A/B -- measured: the AudioDec launch gets 3.4 us shorter, the AudioEnc launch 6 us longer: its passengers only find CUs when xcone_kernel's work ends, ~4 us before the launch's own teams do: 88.9 against 86.2 us per frame)
   CHK(v3_aepre_table(c, w, B, c->c1qw_chain));
   c->sig_ptr = cwait ? c->wait_ctr : (unsigned*)c->ctr_chain;
   if (c->xg_on || c->xc_on) {
