@@ -182,6 +182,7 @@ struct dctts_ctx {
   // k = 1 layers around the mel frame, one launch in team form (the side stream then stops behind HC_4); 1 = xmlp_kernel: the seven k = 1 layers in team form
   // (HC_5 .. HC_7 stay split between the chain's run and the side stream); 0 = mlp_rows_kernel (round 2: split by rows)
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
+  bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (a chain piece = two launches)
   bool ae_pass_split = false;          // round 4: AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch (a row ahead), only the C1Q . W2 row stays in the AudioDec launch
   bool side_pre = false;               // the small presum GEMMs (AudioEnc's presums of the next row, the newest C1Q . W2 row) run on the SIDE stream, which has the slack since xtail_kernel (round 4), instead of as passenger workgroups of the chain's AudioDec launch
   bool attn_fold = false;              // the newest row's attention + AudioDec C_1 run behind the AudioEnc run's last layer inside xgroup_kernel (chain_tail >= 1) instead of as two more launches

@@ -481,7 +481,7 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +
                         std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
-                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((int)c->ae_pass_split) + ":" + std::to_string(c->trace_frame) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string((int)c->attn_fold) + ":" +
+                        std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((int)c->ae_pass_split) + ":" + std::to_string(c->trace_frame) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string((int)c->dec_merge) + ":" + std::to_string((int)c->attn_fold) + ":" +
                         std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all);
   if (c->xg_tab && c->xg_geom == g) return 0;
   (void)hipDeviceSynchronize();
@@ -538,7 +538,8 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
         p.c1_raw = w.c1q.p + (w.c1q.row0 + j) * (long)w.c1q.stride; p.raw_bs = (int)(w.c1q.bstride * w.c1q.stride);
         p.c1_pout = w.pd[0]; p.c1_stats = w.sd[0];
       }
-      arrivals += (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(L - 1 + p.attn) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
+      if (!(net == 0 && c->dec_merge))                          // (merged form: the AudioDec run is part of xtail_kernel's launch, which has barrier words of its own)
+        arrivals += (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(L - 1 + p.attn) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
       if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
         if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
@@ -732,8 +733,9 @@ static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
 }
 
 // xtail_kernel's per-frame parameters: AudioDec's last three highway layers (HC_5 .. HC_7 over 5 / 3 / 1 rows per utterance) + the k = 1 layers
-static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
-  const std::string g = geom("xtail", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string(c->trace_frame);
+static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
+  const std::string g = geom("xtail", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string(c->trace_frame) + ":" +
+                        std::to_string((int)c->dec_merge) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.pb3[1]);
   if (c->xtail_tab && c->xtail_geom == g) return 0;
   (void)hipDeviceSynchronize();
   if (c->xtail_tab) { (void)hipFree(c->xtail_tab); c->xtail_tab = nullptr; }
@@ -752,9 +754,32 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   std::vector<XTailParams> tab((size_t)T);
   for (int j = 0; j < T; ++j) {
     XTailParams p; memset(&p, 0, sizeof(p));
-    CHK(fill_xmlp(c, w, B, T, j, h0 - 1, m, 10, &p.m));
+    CHK(fill_xmlp(c, w, B, T, j, h0 - 1, m, c->dec_merge ? 13 : 10, &p.m));
     p.m.xch_set = m.bpad * 512; p.m.sch_set = m.bpad * 64;      // (value, tag) pairs
     const long par = j & 1;
+    if (c->dec_merge) {
+      // merged form: AudioDec HC_2 .. HC_4 at the newest row run in front (what the AudioDec run of xgroup_kernel did, v3_xgroup_table), and this launch is the
+      // first one of chain piece j: it publishes the chain's counter, waits for side-stream piece j, and carries the passengers
+      const std::vector<DevLayer>& ADc = c->ad_c;                         // (centre tap in wp16)
+      p.np = 3;
+      p.pP0 = w.pd[0]; p.pstats0 = w.sd[0]; p.pg1 = ADc[0].g1; p.pb1 = ADc[0].b1;
+      for (int k = 0; k < 3; ++k) {
+        const size_t i = 1 + (size_t)k; const DevLayer& Ly = ADc[i];
+        if (!Ly.hc || Ly.cout != 256 || Ly.cin != 256 || !Ly.wp16 || !Ly.wp16c || Ly.tap2) return fail(DCTTS_ERR_STATE, "xtail: the newest-row layers are 256-channel causal k=3 highway layers");
+        XTailP& q = p.pl[k];
+        q.wp = Ly.wp16; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2;
+        q.presum = w.pb3[i] + par * w.pb3_set[i] + (long)(c->cone_len[i] - 1) * 512; q.presum_bs = c->cone_len[i] * 512;
+      }
+      p.xchp = m.xch[0]; p.schp = m.sch[0]; p.xchp_set = m.bpad * 512; p.schp_set = m.bpad * 64;
+      if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
+      if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
+      if (c->ae_pass && j + 1 < T) {                                      // passengers: AudioEnc's presums of row j + 1 and row j of the C1Q . W2 cache (counted: rowc1_kernel polls psig)
+        const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
+        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers;
+        p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;
+        p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
+      }
+    }
     p.nh = 3; p.nin0 = 3 * nout[0]; p.frame = j;
     for (int k = 0; k < 3; ++k) {
       const DevLayer& Ly = AD[h0 + k];
@@ -792,8 +817,10 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
     const bool prof = c->prof_id == DCTTS_PROF_XTAIL && c->prof_frame;      // measurement (dctts_hip_debug.h): HIP events around the launch of every 16th frame
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
-    if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
-    else hipLaunchKernelGGL(xtail_kernel<false>, dim3(128), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
+    int pass = 0;                                                 // passenger workgroups, as in the table
+    if (c->dec_merge && c->ae_pass && j + 1 < c->xg_T) pass = c->aepre_layers * (((B + 31) / 32) * (c->cfg.d / 32));
+    if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
+    else hipLaunchKernelGGL(xtail_kernel<false>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }
     return 0;
@@ -817,7 +844,11 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
 static int v3_chain_dec(dctts_ctx* c, const DecodeWs& w, int B, int j, hipStream_t sm) {
   const std::vector<DevLayer>& AD = c->ad_c;
   const int par = j & 1;
-  if (c->xg_on) { c->sig_next = 0; c->wait2_next = 0; return v3_xgroup_launch(c, B, j, 0, sm); }   // HC_2 .. HC_7 as one launch (its table entry carries the piece's signal / wait)
+  if (c->xg_on) {                                               // the newest-row layers as one launch (its table entry carries the piece's signal / wait) ...
+    c->sig_next = 0; c->wait2_next = 0;
+    if (c->dec_merge) return 0;                                 // ... or as the front of xtail_kernel's launch (v3_mlp_launch, called next)
+    return v3_xgroup_launch(c, B, j, 0, sm);
+  }
   for (size_t i = 1; i < AD.size(); ++i) {
     if (!AD[i].hc) break;                                       // C_8 .. C_11 run inside mlp_rows_kernel (launched by the caller)
     SplitExtra ex;
@@ -913,9 +944,18 @@ static int write_trace3(dctts_ctx* c, int j) {
   {
     const long long* o = &h[64 * 64 * 32 - 64];
     if (o[0] && c->tail_on) {
-      fprintf(f, "# xtail_kernel (workgroup 0, thread 0), microseconds since its entry: rows staged + newest row rebuilt | per highway layer: MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
-      fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
-      for (int i = 2; i < 60 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i <= 16 && (i - 2) % 5 == 4) ? " |" : "");
+      int i0 = 2;
+      if (c->dec_merge) {
+        fprintf(f, "# xtail_kernel, merged form (workgroup 0, thread 0), microseconds since its entry: first row built (incl. the wait for the side stream) | end of each newest-row layer (HC_2 .. HC_4) | cone rows in LDS | per cone layer (HC_5 .. HC_7): MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
+        fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
+        for (int i = 2; i < 5 && o[i]; ++i) fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0);
+        fprintf(f, " | %6.2f |", (o[5] - o[0]) / 100.0);
+        i0 = 6;
+      } else {
+        fprintf(f, "# xtail_kernel (workgroup 0, thread 0), microseconds since its entry: rows staged + newest row rebuilt | per highway layer: MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
+        fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
+      }
+      for (int i = i0; i < 60 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i < i0 + 15 && (i - i0) % 5 == 4) ? " |" : "");
       fprintf(f, "\n");
     } else if (o[0]) {
       fprintf(f, "# mlp_rows_kernel (workgroup 0, thread 0), microseconds since its entry: rows rebuilt | per layer: loads landed, FMAs done, partial sums exchanged, row finished\n");
@@ -959,6 +999,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
              c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;      // (behind rowhc2_kernel)
   c->tail_on = c->xg_on && c->xc_on && c->chain_tail >= 2 && c->audiodec.size() == 11 && c->cone_len.size() > 6 && c->cone_len[4] == 5 && c->cone_len[5] == 3 && c->cone_len[6] == 1;
   c->xmlp_on = c->xg_on && c->chain_tail >= 1 && !c->tail_on;
+  c->dec_merge = c->tail_on && c->chain_tail == 2;          // (5: xtail_kernel behind an AudioDec run of xgroup_kernel, the first round-4 form -- A/B)
   c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->chain_tail != 3 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;      // (3: xtail_kernel without the fold -- A/B)
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's
   // counter, and xcone_kernel's last team writes the side stream's
@@ -984,7 +1025,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     HIPCHK(hipMemsetAsync(m.bar, 0, (3 * m.bar_words + 64) * sizeof(unsigned), st));      // the three sets of team barriers and the error word
     if (c->xmlp_on) CHK(v3_xmlp_table(c, w, B, T));
     if (c->tail_on) {
-      CHK(v3_xtail_table(c, w, B, T));
+      CHK(v3_xtail_table(c, w, B, T, insig, cwait));
       HIPCHK(hipMemsetAsync(m.xch_m, 0, (size_t)(2 * m.bpad * 512 + 2 * m.bpad * 64) * sizeof(float), st));      // the tagged exchange: a tag of the previous decode must not look current
     }
   }

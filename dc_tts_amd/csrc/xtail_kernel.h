@@ -34,6 +34,11 @@ struct XTailHc {
   const float* g1; const float* b1; const float* g2; const float* b2;
   int nin, nout, ts, pad_;               // rows per utterance in / out; the input row of (output row r, tap) is r + (2 - tap) * ts
 };
+struct XTailP {                          // a newest-row layer of the merged form
+  const float* wp;                       // centre tap, 16-column tiles: [tile = 2 grp + h][16 k-groups][lane][4]
+  const float* presum; int presum_bs; int pad_;     // bias + older taps of row b at presum + b * presum_bs (written by the side stream)
+  const float* g1; const float* b1; const float* g2; const float* b2;
+};
 struct XTailParams {
   XMlpParams m;                          // the k = 1 layers; m.P0 / stats0 / g1 .. b2 / res describe the producer of the FIRST highway layer's newest input row (HC_4)
   XTailHc hc[3]; int nh; int nin0;       // highway layers; input rows per utterance of the first one
@@ -43,6 +48,17 @@ struct XTailParams {
   int in_off[16];                        // ... + in_off[q] * xin_stride for input row q (in_off[0] == 0: the newest row, rebuilt here)
   float* xch; float* sch;                // exchange for the highway layers: [2][groups][20][512] pre-norm rows, [2][groups][20][16][4] statistics
   int xch_set, sch_set;
+  // ---- merged form (np == 3): the NEWEST-ROW layers in front of the cone layers -- AudioDec HC_2 .. HC_4 at row t, what xgroup_kernel's AudioDec run computed one launch
+  //      earlier (K = 256: the centre tap; the older taps arrive as the side stream's presum), so that a chain piece is two launches and their row stays in LDS
+  int np; int pad2;
+  const float* pP0; const float* pstats0; const float* pg1; const float* pb1;      // C_1's pre-norm rows [b][256], partial statistics [b][16][4], layer-norm parameters
+  XTailP pl[3];
+  float* xchp; float* schp; int xchp_set, schp_set;       // their exchange: [2][B_pad][512] pre-norm rows, [2][B_pad][16][4] statistics (xgroup_kernel's layout)
+  unsigned* sig; unsigned sig_val;                        // first launch of a chain piece: *sig = sig_val ("every earlier piece of this stream is complete")
+  const unsigned* wait2; unsigned wait_val;               // ... and the presums + cone rows come from the side stream: poll *wait2 >= wait_val first
+  // passengers (xgroup_kernel.h): workgroups behind the 128 team workgroups run independent hbulk_body items on compute units nobody is using
+  const SplitParams* ptab; int p_blocks, p_ipl, p_step; int p_count_from;
+  unsigned* pdone; unsigned pdone_target; unsigned* psig; unsigned psig_val;
   long long* ts;                         // measurement (DCTTS_TRACE, TS instantiation): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
 };
 
@@ -79,8 +95,9 @@ constexpr int XT_MAXM = 20;              // rows a team's layer can have (5 per 
 // grid: 128 blocks of 512 threads, whatever the batch
 template <bool TS = false>
 __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restrict__ pp) {
-  __shared__ __attribute__((aligned(16))) float bufA[60 * XT_LDR];           // the first layer's input rows (4 x 15), later the second layer's output (4 x 3)
-  __shared__ __attribute__((aligned(16))) float bufB[XT_MAXM * XT_LDR];      // the first layer's output (4 x 5), later the third layer's (4 x 1)
+  __shared__ __attribute__((aligned(16))) float lds_rows[(60 + XT_MAXM) * XT_LDR];
+  float* const bufA = lds_rows;                          // the first layer's input rows (4 x 15), later the second layer's output (4 x 3)
+  float* const bufB = lds_rows + 60 * XT_LDR;            // the first layer's output (4 x 5), later the third layer's (4 x 1)
   __shared__ __attribute__((aligned(16))) float red[2 * 4096];               // split-K partial sums of two row tiles: [tile][wave][h][j][lane]
   __shared__ __attribute__((aligned(16))) float sstat[XT_MAXM * 4];          // per row: mean / rstd of the gate half, of the info half
   __shared__ int s_go;
@@ -89,21 +106,32 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
   typedef const __attribute__((address_space(4))) XTailParams CP;
   CP& p = *(CP*)pp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= 128) {                          // a passenger (merged form only): the row buffers are its scratch (hsplit_smem(32) = 64 KB)
+    __shared__ long s_prow[2][32];
+    const int nd = p.p_blocks / p.p_ipl, q = (int)blockIdx.x - 128, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
+    const int ncount = nd - p.p_count_from, layer = qd < ncount ? p.p_count_from + qd : qd - ncount;      // the counted descriptors are dispatched first
+    ConstSplitParams& sp = *((ConstSplitParams*)p.ptab + layer);
+    hbulk_body<8, ConstSplitParams>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, lds_rows, s_prow);
+    if (p.pdone && layer >= p.p_count_from) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                   // every thread's stores are out
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // ... and written back past this XCD's L2
+        const unsigned old = __hip_atomic_fetch_add(p.pdone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (old + 1u == p.pdone_target) __hip_atomic_store(p.psig, p.psig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
   const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
   const int B = p.m.B;
   if (team * 4 >= B) return;
-  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
-  const int cr = lane >> 4, cc = lane & 15;
-  const int etile = wave >> 2, ej = wave & 3, ecol = lane & 15;
-  const int pcol = etile * 256 + grp * 16 + ecol;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.m.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
-  const int nl = p.m.nl, nh = p.nh;
+  const int nl = p.m.nl, nh = p.nh, np = p.np;
   if (tid < (int)(sizeof(XMlpLayer) * 7 / 4)) reinterpret_cast<uint32_t*>(s_lay)[tid] = reinterpret_cast<const uint32_t*>(pp->m.lay)[tid];
-  if (tid == 0) s_go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-  float* const xs = s_xs[wave];
-  const unsigned ch0 = (unsigned)(16 * wave + cc), ch1 = ch0 + 128u;
+  if (tid == 0 && !np) s_go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;      // (merged form: set with the wait for the side stream below)
   // (stamps go to LDS and are copied out at the end: a global store that may be pending makes every later vector-memory wait a full drain)
   __shared__ long long s_ts[TS ? 64 : 1];
   int nts = 0;
@@ -111,9 +139,20 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
   stamp();
 
   for (int round = 0, m0 = team * 4; m0 < B; ++round, m0 += 32) {
+    // Everything derived from the thread index is derived INSIDE the round, from a value the compiler cannot see through: hoisted out of this loop (which runs
+    // once up to B = 32), ~100 loop-invariant LDS / global offsets of all the phases below lived in registers for the whole kernel, and the kernel spilled.
+    int tid_r = threadIdx.x;
+    asm volatile("" : "+v"(tid_r));
+    const int tid = tid_r, lane = tid & 63, wave = tid >> 6;
+    const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+    const int cr = lane >> 4, cc = lane & 15;
+    const int etile = wave >> 2, ej = wave & 3, ecol = lane & 15;
+    const int pcol = etile * 256 + grp * 16 + ecol;
+    float* const xs = s_xs[wave];
+    const unsigned ch0 = (unsigned)(16 * wave + cc), ch1 = ch0 + 128u;
     __syncthreads();                                     // (round 0: s_lay / s_go; later rounds: the previous round's last LDS reads)
-    const bool team_ok = s_go != 0;
-    const unsigned rbase = p.m.bar_base + (unsigned)round * (unsigned)(nh + nl) * 16u;
+    bool team_ok = s_go != 0;                            // (merged form, round 0: set behind the wait for the side stream)
+    const unsigned rbase = p.m.bar_base + (unsigned)round * (unsigned)(np + nh + nl) * 16u;
     const int gi = m0 >> 2;                              // utterance group: its rows of the exchange buffers
     auto bof = [&](int u) { return (m0 + u < B) ? m0 + u : m0; };      // an utterance slot past the batch repeats the group's first utterance (never stored)
 
@@ -129,37 +168,8 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
 #pragma unroll
       for (int i = 0; i < 6; ++i) { q0[i] = ldv(wp, wl + (unsigned)i * 256u); q1[i] = ldv(wp, wl + (48u + (unsigned)i) * 256u); }
     };
-    // the newest input row of every utterance: producer's pre-norm row + partial statistics + residual (an earlier launch: plain loads)
-    f32x4 nst = z4, nhg = z4, nhi = z4, nxr = z4, ng1 = z4, nb1 = z4, ng2 = z4, nb2 = z4;
     const int nu = (tid >> 6) & 3;
     const unsigned ncme = (unsigned)(tid & 63) * 4u;
-    {
-      const int su = (tid >> 4) & 3, sg = tid & 15;
-      nst = ldv(p.m.stats0, (unsigned)bof(su) * 64u + (unsigned)sg * 4u);                        // (threads 0 .. 63 use it)
-      const float* pr = p.m.P0 + (long)bof(nu) * p.m.p0_bs;
-      nhg = ldv(pr, ncme); nhi = ldv(pr, 256u + ncme); nxr = ldv(p.m.res + (long)bof(nu) * p.m.res_bs, ncme);      // (threads 0 .. 255 use them)
-    }
-    // ---- stage the first layer's input rows from the side stream's buffer (cone rows of the producing layer at offsets < 0; rows in front of t = 0 are the
-    //      buffer's zero rows = the causal padding, modules.py:173-177); row 0 of every utterance is the newest row, rebuilt below
-    {
-      const int nin = p.nin0;
-      const float* xbase = p.xin - 64 * p.xin_stride;       // (64 zero rows sit in front of every utterance: uniform base + a non-negative 32-bit offset per lane)
-      f32x4 sv[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int it = tid + 512 * k;
-        const int rowi = (it >> 6) < 4 * nin ? (it >> 6) : 0;
-        const int u = rowi / nin, q = rowi - u * nin;
-        sv[k] = ldv(xbase, (unsigned)((long)bof(u) * p.xin_bs + (long)(p.in_off[q] + 64) * p.xin_stride) + ncme);      // (q == 0: any readable row; overwritten below)
-      }
-      load_w(p.hc[0].wp, wA0, wA1);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int it = tid + 512 * k;
-        if ((it >> 6) < 4 * nin) *reinterpret_cast<f32x4*>(&bufA[(it >> 6) * XT_LDR + ncme]) = sv[k];
-      }
-    }
-    ng1 = ldv(p.m.g1, ncme); nb1 = ldv(p.m.b1, ncme); ng2 = ldv(p.m.g2, ncme); nb2 = ldv(p.m.b2, ncme);
     f32x4 vb[2] = {z4, z4};
     float cbias = 0.f;
     auto load_c0 = [&]() {                               // the first k = 1 layer's slice and bias: requested once the last highway layer's exchanged rows have landed
@@ -169,24 +179,220 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
       for (int e = 0; e < 2; ++e) { const int kg = wave + 8 * e; vb[e] = ldv(wb, (unsigned)(grp * nkg + (kg < nkg ? kg : nkg - 1)) * 256u); }
       cbias = p.m.lay[0].bias[grp * 16 + (lane & 15)];
     };
-    if (tid < 64) {
-      const int u = tid >> 4, g = tid & 15;
-      const float m1 = row16_sum(nst[0]) * (1.0f / 16.0f), m2 = row16_sum(nst[2]) * (1.0f / 16.0f);
-      const float d1 = nst[0] - m1, d2 = nst[2] - m2;
-      const float r1 = rsqrt_fast(row16_sum(nst[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
-      const float r2 = rsqrt_fast(row16_sum(nst[3] + 16.0f * d2 * d2) * (1.0f / 256.0f) + 1e-12f);
-      if (g == 0) { sstat[u * 4 + 0] = m1; sstat[u * 4 + 1] = r1; sstat[u * 4 + 2] = m2; sstat[u * 4 + 3] = r2; }
-    }
-    __syncthreads();                                     // (also: the staged rows are in LDS, so the rebuilt rows below overwrite row 0's placeholders)
-    if (tid < 256) {
-      const float m1 = sstat[nu * 4 + 0], r1 = sstat[nu * 4 + 1], m2 = sstat[nu * 4 + 2], r2 = sstat[nu * 4 + 3];
-      f32x4 o;
+    if (np) {
+      // ==== merged form: the three newest-row layers first (xgroup_kernel's layer loop, M = 4 rows: A operand in registers, compact rebuild through s_xs)
+      const int b_ = m0 + arow;
+      const unsigned bb = (arow < 4 && b_ < B) ? (unsigned)b_ : (unsigned)m0;        // lanes of MFMA rows nobody reads run on the team's first row
+      const int erow = aq * 4 + (wave & 3), eb = m0 + erow;
+      const bool wr = erow < 4 && eb < B;
+      const unsigned crow_p = (m0 + cr < B) ? (unsigned)(m0 + cr) : (unsigned)m0;
+      // ---- request order: what the first layer needs (C_1's rows, its statistics and layer-norm parameters, the layer's 16-column tiles), then the FIRST CONE LAYER's
+      //      slice (96 KB per workgroup, 12 MB per launch out of the Infinity Cache: ~3 us): it lands under the newest-row layers instead of in front of the cone layer
+      f32x4 va[2], vg1[2], vbe1[2], vst[4], pw0[2], pw1[2];
+      {
+        const float* wb = p.pl[0].wp + lane * 4;
+        const unsigned w0 = (unsigned)(grp * 2) * 16u * 256u, w1 = w0 + 16u * 256u;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float s_ = sigmoid_fast((nhg[e] - m1) * r1 * ng1[e] + nb1[e]); o[e] = s_ * ((nhi[e] - m2) * r2 * ng2[e] + nb2[e]) + (1.0f - s_) * nxr[e]; }
-      *reinterpret_cast<f32x4*>(&bufA[(nu * p.nin0) * XT_LDR + ncme]) = o;
-    }
-    __syncthreads();
+        for (int e = 0; e < 2; ++e) {
+          const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
+          va[e] = ldv(p.pP0, bb * 256u + ch); vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) vst[g] = ldv(p.pstats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { pw0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); pw1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+      }
+      load_w(p.hc[0].wp, wA0, wA1);
+      // ---- the stream signal and the wait for the side stream (this is the first launch of a chain piece), while those loads are in flight
+      if (tid == 0 && round == 0) {
+        int go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
+        if (p.sig && blockIdx.x == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (p.wait2 && go) {
+          bool ok = false;
+          for (int i = 0; i < (1 << 20) && !ok; ++i) {                       // bounded: about a second
+            ok = __hip_atomic_load(p.wait2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+            if (!ok) __builtin_amdgcn_s_sleep(16);
+          }
+          if (!ok) atomicOr(p.m.err, 16);
+        }
+        s_go = go;
+      }
+      __syncthreads();
+      team_ok = s_go != 0;
+      float addv = 0.f;
+      if (wr) {                                            // presum of the first layer: written by the side stream -> read past the L1 / a possibly stale line
+        const float* ap = p.pl[0].presum + (unsigned)(eb * p.pl[0].presum_bs) + (unsigned)pcol;
+        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(addv) : "v"(ap) : "memory");
+      }
+      auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
+      float4 x[2];
+      {
+        float4 st[4] = {f4(vst[0]), f4(vst[1]), f4(vst[2]), f4(vst[3])};
+        float m1, r1;
+        combine_stats(st, 0, m1, r1);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const f32x4 h = va[e], g = vg1[e], be = vbe1[e];
+          x[e] = make_float4((h[0] - m1) * r1 * g[0] + be[0], (h[1] - m1) * r1 * g[1] + be[1], (h[2] - m1) * r1 * g[2] + be[2], (h[3] - m1) * r1 * g[3] + be[3]);
+        }
+      }
+      float xc[2];                                         // the layer's input at (row cr, channels 16 w + cc and 128 + 16 w + cc) = the next rebuild's highway residual
+      if (arow < 4) { *reinterpret_cast<float4*>(&xs[arow * 32 + c4]) = x[0]; *reinterpret_cast<float4*>(&xs[arow * 32 + 16 + c4]) = x[1]; }
+      xc[0] = xs[cr * 32 + cc]; xc[1] = xs[cr * 32 + 16 + cc];
+      stamp();                                             // first row built (the wait for the side stream is in here)
+      auto player = [&](auto GC) {
+        constexpr int g = decltype(GC)::value;
+        constexpr bool lastp = (g == 2);
+        f32x4 acc0 = z4, acc1 = z4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float4 a = x[e]; const f32x4 b0 = pw0[e], b1 = pw1[e];
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[0], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[2], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[3], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+        // requests that do not depend on the team: this layer's layer-norm parameters (compact), the next layer's tiles and presum
+        float ng1[2], nb1[2], ng2[2], nb2[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const unsigned chc = (unsigned)((8 * e + wave) * 16 + cc);
+          ng1[e] = p.pl[g].g1[chc]; nb1[e] = p.pl[g].b1[chc]; ng2[e] = p.pl[g].g2[chc]; nb2[e] = p.pl[g].b2[chc];
+        }
+        float naddv = 0.f;
+        if constexpr (!lastp) {
+          const float* wb = p.pl[g + 1].wp + lane * 4;
+          const unsigned w0 = (unsigned)(grp * 2) * 16u * 256u, w1 = w0 + 16u * 256u;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) { pw0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); pw1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+          if (wr) naddv = p.pl[g + 1].presum[(unsigned)(eb * p.pl[g + 1].presum_bs) + (unsigned)pcol];      // behind the wait for the side stream; never read before in this launch
+        }
+        __syncthreads();
+        float v_ = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + etile) * 4 + (wave & 3)) * 64 + lane];
+        v_ += addv;
+        const float mg = row16_sum(v_) * (1.0f / 16.0f);
+        const float dv = v_ - mg;
+        const float m2g = row16_sum(dv * dv);
+        constexpr int par = g & 1;
+        if (wr) {
+          p.xchp[(long)par * p.xchp_set + (long)eb * 512 + pcol] = v_;
+          if (ecol == 0) { float* so = p.schp + (long)par * p.schp_set + ((long)eb * 16 + grp) * 4 + etile * 2; so[0] = mg; so[1] = m2g; }
+        }
+        team_barrier(bar, grp, xcc, rbase + (unsigned)(g + 1) * 16u, p.m.err, team_ok);
+        float hg[2], hi[2]; f32x4 stc;
+        {
+          const float* xr = p.xchp + (long)par * p.xchp_set + (long)crow_p * 512 + wave * 16 + cc;   // gate channel 16 w + cc; +128 floats = the second k-group; +256 = info
+          const float* sr = p.schp + (long)par * p.schp_set + (long)crow_p * 64 + cc * 4;             // column group cc's partial statistics of the row
+          asm volatile(
+              "global_load_dword %0, %5, off sc1\n\t"
+              "global_load_dword %1, %5, off offset:512 sc1\n\t"
+              "global_load_dword %2, %5, off offset:1024 sc1\n\t"
+              "global_load_dword %3, %5, off offset:1536 sc1\n\t"
+              "global_load_dwordx4 %4, %6, off sc1\n\t"
+              "s_waitcnt vmcnt(0)"
+              : "=&v"(hg[0]), "=&v"(hg[1]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(stc)
+              : "v"(xr), "v"(sr)
+              : "memory");
+        }
+        {
+          const float m1 = row16_sum(stc[0]) * (1.0f / 16.0f), m2 = row16_sum(stc[2]) * (1.0f / 16.0f);
+          const float d1 = stc[0] - m1, d2 = stc[2] - m2;
+          const float r1 = rsqrt_fast(row16_sum(stc[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+          const float r2 = rsqrt_fast(row16_sum(stc[3] + 16.0f * d2 * d2) * (1.0f / 256.0f) + 1e-12f);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const float s_ = sigmoid_fast((hg[e] - m1) * r1 * ng1[e] + nb1[e]);
+            xc[e] = s_ * ((hi[e] - m2) * r2 * ng2[e] + nb2[e]) + (1.0f - s_) * xc[e];
+            if constexpr (!lastp) xs[cr * 32 + e * 16 + cc] = xc[e];
+            else bufA[(cr * p.nin0) * XT_LDR + (8 * e + wave) * 16 + cc] = xc[e];      // HC_4's newest row: input row 0 of the first cone layer
+          }
+          if constexpr (!lastp) {
+            x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
+            x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
+          }
+        }
+        addv = naddv;
+        stamp();                                           // newest-row layer done
+      };
+      player(std::integral_constant<int, 0>{});
+      // ---- the first cone layer's other input rows (the side stream's cone rows of HC_4: never read before in this launch), requested behind
+      //      the first newest-row layer, written to LDS behind the second (their registers would not fit beside the first layer's operands)
+      f32x4 sv[8];
+      {
+        const int nin = p.nin0;
+        const float* xbase = p.xin - 64 * p.xin_stride;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int it = tid + 512 * k;
+          const int rowi = (it >> 6) < 4 * nin ? (it >> 6) : 0;
+          const int u = rowi / nin, q = rowi - u * nin;
+          sv[k] = ldv(xbase, (unsigned)((long)bof(u) * p.xin_bs + (long)(p.in_off[q] + 64) * p.xin_stride) + ncme);
+        }
+      }
+      player(std::integral_constant<int, 1>{});
+      {                                                    // the staged cone rows (landed with the second hand-off's wait); row 0 of every utterance is a placeholder
+        const int nin = p.nin0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int it = tid + 512 * k;
+          if ((it >> 6) < 4 * nin) *reinterpret_cast<f32x4*>(&bufA[(it >> 6) * XT_LDR + ncme]) = sv[k];
+        }
+      }
+      player(std::integral_constant<int, 2>{});
+      __syncthreads();
+    } else {
+      // the newest input row of every utterance: producer's pre-norm row + partial statistics + residual (an earlier launch: plain loads)
+      f32x4 nst = z4, nhg = z4, nhi = z4, nxr = z4, ng1 = z4, nb1 = z4, ng2 = z4, nb2 = z4;
+      {
+        const int su = (tid >> 4) & 3, sg = tid & 15;
+        nst = ldv(p.m.stats0, (unsigned)bof(su) * 64u + (unsigned)sg * 4u);                        // (threads 0 .. 63 use it)
+        const float* pr = p.m.P0 + (long)bof(nu) * p.m.p0_bs;
+        nhg = ldv(pr, ncme); nhi = ldv(pr, 256u + ncme); nxr = ldv(p.m.res + (long)bof(nu) * p.m.res_bs, ncme);      // (threads 0 .. 255 use them)
+      }
+      // ---- stage the first layer's input rows from the side stream's buffer (cone rows of the producing layer at offsets < 0; rows in front of t = 0 are the
+      //      buffer's zero rows = the causal padding, modules.py:173-177); row 0 of every utterance is the newest row, rebuilt below
+      {
+        const int nin = p.nin0;
+        const float* xbase = p.xin - 64 * p.xin_stride;       // (64 zero rows sit in front of every utterance: uniform base + a non-negative 32-bit offset per lane)
+        f32x4 sv[8];
+  #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int it = tid + 512 * k;
+          const int rowi = (it >> 6) < 4 * nin ? (it >> 6) : 0;
+          const int u = rowi / nin, q = rowi - u * nin;
+          sv[k] = ldv(xbase, (unsigned)((long)bof(u) * p.xin_bs + (long)(p.in_off[q] + 64) * p.xin_stride) + ncme);      // (q == 0: any readable row; overwritten below)
+        }
+        load_w(p.hc[0].wp, wA0, wA1);
+  #pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int it = tid + 512 * k;
+          if ((it >> 6) < 4 * nin) *reinterpret_cast<f32x4*>(&bufA[(it >> 6) * XT_LDR + ncme]) = sv[k];
+        }
+      }
+      ng1 = ldv(p.m.g1, ncme); nb1 = ldv(p.m.b1, ncme); ng2 = ldv(p.m.g2, ncme); nb2 = ldv(p.m.b2, ncme);
+      if (tid < 64) {
+        const int u = tid >> 4, g = tid & 15;
+        const float m1 = row16_sum(nst[0]) * (1.0f / 16.0f), m2 = row16_sum(nst[2]) * (1.0f / 16.0f);
+        const float d1 = nst[0] - m1, d2 = nst[2] - m2;
+        const float r1 = rsqrt_fast(row16_sum(nst[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+        const float r2 = rsqrt_fast(row16_sum(nst[3] + 16.0f * d2 * d2) * (1.0f / 256.0f) + 1e-12f);
+        if (g == 0) { sstat[u * 4 + 0] = m1; sstat[u * 4 + 1] = r1; sstat[u * 4 + 2] = m2; sstat[u * 4 + 3] = r2; }
+      }
+      __syncthreads();                                     // (also: the staged rows are in LDS, so the rebuilt rows below overwrite row 0's placeholders)
+      if (tid < 256) {
+        const float m1 = sstat[nu * 4 + 0], r1 = sstat[nu * 4 + 1], m2 = sstat[nu * 4 + 2], r2 = sstat[nu * 4 + 3];
+        f32x4 o;
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) { const float s_ = sigmoid_fast((nhg[e] - m1) * r1 * ng1[e] + nb1[e]); o[e] = s_ * ((nhi[e] - m2) * r2 * ng2[e] + nb2[e]) + (1.0f - s_) * nxr[e]; }
+        *reinterpret_cast<f32x4*>(&bufA[(nu * p.nin0) * XT_LDR + ncme]) = o;
+      }
+      __syncthreads();
 
+    }
     stamp();                                               // input rows staged, newest row rebuilt
     // ---- one highway layer: A from `bin` (LDS), B from the registers passed in; out rows rebuilt into `bout`
     auto hlayer = [&](auto NITC, const int h, const float* bin, float* bout, const f32x4 (&bq0)[6], const f32x4 (&bq1)[6], auto&& after_landed) {
@@ -257,7 +463,7 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
         }
       }
       stamp();                                             // slice reduced, statistics, published
-      team_barrier(bar, grp, xcc, rbase + (unsigned)(h + 1) * 16u, p.m.err, team_ok);
+      team_barrier(bar, grp, xcc, rbase + (unsigned)(np + h + 1) * 16u, p.m.err, team_ok);
       stamp();                                             // team barrier passed
       // ---- every workgroup rebuilds the layer's M output rows.  ALL requests of the phase in one batch, past the L1: column group (tid & 15)'s partial
       //      statistics of row tid >> 4, and the (gate, info) values of up to three (row, 4-channel) items per thread: item k = tid + 512 k.
@@ -320,7 +526,7 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
     float4 x[2];
     x[0] = *reinterpret_cast<const float4*>(&bin[(arow & 3) * XT_LDR + wave * 16 + c4]);
     x[1] = *reinterpret_cast<const float4*>(&bin[(arow & 3) * XT_LDR + (8 + wave) * 16 + c4]);
-    const unsigned cbase = rbase + (unsigned)nh * 16u;
+    const unsigned cbase = rbase + (unsigned)(np + nh) * 16u;
     for (int l = 0; l < nl; ++l) {
       const int nkg = __builtin_amdgcn_readfirstlane(s_lay[l].nkg), cout = __builtin_amdgcn_readfirstlane(s_lay[l].cout), act = __builtin_amdgcn_readfirstlane(s_lay[l].act);
       const bool last = (l + 1 == nl);
