@@ -955,7 +955,8 @@ static int write_trace3(dctts_ctx* c, int j) {
         fprintf(f, "# xtail_kernel (workgroup 0, thread 0), microseconds since its entry: rows staged + newest row rebuilt | per highway layer: MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
         fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
       }
-      for (int i = i0; i < 60 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i < i0 + 15 && (i - i0) % 5 == 4) ? " |" : "");
+      for (int i = i0; i < 56 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i < i0 + 15 && (i - i0) % 5 == 4) ? " |" : "");
+      if (o[56] && o[58]) fprintf(f, "\n  passengers: the first one ran %.2f .. %.2f, the last one %.2f .. %.2f", (o[56] - o[0]) / 100.0, (o[57] - o[0]) / 100.0, (o[58] - o[0]) / 100.0, (o[59] - o[0]) / 100.0);
       fprintf(f, "\n");
     } else if (o[0]) {
       fprintf(f, "# mlp_rows_kernel (workgroup 0, thread 0), microseconds since its entry: rows rebuilt | per layer: loads landed, FMAs done, partial sums exchanged, row finished\n");

@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       bool ok = false;
       for (int i = 0; i < (1 << 20) && !ok; ++i) {
         ok = __hip_atomic_load(p.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
-        if (!ok) __builtin_amdgcn_s_sleep(16);
+        if (!ok) __builtin_amdgcn_s_sleep(2);                                 // (eight pollers: the next piece of this stream starts when they see it)
       }
       if (!ok) atomicOr(p.wait_err, 1);
     }

@@ -111,7 +111,12 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
     const int nd = p.p_blocks / p.p_ipl, q = (int)blockIdx.x - 128, qd = q / p.p_ipl, item = q - qd * p.p_ipl;
     const int ncount = nd - p.p_count_from, layer = qd < ncount ? p.p_count_from + qd : qd - ncount;      // the counted descriptors are dispatched first
     ConstSplitParams& sp = *((ConstSplitParams*)p.ptab + layer);
+    long long t_in = 0;
+    if constexpr (TS) t_in = wall_clock64();
     hbulk_body<8, ConstSplitParams>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, lds_rows, s_prow);
+    if constexpr (TS) {                                    // measurement: when the first and the last passenger ran (slots 56 .. 59 of the stamps)
+      if (p.ts && tid == 0 && (q == 0 || q == p.p_blocks - 1)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.ts[q == 0 ? 56 : 58] = t_in; p.ts[q == 0 ? 57 : 59] = wall_clock64(); }
+    }
     if (p.pdone && layer >= p.p_count_from) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                   // every thread's stores are out
@@ -123,6 +128,9 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
     }
     return;
   }
+  // merged form: this launch is the first one of a chain piece, so every earlier piece of this stream is complete: say so FIRST -- the side stream's next piece
+  // starts from this word (xcone_kernel's team leaders poll it), and since round 4 the side stream is as long as the chain
+  if (blockIdx.x == 0 && tid == 0 && p.np && p.sig) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
   const int B = p.m.B;
   if (team * 4 >= B) return;
@@ -206,7 +214,6 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
       // ---- the stream signal and the wait for the side stream (this is the first launch of a chain piece), while those loads are in flight
       if (tid == 0 && round == 0) {
         int go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
-        if (p.sig && blockIdx.x == 0) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (p.wait2 && go) {
           bool ok = false;
           for (int i = 0; i < (1 << 20) && !ok; ++i) {                       // bounded: about a second
@@ -319,30 +326,34 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
         stamp();                                           // newest-row layer done
       };
       player(std::integral_constant<int, 0>{});
-      // ---- the first cone layer's other input rows (the side stream's cone rows of HC_4: never read before in this launch), requested behind
-      //      the first newest-row layer, written to LDS behind the second (their registers would not fit beside the first layer's operands)
-      f32x4 sv[8];
-      {
+      // ---- the first cone layer's other input rows (the side stream's cone rows of HC_4: never read before in this launch) in two halves: requested behind
+      //      a newest-row layer, written to LDS behind the next one (all eight requests at once would not fit beside two cone layers' weight slices)
+      f32x4 sv[4];
+      auto stage_req = [&](const int k0) {
         const int nin = p.nin0;
         const float* xbase = p.xin - 64 * p.xin_stride;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int it = tid + 512 * k;
+        for (int k = 0; k < 4; ++k) {
+          const int it = tid + 512 * (k0 + k);
           const int rowi = (it >> 6) < 4 * nin ? (it >> 6) : 0;
           const int u = rowi / nin, q = rowi - u * nin;
           sv[k] = ldv(xbase, (unsigned)((long)bof(u) * p.xin_bs + (long)(p.in_off[q] + 64) * p.xin_stride) + ncme);
         }
-      }
-      player(std::integral_constant<int, 1>{});
-      {                                                    // the staged cone rows (landed with the second hand-off's wait); row 0 of every utterance is a placeholder
+      };
+      auto stage_put = [&](const int k0) {                 // (row 0 of every utterance is a placeholder: the last newest-row layer writes it)
         const int nin = p.nin0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int it = tid + 512 * k;
-          if ((it >> 6) < 4 * nin) *reinterpret_cast<f32x4*>(&bufA[(it >> 6) * XT_LDR + ncme]) = sv[k];
+        for (int k = 0; k < 4; ++k) {
+          const int it = tid + 512 * (k0 + k);
+          if ((it >> 6) < 4 * nin && (it >> 6) % nin != 0) *reinterpret_cast<f32x4*>(&bufA[(it >> 6) * XT_LDR + ncme]) = sv[k];
         }
-      }
+      };
+      stage_req(0);
+      player(std::integral_constant<int, 1>{});
+      stage_put(0);
+      stage_req(4);
       player(std::integral_constant<int, 2>{});
+      stage_put(4);
       __syncthreads();
     } else {
       // the newest input row of every utterance: producer's pre-norm row + partial statistics + residual (an earlier launch: plain loads)
@@ -403,6 +414,15 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
       constexpr bool two = NIT > 2;
       const float bias = y.bias[pcol];
       const unsigned cme = (unsigned)(tid & 63) * 4u;       // the four channels of the rows this thread rebuilds (the same for each of them: 512 is a multiple of 64)
+      // The NEXT layer's weight slice (96 KB per workgroup, contiguous: two adjacent 16-column tiles) is pulled into this XCD's L2 now, one dword per 64-byte
+      // line: its requests go out behind this layer's hand-off (a request in front of the hand-off's loads would be waited for with them), and out of the
+      // Infinity Cache that burst took 2-3 us during which the wave could not issue anything else (stamps: "rows rebuilt"); out of the L2 it takes ~0.7 us.
+      // Not earlier than one layer ahead: the side stream's kernels stream through the same L2.
+      float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f;
+      if (h + 1 < nh) {
+        const float* q = p.hc[h + 1].wp + (unsigned)(grp * 2) * 48u * 256u + (unsigned)(wave * 3) * 1024u + (unsigned)lane * 16u;
+        pf0 = q[0]; pf1 = q[1024]; pf2 = q[2048];
+      }
       // A fragments: lane (arow, aq) holds row tile * 16 + arow, channels 4 aq .. 4 aq + 3 of k-group 6 w + i
       f32x4 a0[6], a1[6];
       {
@@ -481,6 +501,7 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(st), "+v"(hg0), "+v"(hi0), "+v"(hg1), "+v"(hi1), "+v"(hg2), "+v"(hi2) :: "memory");
       }
       stamp();                                             // exchanged rows + statistics landed
+      asm volatile("" :: "v"(pf0), "v"(pf1), "v"(pf2));    // (the prefetched lines' destination registers stay reserved until here: everything has landed)
       after_landed();                                      // (the slot for requests that must not sit in front of the loads above)
       if (tid < 16 * M) {
         const int m = tid >> 4, g = tid & 15;
