@@ -180,71 +180,82 @@ struct RowHc2Params {
 };
 
 // Straight-line on purpose: a load behind a uniform branch is waited for at the join (`s_waitcnt vmcnt(0)`), which made the taps' and keys' loads
-// three to four dependent round trips in the branchy form (13.8 us per launch).  Here everything a row needs is requested in two batches -- what
-// depends only on the row (constants, C1QW, scalars, residual) while the window position is on its way, then the nine VWW rows -- with clamped,
+// three to four dependent round trips in the branchy form (13.8 us per launch).  Everything a row needs is requested in one batch with clamped,
 // always-valid addresses; a tap that does not exist (t' < 0, or the centre tap of the presum row) is dropped by a select, a key beyond the
 // window has weight exactly 0 (window_softmax).
+// Round 4: the operands that do NOT depend on the row -- the nine constant rows (18 KB) and the window's nine V.W.W rows of the utterance (18 KB) --
+// are staged in LDS once per workgroup (its four rows belong to one utterance) instead of being requested by every wave: 17 KB instead of 44 KB of
+// requests per row, and 100 instead of 198 registers (two more waves per SIMD).  The launch is latency-bound (one round trip per wave, 2.6 passes at two
+// waves per SIMD) and sits on the side stream, which bounds the decode frame since the chain's AudioDec layers became one launch: 11.8 us -> see DESIGN.md 2d.
+// The arithmetic (operands, order of the fused multiply-adds) is unchanged.
 __global__ void __launch_bounds__(256) rowhc2_kernel(const RowHc2Params p) {
-  const int lane = threadIdx.x & 63, b = blockIdx.y;
-  const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // wave-uniform: the row's table entries are scalar loads
-  if (r >= p.R) return;
+  __shared__ f32x4 s_c[9 * 128];          // consts: [tap q][beta1.W2 | b1.Wt | 1^T Wt][512 floats]
+  __shared__ f32x4 s_v[9 * 128];          // V.W.W rows of the window: [key k][tap q][512 floats]
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));           // wave-uniform: the row's table entries are scalar loads
+  const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
   const int t = p.frame + p.offs[r];
-  if (t < 0) return;
+  const bool live = r0 < p.R && t >= 0;
+  const int tq = t < 0 ? 0 : t;
   const bool pre_row = (r == p.R - 1);
   const int c0 = lane * 4;
   const int pm = p.pm_all[(long)p.frame * p.B + b];
   const long par = p.frame & 1;
   auto ldq = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
-  // ---- batch 1: independent of the window
+  // ---- the workgroup's shared operands: 2 x 1152 sixteen-byte pieces over 256 threads, global memory -> LDS without a register in between
+  //      (global_load_lds_dwordx4: a wave's 64 pieces land at consecutive LDS addresses behind the wave-uniform base)
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int it = tid + 256 * i;
+    if (it < 1152) {                                                    // (wave-uniform: 1152 = 18 waves' worth)
+      const int piece = it >> 7, k = piece / 3, q = piece - 3 * k;
+      int n = pm + k; if (n > p.N - 1) n = p.N - 1;                     // keys clamped into the utterance: their weight is 0
+      const float* gv = p.VWW + ((long)b * p.kv_bstride + n) * 1536 + q * 512 + (it & 127) * 4;
+      const int wbase = (tid & ~63) + 256 * i;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.consts + it * 4), (__attribute__((address_space(3))) void*)&s_c[wbase], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv, (__attribute__((address_space(3))) void*)&s_v[wbase], 16, 0, 0);
+    }
+  }
+  // ---- the row's own operands
   f32x4 h1 = ldq(p.bias + c0), h2 = ldq(p.bias + 256 + c0);
-  f32x4 e1[3], e2[3], u1[3], u2[3], cs1[3], cs2[3], w1[3], w2[3], s4[3]; float a2[3]; bool ok[3];
+  f32x4 w1[3], w2[3], s4[3]; float a2[3]; bool ok[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    const int tp = t + p.tap_off[q];
+    const int tp = tq + p.tap_off[q];
     ok[q] = tp >= 0 && !(pre_row && q == 2);                          // causal zero padding / the chain contracts the centre tap
     const int tc = tp < 0 ? 0 : tp;
     const float* sc = p.scal + ((long)b * p.s_bstride + p.s_row0 + tc) * 8;
     s4[q] = ldq(sc); a2[q] = sc[4];
-    const float* cq = p.consts + q * 3 * 512;
-    e1[q] = ldq(cq + c0); e2[q] = ldq(cq + 256 + c0);                  // beta1 . W2[q]
-    u1[q] = ldq(cq + 512 + c0); u2[q] = ldq(cq + 512 + 256 + c0);      // b1 . Wt_q
-    cs1[q] = ldq(cq + 1024 + c0); cs2[q] = ldq(cq + 1024 + 256 + c0);  // 1^T Wt_q
     const float* cw = p.C1QW + ((long)b * p.c_bstride + p.c_row0 + tc) * 1536 + q * 512;
     w1[q] = ldq(cw + c0); w2[q] = ldq(cw + 256 + c0);
   }
-  f32x4 xr = ldq(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + t) * p.x1_stride + c0);
+  f32x4 xr = ldq(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + tq) * p.x1_stride + c0);
   f32x4 lg1 = ldq(p.g1 + c0), lb1 = ldq(p.b1 + c0), lg2 = ldq(p.g2 + c0), lb2 = ldq(p.b2 + c0);      // HC_2's own layer-norm parameters
-  // ---- batch 2: the window's rows of VWW (keys clamped into the utterance: their weight is 0)
-  f32x4 v1[3][3], v2[3][3];
+  // every request above is out before anything is used (left alone, the scheduler sinks each load into the code that consumes it)
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    int n = pm + k; if (n > p.N - 1) n = p.N - 1;
-    const float* vw = p.VWW + ((long)b * p.kv_bstride + n) * 1536;
-#pragma unroll
-    for (int q = 0; q < 3; ++q) { v1[q][k] = ldq(vw + q * 512 + c0); v2[q][k] = ldq(vw + q * 512 + 256 + c0); }
-  }
-  // every request above is out before anything is used (left alone, the scheduler sinks each load into the branch that consumes it)
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    asm volatile("; rowhc2: row-only operands of a tap" : "+v"(e1[q]), "+v"(e2[q]), "+v"(u1[q]), "+v"(u2[q]), "+v"(cs1[q]), "+v"(cs2[q]), "+v"(w1[q]), "+v"(w2[q]));
-  }
+  for (int q = 0; q < 3; ++q) asm volatile("; rowhc2: a tap's row operands" : "+v"(w1[q]), "+v"(w2[q]), "+v"(s4[q]), "+v"(a2[q]));
   asm volatile("; rowhc2: row operands" : "+v"(h1), "+v"(h2), "+v"(xr), "+v"(lg1), "+v"(lb1), "+v"(lg2), "+v"(lb2));
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    asm volatile("; rowhc2: window operands of a tap" : "+v"(v1[q][0]), "+v"(v1[q][1]), "+v"(v1[q][2]), "+v"(v2[q][0]), "+v"(v2[q][1]), "+v"(v2[q][2]));
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the pieces are in LDS (LDS-DMA counts as vector memory)
+  __syncthreads();
+  if (!live) return;
   int nk = p.N - pm; if (nk > p.win) nk = p.win;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const float m = s4[q][0], rs = s4[q][1];
     const float a[3] = {s4[q][2], nk > 1 ? s4[q][3] : 0.f, nk > 2 ? a2[q] : 0.f};    // a key beyond the window has weight 0
+    const f32x4 e1 = s_c[(q * 3 + 0) * 128 + lane], e2 = s_c[(q * 3 + 0) * 128 + 64 + lane];       // beta1 . W2[q]
+    const f32x4 u1 = s_c[(q * 3 + 1) * 128 + lane], u2 = s_c[(q * 3 + 1) * 128 + 64 + lane];       // b1 . Wt_q
+    const f32x4 cs1 = s_c[(q * 3 + 2) * 128 + lane], cs2 = s_c[(q * 3 + 2) * 128 + 64 + lane];     // 1^T Wt_q
+    f32x4 v1[3], v2[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v1[k] = s_v[(k * 3 + q) * 128 + lane]; v2[k] = s_v[(k * 3 + q) * 128 + 64 + lane]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float x1 = fmaf(-m, cs1[q][i], u1[q][i]) + w1[q][i];
-      float x2 = fmaf(-m, cs2[q][i], u2[q][i]) + w2[q][i];
+      float x1 = fmaf(-m, cs1[i], u1[i]) + w1[q][i];
+      float x2 = fmaf(-m, cs2[i], u2[i]) + w2[q][i];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) { x1 = fmaf(a[k], v1[q][k][i], x1); x2 = fmaf(a[k], v2[q][k][i], x2); }
-      const float d1 = fmaf(rs, x1, e1[q][i]), d2 = fmaf(rs, x2, e2[q][i]);
+      for (int k = 0; k < 3; ++k) { x1 = fmaf(a[k], v1[k][i], x1); x2 = fmaf(a[k], v2[k][i], x2); }
+      const float d1 = fmaf(rs, x1, e1[i]), d2 = fmaf(rs, x2, e2[i]);
       h1[i] += ok[q] ? d1 : 0.f; h2[i] += ok[q] ? d2 : 0.f;            // a select, not a factor: the operands of a dropped tap may be anything
     }
   }

@@ -162,10 +162,23 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     };
     // Two row tiles per pass: their 96 MFMAs per wave go back to back, then ONE barrier and one fixed-order reduction for both (in-kernel stamps:
     // with one tile per pass a tile cost 2.9 us, 1.3 of them MFMA; the rest -- LDS round trip, barrier, address set-up -- is paid per pass).
+    // Round 4: software-pipelined by one pass -- the split-K reduction of pass k - 1 (LDS reads, adds, the pre-norm stores) sits in the same straight-line
+    // code as the MFMAs of pass k, so the matrix pipe works while the other wave of the SIMD (and this wave's own vector instructions) reduce: with
+    // "MFMAs, barrier, reduce" per pass a pass took 4.5-5 us, 2.56 of them MFMA on a SIMD shared by two waves (stamps).  Still one barrier per pass: pass k
+    // writes red[k & 1] while pass k - 1 is read from red[(k - 1) & 1], and pass k + 1 overwrites that copy only behind barrier k.
     f32x4 a0[6], a1[6], n0[6], n1[6];
     int f0 = 0, f1 = 0;
     load_a(0, n0, f0); fix_a(a0, n0, f0);
     if (ntile > 1) { load_a(1, n1, f1); fix_a(a1, n1, f1); }
+    auto reduce_store = [&](const int tile) {                                  // finish the pass that started at row tile `tile`
+      const float* rb = red[(tile >> 1) & 1];
+      float v0 = bias, v1 = bias;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) { v0 += rb[((w * 2 + etile) * 4 + ej) * 64 + lane]; v1 += rb[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
+      const int me = tile * 16 + aq * 4 + ej;                                 // the rows this thread finishes
+      if (me < M && s_xoff[me] >= 0) pout[(long)(s_prow[me] & 0x3fffffff) * 512 + pcol] = v0;
+      if (tile + 1 < ntile && me + 16 < M && s_xoff[me + 16] >= 0) pout[(long)(s_prow[me + 16] & 0x3fffffff) * 512 + pcol] = v1;
+    };
     for (int tile = 0; tile < ntile; tile += 2) {
       const bool two = tile + 1 < ntile;                                      // uniform
       if (tile + 2 < ntile) load_a(tile + 2, n0, f0);                         // the next pass's rows are in flight during this pass's MFMAs
@@ -179,6 +192,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq1[i][e], acc1, 0, 0, 0);
         }
       }
+      if (tile > 0) reduce_store(tile - 2);                                   // (between the two tiles' MFMAs: nothing here depends on them)
       if (two) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -196,16 +210,9 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
         rb[4096 + ((wave * 2 + 0) * 4 + j) * 64 + lane] = acc2[j]; rb[4096 + ((wave * 2 + 1) * 4 + j) * 64 + lane] = acc3[j];
       }
       lds_barrier();                                                           // LDS only: the next pass's loads keep flying
-      float v0 = bias, v1 = bias;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) { v0 += rb[((w * 2 + etile) * 4 + ej) * 64 + lane]; v1 += rb[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
-      {
-        const int me = tile * 16 + aq * 4 + ej;                               // the rows this thread finishes
-        if (me < M && s_xoff[me] >= 0) pout[(long)(s_prow[me] & 0x3fffffff) * 512 + pcol] = v0;
-        if (two && me + 16 < M && s_xoff[me + 16] >= 0) pout[(long)(s_prow[me + 16] & 0x3fffffff) * 512 + pcol] = v1;
-      }
       fix_a(a0, n0, f0); fix_a(a1, n1, f1);
     }
+    reduce_store((ntile - 1) & ~1);                                            // the last pass
     // ---- the team's pre-norm rows of this layer are complete
     stamp();                                                                   // contraction done
     arrived += 16u;

@@ -1,8 +1,8 @@
-# Where a decode frame goes: per-kernel averages of a decode-only kernel trace (eager launches, T = 80) + the timeline of one steady-state frame
+# Where a decode frame goes: per-kernel averages of a decode-only kernel trace (eager launches, T = ${PT:-160}: the printed frame is at 3/4 of the decode, i.e. with full cones) + the timeline of one steady-state frame
 set -u
 R=$PWD; OUT=$R/gpurun_out/dprobe; mkdir -p $OUT; rm -rf $OUT/trace
 cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/tools/decode_only.py 80 > $OUT/trace.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python $R/tools/decode_only.py ${PT:-160} > $OUT/trace.log 2>&1
 python - <<PY
 import csv, glob
 f = glob.glob("$OUT/trace/**/*kernel_stats.csv", recursive=True)[0]
