@@ -178,9 +178,10 @@ struct dctts_ctx {
   std::vector<hipGraphExec_t> bulk3_g; std::string graphs3_geom;   // one small linear graph per frame for the side stream, frame index baked into every launch
   void* aepre_tab = nullptr; std::string aepre_geom; int aepre_layers = 0;
   void* mlp_tab = nullptr; std::string mlp_geom;
-  // What follows the chain's AudioDec run (DCTTS_CHAIN_TAIL): 2 (default) = xtail_kernel: AudioDec HC_5 .. HC_7 over the few cone rows they need + the seven
-  // k = 1 layers around the mel frame, one launch in team form (the side stream then stops behind HC_4); 1 = xmlp_kernel: the seven k = 1 layers in team form
-  // (HC_5 .. HC_7 stay split between the chain's run and the side stream); 0 = mlp_rows_kernel (round 2: split by rows)
+  // How the chain runs AudioDec behind C_1 (DCTTS_CHAIN_TAIL): 2 (default) = xtail_kernel, merged form: the newest-row layers HC_2 .. HC_4, HC_5 .. HC_7 over the
+  // few cone rows they need and the seven k = 1 layers around the mel frame, ONE launch in team form (the side stream stops behind HC_4); 5 = the same with
+  // HC_2 .. HC_4 as an xgroup_kernel launch in front; 1 = xmlp_kernel: the seven k = 1 layers in team form (HC_5 .. HC_7 stay split between the chain's run
+  // and the side stream); 0 = mlp_rows_kernel (round 2: split by rows); 3 / 4: A/B forms (tools/README.md)
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
   bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (a chain piece = two launches)
   bool ae_pass_split = false;          // round 4: AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch (a row ahead), only the C1Q . W2 row stays in the AudioDec launch

@@ -14,6 +14,14 @@
 // and the side stream stops behind HC_4.  Nothing about the arithmetic changes: every row is the same contraction, two layer-norms, gate and
 // highway mix (modules.py:183-193) as in xcone_kernel / xgroup_kernel; rows that were "presum + centre tap" are now one K = 768 contraction.
 //
+// Merged form (np == 3, the default since the middle of round 4).  The launch in front of this one was xgroup_kernel's AudioDec run: the NEWEST row of HC_2,
+// HC_3 and HC_4 (K = 256: the centre tap; the older taps come from the side stream as a presum), whose last row this kernel then re-read from memory.  Those
+// three layers now run in FRONT of the cone layers in this launch -- same arithmetic (xgroup_kernel's layer loop: M = 4 rows, A operand in registers, compact
+// rebuild) -- so a chain piece is two launches instead of three, the row stays in LDS, the first cone layer's weight slice (96 KB per workgroup) is in
+// flight while the newest-row layers wait for each other, and the cone rows are staged between them.  The launch then also carries what the AudioDec launch
+// carried: the chain's "piece complete" signal, the wait for the side stream, and the passenger workgroups (xgroup_kernel.h).  86.5 -> 83.1 us per frame;
+// with the next cone layer's slice pulled into the L2 one layer ahead (one dword per line: the slice then arrives in ~0.7 us instead of 2-3) 82.1.
+//
 // Team form exactly as xgroup_kernel.h / xmlp_kernel.h: 16 workgroups on one XCD own four utterances, workgroup `grp` owns a (gate, info) pair of
 // 16-column tiles, K is split over the 8 waves (six consecutive k-groups of 16 each), partial sums meet in LDS in a fixed order, pre-norm slices +
 // partial layer-norm statistics are published with plain stores, the team passes its flag-word barrier, and EVERY workgroup rebuilds all rows of
