@@ -85,7 +85,7 @@ __device__ __forceinline__ int window_softmax_regs(const float4 q, const f32x4 (
 
 // ---------------------------------------------------------------------------------------------------------------- bulk: C_1 cone rows
 // x1[b][t] = LN(bias + sum_k a_k VW[b][p+k] + C1Q[b][t]) * gamma + beta for the cone rows t = frame + offs[r] (offs < 0).
-// grid (ceil(R / 4), B), block 256: one wave per row, lane = 4 channels.
+// grid (ceil(R / ROWC1_NW), B), block ROWC1_NW waves: one wave per row, lane = 4 channels.
 struct RowC1Params {
   int B, R; const int* offs; int frame;
   const float* Qh; long q_bstride; long q_row0; int q_stride;        // AudioEnc history (absolute time), Q = its last layer
@@ -100,8 +100,10 @@ struct RowC1Params {
   const unsigned* wait; unsigned wait_val; int* wait_err;
 };
 
+constexpr int ROWC1_NW = 4;              // rows (waves) per workgroup.  Measured with 16: 14.7 instead of 10.4 us per launch -- the launch lives in what the chain's and the
+                                         // passengers' big workgroups leave free on the CUs, and small workgroups fit there (same for ROWHC2_NW: 12 rows 12.7 against 10.4 us)
 __device__ __forceinline__ void rowc1_row(const RowC1Params& p);
-__global__ void __launch_bounds__(256) rowc1_kernel(const RowC1Params p) {
+__global__ void __launch_bounds__(ROWC1_NW * 64) rowc1_kernel(const RowC1Params p) {
   rowc1_row(p);
   if (p.wait && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     bool ok = false;
@@ -113,27 +115,36 @@ __global__ void __launch_bounds__(256) rowc1_kernel(const RowC1Params p) {
   }
 }
 __device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
-  const int lane = threadIdx.x & 63, b = blockIdx.y;
-  const int r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));      // wave-uniform
-  if (r >= p.R) return;
-  const int t = p.frame + p.offs[r];
-  if (t < 0) return;
+  // Round 4: what a workgroup's four rows share -- the window's K and V.W rows of their utterance, C_1's bias and layer-norm parameters: 9 of the 11 KB a row
+  // asked for -- goes global memory -> LDS once per workgroup (global_load_lds_dwordx4, no register in between); a row's own requests are its Q and C1Q rows.
+  __shared__ f32x4 s_sh[9 * 64];           // [K rows of keys 0..2 | V.W rows of keys 0..2 | bias | gamma | beta][256 floats]
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWC1_NW + (tid >> 6));    // wave-uniform
+  const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
+  const int t_ = p.frame + p.offs[r];
+  const bool live = r0 < p.R && t_ >= 0;
+  const int t = t_ < 0 ? 0 : t_;
   const int c0 = lane * 4;
   const int pm = p.pm_all[(long)p.frame * p.B + b];
   auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-  // every request of the row in one batch (keys beyond the window: clamped into the utterance, weight exactly 0)
+  if (tid < 576) {                                                      // (wave-uniform: 576 sixteen-byte pieces = 9 waves' worth)
+    const int piece = tid >> 6;
+    int n = pm + (piece % 3); if (n > p.N - 1) n = p.N - 1;             // keys beyond the window: clamped into the utterance, weight exactly 0
+    const float* src = piece < 3 ? p.K + ((long)b * p.kv_bstride + n) * p.k_stride
+                     : piece < 6 ? p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride
+                     : piece == 6 ? p.bias : (piece == 7 ? p.g : p.be);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (tid & 63) * 4), (__attribute__((address_space(3))) void*)&s_sh[tid & ~63], 16, 0, 0);
+  }
   f32x4 vq = ldq(p.Qh + ((long)b * p.q_bstride + p.q_row0 + t) * p.q_stride + c0);
   f32x4 vcq = ldq(p.C1Q + ((long)b * p.c_bstride + p.c_row0 + t) * p.c_stride + c0);
-  f32x4 vbi = ldq(p.bias + c0), vg = ldq(p.g + c0), vbe = ldq(p.be + c0);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq), "+v"(vcq) :: "memory");               // the pieces are in LDS (LDS-DMA counts as vector memory), the row's operands have landed
+  __syncthreads();
+  if (!live) return;
+  const f32x4 vbi = s_sh[6 * 64 + lane], vg = s_sh[7 * 64 + lane], vbe = s_sh[8 * 64 + lane];
   f32x4 kr[MAXWIN], vr[MAXWIN];
 #pragma unroll
-  for (int k = 0; k < MAXWIN; ++k) {
-    int n = pm + k; if (n > p.N - 1) n = p.N - 1;
-    kr[k] = ldq(p.K + ((long)b * p.kv_bstride + n) * p.k_stride + c0);
-    vr[k] = ldq(p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride + c0);
-  }
-  asm volatile("; rowc1: all operands requested" : "+v"(vq), "+v"(vcq), "+v"(vbi), "+v"(vg), "+v"(vbe), "+v"(kr[0]), "+v"(kr[1]), "+v"(kr[2]), "+v"(vr[0]), "+v"(vr[1]), "+v"(vr[2]));
+  for (int k = 0; k < MAXWIN; ++k) { kr[k] = s_sh[k * 64 + lane]; vr[k] = s_sh[(3 + k) * 64 + lane]; }
   const float4 q = f4(vq), cq = f4(vcq), bi = f4(vbi), g = f4(vg), be = f4(vbe);
   float a[MAXWIN]; int am;
   const int nk = window_softmax_regs(q, kr, pm, p.N, p.win, 1.0f / sqrtf((float)p.d), a, am);
@@ -165,7 +176,7 @@ __device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
 // largest GEMM of the cone (82 rows x 768 x 512 per utterance and frame, 45 % of the bulk FLOPs) becomes ~15 vector FMAs per tap.
 // The same wave then finishes the layer: layer-norm of both halves, sigmoid gate, highway mix with x1[t] (modules.py:188-193).
 // Row r of the table is a cone row (offset < 0) or, last, the chain's presum row (offset 0: taps -2 and -1 only, stored un-normalised).
-// grid (ceil(R / 4), B), block 256: one wave per row; lane = channels 4 lane .. 4 lane + 3 of H1 and of H2.
+// grid (ceil(R / ROWHC2_NW), B), block ROWHC2_NW waves: one wave per row; lane = channels 4 lane .. 4 lane + 3 of H1 and of H2.
 struct RowHc2Params {
   int B, R; const int* offs; int frame; int tap_off[3];
   const float* scal; long s_bstride; long s_row0;                    // rowc1_kernel's per-row scalars
@@ -188,11 +199,12 @@ struct RowHc2Params {
 // requests per row, and 100 instead of 198 registers (two more waves per SIMD).  The launch is latency-bound (one round trip per wave, 2.6 passes at two
 // waves per SIMD) and sits on the side stream, which bounds the decode frame since the chain's AudioDec layers became one launch: 11.8 us -> see DESIGN.md 2d.
 // The arithmetic (operands, order of the fused multiply-adds) is unchanged.
-__global__ void __launch_bounds__(256) rowhc2_kernel(const RowHc2Params p) {
+constexpr int ROWHC2_NW = 4;             // rows (waves) per workgroup: see ROWC1_NW
+__global__ void __launch_bounds__(ROWHC2_NW * 64) rowhc2_kernel(const RowHc2Params p) {
   __shared__ f32x4 s_c[9 * 128];          // consts: [tap q][beta1.W2 | b1.Wt | 1^T Wt][512 floats]
   __shared__ f32x4 s_v[9 * 128];          // V.W.W rows of the window: [key k][tap q][512 floats]
   const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
-  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (tid >> 6));           // wave-uniform: the row's table entries are scalar loads
+  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWHC2_NW + (tid >> 6));   // wave-uniform: the row's table entries are scalar loads
   const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
   const int t = p.frame + p.offs[r];
   const bool live = r0 < p.R && t >= 0;
@@ -205,13 +217,13 @@ __global__ void __launch_bounds__(256) rowhc2_kernel(const RowHc2Params p) {
   // ---- the workgroup's shared operands: 2 x 1152 sixteen-byte pieces over 256 threads, global memory -> LDS without a register in between
   //      (global_load_lds_dwordx4: a wave's 64 pieces land at consecutive LDS addresses behind the wave-uniform base)
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int it = tid + 256 * i;
+  for (int i = 0; i < (1152 + ROWHC2_NW * 64 - 1) / (ROWHC2_NW * 64); ++i) {
+    const int it = tid + ROWHC2_NW * 64 * i;
     if (it < 1152) {                                                    // (wave-uniform: 1152 = 18 waves' worth)
       const int piece = it >> 7, k = piece / 3, q = piece - 3 * k;
       int n = pm + k; if (n > p.N - 1) n = p.N - 1;                     // keys clamped into the utterance: their weight is 0
       const float* gv = p.VWW + ((long)b * p.kv_bstride + n) * 1536 + q * 512 + (it & 127) * 4;
-      const int wbase = (tid & ~63) + 256 * i;
+      const int wbase = it & ~63;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.consts + it * 4), (__attribute__((address_space(3))) void*)&s_c[wbase], 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv, (__attribute__((address_space(3))) void*)&s_v[wbase], 16, 0, 0);
     }

@@ -335,7 +335,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     q.x = w.ad[0].p; q.x_bstride = w.ad[0].bstride; q.x_row0 = w.ad[0].row0; q.x_stride = w.ad[0].stride; q.x_set = w.ad[0].set;
     q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
     if (c->ae_pass && f > 0) { q.wait = c->wait_ctr + 16; q.wait_val = (unsigned)f; q.wait_err = (int*)(c->wait_ctr + 64); }      // row f - 1 of the C1Q . W2 cache: passengers of chain piece f - 1
-    hipLaunchKernelGGL(rowc1_kernel, dim3((q.R + 3) / 4, B), dim3(256), 0, sb, q);
+    hipLaunchKernelGGL(rowc1_kernel, dim3((q.R + ROWC1_NW - 1) / ROWC1_NW, B), dim3(ROWC1_NW * 64), 0, sb, q);
     HIPCHK(hipGetLastError());
   }
   size_t first_gemm = 1;
@@ -353,7 +353,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     q.x2 = w.ad[1].p; q.x2_bstride = w.ad[1].bstride; q.x2_row0 = w.ad[1].row0; q.x2_stride = w.ad[1].stride; q.x2_set = w.ad[1].set;
     q.presum = w.pb3[1] + (long)par * w.pb3_set[1] + (long)(R - 1) * 2 * AD[1].cout; q.presum_rstride = (long)R * 2 * AD[1].cout;
     q.N = N; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
-    hipLaunchKernelGGL(rowhc2_kernel, dim3((R + 3) / 4, B), dim3(256), 0, sb, q);
+    hipLaunchKernelGGL(rowhc2_kernel, dim3((R + ROWHC2_NW - 1) / ROWHC2_NW, B), dim3(ROWHC2_NW * 64), 0, sb, q);
     HIPCHK(hipGetLastError());
     first_gemm = 2;
   }
