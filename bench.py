@@ -40,7 +40,7 @@ PROF_SSRN_HC_TAIL = 50000 + 1 * 10000 + 16 * 100 + 8     # the row-tail launches
 PROF_SSRN_C1025 = 0 * 10000 + 3 * 100 + 11               # hconv_kernel<EPI_C, NT=3, NW=11>: SSRN C_13 .. C_16 (1025 columns)
 PROF_XGROUP = 30002               # include/dctts_hip_debug.h: xgroup_kernel, sampled every 16th frame (prof_rows counts layers)
 PROF_XCONE = 30003                # xcone_kernel (eager decode only)
-PROF_XTAIL = 30004                # xtail_kernel, sampled every 16th frame (prof_rows counts layers: 10 per launch)
+PROF_XTAIL = 30004                # xtail_kernel, sampled every 16th frame
 
 
 def both_roofs(flop, nbytes, ms):
@@ -381,7 +381,8 @@ def main():
                 "avg_launch_ms": None, "rows_per_launch": None, "flop_per_row": row_flop,
                 "note": "runs concurrently with the chain's kernels on the other half of the CUs (128 of 256: at most 0.5 of the roof); its launch ends with "
                         "the team leaders polling the chain's counter, so the event-timed duration includes that wait whenever the chain is the longer stream "
-                        "(it is since round 4: DESIGN.md section 2d); the work itself is ~53 us (in-kernel stamps, profiles/r04_decode_trace.txt)"}
+                        "(the two are within 2 us of each other at the end of round 4: DESIGN.md section 2d); the work itself is ~52 us (in-kernel stamps, "
+                        "profiles/r04_decode_trace.txt)"}
         if n_chain > 0 and chain_layers > 0:
             avg = chain_ms / n_chain
             rpl = chain_layers / n_chain
@@ -484,12 +485,15 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
         eng.prof_enable(PROF_XTAIL); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
         nt, mst = eng.prof_collect()
         if nt:
-            # per utterance and frame: HC_5 / HC_6 / HC_7 over 5 / 3 / 1 rows (K = 768 -> 512 columns) + C_8 .. C_10, C_11 (256 -> 80), AudioEnc C_1 (80 -> 256), C_2, C_3
-            fl = 2.0 * (9 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)
-            by = 4.0 * (3 * 3 * d * 2 * d + 5 * d * d + 2 * d * hp.n_mels) + 4.0 * B * (14 * d + d + hp.n_mels)      # the ten layers' weights once + per utterance the 14 staged rows, the mel frame, the output row
-            kern.append(dict(kernel="xtail_kernel (decode chain, round 4: AudioDec HC_5 .. HC_7 over the 5 / 3 / 1 cone rows they need + the seven k = 1 layers around the mel "
-                                    "frame, ONE launch per frame in team form; the k = 1 layers hand their rows over without a barrier: every value travels with a sequence tag)",
-                             bound="latency (ten dependent all-to-all layers)", launches=nt, avg_launch_ms=round(mst / nt, 5), layers_per_launch=10,
+            # per utterance and frame: the newest row of HC_2 .. HC_4 (K = 256: centre tap -> 512 columns), HC_5 / HC_6 / HC_7 over 5 / 3 / 1 rows (K = 768 -> 512 columns)
+            # + C_8 .. C_10, C_11 (256 -> 80), AudioEnc C_1 (80 -> 256), C_2, C_3
+            fl = 2.0 * (3 * d * 2 * d + 9 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)
+            by = 4.0 * (3 * d * 2 * d + 3 * 3 * d * 2 * d + 5 * d * d + 2 * d * hp.n_mels) + 4.0 * B * (3 * 2 * d + 14 * d + d + hp.n_mels)      # the 13 layers' weights once + per utterance three presum rows, the 14 staged rows, the mel frame, the output row
+            kern.append(dict(kernel="xtail_kernel, merged form (decode chain, round 4: AudioDec's newest-row layers HC_2 .. HC_4, then HC_5 .. HC_7 over the 5 / 3 / 1 cone rows "
+                                    "they need, then the seven k = 1 layers around the mel frame: ONE launch per frame in team form, the first of a chain piece's two launches; it also "
+                                    "carries the presum GEMMs as passenger workgroups, and its event-timed duration includes the wait for the side stream whenever that is the longer one; "
+                                    "the k = 1 layers hand their rows over without a barrier: every value travels with a sequence tag)",
+                             bound="latency (13 dependent all-to-all layers)", launches=nt, avg_launch_ms=round(mst / nt, 5), layers_per_launch=13,
                              **both_roofs(fl * B, by, mst / nt)))
         if n:
             lpl = layers / n
