@@ -128,13 +128,17 @@ __device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
   const int pm = p.pm_all[(long)p.frame * p.B + b];
   auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-  if (tid < 576) {                                                      // (wave-uniform: 576 sixteen-byte pieces = 9 waves' worth)
-    const int piece = tid >> 6;
-    int n = pm + (piece % 3); if (n > p.N - 1) n = p.N - 1;             // keys beyond the window: clamped into the utterance, weight exactly 0
-    const float* src = piece < 3 ? p.K + ((long)b * p.kv_bstride + n) * p.k_stride
-                     : piece < 6 ? p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride
-                     : piece == 6 ? p.bias : (piece == 7 ? p.g : p.be);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (tid & 63) * 4), (__attribute__((address_space(3))) void*)&s_sh[tid & ~63], 16, 0, 0);
+#pragma unroll
+  for (int i = 0; i < (576 + ROWC1_NW * 64 - 1) / (ROWC1_NW * 64); ++i) {
+    const int it = tid + ROWC1_NW * 64 * i;
+    if (it < 576) {                                                     // (wave-uniform: 576 sixteen-byte pieces = 9 waves' worth)
+      const int piece = it >> 6;
+      int n = pm + (piece % 3); if (n > p.N - 1) n = p.N - 1;           // keys beyond the window: clamped into the utterance, weight exactly 0
+      const float* src = piece < 3 ? p.K + ((long)b * p.kv_bstride + n) * p.k_stride
+                       : piece < 6 ? p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride
+                       : piece == 6 ? p.bias : (piece == 7 ? p.g : p.be);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (it & 63) * 4), (__attribute__((address_space(3))) void*)&s_sh[it & ~63], 16, 0, 0);
+    }
   }
   f32x4 vq = ldq(p.Qh + ((long)b * p.q_bstride + p.q_row0 + t) * p.q_stride + c0);
   f32x4 vcq = ldq(p.C1Q + ((long)b * p.c_bstride + p.c_row0 + t) * p.c_stride + c0);
