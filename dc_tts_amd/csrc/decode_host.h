@@ -203,11 +203,13 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
 static int decode_streams_init(dctts_ctx* c) {
   if (c->s_bulk) return 0;
   {
-    // the bulk stream is throughput work that only has to finish within a frame period: lowest priority, so the dispatcher
-    // prefers the latency-critical chain launches (caller's stream) whenever both have workgroups ready
+    // Rounds 2-3: the side ("bulk") stream was throughput work that only had to finish within a frame period -- lowest priority, so that the dispatcher preferred the
+    // chain's launches.  Since round 4 the side stream is as long as the chain, and its team kernel (xcone_kernel) needs all of its 128 workgroups resident to get
+    // through its barriers: with another stream's big kernels on the device (SSRN of the previous batch: tools/soak.py, phase C) a low-priority xcone workgroup could
+    // wait for a CU longer than its team-mates' bounded spins (20 ms; 76 of 1500 decodes reported it).  Highest priority: a freed CU goes to the decode first.
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, lo));
+    HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, hi));
   }
   // the two streams hand data to each other through device memory only: device-scope release on the event markers (no system-scope flush)
   const unsigned evf = (unsigned)hipEventReleaseToDevice | hipEventDisableTiming;
