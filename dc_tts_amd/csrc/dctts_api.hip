@@ -89,6 +89,19 @@ hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_
   return hipErrorInvalidConfiguration;
 }
 
+// a highway layer of 512 channels as quarter-column items (hconv_kernel.h: RAW = 2): rows p.m_base .. p.M - 1 (ConvParams::raw_out / raw_ld set), then the finishing pass
+hipError_t launch_hconv_cols(const ConvShape& s, const ConvParams& p, hipStream_t stream) {
+  const int rows = p.M - p.m_base;
+  if (rows <= 0) return hipSuccess;
+  if (!p.raw_out || s.epi != EPI_HC || s.nt != 4 || s.nw != 8 || p.cout != 512) return hipErrorInvalidValue;
+  const dim3 grid((rows + 31) / 32, 4);
+  hipLaunchKernelGGL((hconv_kernel<EPI_HC, 2, 4, 4, 1, 2>), grid, dim3(256), 0, stream, p);      // (weight requests four k-groups ahead, wave-uniform tile bases: 2.04 -> 2.01 ms for TextEnc)
+  hipError_t e_ = hipGetLastError();
+  if (e_ != hipSuccess) return e_;
+  hipLaunchKernelGGL(hc_tail_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, p, (const float*)p.raw_out, 1);
+  return hipGetLastError();
+}
+
 #define HCONV16_CASE(E, NT_, NW_, BD_, SB_)                                                                   \
   if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                             \
     hipLaunchKernelGGL((hconv16_kernel<E, NT_, NW_, BD_, SB_>), grid, dim3(NW_ * 64), 0, stream, p, m_start); \
@@ -130,6 +143,7 @@ struct DevLayer {
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
   float* wp16r = nullptr;         // SSRN 4T-resolution layers: packing for hconv16_kernel (row-tail launches)
+  bool col_split = false;         // TextEnc's three-tap highway layers: when the 32-row items fill less than 3/4 of the CUs the layer runs as quarter-COLUMN items + a finishing pass (run_conv)
   bool tap_tail = false;          // SSRN highway layers: the rows left over after exact rounds may run as 32-row items x taps (run_conv).  SSRN only: which rows
                                   //   take that form depends on the batch, and Text2Mel's outputs stay bitwise equal across batch compositions
   ConvShape shape16{0, 0, 0};
@@ -515,9 +529,9 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, g.e, g.e, 2 * d, ACT_RELU, &L)); c->textenc.push_back(L);
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, 2 * d, 2 * d, 2 * d, ACT_NONE, &L)); c->textenc.push_back(L);
     for (int rep = 0; rep < 2; ++rep) for (int j = 0, r = 1; j < 4; ++j, r *= 3) {
-      snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, r, false, &L)); c->textenc.push_back(L); }
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, 1, false, &L)); c->textenc.push_back(L); }
-    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 1, 1, false, &L)); c->textenc.push_back(L); }
+      snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, r, false, &L)); L.col_split = true; c->textenc.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, 1, false, &L)); L.col_split = true; c->textenc.push_back(L); }
+    for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 1, 1, false, &L)); L.col_split = true; c->textenc.push_back(L); }
   }
   // ---- AudioEnc (networks.py:73-124), causal
   {
@@ -699,6 +713,23 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   //     (hconv_kernel.h: RAW) -- a third of an item's time per round instead of a whole one;
   //   * of the 4T-resolution k = 1 layers, when it is at most 0.6 of a round: 16-row items (hconv16_kernel.h).
   int tiles32 = (p.M + 31) / 32, m_tail = p.M;
+  // Column split (round 4): TextEnc's 512-channel highway layers run as quarter-column items, three or four of them to a CU at once, + the finishing
+  // pass.  At B = 32 their 180 32-row items fill 70 % of the CUs and a layer takes a whole item's time; as quarters it takes 3/4 of it.  ALWAYS, whatever the
+  // batch: which form a row takes must not depend on the batch it is decoded in (K and V feed the attention; Text2Mel's outputs are bitwise equal across batch
+  // compositions: tests/test_gpu_parity.py), and at sizes where the items fill the rounds the split costs only the finishing pass (~5 %).
+  if (L.col_split && L.shape.epi == EPI_HC && !gather && !rm.step && L.shape.nt == 4 && L.shape.nw == 8 && L.cout == 512) {
+    const int raw_ld = 2 * L.cout;
+    const size_t need = (size_t)p.M * raw_ld;
+    if (need > c->tail_ws_floats) {
+      if (c->tail_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->tail_ws); c->tail_ws = nullptr; c->tail_ws_floats = 0; }
+      HIPCHK(hipMalloc((void**)&c->tail_ws, need * sizeof(float)));
+      c->tail_ws_floats = need;
+    }
+    p.m_base = 0; p.raw_out = c->tail_ws; p.raw_ld = raw_ld;
+    HIPCHK(launch_hconv_cols(L.shape, p, st));
+    if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
+    return 0;
+  }
   const int full = (tiles32 / c->n_cu) * c->n_cu, left = tiles32 - full;
   const bool hc3 = L.tap_tail && L.shape.epi == EPI_HC && L.ntaps == 3 && !gather && (L.shape.nt == 2 || L.shape.nt == 4 || L.shape.nt == 8) && (L.cout % 256) == 0 && L.cout <= 1024;
   // ... and of the 4T-resolution k = 1 layers of SSRN (the ones that carry the 16-row packing): thirds of K instead of taps, same finishing idea

@@ -100,8 +100,15 @@ __device__ __forceinline__ float half_sum32(float v) {
 //     items on hconv16_kernel it cost 0.57 of a round on 144 of the 256 CUs.  Here it is 32-row items x TAPS: workgroup (x, y) contracts tap y only
 //     (a third of K), 216 workgroups in one round at a third of an item's time, bare partial sums to HBM; hc_tail_finish_kernel (below) adds the three
 //     partials and the bias and finishes the rows (two layer-norms, gate, highway mix).
+//   * RAW = 2 (round 4, a highway layer whose 32-row items fill less than three quarters of the CUs -- TextEnc: 180 items on 256 CUs, 205 us per layer whatever
+//     the items do): the items are split by COLUMNS.  Workgroup (x, y) of NW = 4 waves x one (gate, info) tile pair each owns 32 rows x channels
+//     [128 y, 128 y + 128) of both halves and contracts ALL of K; 720 quarter items run three to a CU at once, so a layer takes 3/4 of an item's time (every
+//     split into k equal parts has makespan ceil(180 k / 256) / k: 1 for k = 2 and 3 -- the tap split above --, 3/4 for k = 4).  The pre-norm values go to
+//     raw_out (one part); hc_tail_finish_kernel adds the bias and finishes the rows.  Same weight packing: tile (y NW + wave) NT + i of the 8-wave layout.
 template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0>
 __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
+  constexpr bool KPART = (RAW == 1);        // this workgroup contracts a PART of K (grid y = part)
+  constexpr bool CPART = (RAW == 2);        // this workgroup owns a PART of the columns (grid y = part)
   constexpr int LDA = 36;
   constexpr int NH = (EPI == EPI_HC) ? 2 : 1;
   constexpr int NP = (EPI == EPI_HC) ? NT / 2 : NT;       // output column tiles per wave
@@ -116,11 +123,12 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = SB ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
+  const int wv = CPART ? (int)blockIdx.y * NW + wave : wave;      // the wave's position in the layer's column order
   const int l31 = lane & 31, lhi = lane >> 5;
   const int m0 = (RAW ? p.m_base : 0) + blockIdx.x * 32;
   const int t_base = p.step ? *p.step : 0;
   // RAW: workgroup y contracts PART y of K -- tap y of a three-tap layer, or the y-th third of the 32-channel chunks of a k = 1 layer
-  const int tap0 = (RAW && p.ntaps == 3) ? (int)blockIdx.y : 0;
+  const int tap0 = (KPART && p.ntaps == 3) ? (int)blockIdx.y : 0;
 
   if (tid < 32) {
     const int m = m0 + tid;
@@ -148,11 +156,11 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const long my_inrow = s_inrow[lrow];
   const int cpt = p.cin_p >> 5;          // chunks per tap
   const int cpt3 = (cpt + 2) / 3;
-  const int ch0 = (RAW && p.ntaps != 3) ? ((int)blockIdx.y * cpt3 < cpt ? (int)blockIdx.y * cpt3 : cpt - 1) : 0;     // first chunk of this part inside its tap
-  const int nch = RAW ? ((p.ntaps == 3) ? cpt : ((cpt - ch0 < cpt3) ? cpt - ch0 : cpt3)) : p.ntaps * cpt;
+  const int ch0 = (KPART && p.ntaps != 3) ? ((int)blockIdx.y * cpt3 < cpt ? (int)blockIdx.y * cpt3 : cpt - 1) : 0;     // first chunk of this part inside its tap
+  const int nch = KPART ? ((p.ntaps == 3) ? cpt : ((cpt - ch0 < cpt3) ? cpt - ch0 : cpt3)) : p.ntaps * cpt;
   const int KG = nch * 4;                // k-groups of 8 this workgroup contracts
-  const int KGT = RAW ? p.ntaps * cpt * 4 : KG;     // ... of a packed tile; RAW: this workgroup starts at its part's first k-group
-  const int kg0 = RAW ? (tap0 * cpt + ch0) * 4 : 0;
+  const int KGT = KPART ? p.ntaps * cpt * 4 : KG;     // ... of a packed tile; RAW: this workgroup starts at its part's first k-group
+  const int kg0 = KPART ? (tap0 * cpt + ch0) * 4 : 0;
 
   // Branch-free: a load inside a conditional block makes the wait-count pass fall back to s_waitcnt vmcnt(0) at the join (the
   // weight prefetch behind it then drains twice per chunk).  Rows / columns that must read as zero are redirected to a readable
@@ -161,13 +169,13 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const long safe_row = p.gather ? 0 : p.in_row0;
   int ltap = 0, lcit = 0;                  // (tap, chunk in tap) the loader is at: it walks forward one chunk per call, clamped at the last chunk
   auto load_next = [&](bool& ok) -> float4 {
-    const int c = (RAW ? ch0 + lcit : lcit) * 32 + lc4 * 4;
-    const int tq = RAW ? tap0 + ltap : ltap;
+    const int c = (KPART ? ch0 + lcit : lcit) * 32 + lc4 * 4;
+    const int tq = KPART ? tap0 + ltap : ltap;
     const int toff = (tq == 0) ? p.tap_off[0] : ((tq == 1) ? p.tap_off[1] : p.tap_off[2]);
     ok = row_ok && c < p.cin;
     const long row = row_ok ? my_inrow + toff : safe_row;
     const float4 v = *reinterpret_cast<const float4*>(p.in + row * (long)p.in_stride + (c < p.cin ? c : 0));
-    if (RAW) { if (lcit < nch - 1) ++lcit; }
+    if (KPART) { if (lcit < nch - 1) ++lcit; }
     else if (!(ltap == p.ntaps - 1 && lcit == cpt - 1)) { if (++lcit == cpt) { lcit = 0; ++ltap; } }
     return v;
   };
@@ -175,7 +183,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const float4* wq[NT];                    // SB: wave-uniform bases (scalar registers) + the lane as part of the index
 #pragma unroll
   for (int i = 0; i < NT; ++i)
-    wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wave * NT + i) * KGT + kg0) * 64 + (SB ? 0 : lane);
+    wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wv * NT + i) * KGT + kg0) * 64 + (SB ? 0 : lane);
   const int wl = SB ? lane : 0;
 
   // channel of tile i inside its layer-norm group; the bias is the accumulators' initial value (columns beyond C: zero weights, zero bias -> exactly 0)
@@ -185,8 +193,8 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 #pragma unroll
   for (int i = 0; i < NT; ++i) {
     int ch_, bidx;
-    if (EPI == EPI_HC) { ch_ = (wave * NP + (i >> 1)) * 32 + l31; bidx = (i & 1) * C + ch_; }
-    else { ch_ = (wave * NT + i) * 32 + l31; bidx = ch_; }
+    if (EPI == EPI_HC) { ch_ = (wv * NP + (i >> 1)) * 32 + l31; bidx = (i & 1) * C + ch_; }
+    else { ch_ = (wv * NT + i) * 32 + l31; bidx = ch_; }
     chan[i] = ch_; cval[i] = ch_ < C;
     const float bv = RAW ? 0.f : p.bias[cval[i] ? bidx : 0];
 #pragma unroll
@@ -251,8 +259,8 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
 
   if constexpr (RAW) {                      // bare partial sums of this part: [part][row - m_base][raw_ld], natural column order (HC: H1 | H2)
     const long mt = (long)p.M - p.m_base;
-    const int tap0_ = (int)blockIdx.y;
-    if (p.ntaps != 3 && (int)blockIdx.y * cpt3 >= cpt) {      // (a k = 1 layer with fewer than three chunk groups: this part is empty -- zeros)
+    const int tap0_ = CPART ? 0 : (int)blockIdx.y;
+    if (KPART && p.ntaps != 3 && (int)blockIdx.y * cpt3 >= cpt) {      // (a k = 1 layer with fewer than three chunk groups: this part is empty -- zeros)
 #pragma unroll
       for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -547,5 +555,7 @@ inline int shape_tiles(const ConvShape& s) { return s.nt * s.nw; }
 hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles = -1);
 // the tap-split row tail of a highway layer with three taps: rows p.m_base .. p.M - 1 (ConvParams::raw_out / raw_ld set); then the finishing pass
 hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_t stream);
+// a three-tap 512-channel highway layer as quarter-column items (RAW = 2) + the finishing pass: rows p.m_base .. p.M - 1
+hipError_t launch_hconv_cols(const ConvShape& s, const ConvParams& p, hipStream_t stream);
 
 }  // namespace dctts
