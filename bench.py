@@ -288,6 +288,11 @@ def main():
     eng = Engine(W, hp, device=local, decode_graph=gm)
     eng.set_decode_mode(args.decode_mode)
     L = torch.from_numpy(synthetic_text(hp, B=B, seed=1234 + rank)).cuda()
+    # The caller's stream: a HIGH-PRIORITY HIP stream.  The decode's team kernels need the highest stream priority to stay clear of other streams' kernels on the
+    # device (tools/soak.py phase C); a caller's stream that has it carries the chain's launches itself, on a default-priority stream the library moves
+    # them to a high-priority stream of its own between two events (+0.1 ms per decode).
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.Stream(priority=-1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -407,6 +412,8 @@ def main():
                                    f"max_T={T} mel frames -> ({B},{4 * T},{hp.n_linear}) per GPU; exact-parity incremental decode",
                        "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_mode": args.decode_mode, "decode_graph_mode": gm,
                        "decode_team_kernels": fallback is None,
+                       "caller_stream": "a high-priority HIP stream (the decode's chain launches run on the caller's stream when it has the highest priority; from a "
+                                        "default-priority stream the library moves them to its own high-priority stream between two events: +0.1 ms per decode)",
                        "sharding": f"{world} x {B} utterances, no collective"},
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),

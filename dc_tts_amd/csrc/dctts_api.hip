@@ -223,6 +223,7 @@ struct dctts_ctx {
   int xcone = 1;
   void* xc_tab = nullptr; std::string xc_geom;   // per frame: XConeParams
   hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
+  hipStream_t s_chain = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;      // decode mode 3: the chain's launches run on a high-priority stream of the context between two events on the caller's stream (decode_host.h)
   hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr};
   int sync_values = 1;                 // the two streams meet through stream memory operations (hipStreamWriteValue32 / WaitValue32 on two counters) instead of events
                                        // (DCTTS_SYNC_VALUES=0; rocprofv3 --pmc needs events: read_env)
@@ -236,7 +237,9 @@ struct dctts_ctx {
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
-  float* tail_ws = nullptr; size_t tail_ws_floats = 0;   // run_conv: the tap-split row tail's partial sums [3][tail rows][2C]
+  float* tail_ws = nullptr; size_t tail_ws_floats = 0;   // run_conv: the tap-split row tail's partial sums [3][tail rows][2C] (SSRN layers only)
+  float* cols_ws = nullptr; size_t cols_ws_floats = 0;   // run_conv: the column-split layers' pre-norm rows [rows][2C] (TextEnc only).  NOT tail_ws: SSRN of the previous batch may run on
+                                                         // another stream beside the next batch's TextEnc (tools/soak.py, phase C: with one buffer 536 of 3000 decodes differed, unreported)
   static constexpr int bulk_cap = 176;   // workgroups of a bulk (cone) launch of hbulk_kernel: fewer than CUs so the chain stream finds free ones
   // in-kernel trace (DCTTS_TRACE=<frame>, eager mode): wall-clock stamps of every chain launch of one frame
   long long* trace_buf = nullptr; int trace_n = 0; bool trace_on = false;
@@ -474,6 +477,9 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   destroy_graphs(c);
   for (int i = 0; i < 4; ++i) { if (c->ev_chain[i]) (void)hipEventDestroy(c->ev_chain[i]); if (c->ev_bulk[i]) (void)hipEventDestroy(c->ev_bulk[i]); }
   if (c->s_bulk) (void)hipStreamDestroy(c->s_bulk);
+  if (c->s_chain) (void)hipStreamDestroy(c->s_chain);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_out) (void)hipEventDestroy(c->ev_out);
   if (c->ctr_chain) (void)hipFree(c->ctr_chain);
   if (c->ctr_bulk) (void)hipFree(c->ctr_bulk);
   if (c->wait_ctr) (void)hipFree(c->wait_ctr);
@@ -482,6 +488,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   if (c->tail_ws) (void)hipFree(c->tail_ws);
+  if (c->cols_ws) (void)hipFree(c->cols_ws);
   free_ws(c);
   for (Arena& a : c->warena) (void)hipFree(a.base);
   for (int* p : c->cone_dev) (void)hipFree(p);
@@ -683,7 +690,7 @@ extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
   size_t n = 0;
   for (const Arena& a : c->warena) n += a.size;
   for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
-  n += c->tail_ws_floats * sizeof(float);
+  n += (c->tail_ws_floats + c->cols_ws_floats) * sizeof(float);
   return n;
 }
 
@@ -720,12 +727,12 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   if (L.col_split && L.shape.epi == EPI_HC && !gather && !rm.step && L.shape.nt == 4 && L.shape.nw == 8 && L.cout == 512) {
     const int raw_ld = 2 * L.cout;
     const size_t need = (size_t)p.M * raw_ld;
-    if (need > c->tail_ws_floats) {
-      if (c->tail_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->tail_ws); c->tail_ws = nullptr; c->tail_ws_floats = 0; }
-      HIPCHK(hipMalloc((void**)&c->tail_ws, need * sizeof(float)));
-      c->tail_ws_floats = need;
+    if (need > c->cols_ws_floats) {
+      if (c->cols_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->cols_ws); c->cols_ws = nullptr; c->cols_ws_floats = 0; }
+      HIPCHK(hipMalloc((void**)&c->cols_ws, need * sizeof(float)));
+      c->cols_ws_floats = need;
     }
-    p.m_base = 0; p.raw_out = c->tail_ws; p.raw_ld = raw_ld;
+    p.m_base = 0; p.raw_out = c->cols_ws; p.raw_ld = raw_ld;
     HIPCHK(launch_hconv_cols(L.shape, p, st));
     if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
     return 0;

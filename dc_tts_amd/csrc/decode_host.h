@@ -210,6 +210,12 @@ static int decode_streams_init(dctts_ctx* c) {
     int lo = 0, hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
     HIPCHK(hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, hi));
+    // ... and so do the chain's launches: they run on a high-priority stream of the context, between two events on the caller's stream (decode_impl).  On the caller's
+    // own (default-priority) stream the chain's team kernels met the same fate as xcone_kernel once that one had priority: 9 of 1500 decodes beside SSRN + vocoder
+    // reported a team hand-off time-out of the chain.
+    HIPCHK(hipStreamCreateWithPriority(&c->s_chain, hipStreamNonBlocking, hi));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
   }
   // the two streams hand data to each other through device memory only: device-scope release on the event markers (no system-scope flush)
   const unsigned evf = (unsigned)hipEventReleaseToDevice | hipEventDisableTiming;
@@ -1182,7 +1188,24 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     c->init_pm.clear();
   }
   if (v3) {
-    CHK(decode_v3(c, w, B, N, T, st));
+    CHK(decode_streams_init(c));
+    // The chain's launches need the highest stream priority as well (decode_streams_init).  A caller's stream that has it is used as it is; otherwise the decode proper
+    // runs on the context's own high-priority chain stream between two events on the caller's stream: everything that stream has done so far in front of the decode,
+    // everything it does later behind it (the two hand-overs cost ~0.1 ms per decode: INTEGRATION.md recommends a high-priority stream to callers who care).
+    int lo = 0, hi = 0, pr = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const bool own = st && hipStreamGetPriority(st, &pr) == hipSuccess && pr == hi && hi != lo;
+    if (!own) (void)hipGetLastError();
+    if (own) {
+      CHK(decode_v3(c, w, B, N, T, st));
+    } else {
+      HIPCHK(hipEventRecord(c->ev_in, st));
+      HIPCHK(hipStreamWaitEvent(c->s_chain, c->ev_in, 0));
+      const int rc = decode_v3(c, w, B, N, T, c->s_chain);
+      HIPCHK(hipEventRecord(c->ev_out, c->s_chain));
+      HIPCHK(hipStreamWaitEvent(st, c->ev_out, 0));
+      CHK(rc);
+    }
   } else if (c->use_graph) {
     const std::string g = geom("graph1", B, T, N) + ":" + std::to_string((size_t)w.kv.p);   // the captured launches bake in the TextEnc output pointer
     if (!c->graph_exec || c->graph_geom != g) {
