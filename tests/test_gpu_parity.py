@@ -786,6 +786,33 @@ def test_two_contexts_on_one_gpu_take_turns(weights):
     e2.close()
 
 
+def test_decode_from_a_high_priority_stream_and_beside_ssrn_on_another_stream(weights):
+    """Stream handling of the decode (streams and priorities): called from a default-priority stream the chain's launches run on a high-priority
+    stream of the context between two events, called from a high-priority stream they run on that stream itself -- same result, bitwise.  And one context serves
+    two streams at once: SSRN of the previous batch on a second stream beside TextEnc + decode of the next one (their scratch buffers are separate: with one shared
+    buffer for SSRN's tap-split tails and TextEnc's column split this test -- and 18 % of tools/soak.py's phase C -- returned different values, unreported)."""
+    T = 60
+    eng = engine_for(weights, max_T=T)
+    L = dev(synthetic_text(hp.replace(max_T=T), B=32, seed=31))
+    Y, mx = eng.text2mel(L)
+    Z = eng.ssrn(Y, want_logits=False)[1]
+    eng.synchronize()
+    hi = torch.cuda.Stream(priority=-1)
+    with torch.cuda.stream(hi):
+        Yh, mh = eng.text2mel(L)
+    torch.cuda.synchronize()
+    assert torch.equal(Yh, Y) and torch.equal(mh, mx)
+    s2 = torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(s2):
+            Zs = [eng.ssrn(Y, want_logits=False)[1] for _ in range(3)]
+        Y2, m2 = eng.text2mel(L)
+        torch.cuda.synchronize()
+        eng.decode_status()
+        assert torch.equal(Y2, Y) and torch.equal(m2, mx)
+        for z in Zs: assert torch.equal(z, Z)
+
+
 # ---------------------------------------------------------------- the restore path end to end (synthesize.py:32-40, SURVEY 8f-1)
 def test_checkpoint_directories_to_spectrograms(weights, tmp_path):
     """`python -m dc_tts_amd.synthesize --logdir <prefix>`: two checkpoint directories laid out like hp.logdir-1 / hp.logdir-2 -- written by the
