@@ -11,7 +11,8 @@ What it restates, in float64 numpy with every derivative written out by hand:
     gradients with respect to the network outputs;
   * the Noam learning-rate schedule (utils.py:142-145) and the clip / Adam step of train.py:119-131.
 
-PARITY UNPINNED, like oracle/dctts_ref.py: TensorFlow is not installable here, so nothing ties these derivatives to
+PARITY UNPINNED against TensorFlow (the forward restatement in oracle/dctts_ref.py is pinned to the reference's own Python since round 4, its
+derivatives are not): TensorFlow is not installable here, so nothing ties these derivatives to
 ``tf.gradients``.  They are pinned by mathematics instead: ``tests/test_train_oracle.py`` checks every gradient
 against central finite differences of the float64 forward pass (which IS oracle/dctts_ref.py's forward) and against
 torch.autograd on the same blocks written with torch.nn.functional.
