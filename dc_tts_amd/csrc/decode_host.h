@@ -484,7 +484,8 @@ static XgMem xg_mem(dctts_ctx* c, int B) {
   return m;
 }
 
-// Chain piece j (j = -1 .. T-1) launches, in this order: the AudioDec run of frame j (j >= 0), ..., the AudioEnc run of frame j + 1 (j + 1 < T).
+// Chain piece j (j = -1 .. T-1) launches, in this order: the AudioDec run of frame j (j >= 0; since the merged form of round 4 the front of xtail_kernel's
+// launch, v3_xtail_table, and not launched from this table), ..., the AudioEnc run of frame j + 1 (j + 1 < T).
 // The team barriers count arrivals monotonically over the whole decode, so every launch is told the count it starts from.
 static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xg", B, T) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((size_t)w.ad[0].p) + ":" +

@@ -56,7 +56,7 @@ struct XGroupParams {
   unsigned* sig; unsigned sig_val;                      // first launch of a chain piece: *sig = sig_val ("every earlier piece of this stream is complete")
   const unsigned* wait2; unsigned wait_val;             // first launch of a chain piece: the presums come from the side stream: poll *wait2 >= wait_val first
   // passengers: independent small GEMMs (hbulk_body items, decode_kernels.h) that ride in this launch on compute units nobody is using while the
-  // teams run -- in the AudioDec run's launch, the AudioEnc presums of the next frame (consumed by the AudioEnc run that follows on this stream)
+  // teams run -- in the AudioDec run's launch (the merged form of round 4 carries them in xtail_kernel's launch, the first one of a chain piece), the AudioEnc presums of the next frame (consumed by the AudioEnc run that follows on this stream)
   // and the newest row of the C1Q . W2 cache, which the NEXT side-stream piece needs: those workgroups count themselves and the last one
   // publishes psig_val (rowc1_kernel's tail polls it on the side stream)
   const SplitParams* ptab; int p_blocks, p_ipl, p_step; // descriptors; workgroups behind the teams' (p_blocks = descriptors * p_ipl); items per descriptor; frame index

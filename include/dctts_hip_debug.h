@@ -36,10 +36,10 @@ int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream)
  *   epi*10000 + NT*100 + NW   every launch of hconv_kernel<epi, NT, NW> (epi 0 = C, 1 = HC), e.g. 10808 = SSRN HC_11 / HC_12;
  *   50000 + epi*10000 + NT*100 + NW   the 16-row tail launches hconv16_kernel<epi, NT, NW> of the layers that are split by rows, e.g. 61608 = HC_11 / HC_12's tail;
  *   DCTTS_PROF_XGROUP         xgroup_kernel (a run of newest-row highway layers of the decode chain as one launch), on every 16th frame only;
- *                             prof_rows then counts LAYERS (6 for the AudioDec run, 10 for the AudioEnc run);
+ *                             prof_rows then counts LAYERS (10 for the AudioEnc run, the only run timed; the AudioDec layers are part of xtail_kernel's launch since round 4);
  *   DCTTS_PROF_XCONE          xcone_kernel (the tail of AudioDec's cone on the side stream), frames >= 100, every 16th; eager decode only (graph mode 0);
- *   DCTTS_PROF_XTAIL          xtail_kernel (AudioDec HC_5 .. HC_7 over their cone rows + the seven k = 1 layers around the mel frame, one launch per frame on the chain's
- *                             stream), every 16th frame; prof_rows counts LAYERS (10 per launch);
+ *   DCTTS_PROF_XTAIL          xtail_kernel (merged form: AudioDec's newest-row layers HC_2 .. HC_4, HC_5 .. HC_7 over their cone rows and the seven k = 1 layers around the
+ *                             mel frame, the first launch of a chain piece), every 16th frame; prof_rows is not meaningful for it;
  *   DCTTS_PROF_CHAIN_HC       chain3_kernel<LN_HC, HC> (one newest-row highway layer per launch: the form used when DCTTS_XGROUP=0), every 16th frame;
  *   DCTTS_PROF_BULK_GEMM      hbulk_kernel<12> (the cone GEMM of HC_3 when DCTTS_XCONE=0); eager decode only.  Enabling either of the last two
  *                             switches the corresponding team kernel off for the decodes that follow. */
