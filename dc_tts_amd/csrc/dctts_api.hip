@@ -175,8 +175,25 @@ struct dctts_ctx {
   std::vector<DevLayer> textenc, audioenc, audiodec, ssrn;
   float* embed = nullptr;
   std::vector<int*> cone_dev; std::vector<int> cone_len;
-  std::map<std::string, Buf> ws;       // named workspaces; key includes the geometry
-  std::string ws_geom_textenc, ws_geom_t2m, ws_geom_dec, ws_geom_ssrn;
+  std::map<std::string, Buf> ws;       // named workspaces; the key includes the geometry its prefix is selected for (ws_select)
+  // Workspaces are cached PER GEOMETRY and only grow (round 5): "te." / "t2m." / "dec." / "ssrn." each select the geometry string of the running call, a
+  // buffer "dec.ypad" lives under the key "dec@<geometry>.ypad" in the arena pool "dec@<geometry>.", and a geometry that comes back finds its buffers (and the
+  // decode its device tables: tabcache) as it left them -- no hipDeviceSynchronize, no hipFree when a serving loop alternates between batch shapes.  Only when
+  // the cached workspaces exceed ws_limit bytes does the next call drop ALL of them behind one device synchronisation (ws_trim).
+  std::map<std::string, std::string> ws_sel;
+  hipStream_t ws_stream = nullptr;     // the running call's stream: a NEW arena is zero-filled on it (ordered before the call's kernels)
+  size_t ws_limit = (size_t)96 << 30;
+  std::vector<void*> graveyard; size_t graveyard_bytes = 0;      // outgrown tail_ws / cols_ws buffers: freed by ws_trim / dctts_destroy, never while a stream may still use them
+  struct TabSlot { void* tab = nullptr; void* mem = nullptr; int n0 = 0; };
+  std::map<std::string, TabSlot> tabcache;                       // the decode's device tables per (kind, geometry key)
+  // Calls that share scratch are ordered against each other whatever streams they come from (round 5): every entry point waits for the completion event of the
+  // last call of its group that came from ANOTHER stream and records its own behind its last launch.  Groups: TextEnc (te.*, cols_ws; the decode holds it too --
+  // K / V live in te.kv until the decode ends), the full-sequence AudioEnc / AudioDec functions (t2m.*), the decode (dec.*, the team kernels' exchange memory,
+  // both decode streams), SSRN (ssrn.*, tail_ws).  Calls of DIFFERENT groups on different streams overlap (SSRN of batch n beside the decode of batch n + 1).
+  struct UseGroup { hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false; };
+  enum { GRP_TE = 0, GRP_T2M = 1, GRP_DEC = 2, GRP_SSRN = 3, GRP_N = 4 };
+  UseGroup grp[GRP_N];
+  std::recursive_mutex mu;             // the host side of a context is not re-entrant: entry points of one context are serialised (enqueue only; nothing waits for the GPU under it)
   int use_graph = 0;                   // decode: 0 = every launch eager, 1 = the side stream's work as one hipGraph per frame
   int decode_mode = 3;                 // 3 = two-stream incremental form (the default), 0 = simple form: fused kernels, one stream, a device-side
                                        //     frame counter (cross-check: a different implementation of the same arithmetic)
@@ -219,6 +236,7 @@ struct dctts_ctx {
   const int* fin_xerr = nullptr; const int* fin_werr = nullptr;   // the running decode's own error words (decode_v3 sets them, decode_finish reads them)
   int inject_err = 0;                  // debug hook: error bits OR-ed into the NEXT decode's status (dctts_debug_inject_decode_error)
   int team_fail_streak = 0;            // consecutive failed status reports without a split-team bit: the team kernels are switched off at 3
+  bool safe_once = false;              // dctts_decode_safe_once: the NEXT decode runs one launch per layer with stream-operation meetings, then the settings are as before
   // the tail of AudioDec's cone (HC_3 .. HC_7 and their row passes) as one launch per frame on the side stream (xcone_kernel.h); DCTTS_XCONE=0: nine launches
   int xcone = 1;
   void* xc_tab = nullptr; std::string xc_geom;   // per frame: XConeParams
@@ -262,6 +280,7 @@ struct DevGuard {
   ~DevGuard() { if (prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
 static void destroy_graphs(dctts_ctx* c);
+static void lease_forget(const dctts_ctx* c);
 DevGuard::DevGuard(const dctts_ctx* c) {
   if (!c) return;
   dev = c->device;
@@ -283,12 +302,14 @@ static int get_w(dctts_ctx* c, const std::string& name, const std::vector<int64_
 // every decode launch touches a different layer's weights and buffers, and with one allocation per tensor each launch
 // started with address-translation misses (large contiguous arenas map with big pages and stay within TLB reach).
 static const size_t ARENA_CHUNK = (size_t)512 << 20;
-static int arena_alloc(dctts_ctx* c, std::vector<Arena>& pool, size_t bytes, void** out) {
+// `zero_on`: a workspace arena is zero-filled on the stream of the call that creates it (ordered in front of that call's kernels; calls from other streams are ordered
+// behind it by the use groups); nullptr (weights, at dctts_weights_finalize): a synchronous fill.
+static int arena_alloc(dctts_ctx* c, std::vector<Arena>& pool, size_t bytes, void** out, const hipStream_t* zero_on = nullptr) {
   bytes = (bytes + 255) & ~(size_t)255;
   for (Arena& a : pool) if (a.used + bytes <= a.size) { *out = (char*)a.base + a.used; a.used += bytes; return 0; }
   Arena a; a.size = bytes > ARENA_CHUNK ? bytes : ARENA_CHUNK; a.used = bytes;
   HIPCHK(hipMalloc(&a.base, a.size));
-  HIPCHK(hipMemset(a.base, 0, a.size));
+  if (zero_on) HIPCHK(hipMemsetAsync(a.base, 0, a.size, *zero_on)); else HIPCHK(hipMemset(a.base, 0, a.size));
   pool.push_back(a);
   *out = a.base;
   return 0;
@@ -472,6 +493,7 @@ static void free_ws(dctts_ctx* c) {
 extern "C" int dctts_destroy(dctts_ctx* c) {
   if (!c) return 0;
   DevGuard dev_guard(c);
+  (void)hipDeviceSynchronize();        // nothing of this context may still be running when its memory goes
   if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
   if (c->graph) (void)hipGraphDestroy(c->graph);
   destroy_graphs(c);
@@ -489,18 +511,15 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->trace_buf) (void)hipFree(c->trace_buf);
   if (c->tail_ws) (void)hipFree(c->tail_ws);
   if (c->cols_ws) (void)hipFree(c->cols_ws);
+  for (void* p : c->graveyard) (void)hipFree(p);
+  for (auto& kv : c->tabcache) { if (kv.second.tab) (void)hipFree(kv.second.tab); if (kv.second.mem) (void)hipFree(kv.second.mem); }
+  for (auto& u : c->grp) if (u.done) (void)hipEventDestroy(u.done);
+  lease_forget(c);
   free_ws(c);
   for (Arena& a : c->warena) (void)hipFree(a.base);
   for (int* p : c->cone_dev) (void)hipFree(p);
   for (int* p : c->cone3_dev) (void)hipFree(p);
   if (c->iota_dev) (void)hipFree(c->iota_dev);
-  if (c->aepre_tab) (void)hipFree(c->aepre_tab);
-  if (c->mlp_tab) (void)hipFree(c->mlp_tab);
-  if (c->xmlp_tab) (void)hipFree(c->xmlp_tab);
-  if (c->xtail_tab) (void)hipFree(c->xtail_tab);
-  if (c->xg_tab) (void)hipFree(c->xg_tab);
-  if (c->xc_tab) (void)hipFree(c->xc_tab);
-  if (c->xg_mem) (void)hipFree(c->xg_mem);
   for (auto& e : c->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   delete c;
   return 0;
@@ -659,13 +678,21 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
 }
 
 // ------------------------------------------------------------------------------------------------ workspaces
+// Select the geometry the buffers of `prefix` ("dec.", "ssrn.", ...) belong to for the running call, and the stream a new arena is zero-filled on.
+static void ws_select(dctts_ctx* c, const std::string& prefix, const std::string& geometry, hipStream_t st) {
+  c->ws_sel[prefix] = geometry; c->ws_stream = st;
+}
+
 static int ws_get(dctts_ctx* c, const std::string& name, size_t bytes, void** out) {
-  Buf& b = c->ws[name];
+  const size_t dot = name.find('.');
+  const std::string prefix = name.substr(0, dot + 1);
+  auto sel = c->ws_sel.find(prefix);
+  const std::string pool = name.substr(0, dot) + "@" + (sel == c->ws_sel.end() ? std::string() : sel->second) + ".";
+  Buf& b = c->ws[pool + name.substr(dot + 1)];
   if (b.bytes != bytes) {
-    // new buffer (or a changed size: the old slice stays in the pool until its geometry prefix is dropped)
-    const std::string prefix = name.substr(0, name.find('.') + 1);
-    CHK(arena_alloc(c, c->wsarena[prefix], bytes, &b.p));      // arenas are zero-filled when created: pad rows/columns stay
-    HIPCHK(hipDeviceSynchronize());                            // zero because kernels never write them
+    // a new buffer (or, within one geometry, a changed size: the old slice stays in its pool).  Arenas are zero-filled when created: pad rows / columns stay
+    // zero because kernels never write them.
+    CHK(arena_alloc(c, c->wsarena[pool], bytes, &b.p, &c->ws_stream));
     b.bytes = bytes;
   }
   *out = b.p;
@@ -690,8 +717,17 @@ extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
   size_t n = 0;
   for (const Arena& a : c->warena) n += a.size;
   for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
-  n += (c->tail_ws_floats + c->cols_ws_floats) * sizeof(float);
+  n += (c->tail_ws_floats + c->cols_ws_floats) * sizeof(float) + c->graveyard_bytes;
   return n;
+}
+
+// tail_ws / cols_ws only grow: a bigger buffer is allocated, the outgrown one is kept (another stream's earlier call may still be using it) until ws_trim / dctts_destroy.
+// (Every launch that reads or writes the scratch buffer is fully written before it is read within the same call: no zero fill.)
+static int grow_scratch(dctts_ctx* c, float** buf, size_t* floats, size_t need) {
+  if (*buf) { c->graveyard.push_back(*buf); c->graveyard_bytes += *floats * sizeof(float); *buf = nullptr; *floats = 0; }
+  HIPCHK(hipMalloc((void**)buf, need * sizeof(float)));
+  *floats = need;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ one conv launch
@@ -727,11 +763,7 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   if (L.col_split && L.shape.epi == EPI_HC && !gather && !rm.step && L.shape.nt == 4 && L.shape.nw == 8 && L.cout == 512) {
     const int raw_ld = 2 * L.cout;
     const size_t need = (size_t)p.M * raw_ld;
-    if (need > c->cols_ws_floats) {
-      if (c->cols_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->cols_ws); c->cols_ws = nullptr; c->cols_ws_floats = 0; }
-      HIPCHK(hipMalloc((void**)&c->cols_ws, need * sizeof(float)));
-      c->cols_ws_floats = need;
-    }
+    if (need > c->cols_ws_floats) CHK(grow_scratch(c, &c->cols_ws, &c->cols_ws_floats, need));
     p.m_base = 0; p.raw_out = c->cols_ws; p.raw_ld = raw_ld;
     HIPCHK(launch_hconv_cols(L.shape, p, st));
     if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
@@ -751,11 +783,7 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
     // the row tail of a big highway layer: 32-row items x taps + a finishing pass (hconv_kernel.h: RAW) instead of 16-row items
     const int raw_ld = (L.shape.epi == EPI_HC) ? 2 * L.cout : round_up(L.cout, 32);
     const size_t need = (size_t)3 * (p.M - m_tail) * raw_ld;
-    if (need > c->tail_ws_floats) {
-      if (c->tail_ws) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(c->tail_ws); c->tail_ws = nullptr; c->tail_ws_floats = 0; }
-      HIPCHK(hipMalloc((void**)&c->tail_ws, need * sizeof(float)));
-      c->tail_ws_floats = need;
-    }
+    if (need > c->tail_ws_floats) CHK(grow_scratch(c, &c->tail_ws, &c->tail_ws_floats, need));
     p.m_base = m_tail; p.raw_out = c->tail_ws; p.raw_ld = raw_ld;
     const bool prof16 = (c->prof_id == 50000 + L.shape16.epi * 10000 + L.shape16.nt * 100 + L.shape16.nw);      // (the tail of the same layer, whatever its form)
     hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -784,20 +812,63 @@ static std::string geom(const char* tag, int a, int b, int cdim = 0) {
   char s[96]; snprintf(s, 96, "%s:%d:%d:%d", tag, a, b, cdim); return s;
 }
 
-static void drop_ws_prefix(dctts_ctx* c, const std::string& prefix) {
+static void drop_ws_prefix(dctts_ctx* c, const std::string& prefix) {      // every geometry of `prefix` ("dbg." -> the pools "dbg@...")
+  const std::string pp = prefix.substr(0, prefix.size() - 1) + "@";
   for (auto it = c->ws.begin(); it != c->ws.end();) {
-    if (it->first.compare(0, prefix.size(), prefix) == 0) it = c->ws.erase(it);
+    if (it->first.compare(0, pp.size(), pp) == 0) it = c->ws.erase(it);
     else ++it;
   }
-  auto pit = c->wsarena.find(prefix);
-  if (pit != c->wsarena.end()) { for (Arena& a : pit->second) (void)hipFree(a.base); c->wsarena.erase(pit); }
+  for (auto pit = c->wsarena.begin(); pit != c->wsarena.end();) {
+    if (pit->first.compare(0, pp.size(), pp) == 0) { for (Arena& a : pit->second) (void)hipFree(a.base); pit = c->wsarena.erase(pit); }
+    else ++pit;
+  }
+}
+
+// ---- use groups (dctts_ctx::grp): order this call behind the last call of the group that came from another stream; publish this call's end
+static int grp_acquire(dctts_ctx* c, int g, hipStream_t st) {
+  dctts_ctx::UseGroup& u = c->grp[g];
+  if (u.used && u.last != st) HIPCHK(hipStreamWaitEvent(st, u.done, 0));
+  return 0;
+}
+static int grp_release(dctts_ctx* c, int g, hipStream_t st) {
+  dctts_ctx::UseGroup& u = c->grp[g];
+  if (!u.done) HIPCHK(hipEventCreateWithFlags(&u.done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(u.done, st));
+  u.last = st; u.used = true;
+  return 0;
+}
+
+static size_t ws_cached_bytes(const dctts_ctx* c) {
+  size_t n = c->graveyard_bytes + (c->tail_ws_floats + c->cols_ws_floats) * sizeof(float);
+  for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
+  return n;
+}
+static void drop_decode_tables(dctts_ctx* c);
+// Called at the top of every entry point that uses workspaces: when the cached geometries have outgrown ws_limit, ALL of them are dropped behind one device
+// synchronisation (the only place left where a call waits for the GPU because of a shape change; dctts_set_workspace_limit).
+static int ws_trim(dctts_ctx* c) {
+  if (ws_cached_bytes(c) <= c->ws_limit) return 0;
+  HIPCHK(hipDeviceSynchronize());
+  drop_decode_tables(c);
+  free_ws(c);
+  for (void* p : c->graveyard) (void)hipFree(p);
+  c->graveyard.clear(); c->graveyard_bytes = 0;
+  if (c->tail_ws) { (void)hipFree(c->tail_ws); c->tail_ws = nullptr; c->tail_ws_floats = 0; }
+  if (c->cols_ws) { (void)hipFree(c->cols_ws); c->cols_ws = nullptr; c->cols_ws_floats = 0; }
+  return 0;
+}
+
+extern "C" int dctts_set_workspace_limit(dctts_ctx* c, size_t bytes) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  c->ws_limit = bytes;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ TextEnc
 static int textenc_into(dctts_ctx* c, const int32_t* L, int B, int N, View* kv_out, hipStream_t st) {
   const int D2 = 2 * c->cfg.d;
-  const std::string g = geom("te", B, N);
-  if (g != c->ws_geom_textenc) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "te."); c->ws_geom_textenc = g; }
+  ws_select(c, "te.", geom("te", B, N), st);
   View a, b, kv;
   CHK(ws_view(c, "te.a", B, PAD + N + PAD, PAD, D2, &a));
   CHK(ws_view(c, "te.b", B, PAD + N + PAD, PAD, D2, &b));
@@ -821,18 +892,20 @@ extern "C" int dctts_textenc_fwd(dctts_ctx* c, const int32_t* L, int B, int N, f
   CHK(check_ready(c, dev_guard));
   if (!L || !K || !V || B <= 0 || N <= 0) return fail(DCTTS_ERR_ARG, "textenc: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  CHK(ws_trim(c));
+  CHK(grp_acquire(c, dctts_ctx::GRP_TE, st));
   View kv;
   CHK(textenc_into(c, L, B, N, &kv, st));
   const int d = c->cfg.d;
   HIPCHK(hipMemcpy2DAsync(K, d * sizeof(float), kv.p, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
   HIPCHK(hipMemcpy2DAsync(V, d * sizeof(float), kv.p + d, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
-  return 0;
+  return grp_release(c, dctts_ctx::GRP_TE, st);
 }
 
 // ------------------------------------------------------------------------------------------------ AudioEnc / AudioDec (full sequence)
-static int t2m_ws(dctts_ctx* c, int B, int T, View* a, View* b) {
-  const std::string g = geom("t2m", B, T);
-  if (g != c->ws_geom_t2m) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "t2m."); c->ws_geom_t2m = g; }
+static int t2m_ws(dctts_ctx* c, int B, int T, View* a, View* b, hipStream_t st) {
+  ws_select(c, "t2m.", geom("t2m", B, T), st);
   CHK(ws_view(c, "t2m.a", B, PAD + T, PAD, c->cfg.d, a));
   CHK(ws_view(c, "t2m.b", B, PAD + T, PAD, c->cfg.d, b));
   return 0;
@@ -843,7 +916,10 @@ extern "C" int dctts_audioenc_fwd(dctts_ctx* c, const float* S, int B, int T, fl
   CHK(check_ready(c, dev_guard));
   if (!S || !Q || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audioenc: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  View a, b; CHK(t2m_ws(c, B, T, &a, &b));
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  CHK(ws_trim(c));
+  CHK(grp_acquire(c, dctts_ctx::GRP_T2M, st));
+  View a, b; CHK(t2m_ws(c, B, T, &a, &b, st));
   const RowMap rm{B, T, nullptr, nullptr};
   const View vin{const_cast<float*>(S), T, 0, c->cfg.n_mels}, vout{Q, T, 0, c->cfg.d};
   const size_t nl = c->audioenc.size();
@@ -853,7 +929,7 @@ extern "C" int dctts_audioenc_fwd(dctts_ctx* c, const float* S, int B, int T, fl
     CHK(run_conv(c, c->audioenc[i], cur, nullptr, o, rm, st));
     cur = nxt; View t = nxt; nxt = other; other = t;
   }
-  return 0;
+  return grp_release(c, dctts_ctx::GRP_T2M, st);
 }
 
 extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, float* logits, float* Y, void* stream) {
@@ -861,7 +937,10 @@ extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, fl
   CHK(check_ready(c, dev_guard));
   if (!R || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audiodec: bad argument");
   hipStream_t st = (hipStream_t)stream;
-  View a, b; CHK(t2m_ws(c, B, T, &a, &b));
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  CHK(ws_trim(c));
+  CHK(grp_acquire(c, dctts_ctx::GRP_T2M, st));
+  View a, b; CHK(t2m_ws(c, B, T, &a, &b, st));
   const RowMap rm{B, T, nullptr, nullptr};
   const View vin{const_cast<float*>(R), T, 0, 2 * c->cfg.d}, vout{Y, T, 0, c->cfg.n_mels}, vlog{logits, T, 0, c->cfg.n_mels};
   const size_t nl = c->audiodec.size();
@@ -871,7 +950,7 @@ extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, fl
     CHK(run_conv(c, c->audiodec[i], cur, nullptr, last ? vout : nxt, rm, st, 0, (last && logits) ? &vlog : nullptr));
     cur = nxt; View t = nxt; nxt = other; other = t;
   }
-  return 0;
+  return grp_release(c, dctts_ctx::GRP_T2M, st);
 }
 
 // ------------------------------------------------------------------------------------------------ Attention (full)
@@ -933,9 +1012,11 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
   CHK(check_ready(c, dev_guard));
   if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  CHK(ws_trim(c));
+  CHK(grp_acquire(c, dctts_ctx::GRP_SSRN, st));
   const int cc = c->cfg.c, F = c->cfg.n_linear, Fp = round_up(F, 32);
-  const std::string g = geom("ssrn", B, T);
-  if (g != c->ws_geom_ssrn) { (void)hipDeviceSynchronize(); drop_ws_prefix(c, "ssrn."); c->ws_geom_ssrn = g; }
+  ws_select(c, "ssrn.", geom("ssrn", B, T), st);
   View ws[10];
   CHK(ws_view(c, "ssrn.s1a", B, PAD + T + PAD, PAD, cc, &ws[0])); CHK(ws_view(c, "ssrn.s1b", B, PAD + T + PAD, PAD, cc, &ws[1]));
   CHK(ws_view(c, "ssrn.s2a", B, PAD + 2 * T + PAD, PAD, cc, &ws[2])); CHK(ws_view(c, "ssrn.s2b", B, PAD + 2 * T + PAD, PAD, cc, &ws[3]));
@@ -943,7 +1024,8 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
   CHK(ws_view(c, "ssrn.w4a", B, PAD + 4 * T + PAD, PAD, 2 * cc, &ws[6])); CHK(ws_view(c, "ssrn.w4b", B, PAD + 4 * T + PAD, PAD, 2 * cc, &ws[7]));
   CHK(ws_view(c, "ssrn.z4a", B, 4 * T, 0, Fp, &ws[8])); CHK(ws_view(c, "ssrn.z4b", B, 4 * T, 0, Fp, &ws[9]));
   const View vin{const_cast<float*>(Y), T, 0, c->cfg.n_mels}, vz{Z, 4L * T, 0, F}, vlog{logits, 4L * T, 0, F};
-  return ssrn_layers(c, ws, vin, vz, logits ? &vlog : nullptr, 0, B, T, st);
+  CHK(ssrn_layers(c, ws, vin, vz, logits ? &vlog : nullptr, 0, B, T, st));
+  return grp_release(c, dctts_ctx::GRP_SSRN, st);
 }
 
 // ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)
@@ -957,6 +1039,8 @@ extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const
   CHK(check_ready(c, dev_guard));
   if (!net || !X || !out || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "debug_layer: bad argument");
   hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  HIPCHK(hipDeviceSynchronize());           // a test hook: its scratch ("dbg.") is re-created per call, and run_conv may touch tail_ws / cols_ws of any group
   const std::string n(net);
   const std::vector<DevLayer>* V = n == "textenc" ? &c->textenc : n == "audioenc" ? &c->audioenc : n == "audiodec" ? &c->audiodec : n == "ssrn" ? &c->ssrn : nullptr;
   if (!V || index < 0 || index >= (int)V->size()) return fail(DCTTS_ERR_ARG, "debug_layer: unknown net / index");
@@ -968,6 +1052,7 @@ extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const
   }
   const int cin_real = (L.cin == round_up(c->cfg.n_linear, 32)) ? c->cfg.n_linear : L.cin;
   drop_ws_prefix(c, "dbg.");
+  ws_select(c, "dbg.", "", st);
   View vi;
   CHK(ws_view(c, "dbg.in", B, PAD + T + PAD, PAD, L.cin, &vi));
   for (int b = 0; b < B; ++b)

@@ -20,14 +20,8 @@ struct DecodeWs {
   View scal;                           // rowc1_kernel's per-row scalars, absolute time, stride 8
 };
 
-static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w) {
-  const std::string g = geom("dec", B, T, N);
-  if (g != c->ws_geom_dec) {
-    (void)hipDeviceSynchronize(); drop_ws_prefix(c, "dec."); c->ws_geom_dec = g;
-    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
-    destroy_graphs(c);
-  }
+static int decode_ws(dctts_ctx* c, int B, int N, int T, DecodeWs* w, hipStream_t st) {
+  ws_select(c, "dec.", geom("dec", B, T, N), st);      // (captured graphs are keyed by their own geometry strings and rebuilt where they are used)
   const int d = c->cfg.d, nm = c->cfg.n_mels;
   const long rows = PAD + T + 2;
   // ypad row (PAD + t) holds S[t] = Y[t-1]  (train.py:51); row PAD is the zero frame fed at t = 0
@@ -248,6 +242,28 @@ static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
   return 0;
 }
 
+// ---- the decode's device tables are cached per (kind, key): a key spells everything a table depends on (geometry, buffer addresses, flags), the buffers of a
+// geometry are stable (dctts_ctx::ws), so a geometry that comes back finds its tables again -- nothing is freed on a shape change (round 5; ws_trim drops all)
+static bool tab_lookup(dctts_ctx* c, const char* kind, const std::string& key, dctts_ctx::TabSlot* out) {
+  auto it = c->tabcache.find(std::string(kind) + "|" + key);
+  if (it == c->tabcache.end()) return false;
+  *out = it->second; return true;
+}
+static void tab_store(dctts_ctx* c, const char* kind, const std::string& key, void* tab, void* mem = nullptr, int n0 = 0) {
+  dctts_ctx::TabSlot s; s.tab = tab; s.mem = mem; s.n0 = n0;
+  c->tabcache[std::string(kind) + "|" + key] = s;
+}
+static void drop_decode_tables(dctts_ctx* c) {      // (the caller has synchronised the device)
+  for (auto& kv : c->tabcache) { if (kv.second.tab) (void)hipFree(kv.second.tab); if (kv.second.mem) (void)hipFree(kv.second.mem); }
+  c->tabcache.clear();
+  c->aepre_tab = c->mlp_tab = c->xmlp_tab = c->xtail_tab = c->xg_tab = c->xc_tab = nullptr; c->xg_mem = nullptr;
+  c->aepre_geom.clear(); c->mlp_geom.clear(); c->xmlp_geom.clear(); c->xtail_geom.clear(); c->xg_geom.clear(); c->xc_geom.clear();
+  if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+  if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+  c->graph_geom.clear();
+  destroy_graphs(c);
+}
+
 // ------------------------------------------------------------------------------------------------ decode v3: hoisted taps (decode3_kernels.h)
 // chain piece j (j = -1 .. T-1), caller's stream:
 //     AudioDec HC_2 .. C_11 of frame j  [j >= 0; needs bulk piece j]
@@ -259,6 +275,7 @@ static int capture_piece(hipStream_t cs, hipGraphExec_t* out, F&& body) {
 static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahead) {
   const std::string g = std::to_string(B) + ":" + std::to_string((int)c1qw_ahead) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p);
   if (c->aepre_tab && c->aepre_geom == g) return 0;
+  { dctts_ctx::TabSlot ts; if (tab_lookup(c, "aepre", g, &ts)) { c->aepre_tab = ts.tab; c->aepre_layers = ts.n0; c->aepre_geom = g; return 0; } }
   std::vector<SplitParams> tab;
   const std::vector<DevLayer>& AP = c->ae_p;
   for (int par = 0; par < 2; ++par)
@@ -289,11 +306,11 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahea
       }
     }
   if (tab.empty()) return fail(DCTTS_ERR_STATE, "v3: no causal k=3 AudioEnc layers");
-  (void)hipDeviceSynchronize();
-  if (c->aepre_tab) (void)hipFree(c->aepre_tab);
+  c->aepre_tab = nullptr;
   HIPCHK(hipMalloc(&c->aepre_tab, tab.size() * sizeof(SplitParams)));
   HIPCHK(hipMemcpy(c->aepre_tab, tab.data(), tab.size() * sizeof(SplitParams), hipMemcpyHostToDevice));
   c->aepre_layers = (int)tab.size() / 2; c->aepre_geom = g;
+  tab_store(c, "aepre", g, c->aepre_tab, nullptr, c->aepre_layers);
   return 0;
 }
 
@@ -493,9 +510,8 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
                         std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((int)c->ae_pass_split) + ":" + std::to_string(c->trace_frame) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string((int)c->dec_merge) + ":" + std::to_string((int)c->attn_fold) + ":" +
                         std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.c1q.p) + ":" + std::to_string((size_t)w.pm_all);
   if (c->xg_tab && c->xg_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->xg_tab) { (void)hipFree(c->xg_tab); c->xg_tab = nullptr; }
-  if (c->xg_mem) { (void)hipFree(c->xg_mem); c->xg_mem = nullptr; }
+  { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xg", g, &ts)) { c->xg_tab = ts.tab; c->xg_mem = (float*)ts.mem; c->xg_T = ts.n0; c->xg_geom = g; return 0; } }
+  c->xg_tab = nullptr; c->xg_mem = nullptr;
   HIPCHK(hipMalloc((void**)&c->xg_mem, xg_mem_floats(B) * sizeof(float)));
   HIPCHK(hipMemset(c->xg_mem, 0, xg_mem_floats(B) * sizeof(float)));
   const XgMem m = xg_mem(c, B);
@@ -581,6 +597,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
   HIPCHK(hipMalloc(&c->xg_tab, tab.size() * sizeof(XGroupParams)));
   HIPCHK(hipMemcpy(c->xg_tab, tab.data(), tab.size() * sizeof(XGroupParams), hipMemcpyHostToDevice));
   c->xg_geom = g; c->xg_T = T;
+  tab_store(c, "xg", g, c->xg_tab, c->xg_mem, T);
   return 0;
 }
 
@@ -608,8 +625,8 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
 static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig) {
   const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on);
   if (c->xc_tab && c->xc_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->xc_tab) { (void)hipFree(c->xc_tab); c->xc_tab = nullptr; }
+  { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xc", g, &ts)) { c->xc_tab = ts.tab; c->xc_geom = g; return 0; } }
+  c->xc_tab = nullptr;
   const std::vector<DevLayer>& AD = c->audiodec;
   const XgMem m = xg_mem(c, B);
   size_t i0 = 2, i1 = i0; while (i1 < AD.size() && AD[i1].hc) ++i1;     // HC_3 .. the last highway layer
@@ -649,6 +666,7 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   HIPCHK(hipMalloc(&c->xc_tab, tab.size() * sizeof(XConeParams)));
   HIPCHK(hipMemcpy(c->xc_tab, tab.data(), tab.size() * sizeof(XConeParams), hipMemcpyHostToDevice));
   c->xc_geom = g;
+  tab_store(c, "xc", g, c->xc_tab);
   return 0;
 }
 
@@ -656,8 +674,8 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
 static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   const std::string g = geom("mlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]);
   if (c->mlp_tab && c->mlp_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->mlp_tab) { (void)hipFree(c->mlp_tab); c->mlp_tab = nullptr; }
+  { dctts_ctx::TabSlot ts; if (tab_lookup(c, "mlp", g, &ts)) { c->mlp_tab = ts.tab; c->mlp_geom = g; return 0; } }
+  c->mlp_tab = nullptr;
   const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
   size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;          // last highway layer of AudioDec (HC_7)
   size_t nh = 0; while (nh < AE.size() && !AE[nh].hc) ++nh;                             // AudioEnc k=1 head (C_1..C_3)
@@ -686,6 +704,7 @@ static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   HIPCHK(hipMalloc(&c->mlp_tab, tab.size() * sizeof(MlpRowsParams)));
   HIPCHK(hipMemcpy(c->mlp_tab, tab.data(), tab.size() * sizeof(MlpRowsParams), hipMemcpyHostToDevice));
   c->mlp_geom = g;
+  tab_store(c, "mlp", g, c->mlp_tab);
   return 0;
 }
 
@@ -728,8 +747,8 @@ static int fill_xmlp(dctts_ctx* c, const DecodeWs& w, int B, int T, int j, size_
 static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   const std::string g = geom("xmlp", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem);
   if (c->xmlp_tab && c->xmlp_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->xmlp_tab) { (void)hipFree(c->xmlp_tab); c->xmlp_tab = nullptr; }
+  { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xmlp", g, &ts)) { c->xmlp_tab = ts.tab; c->xmlp_geom = g; return 0; } }
+  c->xmlp_tab = nullptr;
   const std::vector<DevLayer>& AD = c->ad_c;
   size_t lh = 0; for (size_t i = 0; i < AD.size(); ++i) if (AD[i].hc) lh = i;
   const XgMem m = xg_mem(c, B);
@@ -738,6 +757,7 @@ static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   HIPCHK(hipMalloc(&c->xmlp_tab, tab.size() * sizeof(XMlpParams)));
   HIPCHK(hipMemcpy(c->xmlp_tab, tab.data(), tab.size() * sizeof(XMlpParams), hipMemcpyHostToDevice));
   c->xmlp_geom = g;
+  tab_store(c, "xmlp", g, c->xmlp_tab);
   return 0;
 }
 
@@ -746,8 +766,8 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   const std::string g = geom("xtail", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string(c->trace_frame) + ":" +
                         std::to_string((int)c->dec_merge) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.pb3[1]);
   if (c->xtail_tab && c->xtail_geom == g) return 0;
-  (void)hipDeviceSynchronize();
-  if (c->xtail_tab) { (void)hipFree(c->xtail_tab); c->xtail_tab = nullptr; }
+  { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xtail", g, &ts)) { c->xtail_tab = ts.tab; c->xtail_geom = g; return 0; } }
+  c->xtail_tab = nullptr;
   const std::vector<DevLayer>& AD = c->audiodec;                         // (the full layers: all three taps in wp16)
   const size_t h0 = 4;                                                   // C_1, HC_2, HC_3, HC_4 | HC_5, HC_6, HC_7 | C_8 ..
   for (size_t k = 0; k < 3; ++k) {
@@ -817,6 +837,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   HIPCHK(hipMalloc(&c->xtail_tab, tab.size() * sizeof(XTailParams)));
   HIPCHK(hipMemcpy(c->xtail_tab, tab.data(), tab.size() * sizeof(XTailParams), hipMemcpyHostToDevice));
   c->xtail_geom = g;
+  tab_store(c, "xtail", g, c->xtail_tab);
   return 0;
 }
 
@@ -1057,6 +1078,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
     const std::string g = geom("graph3", B, T, N) + ":" + std::to_string(c->bulk_cap) + ":" + std::to_string((size_t)c->mlp_tab) + ":" + std::to_string((int)cwait) + ":" + std::to_string((int)vs) + ":" + std::to_string((int)c->xg_on) + ":" + std::to_string((int)c->xc_on) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((int)c->side_pre) + ":" + std::to_string((size_t)c->xc_tab) + ":" + std::to_string((size_t)c->wait_ctr) + ":" +
                           std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw);
     if (c->bulk3_g.empty() || c->graphs3_geom != g) {
+      if (!c->bulk3_g.empty()) HIPCHK(hipDeviceSynchronize());      // (an earlier decode's graphs may still be running on another stream)
       destroy_graphs(c);
       hipStream_t cs;
       HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -1144,9 +1166,15 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
 // other until the bounded waits give up (a resource deadlock).  Inside a process they are serialised here: a decode waits for the
 // completion event of the last decode another context enqueued on the device.  (Another PROCESS on the same GPU cannot be seen from here: there the bounded
 // waits, the poisoned outputs and dctts_decode_status are the protection, and dc_tts_amd.Engine repeats the decode with one launch per layer.)
-struct DeviceLease { hipEvent_t done = nullptr; const dctts_ctx* owner = nullptr; };
-static std::mutex g_lease_mu;
+struct DeviceLease { std::mutex mu; hipEvent_t done = nullptr; const dctts_ctx* owner = nullptr; };
+static std::mutex g_lease_mu;                    // guards the map only; a device's lease has its own mutex, held across the whole ENQUEUE of a decode (decode_impl)
 static std::map<int, DeviceLease> g_lease;
+static DeviceLease& lease_of(int device) { std::lock_guard<std::mutex> lk(g_lease_mu); return g_lease[device]; }
+static void lease_forget(const dctts_ctx* c) {   // dctts_destroy: the next context allocated at this address must not be taken for the lease's owner
+  DeviceLease& ls = lease_of(c->device);
+  std::lock_guard<std::mutex> lk(ls.mu);
+  if (ls.owner == c) ls.owner = nullptr;
+}
 
 static int decode_status_init(dctts_ctx* c) {
   if (c->dstat) return 0;
@@ -1169,14 +1197,25 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     if (ew & (2 | 8)) c->xgroup_ok = false;
     return fail(DCTTS_ERR_STATE, "decode: an EARLIER decode on this context failed on the device (error word " + std::to_string(ew) + ") and dctts_decode_status was not consulted; its outputs were poisoned (NaN / -1)");
   }
-  {
-    std::lock_guard<std::mutex> lk(g_lease_mu);
-    DeviceLease& ls = g_lease[c->device];
-    if (ls.done && ls.owner != c) HIPCHK(hipStreamWaitEvent(st, ls.done, 0));
-  }
+  // Two host threads decoding on two contexts of one device must not both see the old lease and enqueue overlapping decodes: the device's lease is held from here to the
+  // event record behind this decode's last launch (enqueue only: ~10 ms of host time, nothing waits for the GPU under it).
+  DeviceLease& ls = lease_of(c->device);
+  std::lock_guard<std::mutex> lease_lk(ls.mu);
+  if (ls.done && ls.owner != c) HIPCHK(hipStreamWaitEvent(st, ls.done, 0));
+  // ... and decodes / TextEnc calls of THIS context from other streams (use groups; K / V of this decode live in TextEnc's output buffer until it ends)
+  CHK(grp_acquire(c, dctts_ctx::GRP_TE, st));
+  CHK(grp_acquire(c, dctts_ctx::GRP_DEC, st));
   c->fin_xerr = nullptr; c->fin_werr = nullptr;
+  // dctts_decode_safe_once: THIS decode runs one launch per layer and meets the side stream through stream operations (no team kernel, no bounded in-kernel wait:
+  // nothing in it can time out when the GPU is shared) -- the persistent settings (dctts_set_team_kernels, DCTTS_XGROUP / DCTTS_XCONE / DCTTS_CHAIN_WAIT,
+  // a switch-off by dctts_decode_status) are left exactly as they were
+  struct SafeOnce {
+    dctts_ctx* c; bool on; int xg, xc, cw;
+    explicit SafeOnce(dctts_ctx* c_) : c(c_), on(c_->safe_once), xg(c_->xgroup), xc(c_->xcone), cw(c_->chain_wait_inkernel) { c->safe_once = false; if (on) { c->xgroup = 0; c->xcone = 0; c->chain_wait_inkernel = 0; } }
+    ~SafeOnce() { if (on) { c->xgroup = xg; c->xcone = xc; c->chain_wait_inkernel = cw; } }
+  } safe_once(c);
   DecodeWs w;
-  CHK(decode_ws(c, B, N, T, &w));
+  CHK(decode_ws(c, B, N, T, &w, st));
   const bool v3 = (c->decode_mode == 3);
   if (!v3) { w.rbuf.set = 0; for (auto& v : w.ad) v.set = 0; }            // the simple form uses one copy of every buffer
   CHK(textenc_into(c, L, B, N, &w.kv, st));
@@ -1210,7 +1249,7 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   } else if (c->use_graph) {
     const std::string g = geom("graph1", B, T, N) + ":" + std::to_string((size_t)w.kv.p);   // the captured launches bake in the TextEnc output pointer
     if (!c->graph_exec || c->graph_geom != g) {
-      if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+      if (c->graph_exec) { HIPCHK(hipDeviceSynchronize()); (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
       if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
       hipStream_t cs;
       HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -1256,20 +1295,19 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
                      (long long*)maxatt, (long)B * T, alignments, (long)B * N * T);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->dstat_host, c->dstat, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  {
-    std::lock_guard<std::mutex> lk(g_lease_mu);
-    DeviceLease& ls = g_lease[c->device];
-    if (!ls.done) HIPCHK(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ls.done, st));
-    ls.owner = c;
-  }
-  return 0;
+  if (!ls.done) HIPCHK(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
+  HIPCHK(hipEventRecord(ls.done, st));
+  ls.owner = c;
+  CHK(grp_release(c, dctts_ctx::GRP_DEC, st));
+  return grp_release(c, dctts_ctx::GRP_TE, st);
 }
 
 extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, float* alignments, void* stream) {
   DevGuard dev_guard(c);
   CHK(check_ready(c, dev_guard));
   if (!L || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "decode: bad argument");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  CHK(ws_trim(c));
   return decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream);
 }
 
@@ -1277,6 +1315,8 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
   DevGuard dev_guard(c);
   CHK(check_ready(c, dev_guard));
   if (!L || !Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "synthesize: bad argument");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  CHK(ws_trim(c));
   CHK(decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream));
   CHK(dctts_ssrn_fwd(c, Y, B, T, nullptr, Z, stream));                    // synthesize.py:57
   // SSRN's ReLU layers turn a poisoned (NaN) mel back into finite numbers: Z of a failed decode is poisoned explicitly
@@ -1287,6 +1327,7 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
 
 extern "C" int dctts_decode_status(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   if (c->dstat_host && c->dstat_host[0]) {                  // reported once, then cleared on both sides so that the next decode starts clean
     DevGuard dev_guard(c);
     const int ew = c->dstat_host[0], nfail = c->dstat_host[1];
@@ -1306,8 +1347,22 @@ extern "C" int dctts_decode_status(dctts_ctx* c) {
 
 extern "C" int dctts_set_team_kernels(dctts_ctx* c, int enable) {
   if (!c || enable < 0 || enable > 1) return fail(DCTTS_ERR_ARG, "team kernels: 0 or 1");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   c->xgroup = enable; c->xcone = enable;
   if (enable) { c->xgroup_ok = true; c->team_fail_streak = 0; }
+  return 0;
+}
+
+extern "C" int dctts_debug_team_kernels_state(dctts_ctx* c) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  return (c->xgroup ? 1 : 0) | (c->xcone ? 2 : 0) | (c->xgroup_ok ? 4 : 0);
+}
+
+extern "C" int dctts_decode_safe_once(dctts_ctx* c) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  c->safe_once = true;
   return 0;
 }
 
@@ -1319,6 +1374,7 @@ extern "C" int dctts_debug_inject_decode_error(dctts_ctx* c, int bits) {
 
 extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
   if (!c || enable < 0 || enable > 1) return fail(DCTTS_ERR_ARG, "decode graph mode must be 0 or 1");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   c->use_graph = enable;
   return 0;
 }

@@ -104,6 +104,10 @@ class Engine:
     def device_bytes(self) -> int:
         return int(self.lib.dctts_device_bytes(self._h))
 
+    def set_workspace_limit(self, nbytes: int):
+        """Workspaces are cached per batch geometry and only grow; past this many bytes the next call drops the cache (one device sync)."""
+        self._ok(self.lib.dctts_set_workspace_limit(self._h, int(nbytes)))
+
     def prof_enable(self, kernel_id: int):
         self._ok(self.lib.dctts_prof_enable(self._h, int(kernel_id)))
 
@@ -188,8 +192,10 @@ class Engine:
     # ------------------------------------------------------------------ synthesize.py:45-57
     def _decode(self, call, check: bool):
         """Enqueue a decode; with check=True behave like the reference's `sess.run`: wait for it, and if it failed on the device (a bounded
-        in-launch wait gave up: the GPU is shared with somebody else's kernels) repeat it ONCE with one launch per layer, which cannot fail
-        that way.  Without check the call returns at once; a failed decode's outputs are NaN / -1 and `synchronize()` raises."""
+        in-launch wait gave up: the GPU is shared with somebody else's kernels) repeat it ONCE in the safe form (dctts_decode_safe_once: one
+        launch per layer, the streams meet through stream operations -- nothing in it is bounded, so it cannot time out).  The context's
+        persistent settings (set_team_kernels, a switch-off by decode_status) are not touched by the retry.  Without check the call returns
+        at once; a failed decode's outputs are NaN / -1 and `synchronize()` raises."""
         call()
         if not check:
             return
@@ -197,18 +203,19 @@ class Engine:
         if self.lib.dctts_decode_status(self._h) == 0:
             return
         first = _lib.last_error()
-        self._ok(self.lib.dctts_set_team_kernels(self._h, 0))
-        try:
-            call()
-            torch.cuda.current_stream(self.device).synchronize()
-            if self.lib.dctts_decode_status(self._h) != 0:
-                raise DcttsError(f"decode failed twice: {first} / {_lib.last_error()}")
-        finally:
-            self._ok(self.lib.dctts_set_team_kernels(self._h, 1))
+        self._ok(self.lib.dctts_decode_safe_once(self._h))
+        call()
+        torch.cuda.current_stream(self.device).synchronize()
+        if self.lib.dctts_decode_status(self._h) != 0:
+            raise DcttsError(f"decode failed twice: {first} / {_lib.last_error()}")
 
     def set_team_kernels(self, enable: bool):
         """True (default): runs of dependent decode layers as one launch (xgroup / xcone kernels); False: one launch per layer."""
         self._ok(self.lib.dctts_set_team_kernels(self._h, int(bool(enable))))
+
+    def debug_team_kernels_state(self) -> int:
+        """Test hook (dctts_hip_debug.h): bits 1 / 2 = xgroup / xcone requested, 4 = not switched off by a failed status report."""
+        return int(self.lib.dctts_debug_team_kernels_state(self._h))
 
     def debug_inject_decode_error(self, bits: int = 1):
         """Test hook (dctts_hip_debug.h): the next decode reports a failure and poisons its outputs."""

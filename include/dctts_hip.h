@@ -11,7 +11,14 @@
  *   - tensors are channel-last, contiguous: (B, time, C) float32; ids/indices int32 in,
  *     max_attentions int64 out (tf.argmax default), exactly as the reference graph;
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are stream-ordered
- *     and never synchronise the device, except where noted (weight upload, workspace growth);
+ *     and never synchronise the device, except where noted (weight upload; dropping the workspace
+ *     cache once it outgrows dctts_set_workspace_limit);
+ *   - streams and threads (round 5): any entry point may be called from any stream and any host thread.
+ *     Calls of one context that share scratch memory are ORDERED on the device whatever streams they come
+ *     from -- TextEnc calls with each other and with decodes, decodes with each other, SSRN calls with each
+ *     other (a later call waits for the earlier one's completion event) -- so results never depend on what
+ *     else is in flight; calls of DIFFERENT kinds on different streams overlap (SSRN of batch n beside the
+ *     decode of batch n + 1).  The host side of a context is serialised by a mutex (enqueue only);
  *   - return value 0 = ok, negative = dctts_status; nothing throws across the ABI;
  *   - only training=False (inference) semantics exist: dropout (modules.py:139,195,245) is identity.
  */
@@ -46,7 +53,7 @@ typedef struct {
   int attention_win_size; /* 3 */
 } dctts_config;
 
-/* Lifetime.  One context per (process, GPU); re-entrant per context. */
+/* Lifetime.  One context per (process, GPU); thread-safe per context (see "streams and threads" above). */
 int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg);
 int dctts_destroy(dctts_ctx* ctx);
 const char* dctts_last_error(void);
@@ -98,8 +105,14 @@ int dctts_synthesize(dctts_ctx* ctx, const int32_t* L, int B, int N, int T, floa
  * failed since the previous call (the message has the count and the error bits) and clears the word; a failure nobody asked
  * about makes the next decode call on the context fail instead of running.  Time-outs leave the team kernels on (three failed
  * reports in a row switch them off); a misplaced team switches them off for good.  dc_tts_amd.Engine.synchronize() calls this;
- * Engine.text2mel / synthesize(check=True) also repeat a failed decode once with one launch per layer. */
+ * Engine.text2mel / synthesize(check=True) also repeat a failed decode once in the safe form (dctts_decode_safe_once). */
 int dctts_decode_status(dctts_ctx* ctx);
+
+/* The NEXT decode on this context (only that one) runs in the form that cannot time out: one launch per layer, and the two
+ * decode streams meet through stream wait / write operations instead of bounded in-kernel waits (~1.5x the frame time).  The
+ * persistent settings -- dctts_set_team_kernels, a switch-off by dctts_decode_status -- are left exactly as they were.  This is
+ * what a caller does after dctts_decode_status reported a failed decode (the GPU is shared with somebody else's kernels). */
+int dctts_decode_safe_once(dctts_ctx* ctx);
 
 /* 1 (default): runs of dependent layers of a decode frame are ONE launch whose workgroups meet inside an XCD's L2
  * (csrc/xgroup_kernel.h, xcone_kernel.h); 0: one launch per layer (no hand-offs between the workgroups of a launch; ~1.3x the frame time). */
@@ -122,6 +135,12 @@ int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
 
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
 size_t dctts_device_bytes(const dctts_ctx* ctx);
+
+/* Workspaces and the decode's device tables are cached per geometry (B, T, N) and only grow: a serving loop that alternates
+ * between batch shapes pays an allocation the first time a shape is seen and nothing afterwards (no hipDeviceSynchronize, no
+ * hipFree on a shape change).  When the cached workspaces exceed `bytes` (default 96 GiB of the 288 GB) the next call drops
+ * all of them behind ONE device synchronisation and starts again. */
+int dctts_set_workspace_limit(dctts_ctx* ctx, size_t bytes);
 
 /* Test / measurement hooks (per-layer test entry, calibration copy, kernel timing) are declared in
  * dctts_hip_debug.h: they are not part of the drop-in surface. */

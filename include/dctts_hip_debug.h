@@ -27,6 +27,10 @@ int dctts_debug_seed_prev_max(dctts_ctx* ctx, const int32_t* prev_max, int B);
  * poisoned and the sticky status is raised exactly as for a real time-out; the decode itself runs normally.  bits = 0 withdraws the injection. */
 int dctts_debug_inject_decode_error(dctts_ctx* ctx, int bits);
 
+/* Test hook: the context's PERSISTENT team-kernel settings as bits: 1 = xgroup requested, 2 = xcone requested, 4 = still allowed (not switched off by
+ * dctts_decode_status).  A checked decode's safe retry (dctts_decode_safe_once) must leave this word exactly as it found it. */
+int dctts_debug_team_kernels_state(dctts_ctx* ctx);
+
 /* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
 int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
 

@@ -91,7 +91,7 @@ def reference(float_dtype=np.float32, **hp_overrides):
                 sys.modules.pop(n, None)
             else:
                 sys.modules[n] = m
-        for n in ["tensorflow.nn", "tensorflow.layers", "tensorflow.contrib", "tensorflow.contrib.layers", "tensorflow.train"] + stubs:
+        for n in ["tensorflow.nn", "tensorflow.layers", "tensorflow.contrib", "tensorflow.contrib.layers", "tensorflow.train", "tensorflow.summary"] + stubs:
             sys.modules.pop(n, None)
         tf_shim.set_float(np.float32)
 
@@ -158,3 +158,26 @@ def run_synthesize(weights, test_data=None, float_dtype=np.float32, vocoder=Fals
                    restored=list(tf_shim.RESTORED), variables=requested_variables(ref))
         del tf_shim.RUN_LOG[:]
     return out
+
+
+def build_training_graph(ref, num, weights, global_step=0):
+    """`g = Graph(num=num)` -- i.e. mode="train", train.py:139 -- built by the reference's own constructor, with ONE substitution: the input queue
+    `get_batch()` (train.py:39: TF reader threads over the LJ Speech files, out of scope) is replaced by placeholders of the same dtypes and
+    static shapes (data_load.py:117-131).  Everything behind it -- the decoder-input shift, the four networks with training=True, the five losses,
+    the guided-attention constant, the Noam schedule, the optimizer wiring, the summaries -- runs as written.  Variables come from `weights`
+    (Text2Mel or SSRN scope, whichever Graph(num) creates) and `gs/global_step`.  Returns (g, sess, feeds) with feeds = (L, mels, mags)."""
+    tf = ref.tf
+    hp = ref.hp
+    L = tf.placeholder(tf.int32, shape=(hp.B, None))
+    mels = tf.placeholder(tf.float32, shape=(hp.B, None, hp.n_mels))
+    mags = tf.placeholder(tf.float32, shape=(hp.B, None, hp.n_fft // 2 + 1))
+    fnames = tf.placeholder(tf.string, shape=(hp.B,))
+    ref.train.get_batch = lambda: (L, mels, mags, fnames, 1)
+    g = ref.train.Graph(num=num)
+    sess = tf.Session()
+    sess.run(tf.global_variables_initializer())
+    src = dict(weights)
+    src["gs/global_step"] = np.int32(global_step)
+    tf.register_checkpoint("shim-train", src)
+    tf.train.Saver().restore(sess, tf.train.latest_checkpoint("shim-train"))      # every variable Graph(num) created: the Supervisor's restore (train.py:142)
+    return g, sess, (L, mels, mags)

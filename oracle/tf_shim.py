@@ -12,8 +12,13 @@ So: **the reference's structure is pinned, TensorFlow's kernels are still a rest
 
 Only tests/, tests/golden/make_golden_from_reference.py and oracle/run_reference.py import this.
 
-Scope: every symbol reachable from `Graph(mode="synthesize")` and `synthesize()`; training-only symbols (`tf.summary`,
-optimizers, input queues) raise `NotImplementedError` when called.
+Scope: every symbol reachable from `Graph(mode="synthesize")` and `synthesize()`, and (round 5) from `Graph(num, mode="train")` up to
+the losses and the learning rate (`train.py:82-116`, `utils.py:134-145`): `sigmoid_cross_entropy_with_logits`, `pad(constant_values)`,
+`minimum`, `**`, `clip_by_value`, inert `tf.summary.*`, and an `AdamOptimizer` whose `compute_gradients` / `apply_gradients` build nodes that
+REFUSE to be evaluated (TensorFlow's autodiff and Adam kernel are not restated here: `oracle/train_ref.py`'s gradients are pinned by finite
+differences THROUGH this graph's loss, tests/test_reference_pin.py).  The input queue (`data_load.get_batch`) still raises: the training pin
+replaces it by placeholders.  `DROPOUT_HOOK` lets a test decide what `tf.layers.dropout(training=True)` does (TF's random stream cannot be
+reproduced): it is called at graph construction with (variable scope, rate) and returns the mask function applied at run time.
 
 Graph model: a `Tensor` is a lazy node (function + inputs + static shape + dtype).  `Session.run(fetches, feed_dict)` evaluates
 the ancestors of the fetches iteratively; a fed tensor (placeholder or not: `synthesize.py:57` feeds `g.Y`) cuts the graph.
@@ -53,7 +58,7 @@ string = DType("string")
 
 def _np(dt):
     if isinstance(dt, DType):
-        return {"float32": FLOAT, "float64": np.float64, "int32": np.int32, "int64": np.int64, "bool": np.bool_}[dt.name]
+        return {"float32": FLOAT, "float64": np.float64, "int32": np.int32, "int64": np.int64, "bool": np.bool_, "string": np.object_}[dt.name]
     return np.dtype(dt).type
 
 
@@ -74,6 +79,8 @@ def reset_default_graph():
     global _G
     _G = _Graph()
     del RUN_LOG[:]
+    del DROPOUT_CALLS[:]
+    del SUMMARIES[:]
 
 
 def get_default_graph():
@@ -189,6 +196,9 @@ class Tensor:
 
     def __neg__(self):
         return Tensor(lambda x: -x, [self], self.shape_, self.dtype, "neg")
+
+    def __pow__(self, o):
+        return _binary(np.power, self, o)
 
     def __getitem__(self, idx):
         if not isinstance(idx, tuple):
@@ -512,6 +522,18 @@ def abs(t, name=None):                                                          
     return Tensor(np.abs, [t], t.shape_, t.dtype, "Abs")
 
 
+def minimum(a, b, name=None):
+    return _binary(np.minimum, a, b)
+
+
+def maximum(a, b, name=None):
+    return _binary(np.maximum, a, b)
+
+
+def clip_by_value(t, clip_value_min, clip_value_max, name=None):
+    return Tensor(lambda x: np.clip(x, clip_value_min, clip_value_max), [t], t.shape_, t.dtype, "clip_by_value")
+
+
 # ----------------------------------------------------------------------------------------------- tf.nn
 def _sigmoid(x, name=None):
     one = None
@@ -558,8 +580,16 @@ def _batch_normalization(x, mean, variance, offset, scale, variance_epsilon):
     return Tensor(f, [x, mean, variance, offset, scale], x.shape_, x.dtype, "batchnorm")
 
 
-def _sigmoid_cross_entropy_with_logits(labels=None, logits=None):
-    raise NotImplementedError("training-only symbol (train.py:88,108); the synthesis path never builds it")
+def _sigmoid_cross_entropy_with_logits(_sentinel=None, labels=None, logits=None, name=None):
+    """tf.nn.sigmoid_cross_entropy_with_logits, the documented stable form:  max(x, 0) - x * z + log(1 + exp(-abs(x)))  (train.py:90,108)."""
+    if _sentinel is not None:
+        raise ValueError("Only call `sigmoid_cross_entropy_with_logits` with named arguments (labels=..., logits=...)")
+
+    def f(x, z):
+        if x.shape != z.shape:
+            raise ValueError("logits and labels must have the same shape (%s vs %s)" % (x.shape, z.shape))
+        return np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))
+    return Tensor(f, [logits, labels], logits.shape_, logits.dtype, "logistic_loss")
 
 
 nn = types.ModuleType("tensorflow.nn")
@@ -662,12 +692,17 @@ def _conv2d_transpose(inputs, filters, kernel_size, strides=(1, 1), padding="val
 
 
 _DROPOUT_RNG = np.random.default_rng(0)
+DROPOUT_HOOK = None         # test hook: f(variable scope at the call, rate) -> (x -> dropped x); None: a numpy random mask
+DROPOUT_CALLS = []          # (variable scope, rate, training) of every tf.layers.dropout call, in graph-construction order
 
 
 def _dropout(inputs, rate=0.5, noise_shape=None, seed=None, training=False, name=None):
     """tf.layers.dropout: identity unless training; then keep with probability 1 - rate and scale by 1 / (1 - rate)."""
+    DROPOUT_CALLS.append((_scope_name(), rate, bool(training)))
     if not training or rate == 0:
         return Tensor(lambda x: x, [inputs], inputs.shape_, inputs.dtype, "dropout_identity")
+    if DROPOUT_HOOK is not None:
+        return Tensor(DROPOUT_HOOK(_scope_name(), rate), [inputs], inputs.shape_, inputs.dtype, "dropout_hook")
 
     def f(x):
         keep = _DROPOUT_RNG.random(x.shape) >= rate
@@ -799,12 +834,38 @@ class _Saver:
         _not_on_synthesis_path()
 
 
+def _refuses(what):
+    def f(*a):
+        raise NotImplementedError(what + ": TensorFlow's autodiff / optimizer kernels are not restated by the shim")
+    return f
+
+
+class _AdamOptimizer:
+    """tf.train.AdamOptimizer as train.py:115-125 BUILDS it: `compute_gradients(loss)` yields one (gradient, variable) pair per trainable variable,
+    `apply_gradients` one op.  The nodes exist (the reference's graph construction runs to its last line) and refuse evaluation."""
+
+    def __init__(self, learning_rate=0.001, beta1=0.9, beta2=0.999, epsilon=1e-8, **k):
+        self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+
+    def compute_gradients(self, loss, var_list=None):
+        vs = list(_G.trainable) if var_list is None else list(var_list)
+        return [(Tensor(_refuses("gradient of the loss w.r.t. " + v.op_name), [loss, v], v.shape_, v.dtype, "gradients"), v) for v in vs]
+
+    def apply_gradients(self, grads_and_vars, global_step=None, name=None):
+        gv = list(grads_and_vars)
+        return Tensor(_refuses("train_op"), [g for g, _ in gv], [], None, "Adam")
+
+
 train = types.ModuleType("tensorflow.train")
 train.Saver, train.latest_checkpoint = _Saver, _latest_checkpoint
-train.AdamOptimizer = train.Supervisor = train.slice_input_producer = _not_on_synthesis_path
+train.AdamOptimizer = _AdamOptimizer
+train.Supervisor = train.slice_input_producer = _not_on_synthesis_path
+SUMMARIES = []              # (kind, tag) of every tf.summary.* call: inert, but the reference's list of what it reports is visible to a test
 summary = types.ModuleType("tensorflow.summary")
-summary.scalar = summary.image = summary.merge_all = _not_on_synthesis_path
-decode_raw = py_func = clip_by_value = device = _not_on_synthesis_path
+summary.scalar = lambda tag, t, *a, **k: SUMMARIES.append(("scalar", tag))
+summary.image = lambda tag, t, *a, **k: SUMMARIES.append(("image", tag))
+summary.merge_all = lambda *a, **k: list(SUMMARIES)
+decode_raw = py_func = device = _not_on_synthesis_path
 
 
 # ----------------------------------------------------------------------------------------------- installation
@@ -814,7 +875,7 @@ def install():
     me = sys.modules[__name__]
     installed = []
     for name, mod in (("tensorflow", me), ("tensorflow.nn", nn), ("tensorflow.layers", layers), ("tensorflow.contrib", contrib),
-                      ("tensorflow.contrib.layers", contrib.layers), ("tensorflow.train", train)):
+                      ("tensorflow.contrib.layers", contrib.layers), ("tensorflow.train", train), ("tensorflow.summary", summary)):
         sys.modules[name] = mod
         installed.append(name)
     if "matplotlib" not in sys.modules:

@@ -348,11 +348,9 @@ def adam_step(var, grad, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
 
 
 # ----------------------------------------------------------------------------- train.py:26-134, one training step
-def train_step(num, W, m, v, global_step, batch, hp, dropout_seed=None):
-    """One `sess.run(g.train_op)` of train.py for Graph(num): forward, losses, gradients of every variable of the network being
-    trained, clip + Adam with the Noam learning rate.  W / m / v: {TF variable name: float64 array}, updated in place.
-    batch: num == 1: (L ids (B, N), mels (B, T, n_mels));  num == 2: (mels (B, T, n_mels), mags (B, 4T, n_linear)).
-    Returns the losses (loss_mels, loss_bd1, loss_att) or (loss_mags, loss_bd2)."""
+def train_grads(num, W, global_step, batch, hp, dropout_seed=None):
+    """Forward pass, losses and `optimizer.compute_gradients(loss)` (train.py:119, before the clip) of Graph(num) on one batch:
+    returns (losses, {TF variable name: d loss / d variable}).  batch: see train_step."""
     grads = {}
     drop = None if dropout_seed is None else (hp.dropout_rate, dropout_seed, global_step)      # training=True (train.py:55-72)
     if num == 1:
@@ -378,6 +376,15 @@ def train_step(num, W, m, v, global_step, batch, hp, dropout_seed=None):
         Z = O.sigmoid(logits)
         losses, (dZ, dlog) = ssrn_losses(Z, logits, mags)
         _, grads = network_backward(layers, W, "SSRN", xs, dlog + dZ * Z * (1 - Z), "same", drop)
+    return losses, grads
+
+
+def train_step(num, W, m, v, global_step, batch, hp, dropout_seed=None):
+    """One `sess.run(g.train_op)` of train.py for Graph(num): forward, losses, gradients of every variable of the network being
+    trained, clip + Adam with the Noam learning rate.  W / m / v: {TF variable name: float64 array}, updated in place.
+    batch: num == 1: (L ids (B, N), mels (B, T, n_mels));  num == 2: (mels (B, T, n_mels), mags (B, 4T, n_linear)).
+    Returns the losses (loss_mels, loss_bd1, loss_att) or (loss_mags, loss_bd2)."""
+    losses, grads = train_grads(num, W, global_step, batch, hp, dropout_seed)
     lr = learning_rate_decay(hp.lr, global_step)                                              # train.py:116
     for n, g in grads.items():
         W[n], m[n], v[n] = adam_step(W[n], g, m[n], v[n], global_step + 1, lr)

@@ -813,6 +813,92 @@ def test_decode_from_a_high_priority_stream_and_beside_ssrn_on_another_stream(we
         for z in Zs: assert torch.equal(z, Z)
 
 
+def test_checked_retry_leaves_the_team_kernel_settings_alone(weights):
+    """the safe retry of a checked decode is a ONE-SHOT form of that decode (dctts_decode_safe_once); it must not switch the team kernels back on for a
+    caller who switched them off, nor re-enable them after dctts_decode_status switched them off for good."""
+    T = 24
+    eng = engine_for(weights, max_T=T)
+    L = dev(synthetic_text(hp.replace(max_T=T), B=4, seed=12))
+    Yg, mg = eng.text2mel(L)
+    eng.synchronize()
+    assert eng.debug_team_kernels_state() == 7
+    eng.set_team_kernels(False)
+    try:
+        assert eng.debug_team_kernels_state() & 3 == 0
+        eng.debug_inject_decode_error(16)
+        Y, mx = eng.text2mel(L, check=True)
+        assert eng.debug_team_kernels_state() & 3 == 0, "the retry switched the team kernels back on"
+        assert torch.equal(mx, mg) and float((Y - Yg).abs().max()) < 1e-5
+    finally:
+        eng.set_team_kernels(True)
+    assert eng.debug_team_kernels_state() == 7
+    eng.debug_inject_decode_error(16)
+    Y, mx = eng.text2mel(L, check=True)                       # with them on: retried in the safe form, still on afterwards
+    assert eng.debug_team_kernels_state() == 7 and torch.equal(mx, mg) and float((Y - Yg).abs().max()) < 1e-5
+    Y3, m3 = eng.text2mel(L)
+    eng.synchronize()
+    assert torch.equal(Y3, Yg) and torch.equal(m3, mg)
+
+
+def test_one_engine_two_streams_same_kind_calls_of_different_inputs(weights):
+    """2 x SSRN, 2 x TextEnc and 2 x synthesize of DIFFERENT inputs enqueued concurrently on two streams of ONE engine are bitwise equal to solo runs.
+    Calls that share scratch memory are ordered on the device by the context (use groups, include/dctts_hip.h "streams and threads"), whatever streams they come from."""
+    T = 40
+    h = hp.replace(max_T=T)
+    eng = engine_for(weights, max_T=T)
+    La, Lb = dev(synthetic_text(h, B=32, seed=41)), dev(synthetic_text(h, B=32, seed=42))
+    g = torch.Generator(device="cpu"); g.manual_seed(5)
+    Ma, Mb = torch.rand(32, T, hp.n_mels, generator=g).cuda(), torch.rand(32, T, hp.n_mels, generator=g).cuda()
+    solo = {}
+    for tag, L, M in (("a", La, Ma), ("b", Lb, Mb)):
+        solo[tag] = (eng.text_enc(L), eng.ssrn(M, want_logits=False)[1], eng.synthesize(L))
+    eng.synchronize()
+    assert not torch.equal(solo["a"][1], solo["b"][1]) and not torch.equal(solo["a"][2][0], solo["b"][2][0])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    torch.cuda.synchronize()
+    outs = []
+    for rnd in range(3):
+        order = ((s1, "a", La, Ma), (s2, "b", Lb, Mb)) if rnd % 2 == 0 else ((s2, "b", Lb, Mb), (s1, "a", La, Ma))
+        for what in ("ssrn", "te", "syn"):                     # interleaved: a's SSRN, b's SSRN, a's TextEnc, b's TextEnc, a's synthesize, b's synthesize
+            for st, tag, L, M in order:
+                with torch.cuda.stream(st):
+                    if what == "ssrn": outs.append((tag, 1, eng.ssrn(M, want_logits=False)[1]))
+                    elif what == "te": outs.append((tag, 0, eng.text_enc(L)))
+                    else: outs.append((tag, 2, eng.synthesize(L)))
+    torch.cuda.synchronize()
+    eng.decode_status()
+    for tag, k, got in outs:
+        ref = solo[tag][k]
+        if k == 1: assert torch.equal(got, ref)
+        else: assert all(torch.equal(x, y) for x, y in zip(got, ref)), (tag, k)
+
+
+def test_alternating_batch_shapes_reuse_their_workspaces(weights):
+    """Workspaces and the decode's tables are cached per geometry: B = 32 / B = 6 / T changes alternate without the cache growing after the first round, results
+    bitwise equal each time; past dctts_set_workspace_limit the cache is dropped (one device sync) and everything still works."""
+    eng = engine_for(weights, max_T=30)
+    h = hp.replace(max_T=30)
+    L32, L6 = dev(synthetic_text(h, B=32, seed=51)), dev(synthetic_text(h, B=6, seed=52))
+    first = None
+    sizes = []
+    for rnd in range(3):
+        res = (eng.synthesize(L32), eng.synthesize(L6), eng.synthesize(L32, max_T=18), eng.text2mel(L6, max_T=18))
+        eng.synchronize()
+        sizes.append(eng.device_bytes())
+        if first is None: first = res
+        else:
+            for a, b in zip(first, res): assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert sizes[1] == sizes[0] and sizes[2] == sizes[0], sizes
+    eng.set_workspace_limit(1 << 20)                            # everything cached is over 1 MiB: the next call starts from an empty cache
+    try:
+        res = (eng.synthesize(L32), eng.synthesize(L6))
+        eng.synchronize()
+        for a, b in zip(first[:2], res): assert all(torch.equal(x, y) for x, y in zip(a, b))
+        assert eng.device_bytes() < sizes[0]
+    finally:
+        eng.set_workspace_limit(96 << 30)
+
+
 # ---------------------------------------------------------------- the restore path end to end (synthesize.py:32-40, SURVEY 8f-1)
 def test_checkpoint_directories_to_spectrograms(weights, tmp_path):
     """`python -m dc_tts_amd.synthesize --logdir <prefix>`: two checkpoint directories laid out like hp.logdir-1 / hp.logdir-2 -- written by the

@@ -141,3 +141,140 @@ def test_vocoder_loop_equals_the_reference(weights):
     wav = VR.spectrogram2wav(mag, hp.replace(n_iter=3), np.float64)
     assert wav_ref.dtype == np.float32 and wav_ref.shape == wav.shape
     assert np.abs(wav_ref - wav).max() < 1e-5 * max(1.0, np.abs(wav).max())
+
+
+# ---------------------------------------------------------------- the training graph of train.py:82-131 (round 5: pins oracle/train_ref.py)
+def _train_batch(h, B, N, T, seed):
+    rng = np.random.default_rng(seed)
+    L = np.zeros((B, N), np.int32)
+    for b in range(B):
+        n = int(rng.integers(N // 2, N + 1))
+        L[b, :n - 1] = rng.integers(2, len(h.vocab), n - 1); L[b, n - 1] = 1
+    mels = rng.random((B, T, h.n_mels))
+    mags = rng.random((B, h.r * T, h.n_linear))
+    return L, mels, mags
+
+
+def _w64(weights):
+    return {k: np.asarray(v, np.float64) for k, v in weights.items()}
+
+
+@pytest.mark.parametrize("gs", [0, 7000])
+def test_training_graph_text2mel_losses_equal_the_oracle(weights, gs):
+    """`Graph(num=1)` (mode="train") built by the reference's own constructor on the shim -- only `get_batch()` replaced by placeholders -- against
+    oracle/train_ref.py in float64: Y, alignments, the three losses of train.py:85-100 incl. the -1 padding / crop rule of :93 at N < max_N and T < max_T,
+    mask_sum, the guided-attention constant (utils.py:134-140) and the Noam learning rate (utils.py:142-145).  Dropout off (rate 0): TF's random stream
+    cannot be reproduced; the next test pins WHERE dropout sits."""
+    from oracle import train_ref as TR
+    B, N, T = 2, 40, 24
+    L, mels, mags = _train_batch(hp, B, N, T, 3)
+    with RR.reference(np.float64, B=B, dropout_rate=0.0) as ref:
+        g, sess, (pL, pmels, pmags) = RR.build_training_graph(ref, 1, {k: v for k, v in weights.items() if k.startswith("Text2Mel/")}, global_step=gs)
+        assert set(RR.requested_variables(ref)) == {k for k in weights if k.startswith("Text2Mel/")} | {"gs/global_step"}
+        Y, al, lm, lb, la, loss, msum, lr, gts = sess.run([g.Y, g.alignments, g.loss_mels, g.loss_bd1, g.loss_att, g.loss, g.mask_sum, g.lr, g.gts], {pL: L, pmels: mels})
+        assert len(g.gvs) == len(g.clipped) == 209                                     # one (gradient, variable) pair per Text2Mel variable (train.py:119-124)
+        with pytest.raises(NotImplementedError):
+            sess.run(g.train_op)                                                        # TensorFlow's autodiff / Adam are NOT restated by the shim
+        assert ("scalar", "train/loss_att") in ref.tf.SUMMARIES and ("scalar", "lr") in ref.tf.SUMMARIES
+        ga = ref.utils.guided_attention()
+    W = _w64(weights)
+    losses, grads = TR.train_grads(1, W, gs, (L, mels), hp)
+    assert abs(lm - losses[0]) < 1e-12 and abs(lb - losses[1]) < 1e-12 and abs(la - losses[2]) < 1e-12 and abs(loss - sum(losses)) < 1e-12
+    assert msum == B * N * T                                                            # only the real (N, T) block of the padded alignments counts (train.py:93-96)
+    assert abs(lr - TR.learning_rate_decay(hp.lr, gs)) < 1e-18
+    assert ga.dtype == np.float32 and ga.shape == (hp.max_N, hp.max_T)
+    assert np.abs(ga - TR.guided_attention(hp.max_N, hp.max_T)).max() < 1e-7 and np.array_equal(np.asarray(gts), ga)
+    assert set(grads) == {k for k in weights if k.startswith("Text2Mel/")}
+
+
+def test_training_graph_ssrn_losses_equal_the_oracle(weights):
+    """`Graph(num=2)`: SSRN on the ground-truth mels (train.py:69-72), loss_mags + loss_bd2 (train.py:102-110), float64."""
+    from oracle import train_ref as TR
+    B, T = 2, 6
+    _, mels, mags = _train_batch(hp, B, 8, T, 4)
+    with RR.reference(np.float64, B=B, dropout_rate=0.0) as ref:
+        g, sess, (pL, pmels, pmags) = RR.build_training_graph(ref, 2, {k: v for k, v in weights.items() if k.startswith("SSRN/")})
+        assert set(RR.requested_variables(ref)) == {k for k in weights if k.startswith("SSRN/")} | {"gs/global_step"}
+        Z, l1, l2, loss = sess.run([g.Z, g.loss_mags, g.loss_bd2, g.loss], {pmels: mels, pmags: mags})
+        assert len(g.gvs) == 80 and not hasattr(g, "loss_att")
+    losses, grads = TR.train_grads(2, _w64(weights), 0, (mels, mags), hp)
+    assert abs(l1 - losses[0]) < 1e-12 and abs(l2 - losses[1]) < 1e-12 and abs(loss - sum(losses)) < 1e-12
+    assert Z.shape == (B, 4 * T, hp.n_linear)
+
+
+def test_training_graph_dropout_sits_where_the_oracle_puts_it(weights):
+    """training=True puts `tf.layers.dropout(rate=hp.dropout_rate)` behind every conv1d / hc / conv1d_transpose block and nowhere else (modules.py:139,195,245).
+    The shim's dropout calls -- made by the reference's modules.py -- are given the ORACLE's counter-hash mask for (network, layer index): the losses of both
+    graphs then agree to rounding, which they cannot if one block's dropout were missing, doubled, at another rate or keyed to another layer."""
+    from oracle import train_ref as TR
+    B, N, T = 2, 30, 16
+    L, mels, mags = _train_batch(hp, B, N, T, 5)
+    seed, gs = 17, 3
+    lists = {"Text2Mel/TextEnc": TR.TEXTENC_LAYERS, "Text2Mel/AudioEnc": TR.AUDIOENC_LAYERS, "Text2Mel/AudioDec": TR.AUDIODEC_LAYERS, "SSRN": TR.SSRN_LAYERS}
+
+    def hook(scope, rate):
+        prefix, layer = scope.rsplit("/", 1)
+        li = [i for i, l in enumerate(lists[prefix]) if l.scope == layer]
+        assert len(li) == 1 and rate == hp.dropout_rate, (scope, rate)
+        key = TR.layer_key(seed, gs, prefix, li[0])
+        return lambda x: TR.dropout(x, key, rate)
+    for num, feed_names in ((1, "Lm"), (2, "mg")):
+        with RR.reference(np.float64, B=B) as ref:
+            ref.tf.DROPOUT_HOOK = hook
+            try:
+                scope = "Text2Mel/" if num == 1 else "SSRN/"
+                g, sess, (pL, pmels, pmags) = RR.build_training_graph(ref, num, {k: v for k, v in weights.items() if k.startswith(scope)}, global_step=gs)
+                calls = list(ref.tf.DROPOUT_CALLS)
+                if num == 1:
+                    got = sess.run([g.loss_mels, g.loss_bd1, g.loss_att], {pL: L, pmels: mels})
+                else:
+                    got = sess.run([g.loss_mags, g.loss_bd2], {pmels: mels[:, :4], pmags: mags[:, :16]})
+            finally:
+                ref.tf.DROPOUT_HOOK = None
+        n_blocks = (len(TR.TEXTENC_LAYERS) - 1 + len(TR.AUDIOENC_LAYERS) + len(TR.AUDIODEC_LAYERS)) if num == 1 else len(TR.SSRN_LAYERS)
+        assert len(calls) == n_blocks and all(tr and r == hp.dropout_rate for _, r, tr in calls)
+        batch = (L, mels) if num == 1 else (mels[:, :4], mags[:, :16])
+        want, _ = TR.train_grads(num, _w64(weights), gs, batch, hp, dropout_seed=seed)
+        for a, b in zip(got, want):
+            assert abs(a - b) < 1e-12, (num, got, want)
+
+
+def test_oracle_gradients_are_the_derivatives_of_the_reference_graphs_loss():
+    """`optimizer.compute_gradients(self.loss)` (train.py:119) is TensorFlow's autodiff of the loss the reference BUILT.  oracle/train_ref.py writes every
+    derivative out by hand; here each is compared with a central finite difference of the REFERENCE GRAPH's own loss (its networks.py / modules.py / train.py
+    executed on the shim, float64) -- on a narrow model (e = d = 8, c = 12, 6 mel bins, 9 linear bins: every layer of all four networks is still there), one
+    randomly chosen entry of EVERY variable, Text2Mel and SSRN."""
+    from dc_tts_amd.weights import synthetic_weights
+    from oracle import train_ref as TR
+    h = hp.replace(e=8, d=8, c=12, n_mels=6, n_fft=16, max_N=14, max_T=11, B=2, dropout_rate=0.0)
+    Wf = synthetic_weights(h, seed=5, perturb=True)
+    W = _w64(Wf)
+    L, mels, mags = _train_batch(h, 2, 10, 7, 6)
+    rng = np.random.default_rng(8)
+    over = dict(e=h.e, d=h.d, c=h.c, n_mels=h.n_mels, n_fft=h.n_fft, max_N=h.max_N, max_T=h.max_T, B=2, dropout_rate=0.0)
+    eps = 1e-6
+    for num in (1, 2):
+        scope = "Text2Mel/" if num == 1 else "SSRN/"
+        batch = (L, mels) if num == 1 else (mels, mags)
+        _, grads = TR.train_grads(num, W, 0, batch, h)
+        names = [k for k in W if k.startswith(scope)]
+        assert set(grads) == set(names)
+        with RR.reference(np.float64, **over) as ref:
+            g, sess, (pL, pmels, pmags) = RR.build_training_graph(ref, num, {k: W[k] for k in names})
+            feeds = {pL: L, pmels: mels} if num == 1 else {pmels: mels, pmags: mags}
+            vals = ref.tf.get_default_graph().values
+            worst = 0.0
+            for n in names:
+                idx = tuple(int(rng.integers(0, s)) for s in W[n].shape)
+                if n.endswith("lookup_table") and idx[0] == 0:
+                    idx = (int(L[0, 0]),) + idx[1:]                  # row 0 of the table is replaced by zeros at lookup time (modules.py:36-38): no gradient there
+                keep = vals[n][idx]
+                vals[n][idx] = keep + eps; lp = float(sess.run(g.loss, feeds))
+                vals[n][idx] = keep - eps; lm = float(sess.run(g.loss, feeds))
+                vals[n][idx] = keep
+                fd = (lp - lm) / (2 * eps)
+                an = float(grads[n][idx])
+                err = abs(fd - an) / max(1e-4, abs(an), abs(fd))
+                worst = max(worst, err)
+                assert err < 2e-5, (n, idx, fd, an)
+        assert worst < 2e-5

@@ -4,6 +4,8 @@
   phase B   N2 decodes at B = 134 (team rounds: more utterance groups than teams)
   phase C   N3 decodes at B = 32 while ANOTHER stream of the same process runs SSRN + the Griffin-Lim vocoder of the "previous batch"
             (unrelated kernels competing for CUs, L2 and the fabric)
+  phase D   N4 rounds of 2 x SSRN, 2 x TextEnc and 2 x synthesize of DIFFERENT inputs enqueued on two streams of the one engine (round 5: same-kind calls are
+            ordered by the context's use groups): every output compared bitwise with the solo run of its input
 
 Every decode's outputs are compared ON THE DEVICE with the first decode of its phase (bitwise: the decode is deterministic); the status word is
 read every `--every` decodes.  A failed decode shows up three ways -- the status report, NaN outputs, a mismatch count -- and all three are printed.
@@ -63,11 +65,58 @@ def phase(eng, name, B, n, every, T, side=None):
     return len(reports) + int(nans) + int(mism)
 
 
+def phase_d(eng, n, every, T=60):
+    h = hp.replace(max_T=T)
+    La, Lb = (torch.from_numpy(synthetic_text(h, B=32, seed=s)).cuda() for s in (61, 62))
+    Ma, Mb = torch.rand(32, T, hp.n_mels, device="cuda"), torch.rand(32, T, hp.n_mels, device="cuda")
+    solo = {}
+    for tag, L, M in (("a", La, Ma), ("b", Lb, Mb)):
+        solo[tag] = (eng.text_enc(L), eng.ssrn(M, want_logits=False)[1], eng.synthesize(L, max_T=T))
+    eng.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+    mism = torch.zeros((), dtype=torch.int64, device="cuda")
+    reports = []
+    t0 = time.time()
+    for i in range(n):
+        order = ((s1, "a", La, Ma), (s2, "b", Lb, Mb)) if i % 2 == 0 else ((s2, "b", Lb, Mb), (s1, "a", La, Ma))
+        for what in (0, 1, 2):
+            for st, tag, L, M in order:
+                with torch.cuda.stream(st):
+                    try:
+                        if what == 0: got = eng.text_enc(L)
+                        elif what == 1: got = (eng.ssrn(M, want_logits=False)[1],)
+                        else: got = eng.synthesize(L, max_T=T)
+                    except DcttsError as e:
+                        reports.append("refused: " + str(e)[:160]); continue
+                    ref = solo[tag][what] if what != 1 else (solo[tag][1],)
+                    bad = torch.zeros((), dtype=torch.bool, device="cuda")
+                    for x, y in zip(got, ref): bad = bad | (x != y).any()
+                    mism_local = bad.to(torch.int64)
+                    # the counter lives on the default stream: add the flag there once this stream's work is done
+                    ev = torch.cuda.Event(); ev.record(st)
+                torch.cuda.current_stream().wait_event(ev)
+                mism += mism_local
+        if (i + 1) % every == 0 or i + 1 == n:
+            torch.cuda.synchronize()
+            try:
+                eng.decode_status()
+            except DcttsError as e:
+                reports.append(f"after {i + 1} rounds: {str(e)[:200]}")
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"D (2 x SSRN + 2 x TextEnc + 2 x synthesize of different inputs on two streams): {n} rounds, B = 32, T = {T}: {dt:.1f} s wall ({1e3 * dt / n:.2f} ms per round); "
+          f"status reports {len(reports)}, outputs that differ from their solo run {int(mism)}")
+    for r in reports[:10]:
+        print("   ", r)
+    return len(reports) + int(mism)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n1", type=int, default=5000)
     ap.add_argument("--n2", type=int, default=500)
     ap.add_argument("--n3", type=int, default=1500)
+    ap.add_argument("--n4", type=int, default=1000)
     ap.add_argument("--every", type=int, default=250)
     a = ap.parse_args()
     torch.cuda.set_device(0)
@@ -91,6 +140,7 @@ def main():
                 voc.spectrogram2wav_device(Z)
         state["i"] += 1
     bad += phase(eng, "C (SSRN + vocoder on a second stream)", 32, a.n3, a.every, hp.max_T, side)
+    bad += phase_d(eng, a.n4, a.every)
     print("TOTAL failures:", bad)
     return 0
 
