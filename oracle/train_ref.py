@@ -295,7 +295,9 @@ def guided_attention(max_N, max_T, g=0.2):
     """utils.py:134-140:  W[n, t] = 1 - exp(-(t / max_T - n / max_N)^2 / (2 g^2))."""
     n = np.arange(max_N, dtype=np.float64)[:, None] / float(max_N)
     t = np.arange(max_T, dtype=np.float64)[None, :] / float(max_T)
-    return 1.0 - np.exp(-(t - n) ** 2 / (2.0 * g * g))
+    # the reference fills a float32 array from Python-float arithmetic (utils.py:136-139) and the graph holds it as a float32 constant (train.py:41): the
+    # table every loss sees is the float32 ROUNDING of the formula (found by the reference pin: the float64 formula differs from it by 3e-9 in loss_att)
+    return (1.0 - np.exp(-(t - n) ** 2 / (2.0 * g * g))).astype(np.float32).astype(np.float64)
 
 
 def learning_rate_decay(init_lr, global_step, warmup_steps=4000.0):
