@@ -15,7 +15,8 @@ What the JSON line holds besides the contract's fields (everything is measured i
   kernels             the same figures for xgroup_kernel and xtail_kernel (the chain's launches), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
                       launch) and SSRN's 1025-column layers (event-timed in untimed extra passes)
   phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
-  other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share)
+  other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share); decode-only at B = 64 / 128;
+                      pipelined_depth2[_with_vocoder]: two batches in flight on two streams of one engine (a SECOND line: the headline stays the serial batch)
   cpu_baseline        the reference's loop restated on torch-CPU fp32 (oracle/torch_ref.py) on the host cores, bounded sample; + the numpy
                       oracle and its incremental variant
   host_transfer / gather     PCIe-inclusive figures (never `value`)
@@ -435,6 +436,43 @@ def main():
         dist.destroy_process_group()
 
 
+def pipelined(eng, hp, L, Y_serial, Z_serial, B, T, ms_serial, with_vocoder, n=10):
+    """Steady state of a two-deep pipeline on ONE GPU: the caller's (high-priority) stream runs TextEnc + decode of batch i + 1 while a second stream runs SSRN
+    (and optionally the Griffin-Lim vocoder) of batch i.  Wall clock over n batches incl. the un-overlapped last SSRN, so the figure is slightly pessimistic."""
+    from dc_tts_amd.utils import Vocoder
+    main = torch.cuda.current_stream()
+    s2 = torch.cuda.Stream()
+    voc = Vocoder(hp) if with_vocoder else None
+    res = {}
+
+    def run(k):
+        last = None
+        for _ in range(k):
+            Yi, mi = eng.text2mel(L)
+            ev = torch.cuda.Event(); ev.record(main)
+            with torch.cuda.stream(s2):
+                s2.wait_event(ev)
+                Yi.record_stream(s2)
+                Zi = eng.ssrn(Yi, want_logits=False)[1]
+                wav = voc.spectrogram2wav_device(Zi) if voc is not None else None
+            last = (Yi, Zi, wav)
+        return last
+    run(2); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    Yl, Zl, _ = run(n)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    eng.decode_status()
+    same = bool(torch.equal(Yl, Y_serial)) and bool(torch.equal(Zl, Z_serial))
+    res.update(workload=f"{n} batches of B={B}, max_T={T}: TextEnc + decode of batch i+1 on the caller's stream beside SSRN" + (" + the Griffin-Lim vocoder" if with_vocoder else "") +
+                        " of batch i on a second stream of the same engine (wall clock incl. the last batch's un-overlapped tail)",
+               ms_per_batch=round(dt * 1e3, 3), mel_frames_per_s=round(B * T / dt, 1), vs_serial=round(ms_serial / (dt * 1e3), 3) if not with_vocoder else None,
+               outputs_bitwise_equal_to_serial=same)
+    if voc is not None:
+        voc.close()
+    return res
+
+
 def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     """Untimed passes on rank 0 after the timed region: per-phase times, the two other kernels that matter, the other BASELINE
     configurations that fit one GPU."""
@@ -539,6 +577,19 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
                                         mel_frames_per_s=round(B3 * T / (ms3 * 1e-3), 1), rtf=ms3 * 1e-3 / (B3 * T * hp.seconds_per_mel_frame),
                                         **both_roofs(B3 * T * 187.310e6, B3 * (67200 + 3444000) + 113641532.0, ms3))
     del Y3
+    # ---- decode-only at larger batches (one pass of the decode serves the batch in rounds of 8 teams x 4 utterances: DESIGN.md section 9)
+    for Bx in (64, 128):
+        Lx = torch.from_numpy(synthetic_text(hp, B=Bx, seed=4321)).cuda()
+        msx = timed(lambda: eng.text2mel(Lx), reps=2)
+        oc[f"text2mel_decode_b{Bx}"] = {"workload": f"TextEnc + {T}-step decode, B={Bx} in ONE call", "ms_per_batch": round(msx, 3),
+                                        "mel_frames_per_s": round(Bx * T / (msx * 1e-3), 1), "vs_b32": round((Bx * T / msx) / (B * T / ms_t2m), 3)}
+        del Lx
+    # ---- two batches in flight (NOT the headline: synthesize.py:45-57 is serial): SSRN of batch n on a second stream beside TextEnc + decode of batch n + 1, every
+    #      batch still B utterances; then the same with the vocoder of batch n on that second stream as well.  One engine: calls of different kinds overlap, calls that
+    #      share scratch are ordered by the library (include/dctts_hip.h, "streams and threads").  Outputs are compared bitwise with the serial run's.
+    oc["pipelined_depth2"] = pipelined(eng, hp, L, Y, Z, B, T, ms_step, with_vocoder=False)
+    if not args.no_vocoder:
+        oc["pipelined_depth2_with_vocoder"] = pipelined(eng, hp, L, Y, Z, B, T, ms_step, with_vocoder=True)
     T5, B5 = 1000, 8
     h5 = hp.replace(max_T=T5)
     e5 = Engine(W, h5, device=eng.device_index, decode_graph=gm)

@@ -32,6 +32,8 @@ using namespace dctts;
 
 namespace dctts {
 
+static int g_xc_bd = 3;                      // weight prefetch depth of the XC form (measurement knob DCTTS_XC_BD, read in dctts_create)
+
 // (weight prefetch depth BD, scalar tile bases SB) per shape: what measured best on this MI355X (hconv_kernel.h; profiles/r03_hconv_lab.txt)
 #define HCONV_CASE(E, NT_, NW_, BD_, SB_)                                                        \
   if (s.epi == E && s.nt == NT_ && s.nw == NW_) {                                                \
@@ -42,6 +44,14 @@ namespace dctts {
 hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t stream, int tiles) {
   const dim3 grid(tiles >= 0 ? tiles : (p.M + 31) / 32);
   if (p.M <= 0 || grid.x == 0) return hipSuccess;
+  if (p.wx) {                                // a k = 1 layer of 32 x 32 + 1 columns: 8 waves x 4 tiles + the last column on the vector ALU (hconv_kernel.h: XC)
+    if (s.epi != EPI_C || p.cout != 1025 || p.ntaps != 1 || p.cin_p > 1120) return hipErrorInvalidValue;
+    if (g_xc_bd == 2) hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1>), grid, dim3(512), 0, stream, p);
+    else if (g_xc_bd == 3) hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), grid, dim3(512), 0, stream, p);
+    else if (g_xc_bd == 4) hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 2>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 1>), grid, dim3(512), 0, stream, p);
+    return hipGetLastError();
+  }
   HCONV_CASE(EPI_HC, 2, 8, 2, 0)
   HCONV_CASE(EPI_HC, 4, 8, 2, 0)
   HCONV_CASE(EPI_HC, 8, 8, 1, 1)
@@ -143,6 +153,7 @@ struct DevLayer {
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
   float* wp16r = nullptr;         // SSRN 4T-resolution layers: packing for hconv16_kernel (row-tail launches)
+  float* wpx = nullptr; float* wxcol = nullptr;   // SSRN's 1025-column layers: the first 1024 columns as 32 tiles + the last column's weights (hconv_kernel<..., XC = 1>); the row tail keeps wp
   bool col_split = false;         // TextEnc's three-tap highway layers: when the 32-row items fill less than 3/4 of the CUs the layer runs as quarter-COLUMN items + a finishing pass (run_conv)
   bool tap_tail = false;          // SSRN highway layers: the rows left over after exact rounds may run as 32-row items x taps (run_conv).  SSRN only: which rows
                                   //   take that form depends on the batch, and Text2Mel's outputs stay bitwise equal across batch compositions
@@ -255,6 +266,7 @@ struct dctts_ctx {
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
+  int ssrn_xc = 1;                     // SSRN's 1025-column layers as 8 waves x 4 tiles + one vector-ALU column (DCTTS_SSRN_XC=0: 11 waves x 3 tiles, rounds 1-4)
   float* tail_ws = nullptr; size_t tail_ws_floats = 0;   // run_conv: the tap-split row tail's partial sums [3][tail rows][2C] (SSRN layers only)
   float* cols_ws = nullptr; size_t cols_ws_floats = 0;   // run_conv: the column-split layers' pre-norm rows [rows][2C] (TextEnc only).  NOT tail_ws: SSRN of the previous batch may run on
                                                          // another stream beside the next batch's TextEnc (tools/soak.py, phase C: with one buffer 536 of 3000 decodes differed, unreported)
@@ -369,6 +381,12 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
     L->shape16 = pick_shape16(EPI_C, cout);
     CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, L->shape16.nt * L->shape16.nw, cout, false, 16), &L->wp16r));
   }
+  if (tail && cout == 1025 && L->cin_p <= 1120 && c->ssrn_xc) {
+    CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 32, 1024, false, 32), &L->wpx));
+    std::vector<float> col((size_t)L->cin_p, 0.f);
+    for (int cc = 0; cc < cin_real; ++cc) col[cc] = kv[(size_t)cc * cout + 1024];
+    CHK(upload(c, col, &L->wxcol));
+  }
   L->cin_real = cin_real;
   CHK(upload(c, b->v, &L->bias)); CHK(upload(c, ga->v, &L->g1)); CHK(upload(c, be->v, &L->b1));
   return 0;
@@ -457,7 +475,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
   geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_CHAIN_TAIL", &c->chain_tail);
-  geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
+  geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_SSRN_XC", &c->ssrn_xc); geti("DCTTS_XC_BD", &g_xc_bd);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
   // (it only times out, with wrong results).  Under counter collection the two decode streams meet through events instead.
@@ -777,7 +795,9 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   const bool tap_tail = (hc3 || c3) && left > 0 && 3 * left <= 2 * c->n_cu && !rm.step;      // (not in decode mode 0's captured launches: the partial-sum buffer is allocated on demand)
   if (tap_tail) { tiles32 = full; m_tail = full * 32; }
   else if (L.wp16r && left * 10 <= c->n_cu * 6) { tiles32 = full; m_tail = full * 32; }
+  if (L.wpx) { p.wp = L.wpx; p.wx = L.wxcol; }      // (the main launch only: the row tail below keeps the 33-tile packing)
   HIPCHK(launch_hconv(L.shape, p, st, tiles32));
+  p.wp = L.wp; p.wx = nullptr;
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += m_tail < p.M ? m_tail : p.M; }
   if (m_tail < p.M && tap_tail) {
     // the row tail of a big highway layer: 32-row items x taps + a finishing pass (hconv_kernel.h: RAW) instead of 16-row items

@@ -64,6 +64,7 @@ struct ConvParams {
   int m_base; float* raw_out; int raw_ld;
   float* presum_out;      // when set: row r == R-1 of every utterance is a PRESUM row -- its last tap is not contracted (the decode chain
   long presum_rstride;    //   does that) and bias + the older taps go, un-normalised, to presum_out[b * presum_rstride + column]
+  const float* wx;        // hconv_kernel<..., XC = 1>: the weights of output column NT * NW * 32 (= cout - 1), cin_p floats, zero beyond the real Cin
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -105,8 +106,13 @@ __device__ __forceinline__ float half_sum32(float v) {
 //     [128 y, 128 y + 128) of both halves and contracts ALL of K; 720 quarter items run three to a CU at once, so a layer takes 3/4 of an item's time (every
 //     split into k equal parts has makespan ceil(180 k / 256) / k: 1 for k = 2 and 3 -- the tap split above --, 3/4 for k = 4).  The pre-norm values go to
 //     raw_out (one part); hc_tail_finish_kernel adds the bias and finishes the rows.  Same weight packing: tile (y NW + wave) NT + i of the 8-wave layout.
-template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0>
-__global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
+//   * XC = 1 (round 5, SSRN's 1025-column layers C_13 .. C_16): 33 column tiles on 11 waves sit 3 / 3 / 3 / 2 on the four SIMDs, so every chunk takes 9 tile-times where
+//     8.25 would do.  Here the first 1024 columns are 8 waves x 4 tiles (two waves per SIMD, 8 tile-times) and column 1024 is a dot product on the vector ALU: wave w
+//     owns rows 4 w .. 4 w + 3, a lane multiplies two channels of a chunk (A from the LDS tile every wave reads anyway, the column's weights from a 4 KB LDS copy) and
+//     the 16 lanes of a row are summed with DPP at the end; the value joins the layer-norm statistics in the cross-wave step and is normalised / stored by one lane.
+template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0, int XC = 0>
+__global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const ConvParams p) {      // (XC = 2: the same with registers capped for two workgroups per CU -- measurement variant)
+  static_assert(XC == 0 || (EPI == EPI_C && RAW == 0 && NW == 8), "the extra column rides in the fused k = 1 form: 8 waves x 4 rows");
   constexpr bool KPART = (RAW == 1);        // this workgroup contracts a PART of K (grid y = part)
   constexpr bool CPART = (RAW == 2);        // this workgroup owns a PART of the columns (grid y = part)
   constexpr int LDA = 36;
@@ -120,6 +126,8 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   __shared__ long s_inrow[32];
   __shared__ long s_outrow[32];
   __shared__ long s_out2row[32];
+  __shared__ float xw_s[XC ? 1120 : 1];      // the extra column's weights (cin_p <= 1120)
+  __shared__ float xcol_s[XC ? 32 : 1];      // its 32 pre-norm values (bias included)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = SB ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
@@ -149,6 +157,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
     }
     s_inrow[tid] = inrow; s_outrow[tid] = outrow; s_out2row[tid] = out2row;
   }
+  if constexpr (XC) { for (int i = tid; i < p.cin_p; i += NW * 64) xw_s[i] = p.wx[i]; }
   __syncthreads();
 
   // ---- A loader: thread (lrow, lc4) moves one float4 per chunk
@@ -220,8 +229,15 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   const int aoff = l31 * LDA + lhi * 4;
   float4 a = *reinterpret_cast<const float4*>(&As[0][aoff]);
   int cb = 0;                              // ch % 3
+  const int xoff = (wave * 4 + (lane >> 4)) * LDA + (lane & 15) * 2;      // XC: (row, channel pair) of this lane inside a chunk's tile
+  float xacc = 0.f;
   for (int ch = 0; ch < nch; ++ch) {
     const float* Ab = As[cb];
+    if constexpr (XC) {                    // chunk ch's tile is complete since the barrier of chunk ch - 1 and is not rewritten before chunk ch + 1's
+      const float2 xa = *reinterpret_cast<const float2*>(&Ab[xoff]);
+      const float2 xw = *reinterpret_cast<const float2*>(&xw_s[ch * 32 + (lane & 15) * 2]);
+      xacc = fmaf(xa.x, xw.x, fmaf(xa.y, xw.y, xacc));
+    }
     const int cb1 = (cb == 2) ? 0 : cb + 1, cb2 = (cb1 == 2) ? 0 : cb1 + 1;
     const float* An = As[cb1];
 #pragma unroll
@@ -281,6 +297,12 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
   // Epilogue.  acc[i][j] = conv output (bias included) at row (j&3) + 8*(j>>2) + 4*lhi, column of tile i / lane l31.
   // Requests first, then the two statistics passes, then the stores.
   // =====================================================================================
+  constexpr int CX = NT * NW * 32;           // XC: index of the extra column
+  if constexpr (XC) {
+    float v = xacc;
+    v = hconv_dpp_add<0xB1>(v); v = hconv_dpp_add<0x4E>(v); v = hconv_dpp_add<0x141>(v); v = hconv_dpp_add<0x140>(v);      // the 16 lanes of a row
+    if ((lane & 15) == 0) xcol_s[wave * 4 + (lane >> 4)] = v + p.bias[CX];      // (visible behind the first barrier of the statistics pass)
+  }
   float pg1[NP], pb1[NP], pg2[NP], pb2[NP];
 #pragma unroll
   for (int k = 0; k < NP; ++k) {
@@ -347,6 +369,7 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
       float v = 0.f;
 #pragma unroll
       for (int w = 0; w < NW; ++w) v += red[(w * 2 + h) * 32 + r];
+      if constexpr (XC) { if (pass == 0) v += xcol_s[r]; else { const float d = xcol_s[r] - tot[0][r]; v += d * d; } }
       v *= invC;
       tot[pass][h * 32 + r] = (pass == 0) ? v : 1.0f / sqrtf(v + 1e-12f);
     }
@@ -386,6 +409,21 @@ __global__ void __launch_bounds__(NW * 64) hconv_kernel(const ConvParams p) {
           if (ok && (cval[k] || chan[k] < p.out_zero_to)) op[chan[k]] = cval[k] ? y : 0.f;
         }
       }
+    }
+  }
+  if constexpr (XC) {                        // column CX and the zero pad columns behind it: 16 threads per row
+    const int row = tid >> 4, j = tid & 15;
+    const long orow = s_outrow[row];
+    if (orow >= 0) {
+      float* op = p.out + orow * (long)p.out_stride;
+      if (j == 0) {
+        float y = (xcol_s[row] - tot[0][row]) * tot[1][row] * p.g1[CX] + p.b1[CX];
+        if (p.out2) p.out2[s_out2row[row] * (long)p.out2_stride + CX] = y;
+        if (p.act == ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == ACT_SIGMOID) y = fast_sigmoidf_(y);
+        op[CX] = y;
+      } else if (CX + j < p.out_zero_to) op[CX + j] = 0.f;
+      if (CX + 16 + j < p.out_zero_to) op[CX + 16 + j] = 0.f;
     }
   }
 }

@@ -20,7 +20,7 @@ for src in SRCS:
         sys.exit(1)
     print("#", os.path.relpath(src, ROOT))
     for b in re.split(r"remark: [^\n]*Function Name: ", r.stderr)[1:]:
-        name = b.split("\n")[0].strip()
+        name = b.split("\n")[0].strip().split(" ")[0]
         dn = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
         dn = re.sub(r"\(dctts::\w+Params.*", "", dn).replace("void dctts::", "")
         vals = []
