@@ -590,6 +590,25 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     oc["pipelined_depth2"] = pipelined(eng, hp, L, Y, Z, B, T, ms_step, with_vocoder=False)
     if not args.no_vocoder:
         oc["pipelined_depth2_with_vocoder"] = pipelined(eng, hp, L, Y, Z, B, T, ms_step, with_vocoder=True)
+    # ---- the OPT-IN split-bf16 contraction (dctts_set_split_bf16; NEVER the headline: `dtype` above is f32 and `value` is measured with exact fp32 everywhere).
+    #      A second engine carries the bf16 weight packing; level 1 = SSRN, level 2 = SSRN + TextEnc; Text2Mel's decode stays fp32 in both.
+    eb = Engine(W, hp, device=eng.device_index, decode_graph=gm, split_bf16=2)
+    eb.set_decode_mode(args.decode_mode)
+    sb = {}
+    for level in (1, 2):
+        eb.set_split_bf16(level)
+        ms_b = timed(lambda: eb.synthesize(L))
+        Yb, Zb, mb = eb.synthesize(L); torch.cuda.synchronize(); eb.decode_status()
+        sb[f"level{level}"] = {"what": "SSRN on split-bf16 operands" if level == 1 else "SSRN + TextEnc on split-bf16 operands", "ms_per_batch": round(ms_b, 3),
+                               "mel_frames_per_s": round(B * T / (ms_b * 1e-3), 1), "vs_fp32": round(ms_step / ms_b, 3),
+                               "ssrn_ms": round(timed(lambda: eb.ssrn(Y, want_logits=False)), 3), "textenc_ms": round(timed(lambda: eb.text_enc(L)), 3),
+                               "max_abs_vs_fp32_run": {"Y": float((Yb - Y).abs().max()), "Z": float((Zb - Z).abs().max())},
+                               "attention_trajectory_equal_to_fp32_run": bool(torch.equal(mb, eng.text2mel(L)[1]))}
+    sb["arithmetic"] = ("x = hi + mid (two bf16 terms, round-to-nearest), product = hi.hi + hi.mid + mid.hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate; dropped terms <= 2^-16 |x||w|; "
+                        "bias / layer-norm / gate / activations / the 1025th column in fp32; measured against the float64 oracle: max|dZ| 3.3e-5 (fp32 form: 3.6e-6), "
+                        "tests/test_gpu_parity.py::test_split_bf16_pipeline_error_and_untouched_decode")
+    oc["split_bf16_opt_in"] = sb
+    eb.close()
     T5, B5 = 1000, 8
     h5 = hp.replace(max_T=T5)
     e5 = Engine(W, h5, device=eng.device_index, decode_graph=gm)

@@ -45,6 +45,7 @@ SYMBOLS = {
     "dctts_set_team_kernels": (c_int, [c_void_p, c_int]),
     "dctts_decode_safe_once": (c_int, [c_void_p]),
     "dctts_set_workspace_limit": (c_int, [c_void_p, c_size_t]),
+    "dctts_set_split_bf16": (c_int, [c_void_p, c_int]),
     "dctts_debug_inject_decode_error": (c_int, [c_void_p, c_int]),
     "dctts_debug_team_kernels_state": (c_int, [c_void_p]),
     "dctts_set_decode_graph": (c_int, [c_void_p, c_int]),

@@ -20,6 +20,7 @@
 #include "api_common.h"
 #include "attn_kernels.h"
 #include "decode_kernels.h"
+#include "decode_fallback_kernels.h"
 #include "decode3_kernels.h"
 #include "hconv_kernel.h"
 #include "hconv16_kernel.h"
@@ -31,8 +32,6 @@
 using namespace dctts;
 
 namespace dctts {
-
-static int g_xc_bd = 3;                      // weight prefetch depth of the XC form (measurement knob DCTTS_XC_BD, read in dctts_create)
 
 // (weight prefetch depth BD, scalar tile bases SB) per shape: what measured best on this MI355X (hconv_kernel.h; profiles/r03_hconv_lab.txt)
 #define HCONV_CASE(E, NT_, NW_, BD_, SB_)                                                        \
@@ -46,10 +45,8 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
   if (p.M <= 0 || grid.x == 0) return hipSuccess;
   if (p.wx) {                                // a k = 1 layer of 32 x 32 + 1 columns: 8 waves x 4 tiles + the last column on the vector ALU (hconv_kernel.h: XC)
     if (s.epi != EPI_C || p.cout != 1025 || p.ntaps != 1 || p.cin_p > 1120) return hipErrorInvalidValue;
-    if (g_xc_bd == 2) hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1>), grid, dim3(512), 0, stream, p);
-    else if (g_xc_bd == 3) hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), grid, dim3(512), 0, stream, p);
-    else if (g_xc_bd == 4) hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 2>), grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 1>), grid, dim3(512), 0, stream, p);
+    // ring depth 1 and registers capped at 128 (two workgroups per CU): 10.45 ms per SSRN pass at B = 32 against 10.50 (depth 2, one workgroup per CU) and 10.71 (11 waves x 3 tiles)
+    hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), grid, dim3(512), 0, stream, p);
     return hipGetLastError();
   }
   HCONV_CASE(EPI_HC, 2, 8, 2, 0)
@@ -60,6 +57,29 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
   HCONV_CASE(EPI_C, 2, 8, 2, 0)
   HCONV_CASE(EPI_C, 4, 8, 1, 1)
   HCONV_CASE(EPI_C, 3, 11, 2, 1)
+  return hipErrorInvalidConfiguration;
+}
+
+// The opt-in split-bf16 form (hconv_kernel.h: BF): whole 32-row items, no row tail.  parts = 2: a 64-tile highway layer as two column halves + the finishing pass.
+hipError_t launch_hconv_bf16(const ConvShape& s, const ConvParams& p, hipStream_t stream) {
+  if (p.M <= 0) return hipSuccess;
+  const int items = (p.M + 31) / 32;
+  if (p.wx) {
+    if (s.epi != EPI_C || p.cout != 1025 || p.ntaps != 1 || p.cin_p > 1120) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 1>), dim3(items), dim3(512), 0, stream, p);
+    return hipGetLastError();
+  }
+  if (s.epi == EPI_HC && s.nt == 8 && s.nw == 8) {
+    if (!p.raw_out || p.m_base != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((hconv_kernel<EPI_HC, 4, 8, 2, 1, 2, 0, 1>), dim3(items, 2), dim3(512), 0, stream, p);
+    hipError_t e_ = hipGetLastError();
+    if (e_ != hipSuccess) return e_;
+    hipLaunchKernelGGL(hc_tail_finish_kernel, dim3((p.M + 3) / 4), dim3(256), 0, stream, p, (const float*)p.raw_out, 1);
+    return hipGetLastError();
+  }
+  if (s.epi == EPI_HC && s.nt == 4 && s.nw == 8) { hipLaunchKernelGGL((hconv_kernel<EPI_HC, 4, 8, 1, 1, 0, 0, 1>), dim3(items), dim3(512), 0, stream, p); return hipGetLastError(); }      // (ring depth 1: 274 against 298 us for HC_8's 768 items, tools/micro/hconv_lab)
+  if (s.epi == EPI_C && s.nt == 4 && s.nw == 8) { hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 0, 1>), dim3(items), dim3(512), 0, stream, p); return hipGetLastError(); }
+  if (s.epi == EPI_C && s.nt == 2 && s.nw == 8) { hipLaunchKernelGGL((hconv_kernel<EPI_C, 2, 8, 2, 1, 0, 0, 1>), dim3(items), dim3(512), 0, stream, p); return hipGetLastError(); }
   return hipErrorInvalidConfiguration;
 }
 
@@ -153,6 +173,7 @@ struct DevLayer {
   float *wp = nullptr, *bias = nullptr, *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
   bool deconv_phase = false; int phase = 0;
   float* wp16r = nullptr;         // SSRN 4T-resolution layers: packing for hconv16_kernel (row-tail launches)
+  float* wpb = nullptr;           // opt-in split-bf16 form (dctts_set_split_bf16): the kernel as bf16 (hi, mid) fragments for v_mfma_f32_32x32x16_bf16; the 1025-column layers: their first 1024 columns
   float* wpx = nullptr; float* wxcol = nullptr;   // SSRN's 1025-column layers: the first 1024 columns as 32 tiles + the last column's weights (hconv_kernel<..., XC = 1>); the row tail keeps wp
   bool col_split = false;         // TextEnc's three-tap highway layers: when the 32-row items fill less than 3/4 of the CUs the layer runs as quarter-COLUMN items + a finishing pass (run_conv)
   bool tap_tail = false;          // SSRN highway layers: the rows left over after exact rounds may run as 32-row items x taps (run_conv).  SSRN only: which rows
@@ -266,7 +287,11 @@ struct dctts_ctx {
   hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr; std::string graph_geom;   // decode mode 0: one step, replayed T times
   long long prof_rows = 0;             // output rows covered by the profiled launches since prof_enable
   int n_cu = 256;                      // CUs of the device (hipDeviceProp_t::multiProcessorCount)
-  int ssrn_xc = 1;                     // SSRN's 1025-column layers as 8 waves x 4 tiles + one vector-ALU column (DCTTS_SSRN_XC=0: 11 waves x 3 tiles, rounds 1-4)
+  int bf16_packed = 0;                 // dctts_set_split_bf16 before finalize: 1 = SSRN's layers carry the bf16 packing, 2 = TextEnc's as well
+  int bf16_mode = 0;                   // ... and what runs: 0 = exact fp32 (default), 1 = SSRN on the split-bf16 form, 2 = SSRN + TextEnc
+  int pack_bf16_now = 0;               // (set while finalize builds a network whose layers get the packing)
+  bool bf_now = false;                 // set by the TextEnc / SSRN drivers around their run_conv calls when the split-bf16 form is selected for that network
+  static constexpr int ssrn_xc = 1;    // SSRN's 1025-column layers: 8 waves x 4 tiles + one vector-ALU column in the main launch (rounds 1-4: 11 waves x 3 tiles, what their row tail still runs on)
   float* tail_ws = nullptr; size_t tail_ws_floats = 0;   // run_conv: the tap-split row tail's partial sums [3][tail rows][2C] (SSRN layers only)
   float* cols_ws = nullptr; size_t cols_ws_floats = 0;   // run_conv: the column-split layers' pre-norm rows [rows][2C] (TextEnc only).  NOT tail_ws: SSRN of the previous batch may run on
                                                          // another stream beside the next batch's TextEnc (tools/soak.py, phase C: with one buffer 536 of 3000 decodes differed, unreported)
@@ -358,6 +383,40 @@ static std::vector<float> pack_bw(const std::function<float(int, int, int)>& W, 
       }
   return out;
 }
+// The split-bf16 packing (hconv_kernel.h: BF): [tile][16-k group][hi | mid][lane][8 bf16]; lane l, element e <- k = 16 g + 8 (l >> 5) + e, column l & 31 of the tile.
+// hi = bf16(w), mid = bf16(w - hi), both round-to-nearest-even.  Returned as floats (two bf16 per float) so that it travels through upload().
+static uint16_t f2bf16(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0;
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static float bf16_2f(uint16_t h) { const uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static std::vector<float> pack_bw_bf16(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p, int tiles, int cout, bool hc) {
+  const int KG = ntaps * cin_p / 16;
+  std::vector<uint16_t> out((size_t)tiles * KG * 2 * 64 * 8, 0);
+  for (int gt = 0; gt < tiles; ++gt)
+    for (int kg = 0; kg < KG; ++kg)
+      for (int l = 0; l < 64; ++l) {
+        int col;
+        if (hc) { const int ch = (gt / 2) * 32 + (l & 31); col = ch < cout ? (gt & 1) * cout + ch : -1; }
+        else    { const int ch = gt * 32 + (l & 31);       col = ch < cout ? ch : -1; }
+        if (col < 0) continue;
+        for (int e = 0; e < 8; ++e) {
+          const int k = kg * 16 + 8 * (l >> 5) + e, tap = k / cin_p, cc = k % cin_p;
+          if (cc >= cin_real) continue;
+          const float w = W(tap, cc, col);
+          const uint16_t hi = f2bf16(w), mid = f2bf16(w - bf16_2f(hi));
+          const size_t base = (((size_t)gt * KG + kg) * 2) * 64 * 8;
+          out[base + (size_t)l * 8 + e] = hi;
+          out[base + 64 * 8 + (size_t)l * 8 + e] = mid;
+        }
+      }
+  std::vector<float> f(out.size() / 2);
+  memcpy(f.data(), out.data(), out.size() * 2);
+  return f;
+}
+
 static std::vector<float> pack_b(const std::function<float(int, int, int)>& W, int ntaps, int cin_real, int cin_p,
                                  const ConvShape& s, int cout, bool hc) {
   return pack_bw(W, ntaps, cin_real, cin_p, s.nt * s.nw, cout, hc, 32);
@@ -381,8 +440,12 @@ static int make_C(dctts_ctx* c, const std::string& scope, int cin_real, int cin_
     L->shape16 = pick_shape16(EPI_C, cout);
     CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, L->shape16.nt * L->shape16.nw, cout, false, 16), &L->wp16r));
   }
-  if (tail && cout == 1025 && L->cin_p <= 1120 && c->ssrn_xc) {
-    CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 32, 1024, false, 32), &L->wpx));
+  if (c->pack_bf16_now) {
+    if (cout == 1025) CHK(upload(c, pack_bw_bf16(W, 1, cin_real, L->cin_p, 32, 1024, false), &L->wpb));      // + wxcol below: the last column stays an fp32 dot product
+    else CHK(upload(c, pack_bw_bf16(W, 1, cin_real, L->cin_p, L->shape.nt * L->shape.nw, cout, false), &L->wpb));
+  }
+  if (((tail && c->ssrn_xc) || c->pack_bf16_now) && cout == 1025 && L->cin_p <= 1120) {
+    if (tail && c->ssrn_xc) CHK(upload(c, pack_bw(W, 1, cin_real, L->cin_p, 32, 1024, false, 32), &L->wpx));
     std::vector<float> col((size_t)L->cin_p, 0.f);
     for (int cc = 0; cc < cin_real; ++cc) col[cc] = kv[(size_t)cc * cout + 1024];
     CHK(upload(c, col, &L->wxcol));
@@ -419,6 +482,7 @@ static int make_HC(dctts_ctx* c, const std::string& scope, int C, int k, int rat
     L->shape16 = pick_shape16(EPI_HC, C);
     CHK(upload(c, pack_bw(W, k, C, L->cin_p, L->shape16.nt * L->shape16.nw, C, true, 16), &L->wp16r));
   }
+  if (c->pack_bf16_now) CHK(upload(c, pack_bw_bf16(W, k, C, L->cin_p, L->shape.nt * L->shape.nw, C, true), &L->wpb));
   L->hc = true;
   CHK(upload(c, b->v, &L->bias));
   CHK(upload(c, g1->v, &L->g1)); CHK(upload(c, b1->v, &L->b1));
@@ -449,6 +513,7 @@ static int make_D(dctts_ctx* c, const std::string& scope, int C, DevLayer* even,
       return kv[((size_t)j * C + col) * C + cc];          // kernel[0][j][out][in]
     };
     CHK(upload(c, pack_b(W, L->ntaps, C, L->cin_p, L->shape, C, false), &L->wp));
+    if (c->pack_bf16_now) CHK(upload(c, pack_bw_bf16(W, L->ntaps, C, L->cin_p, L->shape.nt * L->shape.nw, C, false), &L->wpb));
     L->bias = bias; L->g1 = g; L->b1 = bb;
   }
   return 0;
@@ -475,7 +540,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
   geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_CHAIN_TAIL", &c->chain_tail);
-  geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime); geti("DCTTS_SSRN_XC", &c->ssrn_xc); geti("DCTTS_XC_BD", &g_xc_bd);
+  geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
   // (it only times out, with wrong results).  Under counter collection the two decode streams meet through events instead.
@@ -562,6 +627,7 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
   const int d = g.d, cc = g.c, F = g.n_linear, Fp = round_up(F, 32);
   char nm[64];
   // ---- TextEnc (networks.py:14-71)
+  c->pack_bf16_now = c->bf16_packed >= 2;
   {
     const std::string s = "Text2Mel/TextEnc/";
     const HostTensor* tab;
@@ -577,6 +643,7 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 3, 1, false, &L)); L.col_split = true; c->textenc.push_back(L); }
     for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "HC_%d", i++); L = DevLayer(); CHK(make_HC(c, s + nm, 2 * d, 1, 1, false, &L)); L.col_split = true; c->textenc.push_back(L); }
   }
+  c->pack_bf16_now = 0;                 // Text2Mel's decode networks are never run in reduced form: the attention trajectory is fed back
   // ---- AudioEnc (networks.py:73-124), causal
   {
     const std::string s = "Text2Mel/AudioEnc/";
@@ -673,6 +740,7 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     HIPCHK(hipMemcpy(c->iota_dev, io.data(), io.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   // ---- SSRN (networks.py:214-292), SAME
+  c->pack_bf16_now = c->bf16_packed >= 1;
   {
     const std::string s = "SSRN/";
     int i = 1; DevLayer L, L2;
@@ -689,6 +757,7 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
     for (int rep = 0; rep < 2; ++rep) { snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_RELU, &L, false, true)); c->ssrn.push_back(L); }
     snprintf(nm, 64, "C_%d", i++); L = DevLayer(); CHK(make_C(c, s + nm, F, Fp, F, ACT_SIGMOID, &L, false, true)); c->ssrn.push_back(L);
   }
+  c->pack_bf16_now = 0;
   HIPCHK(hipDeviceSynchronize());
   c->hw.clear();
   c->finalized = true;
@@ -774,6 +843,19 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   //     (hconv_kernel.h: RAW) -- a third of an item's time per round instead of a whole one;
   //   * of the 4T-resolution k = 1 layers, when it is at most 0.6 of a round: 16-row items (hconv16_kernel.h).
   int tiles32 = (p.M + 31) / 32, m_tail = p.M;
+  // The opt-in split-bf16 form (dctts_set_split_bf16): whole 32-row items for every row, contraction on the bf16 matrix pipe.  `bf` is set by the network drivers
+  // for TextEnc / SSRN only; the layer must carry the packing.
+  if (c->bf_now && L.wpb && !rm.step && ((L.cout == 1025 && L.wxcol) || (L.shape.nw == 8 && (L.shape.nt == 2 || L.shape.nt == 4 || L.shape.nt == 8)))) {
+    p.wp = L.wpb; p.wx = (L.cout == 1025) ? L.wxcol : nullptr;
+    if (L.shape.epi == EPI_HC && L.shape.nt == 8) {
+      const size_t need = (size_t)p.M * 2 * L.cout;
+      if (need > c->tail_ws_floats) CHK(grow_scratch(c, &c->tail_ws, &c->tail_ws_floats, need));
+      p.m_base = 0; p.raw_out = c->tail_ws; p.raw_ld = 2 * L.cout;
+    }
+    HIPCHK(launch_hconv_bf16(L.shape, p, st));
+    if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
+    return 0;
+  }
   // Column split (round 4): TextEnc's 512-channel highway layers run as quarter-column items, three or four of them to a CU at once, + the finishing
   // pass.  At B = 32 their 180 32-row items fill 70 % of the CUs and a layer takes a whole item's time; as quarters it takes 3/4 of it.  ALWAYS, whatever the
   // batch: which form a row takes must not depend on the batch it is decoded in (K and V feed the attention; Text2Mel's outputs are bitwise equal across batch
@@ -878,6 +960,15 @@ static int ws_trim(dctts_ctx* c) {
   return 0;
 }
 
+extern "C" int dctts_set_split_bf16(dctts_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return fail(DCTTS_ERR_ARG, "split-bf16 mode: 0 (exact fp32), 1 (SSRN), 2 (SSRN + TextEnc)");
+  std::lock_guard<std::recursive_mutex> lk(c->mu);
+  if (!c->finalized) { c->bf16_packed = mode; c->bf16_mode = mode; return 0; }      // before dctts_weights_finalize: the level that gets packed (and runs)
+  if (mode > c->bf16_packed) return fail(DCTTS_ERR_STATE, "split-bf16: this level was not requested before dctts_weights_finalize (the bf16 weight packing does not exist)");
+  c->bf16_mode = mode;
+  return 0;
+}
+
 extern "C" int dctts_set_workspace_limit(dctts_ctx* c, size_t bytes) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   std::lock_guard<std::recursive_mutex> lk(c->mu);
@@ -896,6 +987,7 @@ static int textenc_into(dctts_ctx* c, const int32_t* L, int B, int N, View* kv_o
   const RowMap rm{B, N, nullptr, nullptr};
   const View tab{c->embed, 0, 0, c->cfg.e};
   const size_t nl = c->textenc.size();
+  struct BfScope { dctts_ctx* c; BfScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_now = on; } ~BfScope() { c->bf_now = false; } } bf_scope(c, c->bf16_mode >= 2);
   CHK(run_conv(c, c->textenc[0], tab, (const int*)L, a, rm, st));          // embed + C_2
   View cur = a, nxt = b;
   for (size_t i = 1; i < nl; ++i) {
@@ -1006,6 +1098,7 @@ static int ssrn_layers(dctts_ctx* c, const View* ws, const View& vin0, const Vie
   const RowMap r1{Bs, T, nullptr, nullptr}, r2{Bs, 2 * T, nullptr, nullptr}, r4{Bs, 4 * T, nullptr, nullptr};
   const std::vector<DevLayer>& S = c->ssrn;
   size_t i = 0;
+  struct BfScope { dctts_ctx* c; BfScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_now = on; } ~BfScope() { c->bf_now = false; } } bf_scope(c, c->bf16_mode >= 1);
   CHK(run_conv(c, S[i++], vin, nullptr, s1a, r1, st));            // C_1
   CHK(run_conv(c, S[i++], s1a, nullptr, s1b, r1, st));            // HC_2
   CHK(run_conv(c, S[i++], s1b, nullptr, s1a, r1, st));            // HC_3
@@ -1066,6 +1159,7 @@ extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const
   if (!V || index < 0 || index >= (int)V->size()) return fail(DCTTS_ERR_ARG, "debug_layer: unknown net / index");
   const DevLayer& L = (*V)[index];
   const RowMap rm{B, T, nullptr, nullptr};
+  struct BfScope { dctts_ctx* c; BfScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_now = on; } ~BfScope() { c->bf_now = false; } } bf_scope(c, (n == "ssrn" && c->bf16_mode >= 1) || (n == "textenc" && c->bf16_mode >= 2));
   if (n == "textenc" && index == 0) {      // embed + C_2: X is really int32 ids (B,T)
     const View tab{c->embed, 0, 0, c->cfg.e}, vo{out, T, 0, L.cout};
     return run_conv(c, L, tab, (const int*)X, vo, rm, st);

@@ -25,6 +25,22 @@
 namespace dctts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// Split-bf16 contraction (round 5, OPT-IN: dctts_set_split_bf16; the default and the headline stay exact fp32).  A float is written as two bf16 terms,
+// x = hi + mid + r with hi = bf16(x), mid = bf16(x - hi) (both round-to-nearest: v_cvt_pk_bf16_f32; x - hi is exact) and |r| <= 2^-18 |x|, and a product is
+// accumulated in fp32 from three matrix instructions  hi.hi + hi.mid + mid.hi  (what is dropped, mid.mid and the r terms, is <= 2^-16 of |x||w|), on
+// v_mfma_f32_32x32x16_bf16 at 16x the fp32 matrix rate: 3 x 32 cycles per 16 k against 8 x 64.  The weights are split once at upload, the activations in
+// registers behind the LDS read.  Two packed halves of a pair (x0, x1) -> their (hi, mid) words:
+__device__ __forceinline__ void split_bf16_pair(float x0, float x1, unsigned& hi, unsigned& mid) {
+  const bf16x2_t h = __builtin_convertvector((f32x2_t){x0, x1}, bf16x2_t);
+  hi = __builtin_bit_cast(unsigned, h);
+  const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xffff0000u);
+  const bf16x2_t m = __builtin_convertvector((f32x2_t){x0 - h0, x1 - h1}, bf16x2_t);
+  mid = __builtin_bit_cast(unsigned, m);
+}
 
 enum { EPI_C = 0, EPI_HC = 1 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
@@ -110,9 +126,15 @@ __device__ __forceinline__ float half_sum32(float v) {
 //     8.25 would do.  Here the first 1024 columns are 8 waves x 4 tiles (two waves per SIMD, 8 tile-times) and column 1024 is a dot product on the vector ALU: wave w
 //     owns rows 4 w .. 4 w + 3, a lane multiplies two channels of a chunk (A from the LDS tile every wave reads anyway, the column's weights from a 4 KB LDS copy) and
 //     the 16 lanes of a row are summed with DPP at the end; the value joins the layer-norm statistics in the cross-wave step and is normalised / stored by one lane.
-template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0, int XC = 0>
-__global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const ConvParams p) {      // (XC = 2: the same with registers capped for two workgroups per CU -- measurement variant)
+//   * BF = 1 (round 5, opt-in): the contraction on the bf16 matrix pipe from split operands (above).  p.wp then points at the bf16 packing
+//     [tile][16-k group][hi | mid][lane][8 bf16] (pack_bw_bf16 in dctts_api.hip): lane l holds k = 16 g + 8 (l >> 5) .. + 7 of column l & 31, as
+//     v_mfma_f32_32x32x16_bf16 wants its B operand; the A operand is the same 8 consecutive channels of row l & 31 out of the fp32 LDS tile.  The
+//     accumulators come out in the fp32 instruction's layout, so prologue, statistics and epilogue are shared.  NT <= 4 (a 16-k group of weights is
+//     8 NT registers per ring slot); the 64-tile layers run as two column halves (RAW = 2) + the finishing pass.
+template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0, int XC = 0, int BF = 0>
+__global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const ConvParams p) {      // (XC = 2: the same with registers capped for two workgroups per CU)
   static_assert(XC == 0 || (EPI == EPI_C && RAW == 0 && NW == 8), "the extra column rides in the fused k = 1 form: 8 waves x 4 rows");
+  static_assert(BF == 0 || (RAW != 1 && NT <= 4 && (BD == 1 || BD == 2)), "split-bf16: whole-K items, at most four tiles per wave, ring rotated by the two groups of a chunk");
   constexpr bool KPART = (RAW == 1);        // this workgroup contracts a PART of K (grid y = part)
   constexpr bool CPART = (RAW == 2);        // this workgroup owns a PART of the columns (grid y = part)
   constexpr int LDA = 36;
@@ -194,6 +216,12 @@ __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const
   for (int i = 0; i < NT; ++i)
     wq[i] = reinterpret_cast<const float4*>(p.wp) + ((long)(wv * NT + i) * KGT + kg0) * 64 + (SB ? 0 : lane);
   const int wl = SB ? lane : 0;
+  // BF: [tile][16-k group][hi | mid][lane] of 16-byte fragments; nch * 2 groups per tile (whole-K items only)
+  const uint4* wb[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+    wb[i] = reinterpret_cast<const uint4*>(p.wp) + (long)(wv * NT + i) * (p.ntaps * cpt * 2) * 128 + (SB ? 0 : lane);
+  const int KG16 = nch * 2;
 
   // channel of tile i inside its layer-norm group; the bias is the accumulators' initial value (columns beyond C: zero weights, zero bias -> exactly 0)
   const int C = p.cout;
@@ -214,10 +242,18 @@ __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const
   float4 a0 = load_next(aok);
   float4 a1 = load_next(aok1);
   float4 bq[BD][NT];                       // fragments of k-groups kg .. kg + BD - 1
+  uint4 bh[BD][NT], bm[BD][NT];            // BF: the hi / mid fragments of 16-k groups g .. g + BD - 1
+  if constexpr (!BF) {
 #pragma unroll
-  for (int d = 0; d < BD; ++d)
+    for (int d = 0; d < BD; ++d)
 #pragma unroll
-    for (int i = 0; i < NT; ++i) bq[d][i] = wq[i][(d < KG ? d : KG - 1) * 64 + wl];
+      for (int i = 0; i < NT; ++i) bq[d][i] = wq[i][(d < KG ? d : KG - 1) * 64 + wl];
+  } else {
+#pragma unroll
+    for (int d = 0; d < BD; ++d)
+#pragma unroll
+      for (int i = 0; i < NT; ++i) { const int g = (d < KG16 ? d : KG16 - 1) * 128 + wl; bh[d][i] = wb[i][g]; bm[d][i] = wb[i][g + 64]; }
+  }
   if (!aok) a0 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (!aok1) a1 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) {
@@ -228,6 +264,8 @@ __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const
   __syncthreads();
   const int aoff = l31 * LDA + lhi * 4;
   float4 a = *reinterpret_cast<const float4*>(&As[0][aoff]);
+  const int aoffb = l31 * LDA + lhi * 8;   // BF: 8 consecutive channels of row l31 per 16-k group
+  float4 af0 = *reinterpret_cast<const float4*>(&As[0][aoffb]), af1 = *reinterpret_cast<const float4*>(&As[0][aoffb + 4]);
   int cb = 0;                              // ch % 3
   const int xoff = (wave * 4 + (lane >> 4)) * LDA + (lane & 15) * 2;      // XC: (row, channel pair) of this lane inside a chunk's tile
   float xacc = 0.f;
@@ -240,6 +278,41 @@ __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const
     }
     const int cb1 = (cb == 2) ? 0 : cb + 1, cb2 = (cb1 == 2) ? 0 : cb1 + 1;
     const float* An = As[cb1];
+    if constexpr (BF) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {          // the two 16-k groups of the chunk; the barrier sits between them (same staging as the fp32 loop)
+        const int kg = ch * 2 + q;
+        const int kgn = (kg + BD < KG16) ? kg + BD : KG16 - 1;
+        if (q == 1) {
+          __syncthreads();
+          if (!aok) areg = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ch + 2 < nch && tid < 256) *reinterpret_cast<float4*>(&As[cb2][lrow * LDA + lc4 * 4]) = areg;
+          areg = load_next(aok);             // chunk ch + 3
+        }
+        const float* nx = (q == 0) ? &Ab[aoffb + 16] : &An[aoffb];
+        const float4 an0 = *reinterpret_cast<const float4*>(nx), an1 = *reinterpret_cast<const float4*>(nx + 4);
+        uint4 bhn[NT], bmn[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { bhn[i] = wb[i][kgn * 128 + wl]; bmn[i] = wb[i][kgn * 128 + 64 + wl]; }
+        uint4 ah, am;
+        split_bf16_pair(af0.x, af0.y, ah.x, am.x); split_bf16_pair(af0.z, af0.w, ah.y, am.y);
+        split_bf16_pair(af1.x, af1.y, ah.z, am.z); split_bf16_pair(af1.z, af1.w, ah.w, am.w);
+        const bf16x8_t ahv = __builtin_bit_cast(bf16x8_t, ah), amv = __builtin_bit_cast(bf16x8_t, am);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(bf16x8_t, bh[0][i]), acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahv, __builtin_bit_cast(bf16x8_t, bm[0][i]), acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(amv, __builtin_bit_cast(bf16x8_t, bh[0][i]), acc[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+#pragma unroll
+          for (int d = 0; d + 1 < BD; ++d) { bh[d][i] = bh[d + 1][i]; bm[d][i] = bm[d + 1][i]; }
+          bh[BD - 1][i] = bhn[i]; bm[BD - 1][i] = bmn[i];
+        }
+        af0 = an0; af1 = an1;
+      }
+    } else {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int kg = ch * 4 + gq;
@@ -269,6 +342,7 @@ __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const
         bq[BD - 1][i] = bnext[i];
       }
       a = an;
+    }
     }
     cb = cb1;
   }

@@ -39,7 +39,7 @@ class Engine:
     """Owns the device-resident packed weights and workspaces for one GPU."""
 
     def __init__(self, weights: Dict[str, np.ndarray], hp: Hyperparams = _hp, device: Optional[int] = None,
-                 decode_graph: bool = False, keep_weights: bool = True):
+                 decode_graph: bool = False, keep_weights: bool = True, split_bf16: int = 0):
         if not torch.cuda.is_available():
             raise DcttsError("dc_tts_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = _lib.load()
@@ -52,6 +52,10 @@ class Engine:
         h = ctypes.c_void_p()
         self._ok(self.lib.dctts_create(ctypes.byref(h), self.device_index, ctypes.byref(cfg)))
         self._h = h
+        # split_bf16 (OPT-IN, default 0 = exact fp32): 1 = SSRN, 2 = SSRN + TextEnc contract on the bf16 matrix pipe from split operands (dctts_set_split_bf16);
+        # the level given here is what gets packed at upload, set_split_bf16() then selects any level up to it
+        if split_bf16:
+            self._ok(self.lib.dctts_set_split_bf16(self._h, int(split_bf16)))
         for name, arr in weights.items():
             a = np.ascontiguousarray(arr, dtype=np.float32)
             shape = (ctypes.c_int64 * a.ndim)(*a.shape)
@@ -77,6 +81,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_split_bf16(self, mode: int):
+        """0: exact fp32 (default); 1: SSRN, 2: SSRN + TextEnc on split-bf16 operands -- only levels up to the one the Engine was created with."""
+        self._ok(self.lib.dctts_set_split_bf16(self._h, int(mode)))
 
     def set_decode_graph(self, enable):
         """False/0 (default): eager launches; True/1: the side stream's work as one hipGraph per frame (measured slower)."""

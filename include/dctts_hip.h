@@ -136,6 +136,16 @@ int dctts_set_decode_mode(dctts_ctx* ctx, int mode);
 /* Device memory the context holds for the shapes seen so far (weights + workspaces), bytes. */
 size_t dctts_device_bytes(const dctts_ctx* ctx);
 
+/* OPT-IN reduced-cost contraction for the two throughput networks; the default (0) is exact fp32 everywhere and is what every number quoted as the
+ * metric is measured with.  mode 1: SSRN's convolutions, mode 2: SSRN's and TextEnc's run on the bf16 matrix pipe from SPLIT operands -- every fp32
+ * weight and activation is written as hi + mid (two bf16 terms, round-to-nearest) and a product is accumulated in fp32 as hi.hi + hi.mid + mid.hi
+ * (v_mfma_f32_32x32x16_bf16: 16x the fp32 matrix rate, three instructions instead of eight per 16 k); what is dropped is <= 2^-16 of |x||w| per product.
+ * Bias, layer-norm, gate, activations and the 1025th column stay fp32; AudioEnc / Attention / AudioDec (the decode, whose arg-max is fed back:
+ * synthesize.py:52-54) always run in fp32, so with mode 1 the mel output and the attention trajectory are bit-identical to mode 0.  Call it BEFORE
+ * dctts_weights_finalize with the highest level wanted (the weights get a second, bf16 packing); afterwards any level up to that one can be selected per call
+ * sequence.  Measured error against the float64 oracle: tests/test_gpu_parity.py::test_split_bf16_*, DESIGN.md section 11. */
+int dctts_set_split_bf16(dctts_ctx* ctx, int mode);
+
 /* Workspaces and the decode's device tables are cached per geometry (B, T, N) and only grow: a serving loop that alternates
  * between batch shapes pays an allocation the first time a shape is seen and nothing afterwards (no hipDeviceSynchronize, no
  * hipFree on a shape change).  When the cached workspaces exceed `bytes` (default 96 GiB of the 288 GB) the next call drops

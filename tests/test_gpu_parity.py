@@ -899,6 +899,91 @@ def test_alternating_batch_shapes_reuse_their_workspaces(weights):
         eng.set_workspace_limit(96 << 30)
 
 
+# ---------------------------------------------------------------- the opt-in split-bf16 contraction (dctts_set_split_bf16)
+_bf_engine = {}
+
+
+def bf16_engine(weights):
+    from dc_tts_amd.engine import Engine
+    if "e" not in _bf_engine:
+        _bf_engine["e"] = Engine(weights, hp, split_bf16=2)
+    return _bf_engine["e"]
+
+
+BF_CASES = [c for c in CASES if c.values[0] in ("textenc", "ssrn")]
+
+
+@pytest.mark.parametrize("net,scope,causal,li", BF_CASES)
+def test_split_bf16_layer_vs_oracle(weights, net, scope, causal, li):
+    """Every layer shape class of TextEnc and SSRN on the split-bf16 form (hi.hi + hi.mid + mid.hi on the bf16 matrix pipe, fp32 accumulate) against the oracle at the
+    SAME tolerance as the fp32 form (2e-4), whole 32-row items incl. a ragged one; the fp32 form of the same engine must still be selectable and exact."""
+    fn = {"textenc": textenc_layers, "ssrn": ssrn_layers}[net]
+    layers = fn(hp)
+    l = layers[li]
+    eng = bf16_engine(weights)
+    rng = np.random.default_rng(100 + li)
+    B, T = 2, 75
+    P = O._Scoped(weights, scope, np.float32)
+    di = _dev_index(layers, li, net)
+    if net == "textenc" and li == 1:
+        ids = rng.integers(0, len(hp.vocab), (B, T)).astype(np.int32)
+        ref = O.conv1d(O.embed(ids, P["embed_1/lookup_table"]), P, "C_2", act=O.relu)
+        run = lambda: eng.debug_layer(net, 0, dev(ids), l.cout).cpu().numpy()
+    else:
+        x = rng.standard_normal((B, T, l.cin)).astype(np.float32)
+        if l.kind == "C":
+            ref = O.conv1d(x, P, l.scope, padding="SAME", act=O.relu if l.act == "relu" else None)
+            run = lambda: eng.debug_layer(net, di, dev(x), l.cout).cpu().numpy()
+        elif l.kind == "HC":
+            ref = O.hc(x, P, l.scope, rate=l.rate, padding="SAME")
+            run = lambda: eng.debug_layer(net, di, dev(x), l.cout).cpu().numpy()
+        else:
+            ref = O.conv1d_transpose(x, P, l.scope)
+            run = lambda: eng.debug_layer(net, di, dev(x), l.cout, upsample=2).cpu().numpy()
+    if net == "ssrn" and li == len(layers) - 1:
+        ref = O.sigmoid(ref)
+    eng.set_split_bf16(2)
+    got = run()
+    eng.set_split_bf16(0)
+    got32 = run()
+    eng.set_split_bf16(2)
+    e, e32 = maxabs(got, ref), maxabs(got32, ref)
+    print(f"{net}/{l.scope}: split-bf16 max-abs {e:.2e} (fp32 form {e32:.2e})")
+    assert got.shape == ref.shape and e < 2e-4 and e32 < 2e-4, (e, e32)
+    assert not np.array_equal(got, got32) or l.cin < 16       # (the two forms are different arithmetic: equal outputs would mean the switch does nothing)
+
+
+def test_split_bf16_pipeline_error_and_untouched_decode(weights):
+    """Mode 1 (SSRN only): Text2Mel -- mel frames AND attention trajectory -- is bit-identical to the exact form, Z within the north-star 1e-3 of the float64 oracle;
+    mode 2 (+ TextEnc): the trajectory is still the oracle's, Y and Z within 1e-3.  The measured errors are printed (DESIGN.md section 11 quotes them)."""
+    T = 50
+    h = hp.replace(max_T=T)
+    from dc_tts_amd.engine import Engine
+    eng = Engine(weights, h, split_bf16=2)
+    Lh = synthetic_text(h, B=4, seed=77)
+    L = dev(Lh)
+    eng.set_split_bf16(0); Y0, Z0, m0 = eng.synthesize(L); eng.synchronize()
+    eng.set_split_bf16(1); Y1, Z1, m1 = eng.synthesize(L); eng.synchronize()
+    eng.set_split_bf16(2); Y2, Z2, m2 = eng.synthesize(L); eng.synchronize()
+    assert torch.equal(Y1, Y0) and torch.equal(m1, m0) and not torch.equal(Z1, Z0)
+    W64 = {k: v.astype(np.float64) for k, v in weights.items()}
+    Yr, Zr, traj = O.synthesize(Lh, W64, h, np.float64)
+    np.testing.assert_array_equal(m0.cpu().numpy(), traj); np.testing.assert_array_equal(m2.cpu().numpy(), traj)
+    errs = {"fp32": (maxabs(Y0.cpu().numpy(), Yr), maxabs(Z0.cpu().numpy(), Zr)), "ssrn": (maxabs(Y1.cpu().numpy(), Yr), maxabs(Z1.cpu().numpy(), Zr)),
+            "ssrn+textenc": (maxabs(Y2.cpu().numpy(), Yr), maxabs(Z2.cpu().numpy(), Zr))}
+    print("max-abs vs the float64 oracle (Y, Z):", {k: (f"{a:.2e}", f"{b:.2e}") for k, (a, b) in errs.items()})
+    for k, (ey, ez) in errs.items():
+        assert ey < TOL and ez < TOL, (k, ey, ez)
+    eng.close()
+
+
+def test_split_bf16_needs_the_packing(weights):
+    eng = engine_for(weights)                                     # created without split_bf16: no bf16 packing on the device
+    with pytest.raises(Exception):
+        eng.set_split_bf16(1)
+    eng.set_split_bf16(0)
+
+
 # ---------------------------------------------------------------- the restore path end to end (synthesize.py:32-40, SURVEY 8f-1)
 def test_checkpoint_directories_to_spectrograms(weights, tmp_path):
     """`python -m dc_tts_amd.synthesize --logdir <prefix>`: two checkpoint directories laid out like hp.logdir-1 / hp.logdir-2 -- written by the
