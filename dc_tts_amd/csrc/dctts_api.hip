@@ -325,6 +325,14 @@ DevGuard::DevGuard(const dctts_ctx* c) {
   if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
 }
 static int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// hipMemset on device memory may return before the fill has run (it is queued on the null stream, which a non-blocking stream does not wait for): a buffer that kernels on
+// ANOTHER stream are about to poll or count in must be zero before the call returns.  (Rounds 3-4 got that for free from the hipDeviceSynchronize of every table rebuild;
+// without those, bench.py's first decode at a new batch size lost its team barriers to the late fill -- error word 1.)
+static hipError_t dev_zero_now(void* p, size_t bytes) {
+  hipError_t e = hipMemsetAsync(p, 0, bytes, nullptr);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(nullptr);
+}
 
 // ------------------------------------------------------------------------------------------------ weights
 static int get_w(dctts_ctx* c, const std::string& name, const std::vector<int64_t>& shape, const HostTensor** out) {

@@ -513,7 +513,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xg", g, &ts)) { c->xg_tab = ts.tab; c->xg_mem = (float*)ts.mem; c->xg_T = ts.n0; c->xg_geom = g; return 0; } }
   c->xg_tab = nullptr; c->xg_mem = nullptr;
   HIPCHK(hipMalloc((void**)&c->xg_mem, xg_mem_floats(B) * sizeof(float)));
-  HIPCHK(hipMemset(c->xg_mem, 0, xg_mem_floats(B) * sizeof(float)));
+  HIPCHK(dev_zero_now(c->xg_mem, xg_mem_floats(B) * sizeof(float)));
   const XgMem m = xg_mem(c, B);
   const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
   auto rowp = [](const View& v, long par, int j) { return v.p + par * v.set + (v.row0 + j) * (long)v.stride; };
@@ -588,7 +588,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
         p.p_ipl = ipl; p.p_blocks = (c->aepre_layers - 3) * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;      // (none of them is counted)
       }
       if (piece == c->trace_frame) {                            // DCTTS_TRACE: this piece's two launches record their phase boundaries
-        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
+        if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(dev_zero_now(c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
         p.ts = c->trace_buf + 64 * 64 * 32 - 192 - 256 * (2 - net);
       }
       tab[(size_t)2 * (piece + 1) + net] = p;
@@ -658,7 +658,7 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       if (f + 1 < T) { p.wait = c->wait_ctr; p.wait_val = (unsigned)(f + 1); p.wait_err = (int*)(c->wait_ctr + 64); }      // what side-stream piece f + 1 starts from
     }
     if (f == c->trace_frame) {                                  // DCTTS_TRACE: this frame's launch records its phase boundaries
-      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(dev_zero_now(c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
       p.ts = c->trace_buf + 64 * 64 * 32 - 192;
     }
     tab[f] = p;
@@ -821,7 +821,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       for (int r = 0; r < nout[0]; ++r) p.in_off[kk * nout[0] + r] = AD[h0].tap_off[2 - kk] - r;      // input row q = kk * 5 + r: time t - r + tap offset
     p.xch = m.xch_h; p.sch = m.sch_h; p.xch_set = groups * XT_MAXM * 512; p.sch_set = groups * XT_MAXM * 64;
     if (j == c->trace_frame) {
-      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(hipMemset(c->trace_buf, 0, 64 * 64 * 32 * sizeof(long long))); }
+      if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(dev_zero_now(c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
       p.ts = c->trace_buf + 64 * 64 * 32 - 64;      // (the slot mlp_rows_kernel's stamps use in the row-split form)
     }
     tab[j] = p;
@@ -1022,7 +1022,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   const bool cwait = vs && c->chain_wait_inkernel;          // the chain's wait for the bulk's counter happens inside that launch (chain3_kernel: wait2)
   if (cwait && !c->wait_ctr) {
     HIPCHK(hipMalloc((void**)&c->wait_ctr, 128 * sizeof(unsigned)));
-    HIPCHK(hipMemset(c->wait_ctr, 0, 128 * sizeof(unsigned)));
+    HIPCHK(dev_zero_now(c->wait_ctr, 128 * sizeof(unsigned)));
   }
   CHK(v3_mlp_table(c, w, B, T));
   c->xg_on = c->xgroup != 0 && c->xgroup_ok && c->prof_id != DCTTS_PROF_CHAIN_HC;      // (that timing id looks at chain3_kernel launches; so does DCTTS_TRACE with DCTTS_XGROUP=0)
@@ -1179,7 +1179,7 @@ static void lease_forget(const dctts_ctx* c) {   // dctts_destroy: the next cont
 static int decode_status_init(dctts_ctx* c) {
   if (c->dstat) return 0;
   HIPCHK(hipMalloc((void**)&c->dstat, 4 * sizeof(int)));
-  HIPCHK(hipMemset(c->dstat, 0, 4 * sizeof(int)));
+  HIPCHK(dev_zero_now(c->dstat, 4 * sizeof(int)));
   HIPCHK(hipHostMalloc((void**)&c->dstat_host, 4 * sizeof(int), 0));
   for (int i = 0; i < 4; ++i) c->dstat_host[i] = 0;
   return 0;
@@ -1332,7 +1332,7 @@ extern "C" int dctts_decode_status(dctts_ctx* c) {
     DevGuard dev_guard(c);
     const int ew = c->dstat_host[0], nfail = c->dstat_host[1];
     c->dstat_host[0] = 0; c->dstat_host[1] = 0;
-    (void)hipMemset(c->dstat, 0, 2 * sizeof(int));
+    (void)dev_zero_now(c->dstat, 2 * sizeof(int));
     // only a team that is not on one XCD (bits 2 / 8) says something permanent about this device; time-outs (bits 1 / 4 / 16 / 32: CUs or the side stream held
     // up by somebody else's work) are transient -- the team kernels stay on unless three reports in a row fail
     if (ew & (2 | 8)) c->xgroup_ok = false;

@@ -8,6 +8,7 @@
 #include <limits>
 #include <string>
 #include <utility>
+#include <mutex>
 #include <vector>
 
 #include "../../include/dctts_hip.h"
@@ -37,7 +38,21 @@ struct dctts_vocoder {
   VBuf spec, X, fr0, fr1, yraw, pw;
   bool prof = false;                                  // HIP events around every gl_iter_wave launch (dctts_vocoder_prof_*)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  // One set of scratch buffers per handle: calls from different streams are ordered on the device (a call waits for the completion event of the last call that
+  // came from another stream), the host side is serialised by a mutex (round 5; same rule as a dctts_ctx's use groups)
+  std::mutex mu; hipEvent_t done = nullptr; hipStream_t last = nullptr; bool used = false;
 };
+
+static int voc_acquire(dctts_vocoder* v, hipStream_t st) {
+  if (v->used && v->last != st) VHIPCHK(hipStreamWaitEvent(st, v->done, 0));
+  return 0;
+}
+static int voc_release(dctts_vocoder* v, hipStream_t st) {
+  if (!v->done) VHIPCHK(hipEventCreateWithFlags(&v->done, hipEventDisableTiming));
+  VHIPCHK(hipEventRecord(v->done, st));
+  v->last = st; v->used = true;
+  return 0;
+}
 
 static int vgrow(VBuf& b, size_t bytes) {
   if (b.bytes >= bytes) return 0;
@@ -83,6 +98,7 @@ extern "C" int dctts_vocoder_destroy(dctts_vocoder* v) {
   (void)hipDeviceSynchronize();
   for (auto& e : v->prof_ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (VBuf* b : {&v->spec, &v->X, &v->fr0, &v->fr1, &v->yraw, &v->pw}) if (b->p) (void)hipFree(b->p);
+  if (v->done) (void)hipEventDestroy(v->done);
   if (v->window) (void)hipFree(v->window);
   if (v->wss) (void)hipFree(v->wss);
   if (v->w1024) (void)hipFree(v->w1024);
@@ -161,19 +177,23 @@ extern "C" int dctts_griffin_lim(dctts_vocoder* v, const float* spec, int B, int
   if (n_iter < 0) return dctts_set_error(DCTTS_ERR_ARG, "n_iter < 0");
   if (X_best && n_iter == 0) return dctts_set_error(DCTTS_ERR_ARG, "X_best needs n_iter >= 1");
   VHIPCHK(hipSetDevice(v->device));
+  std::lock_guard<std::mutex> lk(v->mu);
+  hipStream_t st = (hipStream_t)stream;
+  VCHK(voc_acquire(v, st));
   VocGeom g;
   VCHK(geom(v, B, F, &g));
-  hipStream_t st = (hipStream_t)stream;
   VCHK(run_griffin_lim(v, g, spec, B, n_iter, (float2*)X_best, y, st));
-  return 0;
+  return voc_release(v, st);
 }
 
 extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, int F, float* wav, int32_t* bounds, void* stream) {
   if (!v || !mag || !wav) return dctts_set_error(DCTTS_ERR_ARG, "null argument");
   VHIPCHK(hipSetDevice(v->device));
+  std::lock_guard<std::mutex> lk(v->mu);
+  hipStream_t st = (hipStream_t)stream;
+  VCHK(voc_acquire(v, st));
   VocGeom g;
   VCHK(geom(v, B, F, &g));
-  hipStream_t st = (hipStream_t)stream;
   const long n = (long)B * F * VOC_BINS;
   VCHK(vgrow(v->spec, (size_t)n * sizeof(float)));
   VCHK(vgrow(v->yraw, (size_t)B * g.L * sizeof(float)));
@@ -190,7 +210,7 @@ extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, 
     hipLaunchKernelGGL(trim_bounds_kernel, dim3(B), dim3(256), 0, st, (const float*)v->pw.p, (int*)bounds, g.L, n_tf, fhop, v->cfg.trim_top_db);
   }
   VHIPCHK(hipGetLastError());
-  return 0;
+  return voc_release(v, st);
 }
 
 extern "C" int dctts_vocoder_prof_enable(dctts_vocoder* v, int enable) {

@@ -873,6 +873,22 @@ def test_one_engine_two_streams_same_kind_calls_of_different_inputs(weights):
         else: assert all(torch.equal(x, y) for x, y in zip(got, ref)), (tag, k)
 
 
+def test_first_decode_at_a_new_geometry_is_valid(weights):
+    """Found by bench.py in round 5: the first decode at a batch size not seen before allocated the team kernels' exchange memory and zeroed it with hipMemset, which may
+    run AFTER the call returns (null stream) -- i.e. in the middle of the decode, wiping its team barriers (error word 1).  Rounds 3-4 hid that behind the
+    hipDeviceSynchronize of every table rebuild.  Every geometry here is new to a fresh engine; each first decode must be valid and equal to its repetition."""
+    from dc_tts_amd.engine import Engine
+    eng = Engine(weights, hp.replace(max_T=64))
+    for B, T in ((128, 40), (70, 33), (5, 64), (37, 21), (64, 48), (96, 17)):
+        L = dev(synthetic_text(hp.replace(max_T=T), B=B, seed=B + T))
+        Y1, m1 = eng.text2mel(L, max_T=T)
+        eng.synchronize()                                            # raises if the decode failed on the device
+        Y2, m2 = eng.text2mel(L, max_T=T)
+        eng.synchronize()
+        assert bool(torch.isfinite(Y1).all()) and torch.equal(Y1, Y2) and torch.equal(m1, m2), (B, T)
+    eng.close()
+
+
 def test_alternating_batch_shapes_reuse_their_workspaces(weights):
     """Workspaces and the decode's tables are cached per geometry: B = 32 / B = 6 / T changes alternate without the cache growing after the first round, results
     bitwise equal each time; past dctts_set_workspace_limit the cache is dropped (one device sync) and everything still works."""
