@@ -9,9 +9,9 @@ Multi-GPU: utterances shard embarrassingly, 32 per GPU, no collective on the dat
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 What the JSON line holds besides the contract's fields (everything is measured in this run unless it says otherwise):
-  roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r04_kernel_stats.md): xcone_kernel, the re-evaluation of
+  roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r05_kernel_stats.md): xcone_kernel, the re-evaluation of
                       AudioDec's dependency cone on the decode's side stream; HIP-event timed on ITS stream inside the timed region (every 16th
-                      frame from frame 100 on), fp32-MFMA bound; `traffic` = PMC bytes per launch (profiles/r04_pmc_decode.json, separate passes)
+                      frame from frame 100 on), fp32-MFMA bound; `traffic` = PMC bytes per launch (profiles/r05_pmc_decode.json, separate passes)
   kernels             the same figures for xgroup_kernel and xtail_kernel (the chain's launches), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
                       launch) and SSRN's 1025-column layers (event-timed in untimed extra passes)
   phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
@@ -38,7 +38,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 PROF_SSRN_HC = 1 * 10000 + 8 * 100 + 8    # hconv_kernel<EPI_HC, NT=8, NW=8>: SSRN HC_11 / HC_12 (C = 1024)
 PROF_SSRN_HC_TAIL = 50000 + 1 * 10000 + 16 * 100 + 8     # the row-tail launches of the same layers (tap-split items + finishing pass; the id is the 16-row shape's)
-PROF_SSRN_C1025 = 0 * 10000 + 3 * 100 + 11               # hconv_kernel<EPI_C, NT=3, NW=11>: SSRN C_13 .. C_16 (1025 columns)
+PROF_SSRN_C1025 = 0 * 10000 + 3 * 100 + 11               # SSRN C_13 .. C_16 (1025 columns): the id is their row-tail shape <EPI_C, NT=3, NW=11>; the main launch is the XC form since round 5
 PROF_XGROUP = 30002               # include/dctts_hip_debug.h: xgroup_kernel, sampled every 16th frame (prof_rows counts layers)
 PROF_XCONE = 30003                # xcone_kernel (eager decode only)
 PROF_XTAIL = 30004                # xtail_kernel, sampled every 16th frame
@@ -372,7 +372,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         d = hp.d
-        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r04_kernel_stats.md): xcone_kernel, AudioDec HC_3 and HC_4
+        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r05_kernel_stats.md): xcone_kernel, AudioDec HC_3 and HC_4
         #      over the rows of a frame's dependency cone (45 and 15 rows per utterance incl. the presum row) + their layer-norm / gate passes (round 4:
         #      HC_5 .. HC_7 moved to the chain's xtail_kernel), one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one
         #      layer: a (3 x 256) x 512 fp32 contraction = 2 * 768 * 512 FLOP; algorithmic bytes of a launch = the rows in and out (256 channels each) +
@@ -397,12 +397,12 @@ def main():
             roof.update(avg_launch_ms=round(avg, 5), rows_per_launch=round(rpl, 1), flop_per_launch=row_flop * rpl, algorithmic_bytes_per_launch=alg_bytes,
                         achieved=round(tf, 3), frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                         frac_hbm=round(alg_bytes / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5))
-        tj = os.path.join(ROOT, "profiles", "r04_pmc_decode.json")
+        tj = os.path.join(ROOT, "profiles", "r05_pmc_decode.json")
         if os.path.exists(tj):
             pj = json.load(open(tj))
             if "xcone_kernel" in pj:
                 roof["traffic"] = pj["xcone_kernel"]["hbm_bytes_per_launch"]
-                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes on this tree: profiles/r04_pmc_decode.json; includes Infinity-Cache hits)"
+                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes on this tree: profiles/r05_pmc_decode.json; includes Infinity-Cache hits)"
         flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6      # SURVEY 8d, per mel frame and utterance
         out = {
             "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
@@ -481,9 +481,11 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     d, c = hp.d, hp.c
     res = {}
     # ---- phases
-    ms_te = timed(lambda: eng.text_enc(L))
+    # (order matters: this runs behind the host gather, i.e. after ~0.1 s of GPU idle, and a 2 ms kernel sequence timed first reads 10 % slow while the clocks come back --
+    #  TextEnc 2.2 ms measured first against 1.95 ms behind any other work, tools/scratch/te_bench_dbg.py; in the pipeline it runs right behind the previous batch's SSRN)
     ms_t2m = timed(lambda: eng.text2mel(L))
     ms_ssrn = timed(lambda: eng.ssrn(Y, want_logits=False))
+    ms_te = timed(lambda: eng.text_enc(L), reps=10)
     dec_ms = ms_t2m - ms_te
     res["phases"] = {"textenc_ms": round(ms_te, 3), "text2mel_total_ms": round(ms_t2m, 3),
                      "decode_us_per_step": round(dec_ms * 1e3 / T, 2), "ssrn_ms": round(ms_ssrn, 3)}
@@ -512,7 +514,7 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
                          **both_roofs(2.0 * rpl * 3 * C * 2 * C, 4.0 * (rpl * C * 2 + 3 * C * 2 * C), ms / n)))
     F = hp.n_linear
     for kid, what, K_, N_ in ((PROF_SSRN_HC_TAIL, "hconv_kernel<EPI_HC,NT=8,NW=8,RAW> + hc_tail_finish_kernel (SSRN HC_11 / HC_12: the rows left after three exact rounds, as 72 32-row items x 3 taps + a finishing pass)", 3 * 2 * c, 2 * 2 * c),
-                              (PROF_SSRN_C1025, "hconv_kernel<EPI_C,NT=3,NW=11> (SSRN C_14 / C_15 / C_16 and C_13: 1025 columns, k=1, fused LN + activation)", None, F)):
+                              (PROF_SSRN_C1025, "hconv_kernel<EPI_C,NT=4,NW=8,XC> (SSRN C_14 / C_15 / C_16 and C_13: 1025 columns, k=1, fused LN + activation; round 5: 8 waves x 4 tiles + the 1025th column on the vector ALU, main launch)", None, F)):
         eng.prof_enable(kid)
         for _ in range(2):
             eng.ssrn(Y, want_logits=False)
@@ -549,7 +551,7 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
                             "4-utterance team, rows and statistics exchanged through the L2 of the team's XCD)",
                      bound="latency (16 dependent all-to-all layers per frame)", launches=n, avg_launch_ms=round(ms / n, 5), layers_per_launch=lpl,
                      algorithmic_bytes_per_layer=lay_bytes, flop_per_layer=lay_flop, **both_roofs(lay_flop * lpl, lay_bytes * lpl, ms / n))
-            tj = os.path.join(ROOT, "profiles", "r04_pmc_decode.json")
+            tj = os.path.join(ROOT, "profiles", "r05_pmc_decode.json")
             if os.path.exists(tj):
                 pj = json.load(open(tj))
                 if "xgroup_kernel" in pj:

@@ -1,20 +1,20 @@
 #!/bin/bash
-# Reproduces everything under profiles/ (round 4) on a 1x MI355X box (run from the repo root; ~5 minutes of GPU time).
+# Reproduces everything under profiles/ (round 5) on a 1x MI355X box (run from the repo root; ~5 minutes of GPU time).
 # Every profiler command is wrapped in `timeout`; --pmc passes are separate runs with --kernel-trace only.
 set -u
 R=$PWD
-OUT=${1:-$R/gpurun_out/profile_r04}
+OUT=${1:-$R/gpurun_out/profile_r05}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-STEPS=${STEPS:-123457}           # e.g. STEPS=127 bash tools/profile_all.sh: only the bench line, the kernel trace and the layer table
+STEPS=${STEPS:-12345789}           # e.g. STEPS=127 bash tools/profile_all.sh: only the bench line, the kernel trace and the layer table
 want() { case "$STEPS" in *$1*) return 0;; *) return 1;; esac; }
-# 1. the bench line (metric, roofline of the time-dominant kernel, kernels, other configs, cpu_baseline, vocoder)  -> profiles/r04_bench.json
+# 1. the bench line (metric, roofline of the time-dominant kernel, kernels, other configs, cpu_baseline, vocoder)  -> profiles/r05_bench.json
 want 1 && timeout 600 python "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
-# 2. per-kernel time of the same workload                                               -> profiles/r04_kernel_stats.{csv,md}
+# 2. per-kernel time of the same workload                                               -> profiles/r05_kernel_stats.{csv,md}
 want 2 && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kernel_stats" -- \
     python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-vocoder --no-extras > "$OUT/kernel_stats.log" 2>&1
-# 3. HBM traffic of the decode kernels (FETCH_SIZE x2 per the gfx950 correction; WRITE_SIZE exact)   -> profiles/r04_pmc.{md,json}
+# 3. HBM traffic of the decode kernels (FETCH_SIZE x2 per the gfx950 correction; WRITE_SIZE exact)   -> profiles/r05_pmc.{md,json}
 #    Counter collection serialises dispatches ACROSS queues, so a launch that waits for the other stream's counter (stream memory
 #    operations, in-kernel signals) would wait for ever: the counter passes let the two streams meet through events (DCTTS_SYNC_VALUES=0).
 export DCTTS_SYNC_VALUES=0
@@ -36,6 +36,14 @@ want 5 && DCTTS_PIECETIME=100 DM=3 GM=0 timeout 120 python "$R/tools/decode_time
 # 7. TextEnc and SSRN launch by launch
 want 7 && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/layers" -- python "$R/tools/layer_trace.py" > "$OUT/layers.log" 2>&1)
 want 7 && python tools/layer_trace_table.py "$OUT/layers" > "$OUT/layers.txt"
+# 8. the throughput kernel's variants on four layer shapes, each timed in turn behind a cache-thrashing pass (product template only)   -> profiles/r05_hconv_lab.txt
+want 8 && (hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dc_tts_amd/csrc tools/micro/hconv_lab.hip -o tools/micro/kp_hconv_lab 2> "$OUT/hconv_lab_build.log"; timeout 300 tools/micro/kp_hconv_lab 9 > "$OUT/hconv_lab.txt" 2>&1)
+# 9. what the two decode streams' pieces take in the default form and with the cone's last layers back on the side stream      -> profiles/r05_chain_tail_split.txt
+want 9 && for tail in 2 1 5; do
+  echo "== DCTTS_CHAIN_TAIL=$tail"
+  for rep in 1 2; do DCTTS_CHAIN_TAIL=$tail GM=0 HP=1 timeout 120 python tools/decode_time.py 2>&1 | grep -E "text2mel|rror"; done
+  DCTTS_CHAIN_TAIL=$tail DCTTS_PIECETIME=150 GM=0 HP=1 NREP=1 timeout 120 python tools/decode_time.py 2>&1 | grep -E "frame 15[0-7]" | tail -8
+done > "$OUT/chain_tail_split.txt" 2>&1
 want 2 && find "$OUT/kernel_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 rm -rf "$OUT/kernel_stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/layers"
 echo "done: $OUT"
