@@ -207,6 +207,7 @@ struct dctts_ctx {
   std::vector<DevLayer> textenc, audioenc, audiodec, ssrn;
   float* embed = nullptr;
   std::vector<int*> cone_dev; std::vector<int> cone_len;
+  std::vector<int> cone_contig;        // per AudioDec layer: its cone offsets are 0, -1, -2, ... without a gap (C_1, HC_2: the row phases compute t instead of loading the table)
   std::map<std::string, Buf> ws;       // named workspaces; the key includes the geometry its prefix is selected for (ws_select)
   // Workspaces are cached PER GEOMETRY and only grow (round 5): "te." / "t2m." / "dec." / "ssrn." each select the geometry string of the running call, a
   // buffer "dec.ypad" lives under the key "dec@<geometry>.ypad" in the arena pool "dec@<geometry>.", and a geometry that comes back finds its buffers (and the
@@ -248,6 +249,7 @@ struct dctts_ctx {
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
   bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (a chain piece = two launches)
   bool ae_pass_split = false;          // round 4: AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch (a row ahead), only the C1Q . W2 row stays in the AudioDec launch
+  bool side_fold = true;               // round 5: rowc1 / rowhc2 as the first phases of xcone_kernel's launch (DCTTS_XCONE=2: three launches per side-stream piece, rounds 3-4)
   bool side_pre = false;               // the small presum GEMMs (AudioEnc's presums of the next row, the newest C1Q . W2 row) run on the SIDE stream, which has the slack since xtail_kernel (round 4), instead of as passenger workgroups of the chain's AudioDec launch
   bool attn_fold = false;              // the newest row's attention + AudioDec C_1 run behind the AudioEnc run's last layer inside xgroup_kernel (chain_tail >= 1) instead of as two more launches
   void* xmlp_tab = nullptr; std::string xmlp_geom;
@@ -678,6 +680,7 @@ extern "C" int dctts_weights_finalize(dctts_ctx* c) {
       HIPCHK(hipMalloc((void**)&dp, v.size() * sizeof(int)));
       HIPCHK(hipMemcpy(dp, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
       c->cone_dev.push_back(dp); c->cone_len.push_back((int)v.size());
+      { bool cg = true; for (size_t q = 0; q < v.size(); ++q) cg = cg && v[q] == -(int)q; c->cone_contig.push_back(cg ? 1 : 0); }
       std::vector<int> v3(v.begin() + 1, v.end()); v3.push_back(0);       // v[0] == 0: the newest row goes last (presum row)
       HIPCHK(hipMalloc((void**)&dp, v3.size() * sizeof(int)));
       HIPCHK(hipMemcpy(dp, v3.data(), v3.size() * sizeof(int), hipMemcpyHostToDevice));

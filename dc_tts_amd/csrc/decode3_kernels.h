@@ -98,53 +98,29 @@ struct RowC1Params {
   // the launch behind this one (rowhc2_kernel) needs the newest C1Q . W2 row, computed by passengers of the chain's xgroup_kernel launch:
   // ONE thread of this launch polls their counter before it exits (bounded; a time-out raises wait_err), so the stream cannot go on before
   const unsigned* wait; unsigned wait_val; int* wait_err;
+  int contig;                        // the offset table is -1, -2, ..., -R (checked on the host): xcone_kernel's folded form computes t = frame - 1 - r instead of loading offs[r]
 };
 
 constexpr int ROWC1_NW = 4;              // rows (waves) per workgroup.  Measured with 16: 14.7 instead of 10.4 us per launch -- the launch lives in what the chain's and the
                                          // passengers' big workgroups leave free on the CUs, and small workgroups fit there (same for ROWHC2_NW: 12 rows 12.7 against 10.4 us)
-__device__ __forceinline__ void rowc1_row(const RowC1Params& p);
-__global__ void __launch_bounds__(ROWC1_NW * 64) rowc1_kernel(const RowC1Params p) {
-  rowc1_row(p);
-  if (p.wait && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    bool ok = false;
-    for (int i = 0; i < (1 << 20) && !ok; ++i) {
-      ok = __hip_atomic_load(p.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
-      if (!ok) __builtin_amdgcn_s_sleep(8);
-    }
-    if (!ok) atomicOr(p.wait_err, 1);
+// The three pieces of a C_1 cone row, shared by rowc1_kernel (a launch of its own: one workgroup = four rows of one utterance) and by xcone_kernel's folded form
+// (round 5: the row kernels as the first phases of the side stream's ONE launch; a workgroup = eight waves x three rows of one of its team's utterances):
+//   rowc1_stage   what the rows of an utterance share -- the window's K and V.W rows, C_1's bias and layer-norm parameters (9 KB) -- global memory -> LDS
+//                 (global_load_lds_dwordx4, no register in between; the caller waits for vmcnt(0) and synchronises)
+//   rowc1_finish  one row from its Q and C1Q operands and the staged pieces: 3 dot products, softmax, 3 axpys, layer-norm; stores the row and its scalars
+__device__ __forceinline__ void rowc1_stage(const RowC1Params& p, const int b, const int pm, f32x4* s_sh, const int tid, const int nthreads) {
+  for (int it = tid; it < 576; it += nthreads) {                        // (wave-uniform trip count: 576 sixteen-byte pieces = 9 waves' worth, nthreads a multiple of 64)
+    const int piece = it >> 6;
+    int n = pm + (piece % 3); if (n > p.N - 1) n = p.N - 1;             // keys beyond the window: clamped into the utterance, weight exactly 0
+    const float* src = piece < 3 ? p.K + ((long)b * p.kv_bstride + n) * p.k_stride
+                     : piece < 6 ? p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride
+                     : piece == 6 ? p.bias : (piece == 7 ? p.g : p.be);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (it & 63) * 4), (__attribute__((address_space(3))) void*)&s_sh[it & ~63], 16, 0, 0);
   }
 }
-__device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
-  // Round 4: what a workgroup's four rows share -- the window's K and V.W rows of their utterance, C_1's bias and layer-norm parameters: 9 of the 11 KB a row
-  // asked for -- goes global memory -> LDS once per workgroup (global_load_lds_dwordx4, no register in between); a row's own requests are its Q and C1Q rows.
-  __shared__ f32x4 s_sh[9 * 64];           // [K rows of keys 0..2 | V.W rows of keys 0..2 | bias | gamma | beta][256 floats]
-  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
-  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWC1_NW + (tid >> 6));    // wave-uniform
-  const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
-  const int t_ = p.frame + p.offs[r];
-  const bool live = r0 < p.R && t_ >= 0;
-  const int t = t_ < 0 ? 0 : t_;
-  const int c0 = lane * 4;
-  const int pm = p.pm_all[(long)p.frame * p.B + b];
-  auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
+__device__ __forceinline__ void rowc1_finish(const RowC1Params& p, const int b, const int t, const int pm, const f32x4 vq, const f32x4 vcq, const f32x4* s_sh, const int lane) {
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-#pragma unroll
-  for (int i = 0; i < (576 + ROWC1_NW * 64 - 1) / (ROWC1_NW * 64); ++i) {
-    const int it = tid + ROWC1_NW * 64 * i;
-    if (it < 576) {                                                     // (wave-uniform: 576 sixteen-byte pieces = 9 waves' worth)
-      const int piece = it >> 6;
-      int n = pm + (piece % 3); if (n > p.N - 1) n = p.N - 1;           // keys beyond the window: clamped into the utterance, weight exactly 0
-      const float* src = piece < 3 ? p.K + ((long)b * p.kv_bstride + n) * p.k_stride
-                       : piece < 6 ? p.VW + ((long)b * p.kv_bstride + n) * p.vw_stride
-                       : piece == 6 ? p.bias : (piece == 7 ? p.g : p.be);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (it & 63) * 4), (__attribute__((address_space(3))) void*)&s_sh[it & ~63], 16, 0, 0);
-    }
-  }
-  f32x4 vq = ldq(p.Qh + ((long)b * p.q_bstride + p.q_row0 + t) * p.q_stride + c0);
-  f32x4 vcq = ldq(p.C1Q + ((long)b * p.c_bstride + p.c_row0 + t) * p.c_stride + c0);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq), "+v"(vcq) :: "memory");               // the pieces are in LDS (LDS-DMA counts as vector memory), the row's operands have landed
-  __syncthreads();
-  if (!live) return;
+  const int c0 = lane * 4;
   const f32x4 vbi = s_sh[6 * 64 + lane], vg = s_sh[7 * 64 + lane], vbe = s_sh[8 * 64 + lane];
   f32x4 kr[MAXWIN], vr[MAXWIN];
 #pragma unroll
@@ -170,6 +146,33 @@ __device__ __forceinline__ void rowc1_row(const RowC1Params& p) {
     sc[4] = a[2];
   }
 }
+__global__ void __launch_bounds__(ROWC1_NW * 64) rowc1_kernel(const RowC1Params p) {
+  // Round 4: what a workgroup's four rows share -- 9 of the 11 KB a row asked for -- goes global memory -> LDS once per workgroup; a row's own requests are its Q and C1Q rows.
+  __shared__ f32x4 s_sh[9 * 64];           // [K rows of keys 0..2 | V.W rows of keys 0..2 | bias | gamma | beta][256 floats]
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWC1_NW + (tid >> 6));    // wave-uniform
+  const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
+  const int t_ = p.frame + p.offs[r];
+  const bool live = r0 < p.R && t_ >= 0;
+  const int t = t_ < 0 ? 0 : t_;
+  const int c0 = lane * 4;
+  const int pm = p.pm_all[(long)p.frame * p.B + b];
+  auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
+  rowc1_stage(p, b, pm, s_sh, tid, ROWC1_NW * 64);
+  f32x4 vq = ldq(p.Qh + ((long)b * p.q_bstride + p.q_row0 + t) * p.q_stride + c0);
+  f32x4 vcq = ldq(p.C1Q + ((long)b * p.c_bstride + p.c_row0 + t) * p.c_stride + c0);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(vq), "+v"(vcq) :: "memory");               // the pieces are in LDS (LDS-DMA counts as vector memory), the row's operands have landed
+  __syncthreads();
+  if (live) rowc1_finish(p, b, t, pm, vq, vcq, s_sh, lane);
+  if (p.wait && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    bool ok = false;
+    for (int i = 0; i < (1 << 20) && !ok; ++i) {
+      ok = __hip_atomic_load(p.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.wait_val;
+      if (!ok) __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) atomicOr(p.wait_err, 1);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------------------- bulk: HC_2 cone rows
 // AudioDec HC_2 (networks.py:175-182, the first highway layer; causal k = 3, dilation 1) over its cone rows, WITHOUT a GEMM.
@@ -192,6 +195,7 @@ struct RowHc2Params {
   float* x2; long x2_bstride; long x2_row0; int x2_stride; long x2_set;        // HC_2 output rows
   float* presum; long presum_rstride;                                // presum row of utterance b at presum + b * presum_rstride
   int N, win; const int* pm_all;
+  int contig;                                                        // the offset table is -1, ..., -(R - 1), 0 (checked on the host): t of row r without the dependent load of offs[r]
 };
 
 // Straight-line on purpose: a load behind a uniform branch is waited for at the join (`s_waitcnt vmcnt(0)`), which made the taps' and keys' loads
@@ -204,61 +208,58 @@ struct RowHc2Params {
 // waves per SIMD) and sits on the side stream, which bounds the decode frame since the chain's AudioDec layers became one launch: 11.8 us -> see DESIGN.md 2d.
 // The arithmetic (operands, order of the fused multiply-adds) is unchanged.
 constexpr int ROWHC2_NW = 4;             // rows (waves) per workgroup: see ROWC1_NW
-__global__ void __launch_bounds__(ROWHC2_NW * 64) rowhc2_kernel(const RowHc2Params p) {
-  __shared__ f32x4 s_c[9 * 128];          // consts: [tap q][beta1.W2 | b1.Wt | 1^T Wt][512 floats]
-  __shared__ f32x4 s_v[9 * 128];          // V.W.W rows of the window: [key k][tap q][512 floats]
-  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
-  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWHC2_NW + (tid >> 6));   // wave-uniform: the row's table entries are scalar loads
-  const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
-  const int t = p.frame + p.offs[r];
-  const bool live = r0 < p.R && t >= 0;
-  const int tq = t < 0 ? 0 : t;
-  const bool pre_row = (r == p.R - 1);
-  const int c0 = lane * 4;
-  const int pm = p.pm_all[(long)p.frame * p.B + b];
-  const long par = p.frame & 1;
-  auto ldq = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
-  // ---- the workgroup's shared operands: 2 x 1152 sixteen-byte pieces over 256 threads, global memory -> LDS without a register in between
-  //      (global_load_lds_dwordx4: a wave's 64 pieces land at consecutive LDS addresses behind the wave-uniform base)
-#pragma unroll
-  for (int i = 0; i < (1152 + ROWHC2_NW * 64 - 1) / (ROWHC2_NW * 64); ++i) {
-    const int it = tid + ROWHC2_NW * 64 * i;
-    if (it < 1152) {                                                    // (wave-uniform: 1152 = 18 waves' worth)
-      const int piece = it >> 7, k = piece / 3, q = piece - 3 * k;
-      int n = pm + k; if (n > p.N - 1) n = p.N - 1;                     // keys clamped into the utterance: their weight is 0
-      const float* gv = p.VWW + ((long)b * p.kv_bstride + n) * 1536 + q * 512 + (it & 127) * 4;
-      const int wbase = it & ~63;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.consts + it * 4), (__attribute__((address_space(3))) void*)&s_c[wbase], 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv, (__attribute__((address_space(3))) void*)&s_v[wbase], 16, 0, 0);
-    }
+// The pieces of an HC_2 cone row, shared by rowhc2_kernel and xcone_kernel's folded form (see rowc1_stage): stage the utterance's shared operands, request one row's
+// own operands, finish the row.  The arithmetic (operands, order of the fused multiply-adds) is the same wherever a row is computed.
+struct RowHc2Row { f32x4 w1[3], w2[3], s4[3], xr; float a2[3]; bool ok[3]; int t; bool live, pre_row; };
+struct RowHc2Ln { f32x4 g1, b1, g2, b2, h1, h2; };      // HC_2's layer-norm parameters and its bias (the initial value of a row's two halves): the same for every row
+__device__ __forceinline__ void rowhc2_stage(const RowHc2Params& p, const int b, const int pm, f32x4* s_c, f32x4* s_v, const int tid, const int nthreads) {
+  // 2 x 1152 sixteen-byte pieces, global memory -> LDS without a register in between (a wave's 64 pieces land at consecutive LDS addresses behind the wave-uniform base)
+  for (int it = tid; it < 1152; it += nthreads) {                       // (wave-uniform: 1152 = 18 waves' worth)
+    const int piece = it >> 7, k = piece / 3, q = piece - 3 * k;
+    int n = pm + k; if (n > p.N - 1) n = p.N - 1;                       // keys clamped into the utterance: their weight is 0
+    const float* gv = p.VWW + ((long)b * p.kv_bstride + n) * 1536 + q * 512 + (it & 127) * 4;
+    const int wbase = it & ~63;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.consts + it * 4), (__attribute__((address_space(3))) void*)&s_c[wbase], 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv, (__attribute__((address_space(3))) void*)&s_v[wbase], 16, 0, 0);
   }
-  // ---- the row's own operands
-  f32x4 h1 = ldq(p.bias + c0), h2 = ldq(p.bias + 256 + c0);
-  f32x4 w1[3], w2[3], s4[3]; float a2[3]; bool ok[3];
+}
+__device__ __forceinline__ RowHc2Ln rowhc2_ln(const RowHc2Params& p, const int lane) {
+  auto ldq = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
+  const int c0 = lane * 4;
+  RowHc2Ln l; l.g1 = ldq(p.g1 + c0); l.b1 = ldq(p.b1 + c0); l.g2 = ldq(p.g2 + c0); l.b2 = ldq(p.b2 + c0);
+  l.h1 = ldq(p.bias + c0); l.h2 = ldq(p.bias + 256 + c0);
+  return l;
+}
+__device__ __forceinline__ void rowhc2_load(const RowHc2Params& p, const int b, const int r0, const int lane, RowHc2Row& o) {
+  auto ldq = [](const float* q) { return *reinterpret_cast<const f32x4*>(q); };
+  const int r = r0 < p.R ? r0 : p.R - 1;                                                 // (a wave past the table computes the last row again and stores nothing)
+  o.t = p.contig ? (r == p.R - 1 ? p.frame : p.frame - 1 - r) : p.frame + p.offs[r];
+  o.live = r0 < p.R && o.t >= 0;
+  const int tq = o.t < 0 ? 0 : o.t;
+  o.pre_row = (r == p.R - 1);
+  const int c0 = lane * 4;
+  const long par = p.frame & 1;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int tp = tq + p.tap_off[q];
-    ok[q] = tp >= 0 && !(pre_row && q == 2);                          // causal zero padding / the chain contracts the centre tap
+    o.ok[q] = tp >= 0 && !(o.pre_row && q == 2);                      // causal zero padding / the chain contracts the centre tap
     const int tc = tp < 0 ? 0 : tp;
     const float* sc = p.scal + ((long)b * p.s_bstride + p.s_row0 + tc) * 8;
-    s4[q] = ldq(sc); a2[q] = sc[4];
+    o.s4[q] = ldq(sc); o.a2[q] = sc[4];
     const float* cw = p.C1QW + ((long)b * p.c_bstride + p.c_row0 + tc) * 1536 + q * 512;
-    w1[q] = ldq(cw + c0); w2[q] = ldq(cw + 256 + c0);
+    o.w1[q] = ldq(cw + c0); o.w2[q] = ldq(cw + 256 + c0);
   }
-  f32x4 xr = ldq(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + tq) * p.x1_stride + c0);
-  f32x4 lg1 = ldq(p.g1 + c0), lb1 = ldq(p.b1 + c0), lg2 = ldq(p.g2 + c0), lb2 = ldq(p.b2 + c0);      // HC_2's own layer-norm parameters
-  // every request above is out before anything is used (left alone, the scheduler sinks each load into the code that consumes it)
-#pragma unroll
-  for (int q = 0; q < 3; ++q) asm volatile("; rowhc2: a tap's row operands" : "+v"(w1[q]), "+v"(w2[q]), "+v"(s4[q]), "+v"(a2[q]));
-  asm volatile("; rowhc2: row operands" : "+v"(h1), "+v"(h2), "+v"(xr), "+v"(lg1), "+v"(lb1), "+v"(lg2), "+v"(lb2));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the pieces are in LDS (LDS-DMA counts as vector memory)
-  __syncthreads();
-  if (!live) return;
+  o.xr = ldq(p.x1 + par * p.x1_set + ((long)b * p.x1_bstride + p.x1_row0 + tq) * p.x1_stride + c0);
+}
+__device__ __forceinline__ void rowhc2_finish(const RowHc2Params& p, const int b, const int pm, const RowHc2Row& o, const RowHc2Ln& ln, const f32x4* s_c, const f32x4* s_v, const int lane) {
+  const int c0 = lane * 4;
+  const long par = p.frame & 1;
+  f32x4 h1 = ln.h1, h2 = ln.h2;
   int nk = p.N - pm; if (nk > p.win) nk = p.win;
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    const float m = s4[q][0], rs = s4[q][1];
-    const float a[3] = {s4[q][2], nk > 1 ? s4[q][3] : 0.f, nk > 2 ? a2[q] : 0.f};    // a key beyond the window has weight 0
+    const float m = o.s4[q][0], rs = o.s4[q][1];
+    const float a[3] = {o.s4[q][2], nk > 1 ? o.s4[q][3] : 0.f, nk > 2 ? o.a2[q] : 0.f};    // a key beyond the window has weight 0
     const f32x4 e1 = s_c[(q * 3 + 0) * 128 + lane], e2 = s_c[(q * 3 + 0) * 128 + 64 + lane];       // beta1 . W2[q]
     const f32x4 u1 = s_c[(q * 3 + 1) * 128 + lane], u2 = s_c[(q * 3 + 1) * 128 + 64 + lane];       // b1 . Wt_q
     const f32x4 cs1 = s_c[(q * 3 + 2) * 128 + lane], cs2 = s_c[(q * 3 + 2) * 128 + 64 + lane];     // 1^T Wt_q
@@ -267,22 +268,40 @@ __global__ void __launch_bounds__(ROWHC2_NW * 64) rowhc2_kernel(const RowHc2Para
     for (int k = 0; k < 3; ++k) { v1[k] = s_v[(k * 3 + q) * 128 + lane]; v2[k] = s_v[(k * 3 + q) * 128 + 64 + lane]; }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float x1 = fmaf(-m, cs1[i], u1[i]) + w1[q][i];
-      float x2 = fmaf(-m, cs2[i], u2[i]) + w2[q][i];
+      float x1 = fmaf(-m, cs1[i], u1[i]) + o.w1[q][i];
+      float x2 = fmaf(-m, cs2[i], u2[i]) + o.w2[q][i];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { x1 = fmaf(a[k], v1[k][i], x1); x2 = fmaf(a[k], v2[k][i], x2); }
       const float d1 = fmaf(rs, x1, e1[i]), d2 = fmaf(rs, x2, e2[i]);
-      h1[i] += ok[q] ? d1 : 0.f; h2[i] += ok[q] ? d2 : 0.f;            // a select, not a factor: the operands of a dropped tap may be anything
+      h1[i] += o.ok[q] ? d1 : 0.f; h2[i] += o.ok[q] ? d2 : 0.f;        // a select, not a factor: the operands of a dropped tap may be anything
     }
   }
-  if (pre_row) {
+  if (o.pre_row) {
     float* pr = p.presum + (long)b * p.presum_rstride;
     *reinterpret_cast<f32x4*>(pr + c0) = h1; *reinterpret_cast<f32x4*>(pr + 256 + c0) = h2;
     return;
   }
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-  const float4 o = norm_hc_vals(f4(h1), f4(h2), f4(xr), f4(lg1), f4(lb1), f4(lg2), f4(lb2));
-  *reinterpret_cast<float4*>(p.x2 + par * p.x2_set + ((long)b * p.x2_bstride + p.x2_row0 + t) * p.x2_stride + c0) = o;
+  const float4 out = norm_hc_vals(f4(h1), f4(h2), f4(o.xr), f4(ln.g1), f4(ln.b1), f4(ln.g2), f4(ln.b2));
+  *reinterpret_cast<float4*>(p.x2 + par * p.x2_set + ((long)b * p.x2_bstride + p.x2_row0 + o.t) * p.x2_stride + c0) = out;
+}
+__global__ void __launch_bounds__(ROWHC2_NW * 64) rowhc2_kernel(const RowHc2Params p) {
+  __shared__ f32x4 s_c[9 * 128];          // consts: [tap q][beta1.W2 | b1.Wt | 1^T Wt][512 floats]
+  __shared__ f32x4 s_v[9 * 128];          // V.W.W rows of the window: [key k][tap q][512 floats]
+  const int tid = threadIdx.x, lane = tid & 63, b = blockIdx.y;
+  const int r0 = __builtin_amdgcn_readfirstlane(blockIdx.x * ROWHC2_NW + (tid >> 6));   // wave-uniform: the row's table entries are scalar loads
+  const int pm = p.pm_all[(long)p.frame * p.B + b];
+  rowhc2_stage(p, b, pm, s_c, s_v, tid, ROWHC2_NW * 64);
+  RowHc2Row o;
+  rowhc2_load(p, b, r0, lane, o);
+  RowHc2Ln ln = rowhc2_ln(p, lane);
+  // every request above is out before anything is used (left alone, the scheduler sinks each load into the code that consumes it)
+#pragma unroll
+  for (int q = 0; q < 3; ++q) asm volatile("; rowhc2: a tap's row operands" : "+v"(o.w1[q]), "+v"(o.w2[q]), "+v"(o.s4[q]), "+v"(o.a2[q]));
+  asm volatile("; rowhc2: row operands" : "+v"(ln.h1), "+v"(ln.h2), "+v"(o.xr), "+v"(ln.g1), "+v"(ln.b1), "+v"(ln.g2), "+v"(ln.b2));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the pieces are in LDS (LDS-DMA counts as vector memory)
+  __syncthreads();
+  if (o.live) rowhc2_finish(p, b, pm, o, ln, s_c, s_v, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- chain: attention row j

@@ -340,6 +340,43 @@ static int v3_vw(dctts_ctx* c, const DecodeWs& w, int B, int N, hipStream_t st) 
   return 0;
 }
 
+// The two row operations of a side-stream piece (decode3_kernels.h): AudioDec C_1 and HC_2 over their cone rows for frame f.  Launches of their own, or -- round 5,
+// the folded form -- the first two phases of xcone_kernel's launch, whose per-frame table then carries these parameters.
+static RowC1Params fill_rowc1(dctts_ctx* c, const DecodeWs& w, int B, int N, int f) {
+  const std::vector<DevLayer>& AD = c->audiodec;
+  const int d = c->cfg.d;
+  RowC1Params q; memset(&q, 0, sizeof(q));
+  q.B = B; q.R = c->cone_len[0] - 1; q.offs = c->cone3_dev[0]; q.frame = f;
+  q.Qh = w.ae.back().p; q.q_bstride = w.ae.back().bstride; q.q_row0 = w.ae.back().row0; q.q_stride = d;
+  q.K = w.kv.p; q.k_stride = 2 * d; q.VW = w.vw; q.vw_stride = d; q.kv_bstride = N;
+  q.C1Q = w.c1q.p; q.c_bstride = w.c1q.bstride; q.c_row0 = w.c1q.row0; q.c_stride = w.c1q.stride;
+  q.bias = AD[0].bias; q.g = AD[0].g1; q.be = AD[0].b1;
+  q.N = N; q.d = d; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
+  q.x = w.ad[0].p; q.x_bstride = w.ad[0].bstride; q.x_row0 = w.ad[0].row0; q.x_stride = w.ad[0].stride; q.x_set = w.ad[0].set;
+  q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
+  if (c->ae_pass && f > 0) { q.wait = c->wait_ctr + 16; q.wait_val = (unsigned)f; q.wait_err = (int*)(c->wait_ctr + 64); }      // row f - 1 of the C1Q . W2 cache: passengers of chain piece f - 1
+  q.contig = c->cone_contig[0];
+  return q;
+}
+static RowHc2Params fill_rowhc2(dctts_ctx* c, const DecodeWs& w, int B, int N, int f) {
+  const std::vector<DevLayer>& AD = c->audiodec;
+  const int par = f & 1;
+  RowHc2Params q; memset(&q, 0, sizeof(q));
+  const int R = c->cone_len[1];
+  q.B = B; q.R = R; q.offs = c->cone3_dev[1]; q.frame = f;
+  for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = AD[1].tap_off[t3];
+  q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
+  q.VWW = w.vww; q.kv_bstride = N;
+  q.C1QW = w.c1qw.p; q.c_bstride = w.c1qw.bstride; q.c_row0 = w.c1qw.row0;
+  q.consts = c->hc2_consts; q.bias = AD[1].bias; q.g1 = AD[1].g1; q.b1 = AD[1].b1; q.g2 = AD[1].g2; q.b2 = AD[1].b2;
+  q.x1 = w.ad[0].p; q.x1_bstride = w.ad[0].bstride; q.x1_row0 = w.ad[0].row0; q.x1_stride = w.ad[0].stride; q.x1_set = w.ad[0].set;
+  q.x2 = w.ad[1].p; q.x2_bstride = w.ad[1].bstride; q.x2_row0 = w.ad[1].row0; q.x2_stride = w.ad[1].stride; q.x2_set = w.ad[1].set;
+  q.presum = w.pb3[1] + (long)par * w.pb3_set[1] + (long)(R - 1) * 2 * AD[1].cout; q.presum_rstride = (long)R * 2 * AD[1].cout;
+  q.N = N; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
+  q.contig = c->cone_contig[1];
+  return q;
+}
+
 static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, int f, hipStream_t sb, unsigned wait_val) {
   const int d = c->cfg.d;
   const std::vector<DevLayer>& AD = c->audiodec;
@@ -349,37 +386,20 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
   // (with the team kernels the side stream is the longer one: AudioEnc's presums then run on the chain's stream, in front of the piece that uses them)
   // (wait_val != 0: the launch first polls the chain's counter for that value -- the piece's input row comes from the chain's stream)
   if (!c->c1qw_chain) CHK(v3_aepre(c, B, f + 1, sb, c->xc_on ? 2 : 0, wait_val));
-  if (c->cone_len[0] > 1) {
-    RowC1Params q; memset(&q, 0, sizeof(q));
-    q.B = B; q.R = c->cone_len[0] - 1; q.offs = c->cone3_dev[0]; q.frame = f;
-    q.Qh = w.ae.back().p; q.q_bstride = w.ae.back().bstride; q.q_row0 = w.ae.back().row0; q.q_stride = d;
-    q.K = w.kv.p; q.k_stride = 2 * d; q.VW = w.vw; q.vw_stride = d; q.kv_bstride = N;
-    q.C1Q = w.c1q.p; q.c_bstride = w.c1q.bstride; q.c_row0 = w.c1q.row0; q.c_stride = w.c1q.stride;
-    q.bias = AD[0].bias; q.g = AD[0].g1; q.be = AD[0].b1;
-    q.N = N; q.d = d; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
-    q.x = w.ad[0].p; q.x_bstride = w.ad[0].bstride; q.x_row0 = w.ad[0].row0; q.x_stride = w.ad[0].stride; q.x_set = w.ad[0].set;
-    q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
-    if (c->ae_pass && f > 0) { q.wait = c->wait_ctr + 16; q.wait_val = (unsigned)f; q.wait_err = (int*)(c->wait_ctr + 64); }      // row f - 1 of the C1Q . W2 cache: passengers of chain piece f - 1
+  const bool fold = c->xc_on && c->side_fold;            // round 5: both row operations are the first phases of xcone_kernel's launch (its per-frame table carries their parameters)
+  if (c->cone_len[0] > 1 && !fold) {
+    const RowC1Params q = fill_rowc1(c, w, B, N, f);
     hipLaunchKernelGGL(rowc1_kernel, dim3((q.R + ROWC1_NW - 1) / ROWC1_NW, B), dim3(ROWC1_NW * 64), 0, sb, q);
     HIPCHK(hipGetLastError());
   }
   size_t first_gemm = 1;
   if (AD.size() > 1 && AD[1].wpp && AD[1].tap_off[1] == -1) {
     // HC_2 over its cone rows + its presum row: a row operation on the cached V.W / Q.W products (no GEMM, no separate LN pass)
-    RowHc2Params q; memset(&q, 0, sizeof(q));
-    const int R = c->cone_len[1];
-    q.B = B; q.R = R; q.offs = c->cone3_dev[1]; q.frame = f;
-    for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = AD[1].tap_off[t3];
-    q.scal = w.scal.p; q.s_bstride = w.scal.bstride; q.s_row0 = w.scal.row0;
-    q.VWW = w.vww; q.kv_bstride = N;
-    q.C1QW = w.c1qw.p; q.c_bstride = w.c1qw.bstride; q.c_row0 = w.c1qw.row0;
-    q.consts = c->hc2_consts; q.bias = AD[1].bias; q.g1 = AD[1].g1; q.b1 = AD[1].b1; q.g2 = AD[1].g2; q.b2 = AD[1].b2;
-    q.x1 = w.ad[0].p; q.x1_bstride = w.ad[0].bstride; q.x1_row0 = w.ad[0].row0; q.x1_stride = w.ad[0].stride; q.x1_set = w.ad[0].set;
-    q.x2 = w.ad[1].p; q.x2_bstride = w.ad[1].bstride; q.x2_row0 = w.ad[1].row0; q.x2_stride = w.ad[1].stride; q.x2_set = w.ad[1].set;
-    q.presum = w.pb3[1] + (long)par * w.pb3_set[1] + (long)(R - 1) * 2 * AD[1].cout; q.presum_rstride = (long)R * 2 * AD[1].cout;
-    q.N = N; q.win = c->cfg.attention_win_size; q.pm_all = w.pm_all;
-    hipLaunchKernelGGL(rowhc2_kernel, dim3((R + ROWHC2_NW - 1) / ROWHC2_NW, B), dim3(ROWHC2_NW * 64), 0, sb, q);
-    HIPCHK(hipGetLastError());
+    if (!fold) {
+      const RowHc2Params q = fill_rowhc2(c, w, B, N, f);
+      hipLaunchKernelGGL(rowhc2_kernel, dim3((q.R + ROWHC2_NW - 1) / ROWHC2_NW, B), dim3(ROWHC2_NW * 64), 0, sb, q);
+      HIPCHK(hipGetLastError());
+    }
     first_gemm = 2;
   }
   if (c->side_pre && f + 1 < T) CHK(v3_aepre(c, B, f + 1, sb, 1));      // AudioEnc's presums of row f + 1 (inputs: rows <= f - 1): consumed by the AudioEnc run of chain piece f, which starts behind this piece
@@ -388,7 +408,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     const bool prof = c->prof_id == DCTTS_PROF_XCONE && f >= 100 && (f & 15) == 8;          // full-size cones only; eager decode only (graph mode 0)
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, sb)); }
-    hipLaunchKernelGGL(xcone_kernel, dim3(128), dim3(512), 0, sb, xp);
+    hipLaunchKernelGGL(xcone_kernel, dim3(128), dim3(512), 0, sb, xp, (const int*)(w.pm_all + (long)f * B));
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < (c->tail_on ? (size_t)4 : AD.size()); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
     return 0;
@@ -623,7 +643,10 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
 
 // ---- xcone_kernel plumbing: one XConeParams per frame in device memory (layers HC_3 .. HC_7 of AudioDec's cone, parity copies folded in)
 static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig) {
-  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on);
+  const bool fold = c->side_fold && c->cone_len[0] - 1 <= 96 && c->cone_len[1] <= 96 && c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;
+  c->side_fold = fold;
+  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on) +
+                        ":" + std::to_string((int)fold) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.scal.p);
   if (c->xc_tab && c->xc_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xc", g, &ts)) { c->xc_tab = ts.tab; c->xc_geom = g; return 0; } }
   c->xc_tab = nullptr;
@@ -651,7 +674,8 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       q.offs = c->cone3_dev[i]; q.R = c->cone_len[i];
       for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = Ly.tap_off[t3];
     }
-    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(2 * L - 1 + tail) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
+    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(2 * L - 1 + tail + (fold ? 2 : 0)) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
+    if (fold) { p.fold = 1; p.rc1 = fill_rowc1(c, w, B, c->cfg.max_N, f); p.rhc2 = fill_rowhc2(c, w, B, c->cfg.max_N, f); }
     if (insig) {                                                // the launch's last team publishes "side-stream piece f complete" itself
       p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)(((B + 3) / 4 < 8) ? (B + 3) / 4 : 8);      // one count per team (at most 8)
       p.sig = c->wait_ctr + 32; p.sig_val = (unsigned)(f + 1);
@@ -964,7 +988,8 @@ static int write_trace3(dctts_ctx* c, int j) {
   {
     const long long* o = &h[64 * 64 * 32 - 192];
     if (o[0]) {
-      fprintf(f, "# xcone_kernel (workgroup 0, thread 0), microseconds since its entry; per layer: row tables | contraction done | barrier passed | row pass done | barrier passed\n ");
+      fprintf(f, "# xcone_kernel (workgroup 0, thread 0), microseconds since its entry%s; per layer: row tables | contraction done | barrier passed | row pass done | barrier passed\n ",
+              c->side_fold ? "; folded form: C_1's cone rows done | barrier passed | HC_2's cone rows done | barrier passed, then" : "");
       int last = 0;
       for (int i = 1; i < 60 && o[i]; ++i) { fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0); last = i; }
       if (last > 0 && o[101] > o[100]) fprintf(f, "   (shader clock over the launch: %.0f MHz)", (double)(o[101] - o[100]) / ((o[last] - o[0]) / 100.0));
@@ -1042,6 +1067,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   //  once that launch's teams have finished (~4 us): the two hbulk_group_kernel launches take 11 + 10.7 us on the side stream, which then bounds the frame at
   //  99.5 us against 89.3)
   c->side_pre = false;
+  c->side_fold = c->xcone == 1 && c->xc_on && bsig;      // (needs the team kernels and their in-kernel stream meetings; v3_xcone_table checks the cone geometry)
   c->c1qw_chain = vs && c->xc_on && !c->side_pre;
   // ... or, with both team kernels, in no launch of its own at all: the AudioEnc presums and that row are passengers of the chain's AudioDec launch
   // (xgroup_kernel.h); the side stream's first launch (rowc1_kernel) polls the row's own counter before it ends

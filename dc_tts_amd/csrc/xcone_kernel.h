@@ -42,6 +42,12 @@ struct XConeParams {
   const unsigned* wait; unsigned wait_val;                // then: the NEXT side-stream piece needs the chain's counter at wait_val; the team leaders poll it here
   int* wait_err;                                          //   (instead of a stream wait operation in front of that piece); a time-out raises this word
   long long* ts;                         // measurement (DCTTS_TRACE): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
+  // Round 5, the folded form (fold != 0): AudioDec C_1 and HC_2 over their cone rows -- the two row operations that used to be launches of their own in front of this
+  // one (rowc1_kernel, rowhc2_kernel: 10.4 + 10.3 us per frame for ~3 us of work each) -- are the first two phases of this launch.  A team needs only ITS four
+  // utterances' rows, so it meets at its own barrier instead of at two launch boundaries: workgroup grp serves utterance grp / 4 of the team with rows
+  // (grp % 4) * 8 + wave + 32 i (eight waves, three rows each), the utterance's shared operands staged in LDS once per workgroup.
+  int fold; int pad_;
+  RowC1Params rc1; RowHc2Params rhc2;
 };
 
 __device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned xcc, unsigned target, int* err, bool go) {
@@ -69,7 +75,9 @@ __device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned x
 }
 
 // grid: 128 blocks of 512 threads, whatever the batch
-__global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restrict__ pp) {
+// pm_row (folded form): prev_max_attentions of this frame, pm_all + frame * B -- a kernel ARGUMENT, so that the window position, which everything of the row phases
+// hangs on, is requested at entry instead of behind the load of the per-frame table
+__global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restrict__ pp, const int* __restrict__ pm_row) {
   __shared__ __attribute__((aligned(16))) float red[2][2 * 8 * 2 * 4 * 64];  // split-K partial sums of two row tiles, double-buffered: one barrier per pass
   __shared__ int s_go;
   __shared__ int s_xoff[256];            // per local row m of the team (M <= 4 * 64): element offset of its input row t in xin, -1 = the row does not exist (t < 0)
@@ -79,14 +87,11 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   // the launch's own parameters in ONE batch of scalar loads (lazily: six dependent batches before the first layer)
   asm volatile("; xcone: parameters, one batch" :: "s"(p.B), "s"(p.L), "s"(p.frame), "s"(p.bar), "s"(p.bar_base), "s"(p.err), "s"(p.ts),
                "s"(p.done), "s"(p.done_target), "s"(p.sig), "s"(p.sig_val), "s"(p.wait), "s"(p.wait_val), "s"(p.wait_err), "s"(p.lay[0].wp));
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x;
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   // the grid is always 128 workgroups (8 teams): a team takes the utterance groups team, team + 8, ... in turn (xgroup_kernel.h says why)
   const int grp = bq & 15, team = bx;
   if (team * 4 >= p.B) return;
-  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
-  const int etile = wave >> 2, ecol = lane & 15, ej = wave & 3;
-  const int pcol = etile * 256 + grp * 16 + ecol;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
@@ -97,6 +102,90 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 60) { p.ts[100 + (nts > 0)] = clock64(); p.ts[nts++] = wall_clock64(); } };   // ([100], [101]: shader clock at the first / latest stamp)
   stamp();
 
+  for (int b0 = team * 4; b0 < p.B; b0 += 32) {
+  const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
+  if (p.fold) {
+    int tid_a = tid;                                                     // (opaque per phase, like tid_o below: what is derived from the thread index stays inside its phase)
+    asm volatile("; xcone: thread index, opaque (phase A)" : "+v"(tid_a));
+    const int lane = tid_a & 63, wave = tid_a >> 6;
+    // ---- phase A: AudioDec C_1 over its cone rows (decode3_kernels.h: rowc1_*), phase B: HC_2 over its cone rows + its presum row (rowhc2_*)
+    const RowC1Params& ca = pp->rc1; const RowHc2Params& cb = pp->rhc2;
+    f32x4* const s_c = reinterpret_cast<f32x4*>(&red[0][0]);           // phase B's shared operands: 18 KB + 18 KB of the 64 KB split-K buffer (nothing else uses it before the first GEMM pass)
+    f32x4* const s_v = s_c + 9 * 128;
+    f32x4* const s_sh = s_v + 9 * 128;                                  // phase A's: 9 KB behind them
+    const int ub = grp >> 2, q4 = grp & 3;
+    const bool uok = ub < nb;
+    const int b = uok ? b0 + ub : b0;
+    const int pm = pm_row[b];
+    auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
+    __syncthreads();                                                    // (a second round: the previous round's last reads of `red`)
+    rowc1_stage(ca, b, pm, s_sh, tid_a, 512);
+    {
+      f32x4 vq[3], vcq[3]; int tt[3]; bool lv[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int r0 = q4 * 8 + wave + 32 * i;
+        const int r = r0 < ca.R ? r0 : ca.R - 1;
+        const int t_ = ca.contig ? ca.frame - 1 - r : ca.frame + ca.offs[r];
+        lv[i] = uok && r0 < ca.R && t_ >= 0;
+        tt[i] = t_ < 0 ? 0 : t_;
+        vq[i] = ldq(ca.Qh + ((long)b * ca.q_bstride + ca.q_row0 + tt[i]) * ca.q_stride + lane * 4);
+        vcq[i] = ldq(ca.C1Q + ((long)b * ca.c_bstride + ca.c_row0 + tt[i]) * ca.c_stride + lane * 4);
+      }
+      // phase B's shared operands (36 KB per workgroup, ~1.5 us at an LDS-DMA fill rate of ~25 GB/s per CU) do not depend on phase A: requested here, they land while
+      // phase A's rows are finished.  vmcnt counts in issue order, so phase A waits for everything but those requests: 2 x 3 per thread in waves 0 and 1 (1152 pieces over
+      // 512 threads), 2 x 2 in the others.
+      rowhc2_stage(cb, b, pm, s_c, s_v, tid_a, 512);
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 3; ++i) if (lv[i]) rowc1_finish(ca, b, tt[i], pm, vq[i], vcq[i], s_sh, lane);
+    }
+    arrived += 16u;
+    stamp();                                                           // C_1's cone rows done
+    int tid_b = tid;
+    asm volatile("; xcone: thread index, opaque (phase B)" : "+v"(tid_b));
+    const int lane_b = tid_b & 63, wave_b = tid_b >> 6;
+    const RowHc2Ln ln = rowhc2_ln(cb, lane_b);
+    xcone_barrier(bar, grp, xcc, arrived, p.err, s_go != 0);             // C_1's rows and scalars of the team's utterances are in this XCD's L2 (the barrier drains vmcnt and synchronises: the staged pieces are in LDS)
+    stamp();
+    {
+      // three rows per wave, one at a time: with two rows' operands in flight (2 x 43 registers) the kernel, which lives at the 256-register limit, spills
+      // The newest row of the C1Q . W2 cache (time frame - 1) comes from passengers of the chain's launch one piece earlier.  Only HC_2's newest cone row and the
+      // presum row read it (taps reach back, never forward): the wave that owns them polls the passengers' counter (bounded) -- not the team (rounds 3-4 polled at the
+      // END of rowc1_kernel's launch, where the row was always there; at the head of this launch the leader waited 3.4 us for it with the whole team behind it)
+      if (ca.wait && s_go) {
+        const int rfirst = q4 * 8 + wave_b;
+        if (rfirst == 0 || rfirst + 64 == cb.R - 1) {                 // row 0 (t = frame - 1) / the presum row (t = frame: its taps read frame - 1 and frame - 2)
+          bool ok = false;
+          for (int i = 0; i < (1 << 20) && !ok; ++i) {
+            ok = __hip_atomic_load(ca.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ca.wait_val;
+            if (!ok) __builtin_amdgcn_s_sleep(8);
+          }
+          if (!ok && lane_b == 0) atomicOr(ca.wait_err, 1);
+        }
+      }
+#pragma unroll 1
+      for (int i = 0; i < 3; ++i) {
+        RowHc2Row cur;
+        rowhc2_load(cb, b, q4 * 8 + wave_b + 32 * i, lane_b, cur);
+        if (uok && cur.live) rowhc2_finish(cb, b, pm, cur, ln, s_c, s_v, lane_b);
+      }
+    }
+    arrived += 16u;
+    stamp();                                                           // HC_2's cone rows done
+    xcone_barrier(bar, grp, xcc, arrived, p.err, s_go != 0);             // HC_2's rows: the input of the first GEMM layer below
+    stamp();
+  }
+  // Everything the GEMM layers derive from the thread index is derived HERE, from a value the compiler cannot see through: hoisted to the kernel's entry, the ~40
+  // per-lane offsets and 64-bit weight addresses lived in registers across the row phases above and the kernel spilled (600 bytes of scratch; xtail_kernel.h has the same trick)
+  int tid_o = tid;
+  asm volatile("; xcone: thread index, opaque" : "+v"(tid_o));
+  const int lane = tid_o & 63, wave = tid_o >> 6;
+  const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
+  const int etile = wave >> 2, ecol = lane & 15, ej = wave & 3;
+  const int pcol = etile * 256 + grp * 16 + ecol;
   // this workgroup's slice of a layer's weights, two column tiles.  Wave w owns the SIX CONSECUTIVE k-groups 6 w .. 6 w + 5 (k = 96 w .. 96 w + 95 of
   // the 768 = 3 taps x 256 channels), not w, w + 8, ...: its six A requests per row then cover 384 contiguous bytes = three whole 128-byte
   // lines.  (With one 64-byte piece per row and request, in-kernel stamps showed a pass's 96 KB of rows taking ~4 us to land: ~25 GB/s per CU.)
@@ -107,8 +196,6 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
 #pragma unroll
     for (int i = 0; i < 6; ++i) { q0[i] = ldv(wb, w0 + (unsigned)(6 * wave + i) * 256u); q1[i] = ldv(wb, w1 + (unsigned)(6 * wave + i) * 256u); }
   };
-  for (int b0 = team * 4; b0 < p.B; b0 += 32) {
-  const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
   load_w(0, bq0, bq1);
   for (int li = 0; li < p.L; ++li) {
     {                                      // ... and a layer's descriptor in one batch (lazily: three dependent batches at the top of every layer, more in the row pass)

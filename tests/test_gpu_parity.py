@@ -354,7 +354,7 @@ def test_decode_vs_oracle_loop(weights, graph, mode):
     assert trajr.max() > 10
 
 
-@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0", "DCTTS_XGROUP=0,DCTTS_XCONE=0", "DCTTS_CHAIN_TAIL=0", "DCTTS_CHAIN_TAIL=1", "DCTTS_CHAIN_TAIL=5"])
+@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0", "DCTTS_XCONE=2", "DCTTS_XGROUP=0,DCTTS_XCONE=0", "DCTTS_CHAIN_TAIL=0", "DCTTS_CHAIN_TAIL=1", "DCTTS_CHAIN_TAIL=5"])
 def test_decode_stream_meeting_variants(weights, knob):
     """The chain and side streams of the decode meet inside kernels (default: counters polled / written by the launches themselves, passenger
     workgroups), with stream wait / write operations (DCTTS_CHAIN_WAIT=0), or through events (DCTTS_SYNC_VALUES=0: what rocprofv3 --pmc
