@@ -12,7 +12,7 @@ What the JSON line holds besides the contract's fields (everything is measured i
   roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r05_kernel_stats.md): xcone_kernel, the re-evaluation of
                       AudioDec's dependency cone on the decode's side stream; HIP-event timed on ITS stream inside the timed region (every 16th
                       frame from frame 100 on), fp32-MFMA bound; `traffic` = PMC bytes per launch (profiles/r05_pmc_decode.json, separate passes)
-  kernels             the same figures for xgroup_kernel and xtail_kernel (the chain's launches), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
+  kernels             the same figures for xchain_kernel (the chain's launch; DCTTS_CHAIN_TAIL=6: xtail_kernel and xgroup_kernel), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
                       launch) and SSRN's 1025-column layers (event-timed in untimed extra passes)
   phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
   other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share); decode-only at B = 64 / 128;
@@ -531,7 +531,30 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
         n, ms = eng.prof_collect(); layers = eng.prof_rows()
         eng.prof_enable(PROF_XTAIL); eng.text2mel(L); torch.cuda.synchronize(); eng.prof_enable(-1)
         nt, mst = eng.prof_collect()
-        if nt:
+        one_launch = bool(nt) and not n          # round 5 default: a chain piece is ONE launch (xchain_kernel); DCTTS_CHAIN_TAIL=6: round 4's two launches
+        if one_launch:
+            fl = 2.0 * (3 * d * 2 * d + 9 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)          # xtail_kernel's part (below)
+            by = 4.0 * (3 * d * 2 * d + 3 * 3 * d * 2 * d + 5 * d * d + 2 * d * hp.n_mels) + 4.0 * B * (3 * 2 * d + 14 * d + d + hp.n_mels)
+            lay_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + B * d + 4 * d)      # one AudioEnc layer: weights 256 x 512, presum / rows out / rows in, statistics, kept row, LN parameters
+            lay_flop = 2.0 * B * d * 2 * d
+            fl_tail = 2.0 * B * (3 * d + d * d)                                               # attention logits over the 3-key window + C_1's Q half (256 x 256)
+            by_tail = 4.0 * (d * d + B * (3 * 2 * d + 3 * d + 2 * d))
+            e = dict(kernel="xchain_kernel (decode chain, round 5: a chain piece as ONE launch in team form -- xtail_kernel's part: AudioDec's newest-row layers HC_2 .. HC_4, "
+                            "HC_5 .. HC_7 over the 5 / 3 / 1 cone rows they need, the seven k = 1 layers around the mel frame; a team barrier; xgroup_kernel's part: the AudioEnc "
+                            "run HC_4 .. HC_13 of the next frame, its attention row and AudioDec C_1.  It also carries the presum GEMMs as passenger workgroups, and its "
+                            "event-timed duration includes the wait for the side stream whenever that is the longer one; the two parts timed separately: "
+                            "profiles/r05_chain_tail_split.txt, DCTTS_CHAIN_TAIL=6)",
+                     bound="latency (25 dependent all-to-all layers)", launches=nt, avg_launch_ms=round(mst / nt, 5), layers_per_launch=25,
+                     **both_roofs(fl * B + 10 * lay_flop + fl_tail, by + 10 * lay_bytes + by_tail, mst / nt))
+            tj = os.path.join(ROOT, "profiles", "r05_pmc_decode.json")
+            if os.path.exists(tj):
+                pj = json.load(open(tj))
+                if "xgroup_kernel" in pj and "xtail_kernel" in pj:
+                    e["traffic"] = pj["xgroup_kernel"]["hbm_bytes_per_launch"] + pj["xtail_kernel"]["hbm_bytes_per_launch"]
+                    e["traffic_note"] = ("PMC bytes per launch of the two parts, added (counter collection runs them as two launches: xtail_kernel + xgroup_kernel): eight "
+                                         "XCD-local copies of every layer's weights, served by the Infinity Cache")
+            kern.append(e)
+        if nt and not one_launch:
             # per utterance and frame: the newest row of HC_2 .. HC_4 (K = 256: centre tap -> 512 columns), HC_5 / HC_6 / HC_7 over 5 / 3 / 1 rows (K = 768 -> 512 columns)
             # + C_8 .. C_10, C_11 (256 -> 80), AudioEnc C_1 (80 -> 256), C_2, C_3
             fl = 2.0 * (3 * d * 2 * d + 9 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)

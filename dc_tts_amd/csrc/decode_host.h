@@ -273,7 +273,7 @@ static void drop_decode_tables(dctts_ctx* c) {      // (the caller has synchroni
 //     AudioEnc presums for row f (one grouped launch) | C_1 cone rows (rowc1_kernel) | per k=3 AudioDec layer: cone rows + the
 //     presum row of frame f in one GEMM, then LN / gate of the cone rows.
 static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahead) {
-  const std::string g = std::to_string(B) + ":" + std::to_string((int)c1qw_ahead) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p);
+  const std::string g = std::to_string(B) + ":" + std::to_string((int)c1qw_ahead) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p) + ":" + std::to_string((int)c->chain_one);
   if (c->aepre_tab && c->aepre_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "aepre", g, &ts)) { c->aepre_tab = ts.tab; c->aepre_layers = ts.n0; c->aepre_geom = g; return 0; } }
   std::vector<SplitParams> tab;
@@ -300,7 +300,8 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahea
           h.ntaps = 2; h.tap_off[0] = h.tap_off[1] = -2; h.cin = H.cin; h.cin_p = H.cin_p;
           h.wp = H.wp; h.bias = H.bias; h.cout = H.cout; h.hc = 1; h.np_out = 6 * H.cout; h.pout = w.c1qw.p + (long)q * 2 * H.cout;
           h.abs_bstride = w.c1qw.bstride; h.abs_row0 = w.c1qw.row0; h.abs_toff = -2;
-          h.step_val = c1qw_ahead ? 1 : 0;       // launched from the chain's stream, one piece earlier (decode_v3): the row is the chain's newest C1Q row
+          h.step_val = (c1qw_ahead && !c->chain_one) ? 1 : 0;       // launched from the chain's stream, one piece earlier (decode_v3): the row is the chain's newest C1Q row
+                                                                    // (chain_one: the passengers' step is already one further: they compute AudioEnc's presums of row j + 2)
           tab.push_back(h);
         }
       }
@@ -788,7 +789,7 @@ static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
 // xtail_kernel's per-frame parameters: AudioDec's last three highway layers (HC_5 .. HC_7 over 5 / 3 / 1 rows per utterance) + the k = 1 layers
 static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xtail", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string(c->trace_frame) + ":" +
-                        std::to_string((int)c->dec_merge) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.pb3[1]);
+                        std::to_string((int)c->dec_merge) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((int)c->chain_one);
   if (c->xtail_tab && c->xtail_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xtail", g, &ts)) { c->xtail_tab = ts.tab; c->xtail_geom = g; return 0; } }
   c->xtail_tab = nullptr;
@@ -807,7 +808,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   std::vector<XTailParams> tab((size_t)T);
   for (int j = 0; j < T; ++j) {
     XTailParams p; memset(&p, 0, sizeof(p));
-    CHK(fill_xmlp(c, w, B, T, j, h0 - 1, m, c->dec_merge ? 13 : 10, &p.m));
+    CHK(fill_xmlp(c, w, B, T, j, h0 - 1, m, c->dec_merge ? (c->chain_one ? 14 : 13) : 10, &p.m));      // (chain_one: + the meeting in front of the AudioEnc run, xchain_kernel)
     p.m.xch_set = m.bpad * 512; p.m.sch_set = m.bpad * 64;      // (value, tag) pairs
     const long par = j & 1;
     if (c->dec_merge) {
@@ -828,8 +829,11 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
       if (c->ae_pass && j + 1 < T) {                                      // passengers: AudioEnc's presums of row j + 1 and row j of the C1Q . W2 cache (counted: rowc1_kernel polls psig)
         const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
-        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers;
-        p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;
+        // chain_one: the AudioEnc run that reads the presums is part of THIS launch, and passengers run on other XCDs: they compute row j + 2's (inputs: rows <= j,
+        // complete since the previous piece) for the next launch; the C1Q . W2 descriptors carry step_val 0 then, so their row stays j
+        const int ps = c->chain_one ? j + 2 : j + 1;
+        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)(ps & 1) * c->aepre_layers;
+        p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = ps; p.p_count_from = c->aepre_layers - 3;
         p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
       }
     }
@@ -873,7 +877,12 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
     if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, st)); }
     int pass = 0;                                                 // passenger workgroups, as in the table
     if (c->dec_merge && c->ae_pass && j + 1 < c->xg_T) pass = c->aepre_layers * (((B + 31) / 32) * (c->cfg.d / 32));
-    if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
+    if (c->chain_one && j + 1 < c->xg_T) {
+      // round 5: the whole chain piece as ONE launch -- these layers, a team barrier, the AudioEnc run of frame j + 1 with the attention row and AudioDec C_1
+      const XGroupParams* pg = (const XGroupParams*)c->xg_tab + (size_t)2 * (j + 1) + 1;
+      if (c->trace_on) hipLaunchKernelGGL(xchain_kernel<true>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j, pg);
+      else hipLaunchKernelGGL(xchain_kernel<false>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j, pg);
+    } else if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
     else hipLaunchKernelGGL(xtail_kernel<false>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }
@@ -923,7 +932,8 @@ static int v3_chain_enc(dctts_ctx* c, const DecodeWs& w, int B, int N, int j, hi
     if (i == 0) {                                               // frame 0 only: S[0] is the zero row
       CHK(run_split(c, 16, AE[0], B, 1, nullptr, j, PRO_RAW, nullptr, nullptr, w.ypad, w.pe[0], sm, nullptr, w.se[0]));
     } else if (c->xg_on && AE[i].hc) {
-      if (!AE[i - 1].hc) CHK(v3_xgroup_launch(c, B, j - 1, 1, sm));    // the whole run of highway layers (HC_4 .. HC_13) of frame j, launched from chain piece j - 1
+      if (!AE[i - 1].hc && !(c->chain_one && j >= 1)) CHK(v3_xgroup_launch(c, B, j - 1, 1, sm));    // the whole run of highway layers (HC_4 .. HC_13) of frame j, launched from chain piece j - 1
+                                                                                                     // (chain_one: it ran as the back of that piece's one launch, v3_mlp_launch)
     } else {
       SplitExtra ex;
       if (AE[i].wp16c) { ex.presum = w.pse[i] + (long)(j & 1) * w.pse_set; ex.presum_rstride = 2 * AE[i].cout; }
@@ -984,6 +994,8 @@ static int write_trace3(dctts_ctx* c, int j) {
     fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
     for (int i = 2; i < 120 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, ((i - 2) % 5 == 4) ? " |" : "");
     fprintf(f, "\n");
+    const long long* ot = &h[64 * 64 * 32 - 64];
+    if (net && c->chain_one && ot[0]) fprintf(f, "  (one launch per chain piece: this run was entered %.2f us after xtail_kernel's part of the launch below was)\n", (o[0] - ot[0]) / 100.0);
   }
   {
     const long long* o = &h[64 * 64 * 32 - 192];
@@ -1055,8 +1067,9 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
              c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;      // (behind rowhc2_kernel)
   c->tail_on = c->xg_on && c->xc_on && c->chain_tail >= 2 && c->audiodec.size() == 11 && c->cone_len.size() > 6 && c->cone_len[4] == 5 && c->cone_len[5] == 3 && c->cone_len[6] == 1;
   c->xmlp_on = c->xg_on && c->chain_tail >= 1 && !c->tail_on;
-  c->dec_merge = c->tail_on && c->chain_tail == 2;          // (5: xtail_kernel behind an AudioDec run of xgroup_kernel, the first round-4 form -- A/B)
+  c->dec_merge = c->tail_on && (c->chain_tail == 2 || c->chain_tail == 6);          // (5: xtail_kernel behind an AudioDec run of xgroup_kernel, the first round-4 form -- A/B)
   c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->chain_tail != 3 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;      // (3: xtail_kernel without the fold -- A/B)
+  c->chain_one = c->dec_merge && c->chain_tail == 2 && c->attn_fold;      // (6: the chain piece as two launches, round 4's form -- A/B)
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's
   // counter, and xcone_kernel's last team writes the side stream's
   const bool bsig = cwait && c->xc_on;
@@ -1072,6 +1085,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   // ... or, with both team kernels, in no launch of its own at all: the AudioEnc presums and that row are passengers of the chain's AudioDec launch
   // (xgroup_kernel.h); the side stream's first launch (rowc1_kernel) polls the row's own counter before it ends
   c->ae_pass = bsig && c->xg_on && c->cone_len[0] > 1 && !c->side_pre;
+  c->chain_one = c->chain_one && c->ae_pass;
   c->ae_pass_split = c->ae_pass && c->chain_tail == 4;      // (4: A/B -- measured: the AudioDec launch gets 3.4 us shorter, the AudioEnc launch 6 us longer: its passengers only find CUs when xcone_kernel's work ends, ~4 us before the launch's own teams do: 88.9 against 86.2 us per frame)
   CHK(v3_aepre_table(c, w, B, c->c1qw_chain));
   c->sig_ptr = cwait ? c->wait_ctr : (unsigned*)c->ctr_chain;
@@ -1125,6 +1139,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   }
   CHK(v3_vw(c, w, B, N, st));                                              // V . W_top, once per batch
   CHK(v3_aepre(c, B, 0, st));                                              // row 0's AudioEnc presums (= the biases: every tap reads padding)
+  if (c->chain_one && T > 1) CHK(v3_aepre(c, B, 1, st, 1));                // ... and row 1's (the same): piece j's passengers compute row j + 2's in this form
   HIPCHK(hipEventRecord(c->ev_fork, st));
   HIPCHK(hipStreamWaitEvent(sb, c->ev_fork, 0));
   const int tstep = c->trace_frame;

@@ -87,9 +87,13 @@ __device__ __forceinline__ unsigned xg_xcc_id() {
   return v & 0xfu;
 }
 
-// grid: 128 blocks of 512 threads, whatever the batch (+ p_blocks passengers, with hsplit_smem(32) bytes of dynamic LDS)
-template <bool TS = false>                 // TS: the stamped instantiation (DCTTS_TRACE); the production kernel carries no trace of the stamps
-__global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) {
+// The kernel's body as a function: xgroup_kernel below is a launch of its own (the AudioEnc run of the first chain piece, the fallback forms); since round 5 the
+// AudioEnc run of every other piece runs BEHIND xtail_kernel's layers in the same launch (xtail_kernel.h: xchain_kernel), where the team stays on its CUs and its XCD.
+// `meet` is called once, by every thread of a team workgroup, when the first layer's requests that do not depend on the front of the launch are out (weights,
+// layer-norm parameters, the history row) and before the first request that does (the producer's pre-norm rows): xchain_kernel
+// passes the team's barrier, xgroup_kernel nothing.
+template <bool TS = false, typename Meet>   // TS: the stamped instantiation (DCTTS_TRACE); the production kernel carries no trace of the stamps
+__device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp, Meet meet) {
   __shared__ __attribute__((aligned(16))) float red[8 * 2 * 4 * 64];
   __shared__ int s_go;
   // the layers' descriptors, copied once: read through the scalar cache a layer's fields arrive as several dependent scalar loads inside the layer
@@ -176,22 +180,27 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
 #pragma unroll
       for (int e = 0; e < 2; ++e) { vtb0[e] = z4; vtb1[e] = z4; }
     }
-    {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-        va[e] = ldv(p.P0, bb * (unsigned)p.p0_bs + ch);
-        vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
-        if (t2) vta[e] = ldv(p.lay[0].xt, bb * (unsigned)p.lay[0].xt_bs + ch);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
+    for (int e = 0; e < 2; ++e) {
+      const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
+      vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
+      if (t2) vta[e] = ldv(p.lay[0].xt, bb * (unsigned)p.lay[0].xt_bs + ch);
     }
   }
+  const int cr = lane >> 4, cc = lane & 15;
+  const unsigned crow = (m0 + cr < p.B) ? (unsigned)(m0 + cr) : 0u;
   if (round == 0) {
     constexpr int NW32 = (int)(sizeof(XGroupLayer) * 10 / 4);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(pp->lay);
     if (tid < NW32) reinterpret_cast<uint32_t*>(s_lay)[tid] = src[tid];
+    meet();
+  }
+  // ---- what the launch's front (or the launch before this one) produced: the pre-norm rows and their partial statistics
+  {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) va[e] = ldv(p.P0, bb * (unsigned)p.p0_bs + (unsigned)((8 * e + wave) * 16 + c4));
+#pragma unroll
+    for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
   }
   // ---- placement check, the stream signal, and the wait for the side stream (first launch of a chain piece), while those loads are in flight
   if (tid == 0 && round == 0) {
@@ -212,7 +221,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   float addv = 0.f;
   if (wr) {                                                                // presum of layer 0: written by the side stream -> read past the L1 / a possibly stale line
     const float* ap = p.lay[0].presum + (unsigned)(eb * p.lay[0].presum_bs) + (unsigned)pcol;
-    asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(addv) : "v"(ap) : "memory");
+    addv = __hip_atomic_load(ap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (sc0 sc1; waited for where it is used, behind the first contraction)
   }
   auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
   float4 x[2];                            // the current layer's input row fragments (also the next rebuild's highway residual)
@@ -230,8 +239,6 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   // The rebuild of a layer's input (layer-norm of both halves, sigmoid gate, highway mix) is done in a COMPACT layout: lane (cr, cc) owns row cr and the
   // two channels 16 w + cc and 128 + 16 w + cc.  In the A-operand layout every lane rebuilt 8 values, 6 of them for padding rows: ~165 instructions with
   // 8 v_exp + 8 v_rcp per wave and layer, twice per SIMD, between "rows landed" and the first MFMA.  Compact: 2 values per lane and an LDS hop.
-  const int cr = lane >> 4, cc = lane & 15;
-  const unsigned crow = (m0 + cr < p.B) ? (unsigned)(m0 + cr) : 0u;
   float* const xs = s_xs[wave];
   float xc[2];                                                             // this layer's input at (cr, channel e) = the next rebuild's highway residual
   if (arow < 4) { *reinterpret_cast<float4*>(&xs[arow * 32 + c4]) = x[0]; *reinterpret_cast<float4*>(&xs[arow * 32 + 16 + c4]) = x[1]; }
@@ -375,25 +382,25 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   }
   if (p.attn) {
     // ---- the attention tail, OUTSIDE the layer loop: with its operands requested in the loop's prefetch slot the loop carried 47 more registers and
-    //      every layer got ~0.3 us slower (stamps).  None of the operands depends on this run -- C_1's 16-column tile, the window's K rows for this lane's
-    //      row and channels, V . W_top of the window for the (row, column) this lane finishes, the window position itself -- so they are one batch here.
+    //      every layer got ~0.3 us slower (stamps); requested in front of the first layer and held through the run (19 registers, round 5) the frame did not
+    //      get shorter (A/B on one box: 79.6 against 79.4 us).  None of the operands depends on this run -- C_1's 16-column tile, the window's K rows for this
+    //      lane's row and channels, V . W_top of the window for the (row, column) this lane finishes, the window position itself -- so they are one batch here.
+    f32x4 vc1[2];
     float kk[3][2], vwv[3], c1b;
     int pm_e;
     {
-    // the attention tail's operands: none of them depends on this run -- C_1's 16-column tile, the window's K rows for this lane's row and channels,
-    // V . W_top of the window for the (row, column) this lane finishes, the window position itself
     const float* wb = p.c1_wp + lane * 4;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) vb0[e] = ldv(wb, (unsigned)(grp * 16 + wave + 8 * e) * 256u);
+    for (int e = 0; e < 2; ++e) vc1[e] = ldv(wb, (unsigned)(grp * 16 + wave + 8 * e) * 256u);
     const int pm_c = p.pm[crow];
-    pm_e = p.pm[(wr || (erow < 4 && eb < p.B)) ? eb : (int)crow];
+    pm_e = p.pm[wr ? eb : (int)crow];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       int nc = pm_c + k; if (nc > p.N - 1) nc = p.N - 1;                 // beyond the window: clamped into the utterance, weight exactly 0
       const float* kr = p.K + ((long)crow * p.kv_bs + nc) * p.k_stride;
       kk[k][0] = kr[wave * 16 + cc]; kk[k][1] = kr[128 + wave * 16 + cc];
       int ne = pm_e + k; if (ne > p.N - 1) ne = p.N - 1;
-      vwv[k] = p.VW[(((erow < 4 && eb < p.B) ? (long)eb : (long)crow) * p.kv_bs + ne) * p.vw_stride + grp * 16 + ecol];
+      vwv[k] = p.VW[((wr ? (long)eb : (long)crow) * p.kv_bs + ne) * p.vw_stride + grp * 16 + ecol];
     }
     c1b = p.c1_bias[grp * 16 + ecol];
     }
@@ -413,7 +420,7 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
     f32x4 accc = z4;
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-      const float4 a = x[e]; const f32x4 b0 = vb0[e];
+      const float4 a = x[e]; const f32x4 b0 = vc1[e];
       accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], accc, 0, 0, 0); accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], accc, 0, 0, 0);
       accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], accc, 0, 0, 0); accc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], accc, 0, 0, 0);
     }
@@ -464,5 +471,9 @@ __global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restr
   }
   }                                        // next utterance group of this team
 }
+
+// grid: 128 blocks of 512 threads, whatever the batch (+ p_blocks passengers, with hsplit_smem(32) bytes of dynamic LDS)
+template <bool TS = false>
+__global__ void __launch_bounds__(512) xgroup_kernel(const XGroupParams* __restrict__ pp) { xgroup_body<TS>(pp, []() {}); }
 
 }  // namespace dctts

@@ -70,8 +70,9 @@ struct XTailParams {
   long long* ts;                         // measurement (DCTTS_TRACE, TS instantiation): workgroup 0 / thread 0 records 100 MHz wall-clock stamps at its phase boundaries
 };
 
+template <bool DRAINED = false>          // DRAINED: the caller has waited for its stores itself (and has requests in flight that the barrier need not wait for)
 __device__ __forceinline__ void team_barrier(unsigned* bar, int grp, unsigned xcc, unsigned target, int* err, bool go) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this thread's stores are in the L2
+  if constexpr (!DRAINED) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's stores are in the L2
   __syncthreads();
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
@@ -100,9 +101,9 @@ __device__ __forceinline__ f32x4 ld4_sc1(const float* p) {                  // p
 constexpr int XT_LDR = 260;              // LDS row stride (floats) of the activation rows
 constexpr int XT_MAXM = 20;              // rows a team's layer can have (5 per utterance)
 
-// grid: 128 blocks of 512 threads, whatever the batch
+// The kernel's body as a function (returns false for a workgroup that has nothing to do behind it: a passenger, a team without utterances)
 template <bool TS = false>
-__global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restrict__ pp) {
+__device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
   __shared__ __attribute__((aligned(16))) float lds_rows[(60 + XT_MAXM) * XT_LDR];
   float* const bufA = lds_rows;                          // the first layer's input rows (4 x 15), later the second layer's output (4 x 3)
   float* const bufB = lds_rows + 60 * XT_LDR;            // the first layer's output (4 x 5), later the third layer's (4 x 1)
@@ -134,14 +135,14 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
         if (old + 1u == p.pdone_target) __hip_atomic_store(p.psig, p.psig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
-    return;
+    return false;
   }
   // merged form: this launch is the first one of a chain piece, so every earlier piece of this stream is complete: say so FIRST -- the side stream's next piece
   // starts from this word (xcone_kernel's team leaders poll it), and since round 4 the side stream is as long as the chain
   if (blockIdx.x == 0 && tid == 0 && p.np && p.sig) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
   const int B = p.m.B;
-  if (team * 4 >= B) return;
+  if (team * 4 >= B) return false;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.m.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
@@ -666,6 +667,34 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
     }
   }
   if constexpr (TS) { if (p.ts && blockIdx.x == 0 && tid == 0) for (int i = 0; i < nts; ++i) p.ts[i] = s_ts[i]; }
+  return true;
+}
+
+// grid: 128 blocks of 512 threads, whatever the batch (+ the passengers)
+template <bool TS = false>
+__global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restrict__ pp) { (void)xtail_body<TS>(pp); }
+
+// Round 5: a chain piece as ONE launch -- xtail_kernel's layers (AudioDec behind C_1, the k = 1 layers around the mel frame), the team's barrier, then xgroup_kernel's
+// AudioEnc run of the next frame + attention row + AudioDec C_1.  What the launch boundary between them cost: ~1.7 us of gap + ~3 us until xgroup_kernel's first row was
+// built, against one team barrier here (0.9 us): the team's workgroups are where they were, their XCD's L2 has what the k = 1 layers just wrote.  What the boundary
+// gave for free and needs care now: (a) the k = 1 layers' last output (AudioEnc C_3's pre-norm rows + statistics) is read by the AudioEnc run's first layer -- behind the
+// team barrier, by plain loads of lines this launch has not touched before (the L1 was invalidated at its start); (b) AudioEnc's presums of the next row used to come
+// from THIS launch's passengers, workgroups on other XCDs: they now compute the row after that (inputs: rows that are final since the previous piece), so that what
+// the AudioEnc run reads was written one launch earlier (decode_host.h: v3_xtail_table).
+// Measured (B = 32, one box, A/B): 80.4 -> 78.8 us per frame.  Tried on top and worth nothing: the attention tail's operands requested in front of the AudioEnc
+// run's first layer; this frame's XGroupParams entry and the next frame's XTailParams entry touched at the launch's start (first-touch scalar loads).
+template <bool TS = false>
+__global__ void __launch_bounds__(512) xchain_kernel(const XTailParams* __restrict__ pt, const XGroupParams* __restrict__ pg) {
+  if (!xtail_body<TS>(pt)) return;
+  typedef const __attribute__((address_space(4))) XTailParams CP;
+  CP& p = *(CP*)pt;
+  const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
+  const int rounds = ((p.m.B + 3) / 4 + 7) / 8;
+  const unsigned target = p.m.bar_base + (unsigned)rounds * (unsigned)(p.np + p.nh + p.m.nl) * 16u + 16u;      // one more meeting than xtail_body's layers (the host counts it)
+  const bool go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the k = 1 layers' last stores are in the L2 ...
+  // ... and the team meets while the AudioEnc run's first requests are in flight (weights, layer-norm parameters, history row)
+  xgroup_body<TS>(pg, [&]() { team_barrier<true>(p.m.bar + team * 32, grp, xg_xcc_id(), target, p.m.err, go); });
 }
 
 }  // namespace dctts
