@@ -272,6 +272,7 @@ static void drop_decode_tables(dctts_ctx* c) {      // (the caller has synchroni
 // bulk piece f (f = 0 .. T-1), side stream, after chain piece f-2, overlapping chain piece f-1:
 //     AudioEnc presums for row f (one grouped launch) | C_1 cone rows (rowc1_kernel) | per k=3 AudioDec layer: cone rows + the
 //     presum row of frame f in one GEMM, then LN / gate of the cone rows.
+static inline int aepre_stride(const dctts_ctx* c) { return c->aepre_layers + 3; }      // descriptors per parity copy of the table (v3_aepre_table)
 static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahead) {
   const std::string g = std::to_string(B) + ":" + std::to_string((int)c1qw_ahead) + ":" + std::to_string((size_t)w.ae[0].p) + ":" + std::to_string((size_t)w.pse.back()) + ":" + std::to_string((size_t)w.c1qw.p) + ":" + std::to_string((int)c->chain_one);
   if (c->aepre_tab && c->aepre_geom == g) return 0;
@@ -304,13 +305,21 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahea
                                                                     // (chain_one: the passengers' step is already one further: they compute AudioEnc's presums of row j + 2)
           tab.push_back(h);
         }
+        // ... and the same three once more without the zero half of K (K = 256, hbulk_body<4>): xtail_kernel's passengers run these -- side-stream piece j + 1
+        // waits for them (the fold's second phase polls their counter), and at K = 512 they took 9 - 11 us of which half was zeros (round 5)
+        for (int q = 0; q < 3; ++q) {
+          SplitParams h = tab[tab.size() - 3];
+          const DevLayer& H = c->hc2_wt[q];
+          h.ntaps = 1; h.tap_off[0] = h.tap_off[1] = -2; h.cin = H.cin; h.cin_p = H.cin_p; h.wp = H.wp;
+          tab.push_back(h);
+        }
       }
     }
   if (tab.empty()) return fail(DCTTS_ERR_STATE, "v3: no causal k=3 AudioEnc layers");
   c->aepre_tab = nullptr;
   HIPCHK(hipMalloc(&c->aepre_tab, tab.size() * sizeof(SplitParams)));
   HIPCHK(hipMemcpy(c->aepre_tab, tab.data(), tab.size() * sizeof(SplitParams), hipMemcpyHostToDevice));
-  c->aepre_layers = (int)tab.size() / 2; c->aepre_geom = g;
+  c->aepre_layers = (int)tab.size() / 2 - 3; c->aepre_geom = g;      // (a parity copy = aepre_layers descriptors + the three K = 256 twins: aepre_stride)
   tab_store(c, "aepre", g, c->aepre_tab, nullptr, c->aepre_layers);
   return 0;
 }
@@ -319,7 +328,7 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahea
 // part 0: everything; 1: AudioEnc's presums only (the first aepre_layers - 3 descriptors); 2: the three C1QW descriptors only
 static int v3_aepre(dctts_ctx* c, int B, int f, hipStream_t st, int part = 0, unsigned wait_val = 0) {
   const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
-  const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * c->aepre_layers;
+  const SplitParams* tab = (const SplitParams*)c->aepre_tab + (size_t)(f & 1) * aepre_stride(c);
   int n = c->aepre_layers;
   if (part == 1) n -= 3;
   if (part == 2) { tab += c->aepre_layers - 3; n = 3; }
@@ -596,7 +605,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
           // found them only when this launch's teams had finished (~4 us on the chain); AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch.
           const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
           const int first = c->ae_pass_split ? c->aepre_layers - 3 : 0;
-          p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers + first;
+          p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * aepre_stride(c) + first;
           p.p_ipl = ipl; p.p_blocks = (c->aepre_layers - first) * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3 - first;
           p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
         }
@@ -605,7 +614,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
         // piece j - 2, and their consumer is the AudioEnc run of frame j + 1, a later launch on this stream.  They start when the side stream's xcone_kernel
         // lets go of its CUs (~15 us before this launch ends) and are done before it.
         const int ipl = ((B + 31) / 32) * (c->cfg.d / 32);
-        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * c->aepre_layers;
+        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * aepre_stride(c);
         p.p_ipl = ipl; p.p_blocks = (c->aepre_layers - 3) * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;      // (none of them is counted)
       }
       if (piece == c->trace_frame) {                            // DCTTS_TRACE: this piece's two launches record their phase boundaries
@@ -832,7 +841,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
         // chain_one: the AudioEnc run that reads the presums is part of THIS launch, and passengers run on other XCDs: they compute row j + 2's (inputs: rows <= j,
         // complete since the previous piece) for the next launch; the C1Q . W2 descriptors carry step_val 0 then, so their row stays j
         const int ps = c->chain_one ? j + 2 : j + 1;
-        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)(ps & 1) * c->aepre_layers;
+        p.ptab = (const SplitParams*)c->aepre_tab + (size_t)(ps & 1) * aepre_stride(c);
         p.p_ipl = ipl; p.p_blocks = c->aepre_layers * ipl; p.p_step = ps; p.p_count_from = c->aepre_layers - 3;
         p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
       }

@@ -196,10 +196,14 @@ __device__ __forceinline__ void combine_stats(const float4 (&st)[4], int h, floa
 // so the ~1.5 us a work item used to wait for its first loads, and the scalar set-up before them, overlap the reduction and
 // the stores of the previous one.  The epilogue issues no loads of its own (its two bias values ride along with the item's
 // loads): a load there would have to be waited for with vmcnt(0), i.e. behind everything just issued for the next item.
-template <int NG, typename PT>
+// BD_ = weight groups in flight per wave.  4 for the bulk launches (items stream through a workgroup; the next item's first groups are the prefetch); NG -- every
+// group requested up front -- for a passenger of the chain's launch (xtail_kernel.h): one item per workgroup, on a compute unit the side stream is waiting for, and
+// at 4 in flight the item was two dependent rounds of memory latency long (9 - 11 us for 3.4 us of MFMA).
+// ONE: one item per workgroup (item0 only), and no second round of requests to keep the compute unit for.
+template <int NG, typename PT, int BD_ = 4, bool ONE = false>
 __device__ __forceinline__ void hbulk_body(const PT& p, const int step, const int item0, const int item_stride, const int nitems,
                                            float* smem, long (*s_prow)[32]) {
-  constexpr int MF = 32, NJ = 16, BD = 4, KG = NG * 8;
+  constexpr int MF = 32, NJ = 16, BD = BD_ < NG ? BD_ : NG, KG = NG * 8;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long par = step & 1;
   const int arow = lane & 31, c4 = (lane >> 5) * 4;
@@ -284,8 +288,8 @@ __device__ __forceinline__ void hbulk_body(const PT& p, const int step, const in
     }
     // next item's loads go out now; the last item re-issues itself (clamped) so that no branch surrounds the loads
     const int next = item + item_stride;
-    const bool more = next < nitems;
-    issue(more ? next : item, slot ^ 1);
+    const bool more = ONE ? false : next < nitems;
+    if constexpr (!ONE) issue(more ? next : item, slot ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     // fully unrolled (4 elements per thread): a run-time loop here gets an s_waitcnt vmcnt(0) in its preheader (it contains

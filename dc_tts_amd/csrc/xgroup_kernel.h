@@ -316,6 +316,8 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
       break;
     }
     // ---- publish this workgroup's slice of layer g with PLAIN stores (they stay in this XCD's L2), then arrive at the team's barrier
+    //      (round 5: xtail_kernel's tagged hand-off -- a sequence tag beside every value, the consumers poll the data -- was tried here too: 4 x 8-byte + 2 x 16-byte
+    //      requests per poll, and a poll that comes too early costs a whole L2 round trip; 78.8 against 78.7 us per frame on one box, so the barrier stays)
     const int par = g & 1;
     if (wr) {
       p.xch[(long)par * p.xch_set + (long)eb * 512 + pcol] = v_;

@@ -122,7 +122,12 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
     ConstSplitParams& sp = *((ConstSplitParams*)p.ptab + layer);
     long long t_in = 0;
     if constexpr (TS) t_in = wall_clock64();
-    hbulk_body<8, ConstSplitParams>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, lds_rows, s_prow);
+    if (layer >= p.p_count_from) {                          // the counted ones (the C1Q . W2 cache's newest row): their K = 256 twins, three descriptors on
+      ConstSplitParams& sq = *((ConstSplitParams*)p.ptab + layer + 3);
+      hbulk_body<4, ConstSplitParams, 4, true>(sq, p.p_step + sq.step_val, item, p.p_ipl, p.p_ipl, lds_rows, s_prow);
+    } else {
+      hbulk_body<8, ConstSplitParams, 8, true>(sp, p.p_step + sp.step_val, item, p.p_ipl, p.p_ipl, lds_rows, s_prow);
+    }
     if constexpr (TS) {                                    // measurement: when the first and the last passenger ran (slots 56 .. 59 of the stamps)
       if (p.ts && tid == 0 && (q == 0 || q == p.p_blocks - 1)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); p.ts[q == 0 ? 56 : 58] = t_in; p.ts[q == 0 ? 57 : 59] = wall_clock64(); }
     }
