@@ -493,8 +493,8 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
     res["phase_rooflines"] = {
         "textenc": both_roofs(B * 2 * 3.0789e9, 68.6e6 + B * 0.37e6, ms_te),
         "decode": dict(both_roofs(B * T * (8.167e6 + 142.254e6 + 0.26e6), T * (27285440.0 + B * 125e3), dec_ms),
-                       bound="latency: 16 dependent all-to-all highway layers + 7 k=1 layers + attention + AudioDec C_1 per frame in TWO launches on the chain's "
-                             "stream, beside the cone re-evaluation on the side stream (three launches; the two streams are equally long since round 4); the cone work of AudioDec C_1 / HC_2 runs as row operations on "
+                       bound="latency: 16 dependent all-to-all highway layers + 7 k=1 layers + attention + AudioDec C_1 per frame in ONE launch on the chain's "
+                             "stream (round 5; round 4: two), beside the cone re-evaluation on the side stream (ONE launch, round 4: three; the two streams are about equally long); the cone work of AudioDec C_1 / HC_2 runs as row operations on "
                              "cached products, so fewer FLOPs are EXECUTED than the algorithmic count used here (DESIGN.md section 2)"),
         "ssrn": both_roofs(B * T * 187.310e6, B * (67200 + 3444000) + 113641532.0, ms_ssrn),
     }

@@ -1015,6 +1015,8 @@ static int write_trace3(dctts_ctx* c, int j) {
       for (int i = 1; i < 60 && o[i]; ++i) { fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0); last = i; }
       if (last > 0 && o[101] > o[100]) fprintf(f, "   (shader clock over the launch: %.0f MHz)", (double)(o[101] - o[100]) / ((o[last] - o[0]) / 100.0));
       fprintf(f, "\n");
+      const long long* ot = &h[64 * 64 * 32 - 64];          // the chain launch of the same frame (the stamps are one wall clock): when did this side piece run relative to it?
+      if (ot[0] && c->tail_on && last > 0) fprintf(f, "  (relative to the entry of the chain's launch of this frame: entered %.2f, last stamp %.2f us)\n", (o[0] - ot[0]) / 100.0, (o[last] - ot[0]) / 100.0);
     }
   }
   {

@@ -15,8 +15,8 @@
 // So: grid = 128 workgroups, always; block b belongs to team b % 8 (= its XCD) and owns column group (b / 8) % 16; a team owns FOUR utterances at a
 // time (the newest row of each; utterance groups team, team + 8, ... in turn when B > 32) and all 16 column groups, i.e. everything a layer's
 // layer-norm needs.  Per layer a workgroup contracts
-// K = 256 for its (gate, info) pair of 16-column tiles over 8 waves (chain3_kernel's arithmetic: 16x16x4 fp32 MFMA, fixed-order LDS reduction,
-// partial layer-norm statistics per column group), publishes 4 x 32 pre-norm values + statistics with plain stores, arrives at the team's
+// K = 256 for its (gate, info) pair of 16-column tiles over 8 waves (fixed-order LDS reduction, partial layer-norm statistics per column group; since
+// round 5 on 4 x 4 x 1 fp32 MFMA blocks -- a team's layer has four rows -- instead of chain3_kernel's 16 x 16 x 4 tiles: see the body), publishes 4 x 32 pre-norm values + statistics with plain stores, arrives at the team's
 // barrier (its own word of the team's 64-byte line: no read-modify-write), and reads the other 15 slices past its L1.  Everything that does not depend on the predecessor -- the next layer's
 // weights, presum, layer-norm parameters, a dilation-1 layer's history row -- is requested before the barrier.
 //
@@ -164,31 +164,38 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
   const int eb = m0 + erow;
   const bool wr = erow < 4 && eb < p.B;
 
-  // ---- layer 0: everything that does not come from the side stream by plain loads (the producer is an earlier launch)
-  f32x4 vb0[2], vb1[2], vtb0[2], vtb1[2], vta[2] = {z4, z4}, va[2], vg1[2], vbe1[2], vst[4];
+  // ---- round 5: the contraction runs on v_mfma_f32_4x4x1_16b_f32 -- 16 independent 4 x 4 blocks per instruction, block = lanes 4 i .. 4 i + 3, D[row][lane j]
+  //      += A[row of lane] . B[column of lane j].  A team's layer has FOUR rows: on 16 x 16 x 4 tiles 12 of the 16 rows were padding, and the 16 (K = 512: 32)
+  //      MFMAs of a wave took 512 (1024) cycles of a pipe it shares with a second wave: 0.43 (0.85) us per layer of MFMA issue alone.  Here a wave's block
+  //      (cb, kh) = (lane >> 2) & 7, lane >> 5 owns columns 4 cb .. 4 cb + 3 of the workgroup's 32 (cb < 4: the gate tile, else the info tile) and the 16
+  //      channels of k-group wave + 8 kh; 16 instructions of 8 cycles walk over those channels.  The weights are read from the SAME packing
+  //      ([tile][k-group][lane = (col, k / 4)][4]): lane (cb, kh, j) takes the four float4 of column 4 (cb & 3) + j, sixteen lanes 256 contiguous bytes.
+  const int j4 = lane & 3, cb = (lane >> 2) & 7, kh = lane >> 5;
+  const unsigned kgw = (unsigned)(wave + 8 * kh);
+  const unsigned wlane = (unsigned)(((cb & 3) * 4 + j4) * 4);             // float offset of this lane's column inside a (tile, k-group) block; + 64 per k / 4
+  const unsigned wtile = (unsigned)(grp * 2 + (cb >> 2));
+  const unsigned bj = (m0 + j4 < p.B) ? (unsigned)(m0 + j4) : (unsigned)m0;      // the utterance of this lane's A row
+  f32x4 wq[4], wtq[4], atq[4] = {z4, z4, z4, z4};
+  float p0c[2], g1c[2], b1c[2];
+  f32x4 st0;
+  const int cr = lane >> 4, cc = lane & 15;
+  const unsigned crow = (m0 + cr < p.B) ? (unsigned)(m0 + cr) : (unsigned)m0;
   {
     const bool t2 = p.lay[0].tap2 != 0;
     const unsigned nkg = t2 ? 32u : 16u, kc = t2 ? 16u : 0u;
-    const float* wb = p.lay[0].wp + lane * 4;
-    const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
+    const float* wb = p.lay[0].wp + wlane;
+    const unsigned w0 = (wtile * nkg + kc + kgw) * 256u, wt0 = (wtile * nkg + kgw) * 256u;
 #pragma unroll
-    for (int e = 0; e < 2; ++e) { vb0[e] = ldv(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldv(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
+    for (int q = 0; q < 4; ++q) wq[q] = ldv(wb, w0 + 64u * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wtq[q] = t2 ? ldv(wb, wt0 + 64u * q) : z4;
     if (t2) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) { vtb0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 2; ++e) { vtb0[e] = z4; vtb1[e] = z4; }
+      for (int q = 0; q < 4; ++q) atq[q] = ldv(p.lay[0].xt, bj * (unsigned)p.lay[0].xt_bs + kgw * 16u + 4u * q);
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-      vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
-      if (t2) vta[e] = ldv(p.lay[0].xt, bb * (unsigned)p.lay[0].xt_bs + ch);
-    }
+    for (int e = 0; e < 2; ++e) { const unsigned ch = (unsigned)((8 * e + wave) * 16 + cc); g1c[e] = p.pg1[ch]; b1c[e] = p.pb1[ch]; }
   }
-  const int cr = lane >> 4, cc = lane & 15;
-  const unsigned crow = (m0 + cr < p.B) ? (unsigned)(m0 + cr) : 0u;
   if (round == 0) {
     constexpr int NW32 = (int)(sizeof(XGroupLayer) * 10 / 4);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(pp->lay);
@@ -196,11 +203,10 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     meet();
   }
   // ---- what the launch's front (or the launch before this one) produced: the pre-norm rows and their partial statistics
-  {
+  {                                         // (compact: lane (cr, cc) owns row cr, channels 16 w + cc and 128 + 16 w + cc, and column group cc's statistics)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) va[e] = ldv(p.P0, bb * (unsigned)p.p0_bs + (unsigned)((8 * e + wave) * 16 + c4));
-#pragma unroll
-    for (int g = 0; g < 4; ++g) vst[g] = ldv(p.stats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
+    for (int e = 0; e < 2; ++e) p0c[e] = p.P0[crow * (unsigned)p.p0_bs + (unsigned)((8 * e + wave) * 16 + cc)];
+    st0 = ldv(p.stats0, crow * 64u + (unsigned)(cc * 4));
   }
   // ---- placement check, the stream signal, and the wait for the side stream (first launch of a chain piece), while those loads are in flight
   if (tid == 0 && round == 0) {
@@ -223,51 +229,43 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     const float* ap = p.lay[0].presum + (unsigned)(eb * p.lay[0].presum_bs) + (unsigned)pcol;
     addv = __hip_atomic_load(ap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (sc0 sc1; waited for where it is used, behind the first contraction)
   }
-  auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-  float4 x[2];                            // the current layer's input row fragments (also the next rebuild's highway residual)
-  {
-    float4 st[4] = {f4(vst[0]), f4(vst[1]), f4(vst[2]), f4(vst[3])};
-    float m1, r1;
-    combine_stats(st, 0, m1, r1);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const f32x4 h = va[e], g = vg1[e], be = vbe1[e];
-      x[e] = make_float4((h[0] - m1) * r1 * g[0] + be[0], (h[1] - m1) * r1 * g[1] + be[1], (h[2] - m1) * r1 * g[2] + be[2], (h[3] - m1) * r1 * g[3] + be[3]);
-    }
-  }
-
   // The rebuild of a layer's input (layer-norm of both halves, sigmoid gate, highway mix) is done in a COMPACT layout: lane (cr, cc) owns row cr and the
-  // two channels 16 w + cc and 128 + 16 w + cc.  In the A-operand layout every lane rebuilt 8 values, 6 of them for padding rows: ~165 instructions with
-  // 8 v_exp + 8 v_rcp per wave and layer, twice per SIMD, between "rows landed" and the first MFMA.  Compact: 2 values per lane and an LDS hop.
+  // two channels 16 w + cc and 128 + 16 w + cc: 2 values per lane and an LDS hop into the operand layout (lane (cb, kh, j): row j, the 16 channels of k-group w + 8 kh).
   float* const xs = s_xs[wave];
   float xc[2];                                                             // this layer's input at (cr, channel e) = the next rebuild's highway residual
-  if (arow < 4) { *reinterpret_cast<float4*>(&xs[arow * 32 + c4]) = x[0]; *reinterpret_cast<float4*>(&xs[arow * 32 + 16 + c4]) = x[1]; }
-  xc[0] = xs[cr * 32 + cc]; xc[1] = xs[cr * 32 + 16 + cc];
+  f32x4 ax[4];                                                             // ... and as the contraction's A operand
+  {
+    const float m1 = row16_sum(st0[0]) * (1.0f / 16.0f);
+    const float d1 = st0[0] - m1;
+    const float r1 = rsqrt_fast(row16_sum(st0[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { xc[e] = (p0c[e] - m1) * r1 * g1c[e] + b1c[e]; xs[cr * 32 + e * 16 + cc] = xc[e]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const f32x4*>(&xs[j4 * 32 + kh * 16 + 4 * q]);
+  }
   stamp();                                                                 // first input row built (the wait for the side stream is in here)
   for (int g = 0; g < p.L; ++g) {
     const bool last = (g + 1 == p.L);
     const bool tail = last && p.attn != 0;                                  // the run's output row goes on into the attention + C_1 block below
     const bool t2 = __builtin_amdgcn_readfirstlane(s_lay[g].tap2) != 0;
-    // ---- contraction of layer g
+    // ---- contraction of layer g: 16 (tap2: 32) instructions, two accumulators in turn
     f32x4 acc0 = z4, acc1 = z4;
     if (t2) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const f32x4 a = vta[e], b0 = vtb0[e], b1 = vtb1[e];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[i], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[i], acc1, 0, 0, 0); }
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 a = atq[q], b = wtq[q];
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc1, 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const float4 a = x[e]; const f32x4 b0 = vb0[e], b1 = vb1[e];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[0], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[1], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[2], acc1, 0, 0, 0);
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[3], acc1, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 a = ax[q], b = wq[q];
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc1, 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+    // the wave's partial sums: [lane (cb, kh, j)][row] -- 1 KB per wave (the 16 x 16 tiles wrote 8 KB, three quarters of it padding rows)
+    *reinterpret_cast<f32x4*>(&red[wave * 256 + lane * 4]) = acc0 + acc1;
     // ---- requests that do not depend on the other workgroups: the next layer's weights / presum / history row, this layer's LN parameters
     float ng1[2], nb1[2], ng2[2], nb2[2];                                   // compact (a last layer without the attention tail leaves them unloaded, and leaves the loop before they are used)
     float naddv = 0.f;
@@ -282,15 +280,15 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
       const XGroupLayer& Ln = s_lay[g + 1];
       const bool nt2 = __builtin_amdgcn_readfirstlane(Ln.tap2) != 0;
       const unsigned nkg = nt2 ? 32u : 16u, kc = nt2 ? 16u : 0u;
-      const float* wb = Ln.wp + lane * 4;
-      const unsigned w0 = (unsigned)(grp * 2) * nkg * 256u, w1 = w0 + nkg * 256u;
+      const float* wb = Ln.wp + wlane;
+      const unsigned w0 = (wtile * nkg + kc + kgw) * 256u, wt0 = (wtile * nkg + kgw) * 256u;
 #pragma unroll
-      for (int e = 0; e < 2; ++e) { vb0[e] = ldg4(wb, w0 + (kc + (unsigned)(wave + 8 * e)) * 256u); vb1[e] = ldg4(wb, w1 + (kc + (unsigned)(wave + 8 * e)) * 256u); }
+      for (int q = 0; q < 4; ++q) wq[q] = ldg4(wb, w0 + 64u * q);
       if (nt2) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) { vtb0[e] = ldg4(wb, w0 + (unsigned)(wave + 8 * e) * 256u); vtb1[e] = ldg4(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+        for (int q = 0; q < 4; ++q) wtq[q] = ldg4(wb, wt0 + 64u * q);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) vta[e] = ldg4(Ln.xt, bb * (unsigned)Ln.xt_bs + (unsigned)((8 * e + wave) * 16 + c4));
+        for (int q = 0; q < 4; ++q) atq[q] = ldg4(Ln.xt, bj * (unsigned)Ln.xt_bs + kgw * 16u + 4u * q);
       }
       if (wr) naddv = ldg1(Ln.presum, (unsigned)(eb * Ln.presum_bs) + (unsigned)pcol);      // behind the wait for the side stream; never read before in this launch
     }
@@ -302,9 +300,12 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     }
     stamp();                                                               // contraction issued, partial sums written, prefetches issued
     __syncthreads();
-    float v_ = 0.f;
+    float v_ = 0.f;                                                          // (row wave & 3, column ecol of tile etile): 8 waves x 2 k-halves, fixed order
+    {
+      const float* rp = &red[((etile * 4 + (ecol >> 2)) * 4 + (ecol & 3)) * 4 + (wave & 3)];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + etile) * 4 + (wave & 3)) * 64 + lane];
+      for (int w = 0; w < 8; ++w) { v_ += rp[w * 256]; v_ += rp[w * 256 + 128]; }
+    }
     v_ += addv;
     const float mg = row16_sum(v_) * (1.0f / 16.0f);
     const float dv = v_ - mg;
@@ -376,8 +377,8 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
         xc[e] = s_ * ((hi[e] - m2) * r2 * ng2[e] + nb2[e]) + (1.0f - s_) * xc[e];
         xs[cr * 32 + e * 16 + cc] = xc[e];
       }
-      x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
-      x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const f32x4*>(&xs[j4 * 32 + kh * 16 + 4 * q]);
     }
     addv = naddv;
     if (tail) break;
@@ -406,7 +407,10 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     }
     c1b = p.c1_bias[grp * 16 + ecol];
     }
-    // ---- x / xc hold Q[j] of the team's four utterances.  Keep the row (column group 0), attend, and run C_1 on it.
+    float4 x[2];                                                           // Q[j] as the 16 x 16 x 4 A operand (C_1's tile below keeps that shape: one 16-column tile, 8 MFMAs)
+    x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
+    x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
+    // ---- xs / xc hold Q[j] of the team's four utterances.  Keep the row (column group 0), attend, and run C_1 on it.
     if (grp == 0 && m0 + cr < p.B) {
 #pragma unroll
       for (int e = 0; e < 2; ++e)

@@ -38,12 +38,15 @@ want 7 && (cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -
 want 7 && python tools/layer_trace_table.py "$OUT/layers" > "$OUT/layers.txt"
 # 8. the throughput kernel's variants on four layer shapes, each timed in turn behind a cache-thrashing pass (product template only)   -> profiles/r05_hconv_lab.txt
 want 8 && (hipcc --offload-arch=gfx950 -O3 -std=c++17 -I dc_tts_amd/csrc tools/micro/hconv_lab.hip -o tools/micro/kp_hconv_lab 2> "$OUT/hconv_lab_build.log"; timeout 300 tools/micro/kp_hconv_lab 9 > "$OUT/hconv_lab.txt" 2>&1)
-# 9. what the two decode streams' pieces take in the default form and with the cone's last layers back on the side stream      -> profiles/r05_chain_tail_split.txt
-want 9 && for tail in 2 1 5; do
+# 9. what the two decode streams' pieces take in the default form (2), as two launches per chain piece (6), and with the cone's last layers back on the side stream (1, 5)      -> profiles/r05_chain_tail_split.txt
+want 9 && for tail in 2 6 1 5; do
   echo "== DCTTS_CHAIN_TAIL=$tail"
   for rep in 1 2; do DCTTS_CHAIN_TAIL=$tail GM=0 HP=1 timeout 120 python tools/decode_time.py 2>&1 | grep -E "text2mel|rror"; done
   DCTTS_CHAIN_TAIL=$tail DCTTS_PIECETIME=150 GM=0 HP=1 NREP=1 timeout 120 python tools/decode_time.py 2>&1 | grep -E "frame 15[0-7]" | tail -8
 done > "$OUT/chain_tail_split.txt" 2>&1
+# ... and the two parts of the one-launch chain piece timed as launches of their own (DCTTS_CHAIN_TAIL=6: xtail_kernel + xgroup_kernel, HIP events, bench.py's kernels[])
+want 9 && (echo "== DCTTS_CHAIN_TAIL=6: bench.py kernels[] (xtail_kernel, xgroup_kernel: avg_launch_ms)"; DCTTS_CHAIN_TAIL=6 timeout 400 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-vocoder 2>/dev/null | \
+  python -c "import json,sys; j=json.loads(sys.stdin.readlines()[-1]); [print(k['kernel'][:60], '| launches', k['launches'], '| avg_launch_ms', k['avg_launch_ms']) for k in j.get('kernels', []) if 'decode chain' in k['kernel']]; print('decode_us_per_step', j['phases']['decode_us_per_step'])") >> "$OUT/chain_tail_split.txt" 2>&1
 want 2 && find "$OUT/kernel_stats" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$OUT/kernel_stats.csv"
 rm -rf "$OUT/kernel_stats" "$OUT/pmc_fetch" "$OUT/pmc_write" "$OUT/pmc_sq" "$OUT/layers"
 echo "done: $OUT"
