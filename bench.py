@@ -380,15 +380,16 @@ def main():
         row_flop = 2.0 * 3 * d * 2 * d
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "kernel": "xcone_kernel: AudioDec HC_3 and HC_4 (256 ch, k = 3, dilations 3 / 9) over the rows of a frame's dependency cone "
-                          "(45 / 15 rows per utterance) + their layer-norm / gate row passes, ONE launch per frame on the decode's side stream: 16x16x4 fp32 "
+                          "(45 / 15 rows per utterance) + their layer-norm / gate row passes, ONE launch per frame on the decode's side stream (round 5: the launch also carries AudioDec C_1 / HC_2 over their cone rows as its "
+                          "first two team phases -- row operations that were two launches of their own; the FLOP count here is the GEMM layers' alone): 16x16x4 fp32 "
                           "MFMA, a 16-workgroup team per four utterances inside one XCD, each workgroup keeps its 96 KB weight slice in registers "
-                          "(the cone's last three layers, 5 / 3 / 1 rows per utterance, run on the chain since round 4: kernels[] has xtail_kernel)",
+                          "(the cone's last three layers, 5 / 3 / 1 rows per utterance, run on the chain since round 4: kernels[] has xchain_kernel)",
                 "launches": n_chain, "sampled": "every 16th frame from frame 100 on (full-size cones) of the timed region, HIP events on the side stream",
                 "avg_launch_ms": None, "rows_per_launch": None, "flop_per_row": row_flop,
                 "note": "runs concurrently with the chain's kernels on the other half of the CUs (128 of 256: at most 0.5 of the roof); its launch ends with "
                         "the team leaders polling the chain's counter, so the event-timed duration includes that wait whenever the chain is the longer stream "
-                        "(the two are within 2 us of each other at the end of round 4: DESIGN.md section 2d); the work itself is ~52 us (in-kernel stamps, "
-                        "profiles/r04_decode_trace.txt)"}
+                        "(the two are within 2 us of each other: DESIGN.md section 2); the GEMM layers' work itself is ~48 us, the two row phases ~15 (in-kernel stamps, "
+                        "profiles/r05_decode_trace.txt)"}
         if n_chain > 0 and chain_layers > 0:
             avg = chain_ms / n_chain
             rpl = chain_layers / n_chain

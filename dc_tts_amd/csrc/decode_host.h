@@ -617,7 +617,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
         p.ptab = (const SplitParams*)c->aepre_tab + (size_t)((j + 1) & 1) * aepre_stride(c);
         p.p_ipl = ipl; p.p_blocks = (c->aepre_layers - 3) * ipl; p.p_step = j + 1; p.p_count_from = c->aepre_layers - 3;      // (none of them is counted)
       }
-      if (piece == c->trace_frame) {                            // DCTTS_TRACE: this piece's two launches record their phase boundaries
+      if (c->trace_frame >= 0 && piece == c->trace_frame) {     // DCTTS_TRACE: this piece's two launches record their phase boundaries (unset = -1, which is also the first piece's index)
         if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(dev_zero_now(c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
         p.ts = c->trace_buf + 64 * 64 * 32 - 192 - 256 * (2 - net);
       }
@@ -644,7 +644,7 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
   if (net == 0 && c->ae_pass && piece >= 0 && piece + 1 < c->xg_T) pass = (c->ae_pass_split ? 3 : c->aepre_layers) * ipl_;
   if (net == 1 && c->ae_pass && c->ae_pass_split && piece + 1 >= 0 && piece + 2 < c->xg_T) pass = (c->aepre_layers - 3) * ipl_;
   // always 128 team workgroups (8 teams of 16, one team per XCD): more could starve the other stream of CUs while they poll for it
-  if (piece == c->trace_frame) hipLaunchKernelGGL(xgroup_kernel<true>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);      // DCTTS_TRACE: stamped
+  if (c->trace_frame >= 0 && piece == c->trace_frame) hipLaunchKernelGGL(xgroup_kernel<true>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);      // DCTTS_TRACE: stamped
   else hipLaunchKernelGGL(xgroup_kernel<false>, dim3(128 + pass), dim3(512), pass ? hsplit_smem(32) : 0, st, p);
   HIPCHK(hipGetLastError());
   if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }   // prof_rows counts LAYERS here

@@ -1,4 +1,4 @@
-# Where a decode frame goes: per-kernel averages of a decode-only kernel trace (eager launches, T = ${PT:-160}: the printed frame is at 3/4 of the decode, i.e. with full cones) + the timeline of one steady-state frame
+# Where a decode frame goes (round 5: two launches per frame, xchain_kernel on the chain and xcone_kernel on the side stream): per-kernel averages of a decode-only kernel trace (eager launches, T = ${PT:-160}: the printed frame is at 3/4 of the decode, i.e. with full cones) + the timeline of one steady-state frame
 set -u
 R=$PWD; OUT=$R/gpurun_out/dprobe; mkdir -p $OUT; rm -rf $OUT/trace
 cd /tmp; export TMPDIR=/tmp
@@ -10,4 +10,4 @@ rows = list(csv.DictReader(open(f)))
 for r in rows[:14]:
     print(f'{int(r["Calls"]):6d} calls  avg {float(r["AverageNs"])/1e3:8.2f} us  total {float(r["TotalDurationNs"])/1e6:8.2f} ms  {r["Percentage"]:>6}%  {r["Name"][:100]}')
 PY
-python $R/tools/trace_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) rowc1 26
+python $R/tools/trace_timeline.py $(find $OUT/trace -name "*kernel_trace.csv" | head -1) xcone_kernel 10
