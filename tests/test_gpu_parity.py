@@ -354,14 +354,15 @@ def test_decode_vs_oracle_loop(weights, graph, mode):
     assert trajr.max() > 10
 
 
-@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0", "DCTTS_XCONE=2", "DCTTS_XGROUP=0,DCTTS_XCONE=0", "DCTTS_CHAIN_TAIL=0", "DCTTS_CHAIN_TAIL=1", "DCTTS_CHAIN_TAIL=5"])
+@pytest.mark.parametrize("knob", ["DCTTS_SYNC_VALUES=0", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0", "DCTTS_XCONE=0", "DCTTS_XCONE=2", "DCTTS_XGROUP=0,DCTTS_XCONE=0", "DCTTS_CHAIN_TAIL=0", "DCTTS_CHAIN_TAIL=1", "DCTTS_CHAIN_TAIL=5", "DCTTS_CHAIN_TAIL=6", "DCTTS_CHAIN_TAIL=6,DCTTS_XCONE=2"])
 def test_decode_stream_meeting_variants(weights, knob):
     """The chain and side streams of the decode meet inside kernels (default: counters polled / written by the launches themselves, passenger
     workgroups), with stream wait / write operations (DCTTS_CHAIN_WAIT=0), or through events (DCTTS_SYNC_VALUES=0: what rocprofv3 --pmc
     needs); DCTTS_XGROUP=0 / DCTTS_XCONE=0 run the chain's / the side stream's highway layers as one launch per layer instead of the
     team kernels (the form a decode falls back to after a failed team hand-off); DCTTS_CHAIN_TAIL selects what follows the chain's AudioDec run:
-    2 (default) xtail_kernel in its merged form (the newest-row layers HC_2 .. HC_4, HC_5 .. HC_7 over their few cone rows and the seven k = 1 layers: one launch),
-    5 the same behind an AudioDec run of xgroup_kernel (two launches), 1 xmlp_kernel (the k = 1 layers in team form, HC_5 .. HC_7 split between chain and
+    2 (default) the whole chain piece as ONE launch (xchain_kernel, round 5: xtail_kernel's layers -- the newest-row layers HC_2 .. HC_4, HC_5 .. HC_7 over their
+    few cone rows, the seven k = 1 layers -- a team barrier, then xgroup_kernel's AudioEnc run + attention + C_1), 6 the same as two launches (round 4's form),
+    5 xtail_kernel behind an AudioDec run of xgroup_kernel (three launches), 1 xmlp_kernel (the k = 1 layers in team form, HC_5 .. HC_7 split between chain and
     side stream), 0 mlp_rows_kernel (round 2's row-split form).  The knobs are read when a context is created.  Every
     variant must reproduce the oracle loop: trajectory integer-exact."""
     from dc_tts_amd.engine import Engine
