@@ -248,7 +248,7 @@ struct dctts_ctx {
   // and the side stream); 0 = mlp_rows_kernel (round 2: split by rows); 3 / 4: A/B forms (tools/README.md)
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
   bool chain_one = false;              // round 5 (chain_tail == 2): a chain piece is ONE launch -- xtail_kernel's layers, a team barrier, the AudioEnc run + attention + C_1 (xchain_kernel); 6: two launches (round 4)
-  bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (a chain piece = two launches)
+  bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (chain_tail 2 and 6)
   bool ae_pass_split = false;          // round 4: AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch (a row ahead), only the C1Q . W2 row stays in the AudioDec launch
   bool side_fold = true;               // round 5: rowc1 / rowhc2 as the first phases of xcone_kernel's launch (DCTTS_XCONE=2: three launches per side-stream piece, rounds 3-4)
   bool side_pre = false;               // the small presum GEMMs (AudioEnc's presums of the next row, the newest C1Q . W2 row) run on the SIDE stream, which has the slack since xtail_kernel (round 4), instead of as passenger workgroups of the chain's AudioDec launch

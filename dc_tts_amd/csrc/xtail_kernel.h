@@ -17,7 +17,7 @@
 // Merged form (np == 3, the default since the middle of round 4).  The launch in front of this one was xgroup_kernel's AudioDec run: the NEWEST row of HC_2,
 // HC_3 and HC_4 (K = 256: the centre tap; the older taps come from the side stream as a presum), whose last row this kernel then re-read from memory.  Those
 // three layers now run in FRONT of the cone layers in this launch -- same arithmetic (xgroup_kernel's layer loop: M = 4 rows, A operand in registers, compact
-// rebuild) -- so a chain piece is two launches instead of three, the row stays in LDS, the first cone layer's weight slice (96 KB per workgroup) is in
+// rebuild) -- so a chain piece was two launches instead of three (round 5: ONE, xchain_kernel at the end of this file), the row stays in LDS, the first cone layer's weight slice (96 KB per workgroup) is in
 // flight while the newest-row layers wait for each other, and the cone rows are staged between them.  The launch then also carries what the AudioDec launch
 // carried: the chain's "piece complete" signal, the wait for the side stream, and the passenger workgroups (xgroup_kernel.h).  86.5 -> 83.1 us per frame;
 // with the next cone layer's slice pulled into the L2 one layer ahead (one dword per line: the slice then arrives in ~0.7 us instead of 2-3) 82.1.
@@ -57,7 +57,7 @@ struct XTailParams {
   float* xch; float* sch;                // exchange for the highway layers: [2][groups][20][512] pre-norm rows, [2][groups][20][16][4] statistics
   int xch_set, sch_set;
   // ---- merged form (np == 3): the NEWEST-ROW layers in front of the cone layers -- AudioDec HC_2 .. HC_4 at row t, what xgroup_kernel's AudioDec run computed one launch
-  //      earlier (K = 256: the centre tap; the older taps arrive as the side stream's presum), so that a chain piece is two launches and their row stays in LDS
+  //      earlier (K = 256: the centre tap; the older taps arrive as the side stream's presum), so that their row stays in LDS (and a chain piece was two launches; round 5: one)
   int np; int pad2;
   const float* pP0; const float* pstats0; const float* pg1; const float* pb1;      // C_1's pre-norm rows [b][256], partial statistics [b][16][4], layer-norm parameters
   XTailP pl[3];
