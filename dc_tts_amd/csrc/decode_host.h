@@ -999,7 +999,7 @@ static int write_trace3(dctts_ctx* c, int j) {
   for (int net = 0; net < 2; ++net) {
     const long long* o = &h[64 * 64 * 32 - 192 - 256 * (2 - net)];
     if (!o[0]) continue;
-    fprintf(f, "# xgroup_kernel, %s run (workgroup 0, thread 0), microseconds since its entry: first row built | per layer: contraction + partial sums written, slice reduced, published, barrier passed, exchanged rows landed\n ", net ? "AudioEnc" : "AudioDec");
+    fprintf(f, "# xgroup_kernel, %s run (workgroup 0, thread 0), microseconds since its entry: first row built | per layer: contraction + partial sums written, slice reduced, published, barrier passed, exchanged rows landed; behind the last layer, the attention + C_1 tail: output row rebuilt, operands landed + contraction written, finished\n ", net ? "AudioEnc" : "AudioDec");
     fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
     for (int i = 2; i < 120 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, ((i - 2) % 5 == 4) ? " |" : "");
     fprintf(f, "\n");

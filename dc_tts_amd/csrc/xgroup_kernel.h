@@ -384,6 +384,7 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     if (tail) break;
   }
   if (p.attn) {
+    stamp();                                                               // (tail: last layer's output row rebuilt)
     // ---- the attention tail, OUTSIDE the layer loop: with its operands requested in the loop's prefetch slot the loop carried 47 more registers and
     //      every layer got ~0.3 us slower (stamps); requested in front of the first layer and held through the run (19 registers, round 5) the frame did not
     //      get shorter (A/B on one box: 79.6 against 79.4 us).  None of the operands depends on this run -- C_1's 16-column tile, the window's K rows for this
@@ -432,6 +433,7 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[((wave * 2 + 0) * 4 + j) * 64 + lane] = accc[j];
+    stamp();                                                               // (tail: operands landed, logits' partial sums and C_1's contraction written)
     __syncthreads();
     if (wave < 4) {
       // wave w finishes row w of the team (lanes 0 .. 15: the tile's 16 columns): masked softmax over <= 3 keys, arg-max of the post-softmax row with the
@@ -474,6 +476,7 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
         if (grp == 0 && ecol == 0) p.pm_next[b_] = pm_e + am;           // max_attentions[:, j] (synthesize.py:54)
       }
     }
+    stamp();                                                               // (tail: softmax, C_1 row finished, stores issued)
   }
   }                                        // next utterance group of this team
 }

@@ -190,6 +190,11 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) { q0[i] = ldv(wp, wl + (unsigned)i * 256u); q1[i] = ldv(wp, wl + (48u + (unsigned)i) * 256u); }
     };
+    auto load_w3 = [&](auto PC, const float* wp, f32x4 (&q0)[6], f32x4 (&q1)[6]) {      // a third of the slice (k-groups 2 part, 2 part + 1 of both tiles)
+      constexpr int part = decltype(PC)::value;
+#pragma unroll
+      for (int i = 2 * part; i < 2 * part + 2; ++i) { q0[i] = ldv(wp, wl + (unsigned)i * 256u); q1[i] = ldv(wp, wl + (48u + (unsigned)i) * 256u); }
+    };
     const int nu = (tid >> 6) & 3;
     const unsigned ncme = (unsigned)(tid & 63) * 4u;
     f32x4 vb[2] = {z4, z4};
@@ -210,21 +215,22 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
       const unsigned crow_p = (m0 + cr < B) ? (unsigned)(m0 + cr) : (unsigned)m0;
       // ---- request order: what the first layer needs (C_1's rows, its statistics and layer-norm parameters, the layer's 16-column tiles), then the FIRST CONE LAYER's
       //      slice (96 KB per workgroup, 12 MB per launch out of the Infinity Cache: ~3 us): it lands under the newest-row layers instead of in front of the cone layer
-      f32x4 va[2], vg1[2], vbe1[2], vst[4], pw0[2], pw1[2];
+      // (round 5: the contraction on 4 x 4 x 1 MFMA blocks, as in xgroup_kernel.h -- a team's layer has four rows; lane (cb, kh, j): columns 4 cb .. 4 cb + 3 of the
+      // workgroup's 32, the 16 channels of k-group wave + 8 kh, row j; the weights come out of the same packing through another lane -> address map)
+      const int j4 = lane & 3, cb4 = (lane >> 2) & 7, kh = lane >> 5;
+      const unsigned pwoff = ((unsigned)(grp * 2 + (cb4 >> 2)) * 16u + (unsigned)(wave + 8 * kh)) * 256u + (unsigned)(((cb4 & 3) * 4 + j4) * 4);
+      float p0c[2], g1c[2], b1c[2];
+      f32x4 st0, pw[4];
       {
-        const float* wb = p.pl[0].wp + lane * 4;
-        const unsigned w0 = (unsigned)(grp * 2) * 16u * 256u, w1 = w0 + 16u * 256u;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const unsigned ch = (unsigned)((8 * e + wave) * 16 + c4);
-          va[e] = ldv(p.pP0, bb * 256u + ch); vg1[e] = ldv(p.pg1, ch); vbe1[e] = ldv(p.pb1, ch);
+          const unsigned ch = (unsigned)((8 * e + wave) * 16 + cc);
+          p0c[e] = p.pP0[crow_p * 256u + ch]; g1c[e] = p.pg1[ch]; b1c[e] = p.pb1[ch];
         }
+        st0 = ldv(p.pstats0, crow_p * 64u + (unsigned)(cc * 4));
 #pragma unroll
-        for (int g = 0; g < 4; ++g) vst[g] = ldv(p.pstats0, bb * 64u + (unsigned)((aq * 4 + g) * 4));
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { pw0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); pw1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+        for (int q = 0; q < 4; ++q) pw[q] = ldv(p.pl[0].wp, pwoff + 64u * q);
       }
-      load_w(p.hc[0].wp, wA0, wA1);
       // ---- the stream signal and the wait for the side stream (this is the first launch of a chain piece), while those loads are in flight
       if (tid == 0 && round == 0) {
         int go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;     // an earlier launch of this decode already failed: no more waiting, the decode is reported invalid
@@ -243,38 +249,36 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
       float addv = 0.f;
       if (wr) {                                            // presum of the first layer: written by the side stream -> read past the L1 / a possibly stale line
         const float* ap = p.pl[0].presum + (unsigned)(eb * p.pl[0].presum_bs) + (unsigned)pcol;
-        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(addv) : "v"(ap) : "memory");
+        addv = __hip_atomic_load(ap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // (sc0 sc1)
       }
-      auto f4 = [](const f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
-      float4 x[2];
-      {
-        float4 st[4] = {f4(vst[0]), f4(vst[1]), f4(vst[2]), f4(vst[3])};
-        float m1, r1;
-        combine_stats(st, 0, m1, r1);
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const f32x4 h = va[e], g = vg1[e], be = vbe1[e];
-          x[e] = make_float4((h[0] - m1) * r1 * g[0] + be[0], (h[1] - m1) * r1 * g[1] + be[1], (h[2] - m1) * r1 * g[2] + be[2], (h[3] - m1) * r1 * g[3] + be[3]);
-        }
-      }
+      // The first cone layer's slice (96 KB per workgroup, 12 MB per launch out of the Infinity Cache: ~3 us) is requested in THIRDS, one behind the presum and one
+      // behind each of the first two newest-row layers (round 5).  Requests return in order and every team barrier drains the wave's requests: in front of the presum
+      // (round 4, with an s_waitcnt vmcnt(0) on it) the first row waited for a slice that nobody needs before the first cone layer; as one batch behind it, the next
+      // barrier did.  A third lands within a layer's span.
+      load_w3(std::integral_constant<int, 0>{}, p.hc[0].wp, wA0, wA1);
       float xc[2];                                         // the layer's input at (row cr, channels 16 w + cc and 128 + 16 w + cc) = the next rebuild's highway residual
-      if (arow < 4) { *reinterpret_cast<float4*>(&xs[arow * 32 + c4]) = x[0]; *reinterpret_cast<float4*>(&xs[arow * 32 + 16 + c4]) = x[1]; }
-      xc[0] = xs[cr * 32 + cc]; xc[1] = xs[cr * 32 + 16 + cc];
+      f32x4 ax[4];                                         // ... and as the contraction's A operand: row j4, the 16 channels of k-group wave + 8 kh
+      {
+        const float m1 = row16_sum(st0[0]) * (1.0f / 16.0f);
+        const float d1 = st0[0] - m1;
+        const float r1 = rsqrt_fast(row16_sum(st0[1] + 16.0f * d1 * d1) * (1.0f / 256.0f) + 1e-12f);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { xc[e] = (p0c[e] - m1) * r1 * g1c[e] + b1c[e]; xs[cr * 32 + e * 16 + cc] = xc[e]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const f32x4*>(&xs[j4 * 32 + kh * 16 + 4 * q]);
+      }
       stamp();                                             // first row built (the wait for the side stream is in here)
       auto player = [&](auto GC) {
         constexpr int g = decltype(GC)::value;
         constexpr bool lastp = (g == 2);
         f32x4 acc0 = z4, acc1 = z4;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float4 a = x[e]; const f32x4 b0 = pw0[e], b1 = pw1[e];
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b0[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b1[0], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b0[1], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b1[1], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b0[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b1[2], acc1, 0, 0, 0);
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b0[3], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b1[3], acc1, 0, 0, 0);
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 a = ax[q], b = pw[q];
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc1, 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+        *reinterpret_cast<f32x4*>(&red[wave * 256 + lane * 4]) = acc0 + acc1;      // [lane (cb, kh, j)][row]
         // requests that do not depend on the team: this layer's layer-norm parameters (compact), the next layer's tiles and presum
         float ng1[2], nb1[2], ng2[2], nb2[2];
 #pragma unroll
@@ -284,16 +288,17 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
         }
         float naddv = 0.f;
         if constexpr (!lastp) {
-          const float* wb = p.pl[g + 1].wp + lane * 4;
-          const unsigned w0 = (unsigned)(grp * 2) * 16u * 256u, w1 = w0 + 16u * 256u;
 #pragma unroll
-          for (int e = 0; e < 2; ++e) { pw0[e] = ldv(wb, w0 + (unsigned)(wave + 8 * e) * 256u); pw1[e] = ldv(wb, w1 + (unsigned)(wave + 8 * e) * 256u); }
+          for (int q = 0; q < 4; ++q) pw[q] = ldv(p.pl[g + 1].wp, pwoff + 64u * q);
           if (wr) naddv = p.pl[g + 1].presum[(unsigned)(eb * p.pl[g + 1].presum_bs) + (unsigned)pcol];      // behind the wait for the side stream; never read before in this launch
         }
         __syncthreads();
-        float v_ = 0.f;
+        float v_ = 0.f;                                      // (row wave & 3, column ecol of tile etile): 8 waves x 2 k-halves, fixed order
+        {
+          const float* rp = &red[((etile * 4 + (ecol >> 2)) * 4 + (ecol & 3)) * 4 + (wave & 3)];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) v_ += red[((w * 2 + etile) * 4 + (wave & 3)) * 64 + lane];
+          for (int w = 0; w < 8; ++w) { v_ += rp[w * 256]; v_ += rp[w * 256 + 128]; }
+        }
         v_ += addv;
         const float mg = row16_sum(v_) * (1.0f / 16.0f);
         const float dv = v_ - mg;
@@ -332,14 +337,15 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
             else bufA[(cr * p.nin0) * XT_LDR + (8 * e + wave) * 16 + cc] = xc[e];      // HC_4's newest row: input row 0 of the first cone layer
           }
           if constexpr (!lastp) {
-            x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
-            x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ax[q] = *reinterpret_cast<const f32x4*>(&xs[j4 * 32 + kh * 16 + 4 * q]);
           }
         }
         addv = naddv;
         stamp();                                           // newest-row layer done
       };
       player(std::integral_constant<int, 0>{});
+      load_w3(std::integral_constant<int, 1>{}, p.hc[0].wp, wA0, wA1);
       // ---- the first cone layer's other input rows (the side stream's cone rows of HC_4: never read before in this launch) in two halves: requested behind
       //      a newest-row layer, written to LDS behind the next one (all eight requests at once would not fit beside two cone layers' weight slices)
       f32x4 sv[4];
@@ -364,6 +370,7 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
       };
       stage_req(0);
       player(std::integral_constant<int, 1>{});
+      load_w3(std::integral_constant<int, 2>{}, p.hc[0].wp, wA0, wA1);
       stage_put(0);
       stage_req(4);
       player(std::integral_constant<int, 2>{});
