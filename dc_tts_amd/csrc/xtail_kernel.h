@@ -190,6 +190,14 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) { q0[i] = ldv(wp, wl + (unsigned)i * 256u); q1[i] = ldv(wp, wl + (48u + (unsigned)i) * 256u); }
     };
+    // the same slice for a FOUR-row layer contracted on 4 x 4 x 1 blocks (the last cone layer, round 5): lane (cb, kh, j) takes column 4 (cb & 3) + j of tile cb >> 2
+    // for the 16 channels of k-groups 6 w + 3 kh + i, i = 0 .. 2 -- twelve float4, q0[0 .. 5] then q1[0 .. 5] in (i, k / 4) order
+    auto load_w4 = [&](const float* wp, f32x4 (&q0)[6], f32x4 (&q1)[6]) {
+      const int cb_ = (lane >> 2) & 7, kh_ = lane >> 5;
+      const unsigned base = ((unsigned)(grp * 2 + (cb_ >> 2)) * 48u + (unsigned)(6 * wave + 3 * kh_)) * 256u + (unsigned)(((cb_ & 3) * 4 + (lane & 3)) * 4);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) { const f32x4 v = ldv(wp, base + (unsigned)(k >> 2) * 256u + (unsigned)(k & 3) * 64u); if (k < 6) q0[k] = v; else q1[k - 6] = v; }
+    };
     auto load_w3 = [&](auto PC, const float* wp, f32x4 (&q0)[6], f32x4 (&q1)[6]) {      // a third of the slice (k-groups 2 part, 2 part + 1 of both tiles)
       constexpr int part = decltype(PC)::value;
 #pragma unroll
@@ -444,6 +452,25 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
         const float* q = p.hc[h + 1].wp + (unsigned)(grp * 2) * 48u * 256u + (unsigned)(wave * 3) * 1024u + (unsigned)lane * 16u;
         pf0 = q[0]; pf1 = q[1024]; pf2 = q[2048];
       }
+      constexpr bool four = (NIT == 1);                    // M = 4: one row per utterance -> 4 x 4 x 1 blocks (round 5; bq0 / bq1 then hold load_w4's layout)
+      if constexpr (four) {
+        const int j4 = lane & 3, kh = lane >> 5;
+        f32x4 acc0 = z4, acc1 = z4;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int g = 6 * wave + 3 * kh + i, tap = g >> 4, cg = g & 15;
+          const float* ar = &bin[(j4 * nin + (2 - tap) * ts) * XT_LDR + cg * 16];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ar + 4 * q);
+            const int k = i * 4 + q;
+            const f32x4 b = k < 6 ? bq0[k < 6 ? k : 0] : bq1[k < 6 ? 0 : k - 6];
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[0], b[0], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[1], b[1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[2], b[2], acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(a[3], b[3], acc1, 0, 0, 0);
+          }
+        }
+        *reinterpret_cast<f32x4*>(&red[wave * 256 + lane * 4]) = acc0 + acc1;      // [lane (cb, kh, j)][row]
+      } else {
       // A fragments: lane (arow, aq) holds row tile * 16 + arow, channels 4 aq .. 4 aq + 3 of k-group 6 w + i
       f32x4 a0[6], a1[6];
       {
@@ -480,13 +507,20 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
         red[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; red[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j];
         if constexpr (two) { red[4096 + ((wave * 2 + 0) * 4 + j) * 64 + lane] = acc2[j]; red[4096 + ((wave * 2 + 1) * 4 + j) * 64 + lane] = acc3[j]; }
       }
+      }
       stamp();                                             // A fragments read, MFMAs issued, partial sums written
       // the layer's layer-norm parameters for this thread's channels: requested now (they land during the reduction and the hand-off), used behind it
       const f32x4 g1 = ldv(y.g1, cme), b1 = ldv(y.b1, cme), g2 = ldv(y.g2, cme), b2 = ldv(y.b2, cme);
       __syncthreads();
       float v0 = bias, v1 = bias;
+      if constexpr (four) {                                // (row ej, column ecol of tile etile): 8 waves x 2 k-halves, fixed order
+        const float* rp = &red[((etile * 4 + (ecol >> 2)) * 4 + (ecol & 3)) * 4 + ej];
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { v0 += red[((w * 2 + etile) * 4 + ej) * 64 + lane]; if constexpr (two) v1 += red[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
+        for (int w = 0; w < 8; ++w) { v0 += rp[w * 256]; v0 += rp[w * 256 + 128]; }
+      } else {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { v0 += red[((w * 2 + etile) * 4 + ej) * 64 + lane]; if constexpr (two) v1 += red[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
+      }
       const int par = h & 1;
       float* const xr_ = p.xch + (long)par * p.xch_set + (long)gi * (XT_MAXM * 512);
       float* const sr_ = p.sch + (long)par * p.sch_set + (long)gi * (XT_MAXM * 64);
@@ -554,7 +588,7 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
     };
     // (the host checks the shape this is unrolled for: 5 / 3 / 1 rows per utterance)
     hlayer(std::integral_constant<int, 3>{}, 0, bufA, bufB, wA0, wA1, [&]() { load_w(p.hc[1].wp, wB0, wB1); });
-    hlayer(std::integral_constant<int, 2>{}, 1, bufB, bufA, wB0, wB1, [&]() { load_w(p.hc[2].wp, wA0, wA1); });
+    hlayer(std::integral_constant<int, 2>{}, 1, bufB, bufA, wB0, wB1, [&]() { load_w4(p.hc[2].wp, wA0, wA1); });
     hlayer(std::integral_constant<int, 1>{}, 2, bufA, bufB, wA0, wA1, [&]() { load_c0(); });
     const float* const bin = bufB;
     // `bin` now holds one row per utterance (row u): the input of the first k = 1 layer
