@@ -393,6 +393,25 @@ def short_text(h, B, seed):
     return L
 
 
+@pytest.mark.parametrize("T", [1, 2, 3])
+def test_decode_first_and_last_pieces_only(weights, T):
+    """max_T = 1, 2, 3: a decode that consists of its first and last chain pieces (and at T = 3 ONE steady-state piece) -- the launches that differ from the
+    steady state (round 5: the first piece is an xgroup_kernel launch, the last one an xtail_kernel launch without the AudioEnc run, the passengers' row-1
+    presums come from a launch in front of the loop) -- at B = 1, 3 and 33 (a lone utterance, a team that is not full, a second round of utterance groups)."""
+    h = hp.replace(max_T=T)
+    eng = engine_for(weights, max_T=T)
+    for B in (1, 3, 33):
+        L = synthetic_text(h, B=B, seed=7)
+        Yr, _, trajr = O.synthesize(L, weights, h, np.float32, run_ssrn=False)
+        for graph in (0, 1):
+            eng.set_decode_graph(graph)
+            Y, mx = eng.text2mel(dev(L))
+            eng.synchronize()
+            np.testing.assert_array_equal(mx.cpu().numpy(), trajr)
+            err = maxabs(Y.cpu().numpy(), Yr)
+            assert err < TOL, f"T {T} B {B} graph {graph}: decode max-abs {err}"
+
+
 @pytest.mark.parametrize("mode", [3, 0])
 def test_decode_end_of_text_window(weights, mode):
     """networks.py:142-147 at the end of the text: once prev_max >= max_N - 2 the window is clipped to 2, then 1 key.  A 10-character
