@@ -12,6 +12,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -162,6 +163,16 @@ int dctts_set_error(int code, const std::string& msg) { return fail(code, msg); 
       return fail(DCTTS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e__) + " @" + std::to_string(__LINE__)); \
   } while (0)
 #define CHK(x) do { int r__ = (x); if (r__ != 0) return r__; } while (0)
+// Device allocations of the workspace / table caches: an out-of-memory failure is remembered (per thread), so that the entry point can drop the caches
+// (ws_trim_now: one device synchronisation) and run the call once more instead of failing a serving loop whose shapes vary (oom_retry).
+static thread_local bool g_oom = false;
+#define HIPALLOC(x)                                                                                 \
+  do {                                                                                              \
+    hipError_t e__ = (x);                                                                           \
+    if (e__ == hipErrorOutOfMemory) { (void)hipGetLastError(); g_oom = true; }                      \
+    if (e__ != hipSuccess)                                                                          \
+      return fail(DCTTS_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e__) + " @" + std::to_string(__LINE__)); \
+  } while (0)
 
 static const int PAD = 64;   // zero rows in front of / behind every tap-read activation buffer (>= 2*27)
 
@@ -215,9 +226,9 @@ struct dctts_ctx {
   // the cached workspaces exceed ws_limit bytes does the next call drop ALL of them behind one device synchronisation (ws_trim).
   std::map<std::string, std::string> ws_sel;
   hipStream_t ws_stream = nullptr;     // the running call's stream: a NEW arena is zero-filled on it (ordered before the call's kernels)
-  size_t ws_limit = (size_t)96 << 30;
+  size_t ws_limit = (size_t)96 << 30;  // dctts_create lowers it to 60 % of the device memory that is free then (dctts_set_workspace_limit overrides)
   std::vector<void*> graveyard; size_t graveyard_bytes = 0;      // outgrown tail_ws / cols_ws buffers: freed by ws_trim / dctts_destroy, never while a stream may still use them
-  struct TabSlot { void* tab = nullptr; void* mem = nullptr; int n0 = 0; };
+  struct TabSlot { void* tab = nullptr; void* mem = nullptr; int n0 = 0; size_t bytes = 0; };
   std::map<std::string, TabSlot> tabcache;                       // the decode's device tables per (kind, geometry key)
   // Calls that share scratch are ordered against each other whatever streams they come from (round 5): every entry point waits for the completion event of the
   // last call of its group that came from ANOTHER stream and records its own behind its last launch.  Groups: TextEnc (te.*, cols_ws; the decode holds it too --
@@ -271,6 +282,7 @@ struct dctts_ctx {
   const int* fin_xerr = nullptr; const int* fin_werr = nullptr;   // the running decode's own error words (decode_v3 sets them, decode_finish reads them)
   int inject_err = 0;                  // debug hook: error bits OR-ed into the NEXT decode's status (dctts_debug_inject_decode_error)
   int team_fail_streak = 0;            // consecutive failed status reports without a split-team bit: the team kernels are switched off at 3
+  std::thread::id safe_once_tid;       // ... requested by this host thread: only a decode call of the same thread consumes it (another thread's decode in between keeps the team kernels)
   bool safe_once = false;              // dctts_decode_safe_once: the NEXT decode runs one launch per layer with stream-operation meetings, then the settings are as before
   // the tail of AudioDec's cone (HC_3 .. HC_7 and their row passes) as one launch per frame on the side stream (xcone_kernel.h); DCTTS_XCONE=0: nine launches
   int xcone = 1;
@@ -293,6 +305,7 @@ struct dctts_ctx {
   int bf16_packed = 0;                 // dctts_set_split_bf16 before finalize: 1 = SSRN's layers carry the bf16 packing, 2 = TextEnc's as well
   int bf16_mode = 0;                   // ... and what runs: 0 = exact fp32 (default), 1 = SSRN on the split-bf16 form, 2 = SSRN + TextEnc
   int pack_bf16_now = 0;               // (set while finalize builds a network whose layers get the packing)
+  bool bf_te = false;                  // ... and the network is TextEnc (scratch of the TextEnc group: run_conv)
   bool bf_now = false;                 // set by the TextEnc / SSRN drivers around their run_conv calls when the split-bf16 form is selected for that network
   static constexpr int ssrn_xc = 1;    // SSRN's 1025-column layers: 8 waves x 4 tiles + one vector-ALU column in the main launch (rounds 1-4: 11 waves x 3 tiles, what their row tail still runs on)
   float* tail_ws = nullptr; size_t tail_ws_floats = 0;   // run_conv: the tap-split row tail's partial sums [3][tail rows][2C] (SSRN layers only)
@@ -349,14 +362,16 @@ static int get_w(dctts_ctx* c, const std::string& name, const std::vector<int64_
 // Device memory comes from a few large arenas (bump allocation, 256-byte aligned) instead of hundreds of small hipMallocs:
 // every decode launch touches a different layer's weights and buffers, and with one allocation per tensor each launch
 // started with address-translation misses (large contiguous arenas map with big pages and stay within TLB reach).
-static const size_t ARENA_CHUNK = (size_t)512 << 20;
+static const size_t ARENA_CHUNK = (size_t)512 << 20;      // weights: one context-lifetime pool
+static const size_t WS_CHUNK = (size_t)64 << 20;          // workspaces: one pool per (prefix, geometry) -- a small geometry (B = 1) must not cost 3 x 512 MiB; bigger buffers get an arena of their own size
 // `zero_on`: a workspace arena is zero-filled on the stream of the call that creates it (ordered in front of that call's kernels; calls from other streams are ordered
 // behind it by the use groups); nullptr (weights, at dctts_weights_finalize): a synchronous fill.
 static int arena_alloc(dctts_ctx* c, std::vector<Arena>& pool, size_t bytes, void** out, const hipStream_t* zero_on = nullptr) {
   bytes = (bytes + 255) & ~(size_t)255;
   for (Arena& a : pool) if (a.used + bytes <= a.size) { *out = (char*)a.base + a.used; a.used += bytes; return 0; }
-  Arena a; a.size = bytes > ARENA_CHUNK ? bytes : ARENA_CHUNK; a.used = bytes;
-  HIPCHK(hipMalloc(&a.base, a.size));
+  const size_t chunk = zero_on ? WS_CHUNK : ARENA_CHUNK;
+  Arena a; a.size = bytes > chunk ? bytes : chunk; a.used = bytes;
+  HIPALLOC(hipMalloc(&a.base, a.size));
   if (zero_on) HIPCHK(hipMemsetAsync(a.base, 0, a.size, *zero_on)); else HIPCHK(hipMemset(a.base, 0, a.size));
   pool.push_back(a);
   *out = a.base;
@@ -574,6 +589,11 @@ extern "C" int dctts_create(dctts_ctx** out, int device, const dctts_config* cfg
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
   read_env(c);
+  {
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) { const size_t lim = fr / 10 * 6; if (lim < c->ws_limit) c->ws_limit = lim; }
+    else (void)hipGetLastError();
+  }
   *out = c;
   return 0;
 }
@@ -817,6 +837,7 @@ extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
   for (const Arena& a : c->warena) n += a.size;
   for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
   n += (c->tail_ws_floats + c->cols_ws_floats) * sizeof(float) + c->graveyard_bytes;
+  for (auto& kv : c->tabcache) n += kv.second.bytes;      // the decode's device tables and team exchange memory
   return n;
 }
 
@@ -824,7 +845,7 @@ extern "C" size_t dctts_device_bytes(const dctts_ctx* c) {
 // (Every launch that reads or writes the scratch buffer is fully written before it is read within the same call: no zero fill.)
 static int grow_scratch(dctts_ctx* c, float** buf, size_t* floats, size_t need) {
   if (*buf) { c->graveyard.push_back(*buf); c->graveyard_bytes += *floats * sizeof(float); *buf = nullptr; *floats = 0; }
-  HIPCHK(hipMalloc((void**)buf, need * sizeof(float)));
+  HIPALLOC(hipMalloc((void**)buf, need * sizeof(float)));
   *floats = need;
   return 0;
 }
@@ -860,9 +881,12 @@ static int run_conv(dctts_ctx* c, const DevLayer& L, const View& in, const int* 
   if (c->bf_now && L.wpb && !rm.step && ((L.cout == 1025 && L.wxcol) || (L.shape.nw == 8 && (L.shape.nt == 2 || L.shape.nt == 4 || L.shape.nt == 8)))) {
     p.wp = L.wpb; p.wx = (L.cout == 1025) ? L.wxcol : nullptr;
     if (L.shape.epi == EPI_HC && L.shape.nt == 8) {
+      // the two column halves' raw output: SSRN-group scratch (tail_ws) -- unless the caller is TextEnc (a config whose 2d-wide highway layers have 64 tiles), whose
+      // group owns cols_ws: TextEnc of the next batch may run beside SSRN of the previous one on another stream
+      float** buf = c->bf_te ? &c->cols_ws : &c->tail_ws; size_t* fl = c->bf_te ? &c->cols_ws_floats : &c->tail_ws_floats;
       const size_t need = (size_t)p.M * 2 * L.cout;
-      if (need > c->tail_ws_floats) CHK(grow_scratch(c, &c->tail_ws, &c->tail_ws_floats, need));
-      p.m_base = 0; p.raw_out = c->tail_ws; p.raw_ld = 2 * L.cout;
+      if (need > *fl) CHK(grow_scratch(c, buf, fl, need));
+      p.m_base = 0; p.raw_out = *buf; p.raw_ld = 2 * L.cout;
     }
     HIPCHK(launch_hconv_bf16(L.shape, p, st));
     if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += p.M; }
@@ -941,7 +965,9 @@ static void drop_ws_prefix(dctts_ctx* c, const std::string& prefix) {      // ev
 // ---- use groups (dctts_ctx::grp): order this call behind the last call of the group that came from another stream; publish this call's end
 static int grp_acquire(dctts_ctx* c, int g, hipStream_t st) {
   dctts_ctx::UseGroup& u = c->grp[g];
-  if (u.used && u.last != st) HIPCHK(hipStreamWaitEvent(st, u.done, 0));
+  // (always, also when the group's last call came from a stream with the same handle: a destroyed stream's handle can be given to a new stream, and a wait for an
+  //  event of the waiting stream itself costs nothing on the device)
+  if (u.used) HIPCHK(hipStreamWaitEvent(st, u.done, 0));
   return 0;
 }
 static int grp_release(dctts_ctx* c, int g, hipStream_t st) {
@@ -955,13 +981,14 @@ static int grp_release(dctts_ctx* c, int g, hipStream_t st) {
 static size_t ws_cached_bytes(const dctts_ctx* c) {
   size_t n = c->graveyard_bytes + (c->tail_ws_floats + c->cols_ws_floats) * sizeof(float);
   for (auto& kv : c->wsarena) for (const Arena& a : kv.second) n += a.size;
+  for (auto& kv : c->tabcache) n += kv.second.bytes;
   return n;
 }
 static void drop_decode_tables(dctts_ctx* c);
 // Called at the top of every entry point that uses workspaces: when the cached geometries have outgrown ws_limit, ALL of them are dropped behind one device
 // synchronisation (the only place left where a call waits for the GPU because of a shape change; dctts_set_workspace_limit).
-static int ws_trim(dctts_ctx* c) {
-  if (ws_cached_bytes(c) <= c->ws_limit) return 0;
+static int ws_trim(dctts_ctx* c, bool force = false) {
+  if (!force && ws_cached_bytes(c) <= c->ws_limit) return 0;
   HIPCHK(hipDeviceSynchronize());
   drop_decode_tables(c);
   free_ws(c);
@@ -971,6 +998,30 @@ static int ws_trim(dctts_ctx* c) {
   if (c->cols_ws) { (void)hipFree(c->cols_ws); c->cols_ws = nullptr; c->cols_ws_floats = 0; }
   return 0;
 }
+
+// An entry point's body, run once more behind a forced trim when a cache allocation ran out of device memory (the failed attempt's launches have completed by
+// then: ws_trim synchronises the device before it frees anything; its use groups published their events on the way out: GroupGuard).
+template <typename F>
+static int oom_retry(dctts_ctx* c, F&& body) {
+  g_oom = false;
+  int rc = body();
+  if (rc != 0 && g_oom) {
+    g_oom = false;
+    const std::string first = g_err;
+    if (ws_trim(c, true) != 0) return fail(DCTTS_ERR_HIP, first);
+    rc = body();
+  }
+  return rc;
+}
+// A call's hold on a use group: acquire() orders it behind the group's last call, and the group's completion event is recorded on EVERY way out once anything
+// may have been enqueued -- an early error return must not leave launches on shared scratch that the next call of the group does not wait for.
+struct GroupGuard {
+  dctts_ctx* c; int g; hipStream_t st; bool held = false;
+  GroupGuard(dctts_ctx* c_, int g_, hipStream_t st_) : c(c_), g(g_), st(st_) {}
+  int acquire() { const int rc = grp_acquire(c, g, st); held = (rc == 0); return rc; }
+  int release() { held = false; return grp_release(c, g, st); }
+  ~GroupGuard() { if (held) (void)grp_release(c, g, st); }
+};
 
 extern "C" int dctts_set_split_bf16(dctts_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return fail(DCTTS_ERR_ARG, "split-bf16 mode: 0 (exact fp32), 1 (SSRN), 2 (SSRN + TextEnc)");
@@ -999,7 +1050,7 @@ static int textenc_into(dctts_ctx* c, const int32_t* L, int B, int N, View* kv_o
   const RowMap rm{B, N, nullptr, nullptr};
   const View tab{c->embed, 0, 0, c->cfg.e};
   const size_t nl = c->textenc.size();
-  struct BfScope { dctts_ctx* c; BfScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_now = on; } ~BfScope() { c->bf_now = false; } } bf_scope(c, c->bf16_mode >= 2);
+  struct BfScope { dctts_ctx* c; BfScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_now = on; c->bf_te = on; } ~BfScope() { c->bf_now = false; c->bf_te = false; } } bf_scope(c, c->bf16_mode >= 2);
   CHK(run_conv(c, c->textenc[0], tab, (const int*)L, a, rm, st));          // embed + C_2
   View cur = a, nxt = b;
   for (size_t i = 1; i < nl; ++i) {
@@ -1017,14 +1068,17 @@ extern "C" int dctts_textenc_fwd(dctts_ctx* c, const int32_t* L, int B, int N, f
   if (!L || !K || !V || B <= 0 || N <= 0) return fail(DCTTS_ERR_ARG, "textenc: bad argument");
   hipStream_t st = (hipStream_t)stream;
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  CHK(ws_trim(c));
-  CHK(grp_acquire(c, dctts_ctx::GRP_TE, st));
-  View kv;
-  CHK(textenc_into(c, L, B, N, &kv, st));
-  const int d = c->cfg.d;
-  HIPCHK(hipMemcpy2DAsync(K, d * sizeof(float), kv.p, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
-  HIPCHK(hipMemcpy2DAsync(V, d * sizeof(float), kv.p + d, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
-  return grp_release(c, dctts_ctx::GRP_TE, st);
+  return oom_retry(c, [&]() -> int {
+    CHK(ws_trim(c));
+    GroupGuard gte(c, dctts_ctx::GRP_TE, st);
+    CHK(gte.acquire());
+    View kv;
+    CHK(textenc_into(c, L, B, N, &kv, st));
+    const int d = c->cfg.d;
+    HIPCHK(hipMemcpy2DAsync(K, d * sizeof(float), kv.p, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpy2DAsync(V, d * sizeof(float), kv.p + d, 2 * d * sizeof(float), d * sizeof(float), (size_t)B * N, hipMemcpyDeviceToDevice, st));
+    return gte.release();
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ AudioEnc / AudioDec (full sequence)
@@ -1041,19 +1095,22 @@ extern "C" int dctts_audioenc_fwd(dctts_ctx* c, const float* S, int B, int T, fl
   if (!S || !Q || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audioenc: bad argument");
   hipStream_t st = (hipStream_t)stream;
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  CHK(ws_trim(c));
-  CHK(grp_acquire(c, dctts_ctx::GRP_T2M, st));
-  View a, b; CHK(t2m_ws(c, B, T, &a, &b, st));
-  const RowMap rm{B, T, nullptr, nullptr};
-  const View vin{const_cast<float*>(S), T, 0, c->cfg.n_mels}, vout{Q, T, 0, c->cfg.d};
-  const size_t nl = c->audioenc.size();
-  View cur = vin, nxt = a, other = b;
-  for (size_t i = 0; i < nl; ++i) {
-    const View& o = (i + 1 == nl) ? vout : nxt;
-    CHK(run_conv(c, c->audioenc[i], cur, nullptr, o, rm, st));
-    cur = nxt; View t = nxt; nxt = other; other = t;
-  }
-  return grp_release(c, dctts_ctx::GRP_T2M, st);
+  return oom_retry(c, [&]() -> int {
+    CHK(ws_trim(c));
+    GroupGuard gt(c, dctts_ctx::GRP_T2M, st);
+    CHK(gt.acquire());
+    View a, b; CHK(t2m_ws(c, B, T, &a, &b, st));
+    const RowMap rm{B, T, nullptr, nullptr};
+    const View vin{const_cast<float*>(S), T, 0, c->cfg.n_mels}, vout{Q, T, 0, c->cfg.d};
+    const size_t nl = c->audioenc.size();
+    View cur = vin, nxt = a, other = b;
+    for (size_t i = 0; i < nl; ++i) {
+      const View& o = (i + 1 == nl) ? vout : nxt;
+      CHK(run_conv(c, c->audioenc[i], cur, nullptr, o, rm, st));
+      cur = nxt; View t = nxt; nxt = other; other = t;
+    }
+    return gt.release();
+  });
 }
 
 extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, float* logits, float* Y, void* stream) {
@@ -1062,19 +1119,22 @@ extern "C" int dctts_audiodec_fwd(dctts_ctx* c, const float* R, int B, int T, fl
   if (!R || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "audiodec: bad argument");
   hipStream_t st = (hipStream_t)stream;
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  CHK(ws_trim(c));
-  CHK(grp_acquire(c, dctts_ctx::GRP_T2M, st));
-  View a, b; CHK(t2m_ws(c, B, T, &a, &b, st));
-  const RowMap rm{B, T, nullptr, nullptr};
-  const View vin{const_cast<float*>(R), T, 0, 2 * c->cfg.d}, vout{Y, T, 0, c->cfg.n_mels}, vlog{logits, T, 0, c->cfg.n_mels};
-  const size_t nl = c->audiodec.size();
-  View cur = vin, nxt = a, other = b;
-  for (size_t i = 0; i < nl; ++i) {
-    const bool last = (i + 1 == nl);
-    CHK(run_conv(c, c->audiodec[i], cur, nullptr, last ? vout : nxt, rm, st, 0, (last && logits) ? &vlog : nullptr));
-    cur = nxt; View t = nxt; nxt = other; other = t;
-  }
-  return grp_release(c, dctts_ctx::GRP_T2M, st);
+  return oom_retry(c, [&]() -> int {
+    CHK(ws_trim(c));
+    GroupGuard gt(c, dctts_ctx::GRP_T2M, st);
+    CHK(gt.acquire());
+    View a, b; CHK(t2m_ws(c, B, T, &a, &b, st));
+    const RowMap rm{B, T, nullptr, nullptr};
+    const View vin{const_cast<float*>(R), T, 0, 2 * c->cfg.d}, vout{Y, T, 0, c->cfg.n_mels}, vlog{logits, T, 0, c->cfg.n_mels};
+    const size_t nl = c->audiodec.size();
+    View cur = vin, nxt = a, other = b;
+    for (size_t i = 0; i < nl; ++i) {
+      const bool last = (i + 1 == nl);
+      CHK(run_conv(c, c->audiodec[i], cur, nullptr, last ? vout : nxt, rm, st, 0, (last && logits) ? &vlog : nullptr));
+      cur = nxt; View t = nxt; nxt = other; other = t;
+    }
+    return gt.release();
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ Attention (full)
@@ -1132,14 +1192,9 @@ static int ssrn_layers(dctts_ctx* c, const View* ws, const View& vin0, const Vie
   return 0;
 }
 
-extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, void* stream) {
-  DevGuard dev_guard(c);
-  CHK(check_ready(c, dev_guard));
-  if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
-  hipStream_t st = (hipStream_t)stream;
-  std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  CHK(ws_trim(c));
-  CHK(grp_acquire(c, dctts_ctx::GRP_SSRN, st));
+static int ssrn_impl(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, hipStream_t st) {
+  GroupGuard gs(c, dctts_ctx::GRP_SSRN, st);
+  CHK(gs.acquire());
   const int cc = c->cfg.c, F = c->cfg.n_linear, Fp = round_up(F, 32);
   ws_select(c, "ssrn.", geom("ssrn", B, T), st);
   View ws[10];
@@ -1150,7 +1205,16 @@ extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float*
   CHK(ws_view(c, "ssrn.z4a", B, 4 * T, 0, Fp, &ws[8])); CHK(ws_view(c, "ssrn.z4b", B, 4 * T, 0, Fp, &ws[9]));
   const View vin{const_cast<float*>(Y), T, 0, c->cfg.n_mels}, vz{Z, 4L * T, 0, F}, vlog{logits, 4L * T, 0, F};
   CHK(ssrn_layers(c, ws, vin, vz, logits ? &vlog : nullptr, 0, B, T, st));
-  return grp_release(c, dctts_ctx::GRP_SSRN, st);
+  return gs.release();
+}
+
+extern "C" int dctts_ssrn_fwd(dctts_ctx* c, const float* Y, int B, int T, float* logits, float* Z, void* stream) {
+  DevGuard dev_guard(c);
+  CHK(check_ready(c, dev_guard));
+  if (!Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "ssrn: bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  return oom_retry(c, [&]() -> int { CHK(ws_trim(c)); return ssrn_impl(c, Y, B, T, logits, Z, st); });
 }
 
 // ------------------------------------------------------------------------------------------------ decode (synthesize.py:45-54)
@@ -1172,6 +1236,7 @@ extern "C" int dctts_debug_layer(dctts_ctx* c, const char* net, int index, const
   const DevLayer& L = (*V)[index];
   const RowMap rm{B, T, nullptr, nullptr};
   struct BfScope { dctts_ctx* c; BfScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_now = on; } ~BfScope() { c->bf_now = false; } } bf_scope(c, (n == "ssrn" && c->bf16_mode >= 1) || (n == "textenc" && c->bf16_mode >= 2));
+  struct TeScope { dctts_ctx* c; TeScope(dctts_ctx* c_, bool on) : c(c_) { c->bf_te = on; } ~TeScope() { c->bf_te = false; } } te_scope(c, n == "textenc" && c->bf16_mode >= 2);
   if (n == "textenc" && index == 0) {      // embed + C_2: X is really int32 ids (B,T)
     const View tab{c->embed, 0, 0, c->cfg.e}, vo{out, T, 0, L.cout};
     return run_conv(c, L, tab, (const int*)X, vo, rm, st);
@@ -1203,6 +1268,7 @@ __global__ void __launch_bounds__(256) calib_copy_kernel(const float4* __restric
 extern "C" int dctts_debug_seed_prev_max(dctts_ctx* c, const int32_t* prev_max, int B) {
   if (!c || !prev_max || B <= 0) return fail(DCTTS_ERR_ARG, "seed_prev_max: bad argument");
   for (int b = 0; b < B; ++b) if (prev_max[b] < 0 || prev_max[b] >= c->cfg.max_N) return fail(DCTTS_ERR_ARG, "seed_prev_max: values must lie in [0, max_N)");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   c->init_pm.assign(prev_max, prev_max + B);
   return 0;
 }
@@ -1216,6 +1282,7 @@ extern "C" int dctts_debug_copy(const float* src, float* dst, size_t nfloats, vo
 // ------------------------------------------------------------------------------------------------ profiling aid
 extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   if (kernel_id >= 0) c->prof_rows = 0;
   c->prof_id = kernel_id;
   return 0;
@@ -1223,6 +1290,7 @@ extern "C" int dctts_prof_enable(dctts_ctx* c, int kernel_id) {
 
 extern "C" int dctts_prof_collect(dctts_ctx* c, int* launches, double* total_ms) {
   if (!c || !launches || !total_ms) return fail(DCTTS_ERR_ARG, "null argument");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   double tot = 0; int n = 0;
   for (size_t i = 0; i < c->prof_ev.size(); ++i) {
     auto& e = c->prof_ev[i];
@@ -1239,6 +1307,7 @@ extern "C" int dctts_prof_collect(dctts_ctx* c, int* launches, double* total_ms)
 
 extern "C" int dctts_prof_rows(dctts_ctx* c, long long* rows) {
   if (!c || !rows) return fail(DCTTS_ERR_ARG, "null argument");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   *rows = c->prof_rows;
   return 0;
 }

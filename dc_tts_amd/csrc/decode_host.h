@@ -249,8 +249,8 @@ static bool tab_lookup(dctts_ctx* c, const char* kind, const std::string& key, d
   if (it == c->tabcache.end()) return false;
   *out = it->second; return true;
 }
-static void tab_store(dctts_ctx* c, const char* kind, const std::string& key, void* tab, void* mem = nullptr, int n0 = 0) {
-  dctts_ctx::TabSlot s; s.tab = tab; s.mem = mem; s.n0 = n0;
+static void tab_store(dctts_ctx* c, const char* kind, const std::string& key, void* tab, size_t bytes, void* mem = nullptr, int n0 = 0) {
+  dctts_ctx::TabSlot s; s.tab = tab; s.mem = mem; s.n0 = n0; s.bytes = bytes;
   c->tabcache[std::string(kind) + "|" + key] = s;
 }
 static void drop_decode_tables(dctts_ctx* c) {      // (the caller has synchronised the device)
@@ -317,10 +317,10 @@ static int v3_aepre_table(dctts_ctx* c, const DecodeWs& w, int B, bool c1qw_ahea
     }
   if (tab.empty()) return fail(DCTTS_ERR_STATE, "v3: no causal k=3 AudioEnc layers");
   c->aepre_tab = nullptr;
-  HIPCHK(hipMalloc(&c->aepre_tab, tab.size() * sizeof(SplitParams)));
+  HIPALLOC(hipMalloc(&c->aepre_tab, tab.size() * sizeof(SplitParams)));
   HIPCHK(hipMemcpy(c->aepre_tab, tab.data(), tab.size() * sizeof(SplitParams), hipMemcpyHostToDevice));
   c->aepre_layers = (int)tab.size() / 2 - 3; c->aepre_geom = g;      // (a parity copy = aepre_layers descriptors + the three K = 256 twins: aepre_stride)
-  tab_store(c, "aepre", g, c->aepre_tab, nullptr, c->aepre_layers);
+  tab_store(c, "aepre", g, c->aepre_tab, tab.size() * sizeof(SplitParams), nullptr, c->aepre_layers);
   return 0;
 }
 
@@ -542,7 +542,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
   if (c->xg_tab && c->xg_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xg", g, &ts)) { c->xg_tab = ts.tab; c->xg_mem = (float*)ts.mem; c->xg_T = ts.n0; c->xg_geom = g; return 0; } }
   c->xg_tab = nullptr; c->xg_mem = nullptr;
-  HIPCHK(hipMalloc((void**)&c->xg_mem, xg_mem_floats(B) * sizeof(float)));
+  HIPALLOC(hipMalloc((void**)&c->xg_mem, xg_mem_floats(B) * sizeof(float)));
   HIPCHK(dev_zero_now(c->xg_mem, xg_mem_floats(B) * sizeof(float)));
   const XgMem m = xg_mem(c, B);
   const std::vector<DevLayer>& AE = c->ae_c; const std::vector<DevLayer>& AD = c->ad_c;
@@ -624,10 +624,10 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       tab[(size_t)2 * (piece + 1) + net] = p;
     }
   }
-  HIPCHK(hipMalloc(&c->xg_tab, tab.size() * sizeof(XGroupParams)));
+  { const hipError_t e_ = hipMalloc(&c->xg_tab, tab.size() * sizeof(XGroupParams)); if (e_ != hipSuccess) { (void)hipFree(c->xg_mem); c->xg_mem = nullptr; c->xg_tab = nullptr; HIPALLOC(e_); } }
   HIPCHK(hipMemcpy(c->xg_tab, tab.data(), tab.size() * sizeof(XGroupParams), hipMemcpyHostToDevice));
   c->xg_geom = g; c->xg_T = T;
-  tab_store(c, "xg", g, c->xg_tab, c->xg_mem, T);
+  tab_store(c, "xg", g, c->xg_tab, tab.size() * sizeof(XGroupParams) + xg_mem_floats(B) * sizeof(float), c->xg_mem, T);
   return 0;
 }
 
@@ -697,10 +697,10 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
     }
     tab[f] = p;
   }
-  HIPCHK(hipMalloc(&c->xc_tab, tab.size() * sizeof(XConeParams)));
+  HIPALLOC(hipMalloc(&c->xc_tab, tab.size() * sizeof(XConeParams)));
   HIPCHK(hipMemcpy(c->xc_tab, tab.data(), tab.size() * sizeof(XConeParams), hipMemcpyHostToDevice));
   c->xc_geom = g;
-  tab_store(c, "xc", g, c->xc_tab);
+  tab_store(c, "xc", g, c->xc_tab, tab.size() * sizeof(XConeParams));
   return 0;
 }
 
@@ -735,10 +735,10 @@ static int v3_mlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
     p.pout = w.pe[nh - 1]; p.stats_out = w.se[nh - 1];
     tab[j] = p;
   }
-  HIPCHK(hipMalloc(&c->mlp_tab, tab.size() * sizeof(MlpRowsParams)));
+  HIPALLOC(hipMalloc(&c->mlp_tab, tab.size() * sizeof(MlpRowsParams)));
   HIPCHK(hipMemcpy(c->mlp_tab, tab.data(), tab.size() * sizeof(MlpRowsParams), hipMemcpyHostToDevice));
   c->mlp_geom = g;
-  tab_store(c, "mlp", g, c->mlp_tab);
+  tab_store(c, "mlp", g, c->mlp_tab, tab.size() * sizeof(MlpRowsParams));
   return 0;
 }
 
@@ -788,10 +788,10 @@ static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
   const XgMem m = xg_mem(c, B);
   std::vector<XMlpParams> tab((size_t)T);
   for (int j = 0; j < T; ++j) CHK(fill_xmlp(c, w, B, T, j, lh, m, 7, &tab[j]));
-  HIPCHK(hipMalloc(&c->xmlp_tab, tab.size() * sizeof(XMlpParams)));
+  HIPALLOC(hipMalloc(&c->xmlp_tab, tab.size() * sizeof(XMlpParams)));
   HIPCHK(hipMemcpy(c->xmlp_tab, tab.data(), tab.size() * sizeof(XMlpParams), hipMemcpyHostToDevice));
   c->xmlp_geom = g;
-  tab_store(c, "xmlp", g, c->xmlp_tab);
+  tab_store(c, "xmlp", g, c->xmlp_tab, tab.size() * sizeof(XMlpParams));
   return 0;
 }
 
@@ -871,10 +871,10 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
     for (int o : offs) if (o == tab[0].in_off[q]) found = true;
     if (!found) return fail(DCTTS_ERR_STATE, "xtail: an input row of HC_5 is not in HC_4's cone");
   }
-  HIPCHK(hipMalloc(&c->xtail_tab, tab.size() * sizeof(XTailParams)));
+  HIPALLOC(hipMalloc(&c->xtail_tab, tab.size() * sizeof(XTailParams)));
   HIPCHK(hipMemcpy(c->xtail_tab, tab.data(), tab.size() * sizeof(XTailParams), hipMemcpyHostToDevice));
   c->xtail_geom = g;
-  tab_store(c, "xtail", g, c->xtail_tab);
+  tab_store(c, "xtail", g, c->xtail_tab, tab.size() * sizeof(XTailParams));
   return 0;
 }
 
@@ -1255,15 +1255,24 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
   std::lock_guard<std::mutex> lease_lk(ls.mu);
   if (ls.done && ls.owner != c) HIPCHK(hipStreamWaitEvent(st, ls.done, 0));
   // ... and decodes / TextEnc calls of THIS context from other streams (use groups; K / V of this decode live in TextEnc's output buffer until it ends)
-  CHK(grp_acquire(c, dctts_ctx::GRP_TE, st));
-  CHK(grp_acquire(c, dctts_ctx::GRP_DEC, st));
+  // (both groups' completion events -- and the device lease's -- are recorded on every way out of this function once something may have been enqueued)
+  GroupGuard gte(c, dctts_ctx::GRP_TE, st), gdec(c, dctts_ctx::GRP_DEC, st);
+  CHK(gte.acquire());
+  CHK(gdec.acquire());
+  struct LeaseDone {
+    DeviceLease& ls; dctts_ctx* c; hipStream_t st;
+    ~LeaseDone() {
+      if (!ls.done && hipEventCreateWithFlags(&ls.done, hipEventDisableTiming) != hipSuccess) { ls.done = nullptr; return; }
+      if (hipEventRecord(ls.done, st) == hipSuccess) ls.owner = c;
+    }
+  } lease_done{ls, c, st};
   c->fin_xerr = nullptr; c->fin_werr = nullptr;
   // dctts_decode_safe_once: THIS decode runs one launch per layer and meets the side stream through stream operations (no team kernel, no bounded in-kernel wait:
   // nothing in it can time out when the GPU is shared) -- the persistent settings (dctts_set_team_kernels, DCTTS_XGROUP / DCTTS_XCONE / DCTTS_CHAIN_WAIT,
   // a switch-off by dctts_decode_status) are left exactly as they were
   struct SafeOnce {
     dctts_ctx* c; bool on; int xg, xc, cw;
-    explicit SafeOnce(dctts_ctx* c_) : c(c_), on(c_->safe_once), xg(c_->xgroup), xc(c_->xcone), cw(c_->chain_wait_inkernel) { c->safe_once = false; if (on) { c->xgroup = 0; c->xcone = 0; c->chain_wait_inkernel = 0; } }
+    explicit SafeOnce(dctts_ctx* c_) : c(c_), on(c_->safe_once && c_->safe_once_tid == std::this_thread::get_id()), xg(c_->xgroup), xc(c_->xcone), cw(c_->chain_wait_inkernel) { if (on) { c->safe_once = false; c->xgroup = 0; c->xcone = 0; c->chain_wait_inkernel = 0; } }
     ~SafeOnce() { if (on) { c->xgroup = xg; c->xcone = xc; c->chain_wait_inkernel = cw; } }
   } safe_once(c);
   DecodeWs w;
@@ -1347,11 +1356,8 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
                      (long long*)maxatt, (long)B * T, alignments, (long)B * N * T);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(c->dstat_host, c->dstat, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-  if (!ls.done) HIPCHK(hipEventCreateWithFlags(&ls.done, hipEventDisableTiming));
-  HIPCHK(hipEventRecord(ls.done, st));
-  ls.owner = c;
-  CHK(grp_release(c, dctts_ctx::GRP_DEC, st));
-  return grp_release(c, dctts_ctx::GRP_TE, st);
+  CHK(gdec.release());
+  return gte.release();
 }
 
 extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, int64_t* maxatt, float* alignments, void* stream) {
@@ -1359,8 +1365,7 @@ extern "C" int dctts_text2mel_decode(dctts_ctx* c, const int32_t* L, int B, int 
   CHK(check_ready(c, dev_guard));
   if (!L || !Y || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "decode: bad argument");
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  CHK(ws_trim(c));
-  return decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream);
+  return oom_retry(c, [&]() -> int { CHK(ws_trim(c)); return decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream); });
 }
 
 extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, int T, float* Y, float* Z, int64_t* maxatt, float* alignments, void* stream) {
@@ -1368,13 +1373,19 @@ extern "C" int dctts_synthesize(dctts_ctx* c, const int32_t* L, int B, int N, in
   CHK(check_ready(c, dev_guard));
   if (!L || !Y || !Z || B <= 0 || T <= 0) return fail(DCTTS_ERR_ARG, "synthesize: bad argument");
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  CHK(ws_trim(c));
-  CHK(decode_impl(c, L, B, N, T, Y, maxatt, alignments, (hipStream_t)stream));
-  CHK(dctts_ssrn_fwd(c, Y, B, T, nullptr, Z, stream));                    // synthesize.py:57
-  // SSRN's ReLU layers turn a poisoned (NaN) mel back into finite numbers: Z of a failed decode is poisoned explicitly
-  hipLaunchKernelGGL(poison_if_failed_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, c->dstat, Z, (long)B * 4 * T * c->cfg.n_linear);
-  HIPCHK(hipGetLastError());
-  return 0;
+  hipStream_t st = (hipStream_t)stream;
+  return oom_retry(c, [&]() -> int {
+    CHK(ws_trim(c));
+    CHK(decode_impl(c, L, B, N, T, Y, maxatt, alignments, st));
+    CHK(ssrn_impl(c, Y, B, T, nullptr, Z, st));                             // synthesize.py:57
+    // SSRN's ReLU layers turn a poisoned (NaN) mel back into finite numbers: Z of a failed decode is poisoned explicitly.  The kernel reads the context's status
+    // block, which the next decode (possibly from another stream) writes: it runs under the decode's use group, whose completion event is recorded behind it.
+    GroupGuard gdec(c, dctts_ctx::GRP_DEC, st);
+    CHK(gdec.acquire());
+    hipLaunchKernelGGL(poison_if_failed_kernel, dim3(256), dim3(256), 0, st, c->dstat, Z, (long)B * 4 * T * c->cfg.n_linear);
+    HIPCHK(hipGetLastError());
+    return gdec.release();
+  });
 }
 
 extern "C" int dctts_decode_status(dctts_ctx* c) {
@@ -1414,12 +1425,13 @@ extern "C" int dctts_debug_team_kernels_state(dctts_ctx* c) {
 extern "C" int dctts_decode_safe_once(dctts_ctx* c) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
-  c->safe_once = true;
+  c->safe_once = true; c->safe_once_tid = std::this_thread::get_id();
   return 0;
 }
 
 extern "C" int dctts_debug_inject_decode_error(dctts_ctx* c, int bits) {
   if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   c->inject_err = bits ? (bits | 64) : 0;
   return 0;
 }
@@ -1433,6 +1445,7 @@ extern "C" int dctts_set_decode_graph(dctts_ctx* c, int enable) {
 
 extern "C" int dctts_set_decode_mode(dctts_ctx* c, int mode) {
   if (!c || (mode != 0 && mode != 3)) return fail(DCTTS_ERR_ARG, "decode mode must be 3 (two-stream incremental form, the default) or 0 (simple one-stream form, cross-check)");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
   c->decode_mode = mode;
   return 0;
 }

@@ -44,7 +44,7 @@ struct dctts_vocoder {
 };
 
 static int voc_acquire(dctts_vocoder* v, hipStream_t st) {
-  if (v->used && v->last != st) VHIPCHK(hipStreamWaitEvent(st, v->done, 0));
+  if (v->used) VHIPCHK(hipStreamWaitEvent(st, v->done, 0));      // (always: a destroyed stream's handle can come back as a new stream's)
   return 0;
 }
 static int voc_release(dctts_vocoder* v, hipStream_t st) {
@@ -53,6 +53,16 @@ static int voc_release(dctts_vocoder* v, hipStream_t st) {
   v->last = st; v->used = true;
   return 0;
 }
+
+// A call's hold on the handle's scratch: the completion event is recorded on every way out once anything may have been enqueued (an early error return
+// must not leave launches on the shared buffers that the next call from another stream does not wait for).
+struct VocGuard {
+  dctts_vocoder* v; hipStream_t st; bool held = false;
+  VocGuard(dctts_vocoder* v_, hipStream_t st_) : v(v_), st(st_) {}
+  int acquire() { const int rc = voc_acquire(v, st); held = (rc == 0); return rc; }
+  int release() { held = false; return voc_release(v, st); }
+  ~VocGuard() { if (held) (void)voc_release(v, st); }
+};
 
 static int vgrow(VBuf& b, size_t bytes) {
   if (b.bytes >= bytes) return 0;
@@ -179,11 +189,12 @@ extern "C" int dctts_griffin_lim(dctts_vocoder* v, const float* spec, int B, int
   VHIPCHK(hipSetDevice(v->device));
   std::lock_guard<std::mutex> lk(v->mu);
   hipStream_t st = (hipStream_t)stream;
-  VCHK(voc_acquire(v, st));
+  VocGuard guard(v, st);
+  VCHK(guard.acquire());
   VocGeom g;
   VCHK(geom(v, B, F, &g));
   VCHK(run_griffin_lim(v, g, spec, B, n_iter, (float2*)X_best, y, st));
-  return voc_release(v, st);
+  return guard.release();
 }
 
 extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, int F, float* wav, int32_t* bounds, void* stream) {
@@ -191,9 +202,11 @@ extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, 
   VHIPCHK(hipSetDevice(v->device));
   std::lock_guard<std::mutex> lk(v->mu);
   hipStream_t st = (hipStream_t)stream;
-  VCHK(voc_acquire(v, st));
+  VocGuard guard(v, st);
+  VCHK(guard.acquire());
   VocGeom g;
   VCHK(geom(v, B, F, &g));
+  if (bounds && g.L <= v->cfg.trim_frame_length / 2) return dctts_set_error(DCTTS_ERR_ARG, "utterance shorter than the trim frame's reflect padding");      // (before anything is launched)
   const long n = (long)B * F * VOC_BINS;
   VCHK(vgrow(v->spec, (size_t)n * sizeof(float)));
   VCHK(vgrow(v->yraw, (size_t)B * g.L * sizeof(float)));
@@ -203,14 +216,13 @@ extern "C" int dctts_spectrogram2wav(dctts_vocoder* v, const float* mag, int B, 
   hipLaunchKernelGGL(deemph_kernel, dim3((g.L + DE_CHUNK - 1) / DE_CHUNK, B), dim3(256), 0, st, (const float*)yraw, wav, g.L, v->cfg.preemphasis);
   if (bounds) {
     const int flen = v->cfg.trim_frame_length, fhop = v->cfg.trim_hop_length;
-    if (g.L <= flen / 2) return dctts_set_error(DCTTS_ERR_ARG, "utterance shorter than the trim frame's reflect padding");
     const int n_tf = 1 + g.L / fhop;
     VCHK(vgrow(v->pw, (size_t)B * n_tf * sizeof(float)));
     hipLaunchKernelGGL(frame_power_kernel, dim3(n_tf, B), dim3(256), 0, st, (const float*)wav, (float*)v->pw.p, g.L, n_tf, flen, fhop);
     hipLaunchKernelGGL(trim_bounds_kernel, dim3(B), dim3(256), 0, st, (const float*)v->pw.p, (int*)bounds, g.L, n_tf, fhop, v->cfg.trim_top_db);
   }
   VHIPCHK(hipGetLastError());
-  return voc_release(v, st);
+  return guard.release();
 }
 
 extern "C" int dctts_vocoder_prof_enable(dctts_vocoder* v, int enable) {

@@ -157,7 +157,9 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       // END of rowc1_kernel's launch, where the row was always there; at the head of this launch the leader waited 3.4 us for it with the whole team behind it)
       if (ca.wait && s_go) {
         const int rfirst = q4 * 8 + wave_b;
-        if (rfirst == 0 || rfirst + 64 == cb.R - 1) {                 // row 0 (t = frame - 1) / the presum row (t = frame: its taps read frame - 1 and frame - 2)
+        // row 0 (t = frame - 1) / the presum row R - 1 (t = frame: its taps read frame - 1 and frame - 2), whichever of this wave's three slots it sits in
+        // (R - 1 < 96: the host folds the row phases only then, v3_xcone_table)
+        if (rfirst == 0 || (rfirst <= cb.R - 1 && ((cb.R - 1 - rfirst) & 31) == 0)) {
           bool ok = false;
           for (int i = 0; i < (1 << 20) && !ok; ++i) {
             ok = __hip_atomic_load(ca.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ca.wait_val;

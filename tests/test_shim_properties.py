@@ -10,8 +10,10 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
-from hypothesis import HealthCheck, given, settings
-from hypothesis import strategies as st
+
+pytest.importorskip("hypothesis")      # not a declared dependency of the package: present in this image, skipped where it is not
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
 
 from oracle import tf_shim as tf
 from oracle import vocoder_ref as V
