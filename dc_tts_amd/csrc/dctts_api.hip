@@ -258,6 +258,8 @@ struct dctts_ctx {
   // HC_2 .. HC_4 as an xgroup_kernel launch in front; 1 = xmlp_kernel: the seven k = 1 layers in team form (HC_5 .. HC_7 stay split between the chain's run
   // and the side stream); 0 = mlp_rows_kernel (round 2: split by rows); 3 / 4: A/B forms (tools/README.md)
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
+  int tail_np = 4, np_eff = 3;         // round 6 (DCTTS_TAIL_NP): newest-row layers in front of the chain launch's cone layers: 4 = HC_2 .. HC_5 (HC_5's older cone rows on the side stream: xcone_kernel runs HC_3 .. HC_5),
+                                       //   3 = rounds 4-5 (HC_2 .. HC_4; the side stream stops behind HC_4); np_eff: what this decode uses (the merged forms only)
   bool chain_one = false;              // round 5 (chain_tail == 2): a chain piece is ONE launch -- xtail_kernel's layers, a team barrier, the AudioEnc run + attention + C_1 (xchain_kernel); 6: two launches (round 4)
   bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (chain_tail 2 and 6)
   bool ae_pass_split = false;          // round 4: AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch (a row ahead), only the C1Q . W2 row stays in the AudioDec launch
@@ -566,7 +568,7 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
   geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_CHAIN_TAIL", &c->chain_tail);
-  geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
+  geti("DCTTS_TAIL_NP", &c->tail_np); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
   // (it only times out, with wrong results).  Under counter collection the two decode streams meet through events instead.

@@ -420,7 +420,7 @@ static int v3_bulk_rest(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, in
     if (prof) { HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, sb)); }
     hipLaunchKernelGGL(xcone_kernel, dim3(128), dim3(512), 0, sb, xp, (const int*)(w.pm_all + (long)f * B));
     HIPCHK(hipGetLastError());
-    if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < (c->tail_on ? (size_t)4 : AD.size()); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
+    if (prof) { HIPCHK(hipEventRecord(e1, sb)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); long rows = 0; for (size_t i = 2; i < (c->tail_on ? (size_t)(c->np_eff + 1) : AD.size()); ++i) if (AD[i].hc) rows += (long)B * c->cone_len[i]; c->prof_rows += rows; }
     return 0;
   }
   for (size_t i = first_gemm; i < AD.size(); ++i) {
@@ -655,7 +655,7 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
 static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig) {
   const bool fold = c->side_fold && c->cone_len[0] - 1 <= 96 && c->cone_len[1] <= 96 && c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;
   c->side_fold = fold;
-  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on) +
+  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string(c->np_eff) +
                         ":" + std::to_string((int)fold) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.scal.p);
   if (c->xc_tab && c->xc_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xc", g, &ts)) { c->xc_tab = ts.tab; c->xc_geom = g; return 0; } }
@@ -664,7 +664,7 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   const XgMem m = xg_mem(c, B);
   size_t i0 = 2, i1 = i0; while (i1 < AD.size() && AD[i1].hc) ++i1;     // HC_3 .. the last highway layer
   const int tail = c->tail_on ? 1 : 0;
-  if (tail) i1 = i0 + 2;                                                 // HC_3, HC_4 and HC_4's cone rows: the chain's xtail_kernel takes it from there
+  if (tail) i1 = i0 + 2 + (size_t)(c->np_eff - 3);                       // HC_3, HC_4 (round 6: + HC_5) and the last one's cone rows: the chain's xtail_kernel takes it from there
   const int L = (int)(i1 - i0);
   if (L < 1 || L > 5) return fail(DCTTS_ERR_STATE, "xcone: 1..5 highway layers behind HC_2");
   std::vector<XConeParams> tab((size_t)T);
@@ -798,19 +798,23 @@ static int v3_xmlp_table(dctts_ctx* c, const DecodeWs& w, int B, int T) {
 // xtail_kernel's per-frame parameters: AudioDec's last three highway layers (HC_5 .. HC_7 over 5 / 3 / 1 rows per utterance) + the k = 1 layers
 static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig, bool cwait) {
   const std::string g = geom("xtail", B, T) + ":" + std::to_string((size_t)w.pd[0]) + ":" + std::to_string((size_t)w.ypad.p) + ":" + std::to_string((size_t)w.ad[0].p) + ":" + std::to_string((size_t)w.pe[0]) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string(c->trace_frame) + ":" +
-                        std::to_string((int)c->dec_merge) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((int)c->chain_one);
+                        std::to_string((int)c->dec_merge) + ":" + std::to_string(c->np_eff) + ":" + std::to_string((int)insig) + ":" + std::to_string((int)cwait) + ":" + std::to_string((size_t)c->sig_ptr) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((size_t)c->aepre_tab) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.pb3[1]) + ":" + std::to_string((int)c->chain_one);
   if (c->xtail_tab && c->xtail_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xtail", g, &ts)) { c->xtail_tab = ts.tab; c->xtail_geom = g; return 0; } }
   c->xtail_tab = nullptr;
   const std::vector<DevLayer>& AD = c->audiodec;                         // (the full layers: all three taps in wp16)
-  const size_t h0 = 4;                                                   // C_1, HC_2, HC_3, HC_4 | HC_5, HC_6, HC_7 | C_8 ..
-  for (size_t k = 0; k < 3; ++k) {
+  const int NPv = c->dec_merge ? c->np_eff : 3, NHv = 6 - NPv;           // newest-row layers in front / cone layers behind them (xtail_kernel.h: NP)
+  const size_t h0 = (size_t)(1 + NPv);                                   // NP = 3: C_1, HC_2, HC_3, HC_4 | HC_5, HC_6, HC_7 | C_8 ..;  NP = 4: ... HC_5 | HC_6, HC_7 | C_8 ..
+  for (size_t k = 0; k < (size_t)NHv; ++k) {
     const DevLayer& Ly = AD[h0 + k];
     if (!Ly.hc || Ly.cout != 256 || Ly.cin != 256 || Ly.cin_p != 256 || Ly.ntaps != 3 || Ly.tap_off[2] != 0 || !Ly.wp16) return fail(DCTTS_ERR_STATE, "xtail: causal k=3 highway layers over 256 channels");
-    if (k > 0 && (Ly.tap_off[0] != -2 || Ly.tap_off[1] != -1)) return fail(DCTTS_ERR_STATE, "xtail: the layers behind the first one have dilation 1");
+    if ((k > 0 || NPv == 4) && (Ly.tap_off[0] != -2 || Ly.tap_off[1] != -1)) return fail(DCTTS_ERR_STATE, "xtail: the layers behind the first one have dilation 1");
   }
-  const int nout[3] = {c->cone_len[h0], c->cone_len[h0 + 1], c->cone_len[h0 + 2]};
-  if (nout[0] != 5 || nout[1] != 3 || nout[2] != 1 || 3 * nout[0] != c->cone_len[h0 - 1] || 4 * nout[0] > XT_MAXM) return fail(DCTTS_ERR_STATE, "xtail: cone 15 / 5 / 3 / 1");
+  int nout[3] = {0, 0, 0};
+  for (int k = 0; k < NHv; ++k) nout[k] = c->cone_len[h0 + k];
+  if (NPv == 3 && (nout[0] != 5 || nout[1] != 3 || nout[2] != 1 || 3 * nout[0] != c->cone_len[h0 - 1] || 4 * nout[0] > XT_MAXM)) return fail(DCTTS_ERR_STATE, "xtail: cone 15 / 5 / 3 / 1");
+  if (NPv == 4 && (nout[0] != 3 || nout[1] != 1 || c->cone_len[h0 - 1] != nout[0] + 2)) return fail(DCTTS_ERR_STATE, "xtail: cone 5 / 3 / 1");
+  const int nin0 = c->cone_len[h0 - 1];                                  // input rows per utterance of the first cone layer (its producer's cone)
   const XgMem m = xg_mem(c, B);
   const int groups = m.bpad / 4;
   const View& xv = w.ad[h0 - 1];                                         // HC_4's output rows: the side stream's xcone_kernel writes its cone rows (parity copy of the frame)
@@ -824,9 +828,9 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       // merged form: AudioDec HC_2 .. HC_4 at the newest row run in front (what the AudioDec run of xgroup_kernel did, v3_xgroup_table), and this launch is the
       // first one of chain piece j: it publishes the chain's counter, waits for side-stream piece j, and carries the passengers
       const std::vector<DevLayer>& ADc = c->ad_c;                         // (centre tap in wp16)
-      p.np = 3;
+      p.np = NPv;
       p.pP0 = w.pd[0]; p.pstats0 = w.sd[0]; p.pg1 = ADc[0].g1; p.pb1 = ADc[0].b1;
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NPv; ++k) {
         const size_t i = 1 + (size_t)k; const DevLayer& Ly = ADc[i];
         if (!Ly.hc || Ly.cout != 256 || Ly.cin != 256 || !Ly.wp16 || !Ly.wp16c || Ly.tap2) return fail(DCTTS_ERR_STATE, "xtail: the newest-row layers are 256-channel causal k=3 highway layers");
         XTailP& q = p.pl[k];
@@ -846,16 +850,20 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
         p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
       }
     }
-    p.nh = 3; p.nin0 = 3 * nout[0]; p.frame = j;
-    for (int k = 0; k < 3; ++k) {
+    p.nh = NHv; p.nin0 = nin0; p.frame = j;
+    for (int k = 0; k < NHv; ++k) {
       const DevLayer& Ly = AD[h0 + k];
       XTailHc& q = p.hc[k];
       q.wp = Ly.wp16; q.bias = Ly.bias; q.g1 = Ly.g1; q.b1 = Ly.b1; q.g2 = Ly.g2; q.b2 = Ly.b2;
-      q.nout = nout[k]; q.nin = k == 0 ? 3 * nout[0] : nout[k - 1]; q.ts = k == 0 ? nout[0] : 1;
+      q.nout = nout[k]; q.nin = k == 0 ? nin0 : nout[k - 1]; q.ts = (k == 0 && NPv == 3) ? nout[0] : 1;      // (the input row of (output row r, tap) is r + (2 - tap) * ts)
     }
     p.xin = xv.p + par * xv.set + (xv.row0 + j) * (long)xv.stride; p.xin_bs = xv.bstride * (long)xv.stride; p.xin_stride = xv.stride;
-    for (int kk = 0; kk < 3; ++kk)
-      for (int r = 0; r < nout[0]; ++r) p.in_off[kk * nout[0] + r] = AD[h0].tap_off[2 - kk] - r;      // input row q = kk * 5 + r: time t - r + tap offset
+    if (NPv == 3) {
+      for (int kk = 0; kk < 3; ++kk)
+        for (int r = 0; r < nout[0]; ++r) p.in_off[kk * nout[0] + r] = AD[h0].tap_off[2 - kk] - r;      // input row q = kk * 5 + r: time t - r + tap offset
+    } else {
+      for (int q = 0; q < nin0; ++q) p.in_off[q] = -q;                      // dilation 1: input row q is time t - q
+    }
     p.xch = m.xch_h; p.sch = m.sch_h; p.xch_set = groups * XT_MAXM * 512; p.sch_set = groups * XT_MAXM * 64;
     if (j == c->trace_frame) {
       if (!c->trace_buf) { HIPCHK(hipMalloc((void**)&c->trace_buf, 64 * 64 * 32 * sizeof(long long))); HIPCHK(dev_zero_now(c->trace_buf, 64 * 64 * 32 * sizeof(long long))); }
@@ -864,12 +872,12 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
     tab[j] = p;
   }
   // every input row the first layer stages (but the newest) must be a cone row the side stream produces
-  for (int q = 1; q < 3 * nout[0]; ++q) {
+  for (int q = 1; q < nin0; ++q) {
     bool found = false;
     std::vector<int> offs((size_t)c->cone_len[h0 - 1]);
     HIPCHK(hipMemcpy(offs.data(), c->cone3_dev[h0 - 1], offs.size() * sizeof(int), hipMemcpyDeviceToHost));
     for (int o : offs) if (o == tab[0].in_off[q]) found = true;
-    if (!found) return fail(DCTTS_ERR_STATE, "xtail: an input row of HC_5 is not in HC_4's cone");
+    if (!found) return fail(DCTTS_ERR_STATE, "xtail: an input row of the first cone layer is not in its producer's cone");
   }
   HIPALLOC(hipMalloc(&c->xtail_tab, tab.size() * sizeof(XTailParams)));
   HIPCHK(hipMemcpy(c->xtail_tab, tab.data(), tab.size() * sizeof(XTailParams), hipMemcpyHostToDevice));
@@ -889,10 +897,17 @@ static int v3_mlp_launch(dctts_ctx* c, int B, int j, hipStream_t st) {
     if (c->chain_one && j + 1 < c->xg_T) {
       // round 5: the whole chain piece as ONE launch -- these layers, a team barrier, the AudioEnc run of frame j + 1 with the attention row and AudioDec C_1
       const XGroupParams* pg = (const XGroupParams*)c->xg_tab + (size_t)2 * (j + 1) + 1;
-      if (c->trace_on) hipLaunchKernelGGL(xchain_kernel<true>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j, pg);
-      else hipLaunchKernelGGL(xchain_kernel<false>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j, pg);
-    } else if (c->trace_on) hipLaunchKernelGGL(xtail_kernel<true>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
-    else hipLaunchKernelGGL(xtail_kernel<false>, dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
+      const XTailParams* pt = (const XTailParams*)c->xtail_tab + j;
+      if (c->np_eff == 4) {
+        if (c->trace_on) hipLaunchKernelGGL((xchain_kernel<true, 4>), dim3(128 + pass), dim3(512), 0, st, pt, pg);
+        else hipLaunchKernelGGL((xchain_kernel<false, 4>), dim3(128 + pass), dim3(512), 0, st, pt, pg);
+      } else if (c->trace_on) hipLaunchKernelGGL((xchain_kernel<true, 3>), dim3(128 + pass), dim3(512), 0, st, pt, pg);
+      else hipLaunchKernelGGL((xchain_kernel<false, 3>), dim3(128 + pass), dim3(512), 0, st, pt, pg);
+    } else if (c->dec_merge && c->np_eff == 4) {
+      if (c->trace_on) hipLaunchKernelGGL((xtail_kernel<true, 4>), dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
+      else hipLaunchKernelGGL((xtail_kernel<false, 4>), dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
+    } else if (c->trace_on) hipLaunchKernelGGL((xtail_kernel<true, 3>), dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);      // DCTTS_TRACE: stamped instantiation
+    else hipLaunchKernelGGL((xtail_kernel<false, 3>), dim3(128 + pass), dim3(512), 0, st, (const XTailParams*)c->xtail_tab + j);
     HIPCHK(hipGetLastError());
     if (prof) { HIPCHK(hipEventRecord(e1, st)); c->prof_ev.emplace_back(e0, e1); c->prof_cnt.push_back(1); c->prof_rows += 10; }
     return 0;
@@ -1015,6 +1030,11 @@ static int write_trace3(dctts_ctx* c, int j) {
       for (int i = 1; i < 60 && o[i]; ++i) { fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0); last = i; }
       if (last > 0 && o[101] > o[100]) fprintf(f, "   (shader clock over the launch: %.0f MHz)", (double)(o[101] - o[100]) / ((o[last] - o[0]) / 100.0));
       fprintf(f, "\n");
+      if (o[60]) {
+        fprintf(f, "  first GEMM layer, per wave: first requests out, then the end of each (row tile, K half) unit:");
+        for (int wv = 0; wv < 8; ++wv) { fprintf(f, "%s w%d", wv ? " |" : "", wv); for (int k = 0; k < 5 && o[60 + wv * 5 + k]; ++k) fprintf(f, " %.2f", (o[60 + wv * 5 + k] - o[0]) / 100.0); }
+        fprintf(f, "\n");
+      }
       const long long* ot = &h[64 * 64 * 32 - 64];          // the chain launch of the same frame (the stamps are one wall clock): when did this side piece run relative to it?
       if (ot[0] && c->tail_on && last > 0) fprintf(f, "  (relative to the entry of the chain's launch of this frame: entered %.2f, last stamp %.2f us)\n", (o[0] - ot[0]) / 100.0, (o[last] - ot[0]) / 100.0);
     }
@@ -1024,16 +1044,18 @@ static int write_trace3(dctts_ctx* c, int j) {
     if (o[0] && c->tail_on) {
       int i0 = 2;
       if (c->dec_merge) {
-        fprintf(f, "# xtail_kernel, merged form (workgroup 0, thread 0), microseconds since its entry: first row built (incl. the wait for the side stream) | end of each newest-row layer (HC_2 .. HC_4) | cone rows in LDS | per cone layer (HC_5 .. HC_7): MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
+        const int npv = c->np_eff;
+        fprintf(f, "# xtail_kernel, merged form (workgroup 0, thread 0), microseconds since its entry: first row built (incl. the wait for the side stream) | end of each newest-row layer (HC_2 .. HC_%d) | cone rows in LDS | per cone layer (HC_%d .. HC_7): MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ", npv + 1, npv + 2);
         fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
-        for (int i = 2; i < 5 && o[i]; ++i) fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0);
-        fprintf(f, " | %6.2f |", (o[5] - o[0]) / 100.0);
-        i0 = 6;
+        for (int i = 2; i < 2 + npv && o[i]; ++i) fprintf(f, " %6.2f", (o[i] - o[0]) / 100.0);
+        fprintf(f, " | %6.2f |", (o[2 + npv] - o[0]) / 100.0);
+        i0 = 3 + npv;
       } else {
         fprintf(f, "# xtail_kernel (workgroup 0, thread 0), microseconds since its entry: rows staged + newest row rebuilt | per highway layer: MFMAs issued + partial sums written, reduced + published, barrier passed, exchanged rows landed, rows rebuilt | then the end of every k = 1 layer\n ");
         fprintf(f, " %6.2f |", (o[1] - o[0]) / 100.0);
       }
-      for (int i = i0; i < 56 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i < i0 + 15 && (i - i0) % 5 == 4) ? " |" : "");
+      const int ncone = c->dec_merge ? 5 * (6 - c->np_eff) : 15;
+      for (int i = i0; i < 56 && o[i]; ++i) fprintf(f, " %6.2f%s", (o[i] - o[0]) / 100.0, (i < i0 + ncone && (i - i0) % 5 == 4) ? " |" : "");
       if (o[56] && o[58]) fprintf(f, "\n  passengers: the first one ran %.2f .. %.2f, the last one %.2f .. %.2f", (o[56] - o[0]) / 100.0, (o[57] - o[0]) / 100.0, (o[58] - o[0]) / 100.0, (o[59] - o[0]) / 100.0);
       fprintf(f, "\n");
     } else if (o[0]) {
@@ -1079,6 +1101,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   c->tail_on = c->xg_on && c->xc_on && c->chain_tail >= 2 && c->audiodec.size() == 11 && c->cone_len.size() > 6 && c->cone_len[4] == 5 && c->cone_len[5] == 3 && c->cone_len[6] == 1;
   c->xmlp_on = c->xg_on && c->chain_tail >= 1 && !c->tail_on;
   c->dec_merge = c->tail_on && (c->chain_tail == 2 || c->chain_tail == 6);          // (5: xtail_kernel behind an AudioDec run of xgroup_kernel, the first round-4 form -- A/B)
+  c->np_eff = (c->dec_merge && c->tail_np == 4) ? 4 : 3;
   c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->chain_tail != 3 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;      // (3: xtail_kernel without the fold -- A/B)
   c->chain_one = c->dec_merge && c->chain_tail == 2 && c->attn_fold;      // (6: the chain piece as two launches, round 4's form -- A/B)
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's

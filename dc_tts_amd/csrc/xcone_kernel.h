@@ -78,7 +78,11 @@ __device__ __forceinline__ bool xcone_barrier(unsigned* bar, int grp, unsigned x
 // pm_row (folded form): prev_max_attentions of this frame, pm_all + frame * B -- a kernel ARGUMENT, so that the window position, which everything of the row phases
 // hangs on, is requested at entry instead of behind the load of the per-frame table
 __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restrict__ pp, const int* __restrict__ pm_row) {
-  __shared__ __attribute__((aligned(16))) float red[2][2 * 8 * 2 * 4 * 64];  // split-K partial sums of two row tiles, double-buffered: one barrier per pass
+  // Round 6: a layer's weight slice lives in LDS (96 KB: the workgroup's two 16-column tiles x 48 k-groups, in the packing's own order: a k-group of a tile is the
+  // 1 KB one ds_read_b128 per lane fetches), and a wave contracts WHOLE row tiles against it -- see the GEMM below.  `aux`: the row phases' staged operands (45 KB),
+  // later the second K halves' partial sums of a layer with four row tiles or fewer (8 KB).
+  __shared__ __attribute__((aligned(16))) float wlds[2 * 48 * 256];
+  __shared__ __attribute__((aligned(16))) float aux[45 * 256];
   __shared__ int s_go;
   __shared__ int s_xoff[256];            // per local row m of the team (M <= 4 * 64): element offset of its input row t in xin, -1 = the row does not exist (t < 0)
   __shared__ int s_prow[256];            // ... its pre-norm row index in pout
@@ -102,6 +106,18 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   auto stamp = [&]() { if (p.ts && blockIdx.x == 0 && tid == 0 && nts < 60) { p.ts[100 + (nts > 0)] = clock64(); p.ts[nts++] = wall_clock64(); } };   // ([100], [101]: shader clock at the first / latest stamp)
   stamp();
 
+  // a layer's weight slice, global memory -> LDS without a register in between (global_load_lds_dwordx4: a wave's 64 lanes x 16 bytes land at consecutive LDS
+  // addresses behind the wave-uniform base).  The slice is contiguous in the packing: tiles 2 grp and 2 grp + 1, 48 k-groups of 1 KB each.
+  // (a wave's 12 one-KB pieces as two halves: the first layer's slice is requested half in each row phase -- a wave's requests return in order and every team
+  //  barrier drains them, so a whole slice behind phase A's operands held that phase's barrier for ~4 us)
+  auto load_slice = [&](const int layer, const int wv, const int k0 = 0, const int k1 = 12) {
+    const float* src = p.lay[layer].wp + (unsigned)(grp * 2) * 48u * 256u + (unsigned)(tid & 63) * 4u;
+    const int w12 = __builtin_amdgcn_readfirstlane(wv) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k)
+      if (k >= k0 && k < k1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (w12 + k) * 256), (__attribute__((address_space(3))) void*)&wlds[(w12 + k) * 256], 16, 0, 0);
+  };
   for (int b0 = team * 4; b0 < p.B; b0 += 32) {
   const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
   if (p.fold) {
@@ -110,7 +126,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     const int lane = tid_a & 63, wave = tid_a >> 6;
     // ---- phase A: AudioDec C_1 over its cone rows (decode3_kernels.h: rowc1_*), phase B: HC_2 over its cone rows + its presum row (rowhc2_*)
     const RowC1Params& ca = pp->rc1; const RowHc2Params& cb = pp->rhc2;
-    f32x4* const s_c = reinterpret_cast<f32x4*>(&red[0][0]);           // phase B's shared operands: 18 KB + 18 KB of the 64 KB split-K buffer (nothing else uses it before the first GEMM pass)
+    f32x4* const s_c = reinterpret_cast<f32x4*>(&aux[0]);              // phase B's shared operands: 18 KB + 18 KB (nothing else uses `aux` before the first GEMM layer)
     f32x4* const s_v = s_c + 9 * 128;
     f32x4* const s_sh = s_v + 9 * 128;                                  // phase A's: 9 KB behind them
     const int ub = grp >> 2, q4 = grp & 3;
@@ -118,7 +134,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     const int b = uok ? b0 + ub : b0;
     const int pm = pm_row[b];
     auto ldq = [](const float* q_) { return *reinterpret_cast<const f32x4*>(q_); };
-    __syncthreads();                                                    // (a second round: the previous round's last reads of `red`)
+    __syncthreads();                                                    // (a second round: the previous round's last reads of `aux`)
     rowc1_stage(ca, b, pm, s_sh, tid_a, 512);
     {
       f32x4 vq[3], vcq[3]; int tt[3]; bool lv[3];
@@ -136,8 +152,11 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       // phase A's rows are finished.  vmcnt counts in issue order, so phase A waits for everything but those requests: 2 x 3 per thread in waves 0 and 1 (1152 pieces over
       // 512 threads), 2 x 2 in the others.
       rowhc2_stage(cb, b, pm, s_c, s_v, tid_a, 512);
-      if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
+      // ... and neither does the first GEMM layer's weight slice (round 6: 96 KB per workgroup into `wlds`, 12 one-KB pieces per wave): its first half is requested
+      // behind them and drained by this phase's barrier, the second half behind phase B's last row's operands
+      load_slice(0, wave, 0, 6);
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(12)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
+      else asm volatile("s_waitcnt vmcnt(10)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
       __syncthreads();
 #pragma unroll
       for (int i = 0; i < 3; ++i) if (lv[i]) rowc1_finish(ca, b, tt[i], pm, vq[i], vcq[i], s_sh, lane);
@@ -172,6 +191,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       for (int i = 0; i < 3; ++i) {
         RowHc2Row cur;
         rowhc2_load(cb, b, q4 * 8 + wave_b + 32 * i, lane_b, cur);
+        if (i == 2) load_slice(0, wave_b, 6, 12);                        // the slice's second half, behind this wave's last row's operands: drained by the barrier behind this phase
         if (uok && cur.live) rowhc2_finish(cb, b, pm, cur, ln, s_c, s_v, lane_b);
       }
     }
@@ -186,19 +206,17 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   asm volatile("; xcone: thread index, opaque" : "+v"(tid_o));
   const int lane = tid_o & 63, wave = tid_o >> 6;
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
-  const int etile = wave >> 2, ecol = lane & 15, ej = wave & 3;
-  const int pcol = etile * 256 + grp * 16 + ecol;
-  // this workgroup's slice of a layer's weights, two column tiles.  Wave w owns the SIX CONSECUTIVE k-groups 6 w .. 6 w + 5 (k = 96 w .. 96 w + 95 of
-  // the 768 = 3 taps x 256 channels), not w, w + 8, ...: its six A requests per row then cover 384 contiguous bytes = three whole 128-byte
-  // lines.  (With one 64-byte piece per row and request, in-kernel stamps showed a pass's 96 KB of rows taking ~4 us to land: ~25 GB/s per CU.)
-  f32x4 bq0[6], bq1[6];
-  auto load_w = [&](int layer, f32x4 (&q0)[6], f32x4 (&q1)[6]) {
-    const float* wb = p.lay[layer].wp + lane * 4;
-    const unsigned w0 = (unsigned)(grp * 2) * 48u * 256u, w1 = w0 + 48u * 256u;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) { q0[i] = ldv(wb, w0 + (unsigned)(6 * wave + i) * 256u); q1[i] = ldv(wb, w1 + (unsigned)(6 * wave + i) * 256u); }
-  };
-  load_w(0, bq0, bq1);
+  const int ecol = lane & 15;
+  // Round 6, the GEMM layers.  Rounds 3-5 kept the workgroup's weight slice in REGISTERS, split K over the eight waves and reduced every pass of two row tiles
+  // through LDS behind a barrier: a pass took ~5.1 us of which 2.56 were MFMA (stamps: HC_3's 12 row tiles 30.6 us, 0.47 of the matrix pipe of the CUs the kernel
+  // owns).  Now the slice is in LDS (`wlds`, see load_slice) and a wave contracts a WHOLE row tile x the workgroup's 32 columns x all of K = 768 on its own: A from
+  // global memory (the XCD's L2) through a ring of eight k-groups in registers, B as two ds_read_b128 per k-group (1 KB each = four MFMAs' operands; 32 LDS cycles
+  // per 256 cycles of matrix pipe over the four SIMDs), no split-K exchange, no barrier inside a layer's contraction.  A layer with four row tiles or fewer (HC_4;
+  // small batches) splits every tile's K into its two halves over a pair of waves, so that eight waves have work: the second half goes through LDS once.
+  // Summation order of a pre-norm value, whatever the form: (bias + sum over k-groups 0 .. 23) + sum over k-groups 24 .. 47, each sum one MFMA accumulator chain
+  // -- results do not depend on how many utterances a team serves (shard-invariant, bitwise).
+  if (!p.fold) { __syncthreads(); load_slice(0, wave); }      // (the split launch form: nothing in front of the GEMM layers to hide the request behind)
+  float* const wl = wlds + lane * 4;
   for (int li = 0; li < p.L; ++li) {
     {                                      // ... and a layer's descriptor in one batch (lazily: three dependent batches at the top of every layer, more in the row pass)
       typedef const __attribute__((address_space(4))) XConeLayer CL;
@@ -208,7 +226,6 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
                    "s"(y.tap_off[0]), "s"(y.tap_off[1]));
     }
     const int R = p.lay[li].R, M = nb * R, ntile = (M + 15) >> 4;
-    const float bias = p.lay[li].bias[pcol];
     const float* xin = p.lay[li].xin;
     const long xbs = p.lay[li].xin_bstride, xr0 = p.lay[li].xin_row0; const int xs = p.lay[li].xin_stride;
     const int to0 = p.lay[li].tap_off[0] * xs, to1 = p.lay[li].tap_off[1] * xs;        // (tap 2 is the row itself: causal)
@@ -225,83 +242,123 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       }
       s_xoff[tid] = xo; s_prow[tid] = pr;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           // (the split launch form's first layer: this wave's pieces of the weight slice are in LDS; otherwise drained by the barrier above)
     __syncthreads();
-    // A fragments of a row tile, RAW: lane (arow, aq) requests row tile * 16 + arow, channels c .. c + 3 of k-group (wave, i).  Rows that do
-    // not exist / a presum row's centre tap must read as zero: the request goes to a readable address and `fix_a` zeroes the registers --
-    // LATER, where the values are consumed: a select right behind a load is a use, and the wait for it would sit in front of the MFMAs
-    // the load is supposed to hide behind (first version: vmcnt(5) .. vmcnt(0) right after the six requests, 2.7 us per tile instead of 1.3).
-    auto load_a = [&](int tile, f32x4 (&a)[6], int& flags) {
+    // ---- the contraction.  unit = (row tile, K half): 24 k-groups of 16 channels.  The layer's ntile = 8 a + b row tiles: wave w takes the tiles w, w + 8, ... below
+    //      8 a, both halves of each (finished from registers); of the b left over, when b <= 4, a PAIR of waves takes a tile -- wave w half w & 1 of tile 8 a + (w >> 1),
+    //      the second half goes through LDS once -- so that HC_3's 12 tiles are three units for every wave (two waves busy on every SIMD to the end) and a layer of
+    //      four tiles or fewer (HC_4, HC_5; small batches) still has work for up to eight waves; b > 4: one tile per wave again.
+    //      A request: lane (arow, aq) reads row tile * 16 + arow, channels 4 aq .. 4 aq + 3 of the
+    //      k-group (a row that does not exist reads a readable address and its result is never stored: MFMA rows are independent; a presum row's centre tap must
+    //      contribute zero: selected where the values are consumed).
+    const int ta = ntile >> 3, tb = ntile & 7;
+    const bool split = tb > 0 && tb <= 4;                                                      // (uniform per workgroup)
+    const int nu_tail = tb == 0 ? 0 : (split ? (wave < 2 * tb ? 1 : 0) : (wave < tb ? 2 : 0));
+    const int nu = 2 * ta + nu_tail;                                                           // this wave's units
+    const float bias0 = p.lay[li].bias[grp * 16 + ecol], bias1 = p.lay[li].bias[256 + grp * 16 + ecol];      // this lane's gate / info column
+    float* const part = aux;                                                                   // split tiles: [tile b][2 tiles of columns][4][64]
+    auto unit_tile = [&](int u) { return u < 2 * ta ? wave + 8 * (u >> 1) : 8 * ta + (split ? (wave >> 1) : wave); };
+    auto unit_half = [&](int u) { return (u >= 2 * ta && split) ? (wave & 1) : (u & 1); };
+    // (BYTE offsets from the uniform base xin, 32 bits: the request then takes the scalar-base + 32-bit-lane-offset form; with element offsets every request carried a
+    //  64-bit shift-and-add, the product could overflow 32 bits for all the compiler knows)
+    auto ldb = [](const float* base, unsigned boff) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + boff); };
+    auto row_off = [&](int tile, int& flag2) {                  // byte offset of this lane's A row (+ its channel quad) in xin
       const int m = tile * 16 + arow;
       const int mi = m < 256 ? m : 255;
       const int xo = s_xoff[mi];
       const bool ok = m < M && xo >= 0;
-      flags = (ok ? 1 : 0) | (((s_prow[mi] >> 30) & 1) ? 2 : 0);
-      const float* xrow = xin + (ok ? xo : xsafe) + c4;                       // (a row that does not exist reads this team's first utterance, time 0: the taps reach back
-                                                                              //  into that utterance's own zero rows, never in front of the buffer)
+      flag2 = (ok && ((s_prow[mi] >> 30) & 1)) ? 1 : 0;
+      return (unsigned)((ok ? xo : xsafe) + c4) * 4u;
+    };
+    // chunk = eight consecutive k-groups (never across a tap: 24 h + 8 c is a multiple of 8): its tap and first channel group
+    auto chunk_off = [&](int h, int c) { const int g = 24 * h + 8 * c, tap = g >> 4; return (unsigned)(((tap == 0) ? to0 : ((tap == 1) ? to1 : 0)) + 16 * (g & 15)) * 4u; };
+    f32x4 acc0 = z4, acc1 = z4, s0 = z4, s1 = z4;
+    if (nu > 0) {
+      f32x4 ring[8];
+      int fl_cur = 0, fl_nxt = 0;
+      unsigned off_cur = row_off(unit_tile(0), fl_cur), off_nxt = off_cur;
+      {
+        const unsigned o = off_cur + chunk_off(unit_half(0), 0);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const int g = 6 * wave + i, tap = g >> 4;                              // wave-uniform
-        const int toff = (tap == 0) ? to0 : ((tap == 1) ? to1 : 0);
-        a[i] = *reinterpret_cast<const f32x4*>(xrow + toff + 16 * (g & 15));
+        for (int i = 0; i < 8; ++i) ring[i] = ldb(xin, o + 64u * i);
       }
-    };
-    auto fix_a = [&](f32x4 (&a)[6], const f32x4 (&raw)[6], int flags) {
+      if (p.ts && li == 0 && blockIdx.x == 0 && lane == 0) p.ts[60 + wave * 5] = wall_clock64();                      // (first requests out)
+      for (int u = 0; u < nu; ++u) {
+        const int tile = unit_tile(u), h = unit_half(u);
+        const bool more = u + 1 < nu;
+        const int hn = more ? unit_half(u + 1) : h;
+        if (more) off_nxt = row_off(unit_tile(u + 1), fl_nxt); else { off_nxt = off_cur; fl_nxt = fl_cur; }      // (the last unit re-requests its own first chunk: no branch around a load)
+        acc0 = z4; acc1 = z4;
+        // (software-pipelined by hand and pinned: the B operands of k-group n + 1 are requested from LDS in front of the MFMAs of k-group n, the A slot is refilled
+        //  behind them, and a scheduling barrier keeps the compiler from sinking either request to its use -- left alone it served the ring one load at a time.
+        //  What the form reaches: tools/micro/mfma_feed_lab.hip -- 38 cycles per MFMA per SIMD against 32 with register operands, one or two waves per SIMD alike; in
+        //  this kernel ~40 (per-wave unit stamps, DCTTS_TRACE).  Spreading the three requests behind single MFMAs (sched_group_barrier) gives 34.7 in the lab and nothing
+        //  here; the requests' coalescing is not it either: with every quad of lanes on one 64-byte line, and with every request on the same line, the layer took as long)
+        f32x4 b0 = *reinterpret_cast<const f32x4*>(wl + (24 * h) * 256), b1 = *reinterpret_cast<const f32x4*>(wl + (48 + 24 * h) * 256);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) a[i] = (!(flags & 1) || ((flags & 2) && ((6 * wave + i) >> 4) == 2)) ? z4 : raw[i];
-    };
-    // Two row tiles per pass: their 96 MFMAs per wave go back to back, then ONE barrier and one fixed-order reduction for both (in-kernel stamps:
-    // with one tile per pass a tile cost 2.9 us, 1.3 of them MFMA; the rest -- LDS round trip, barrier, address set-up -- is paid per pass).
-    // Round 4: software-pipelined by one pass -- the split-K reduction of pass k - 1 (LDS reads, adds, the pre-norm stores) sits in the same straight-line
-    // code as the MFMAs of pass k, so the matrix pipe works while the other wave of the SIMD (and this wave's own vector instructions) reduce: with
-    // "MFMAs, barrier, reduce" per pass a pass took 4.5-5 us, 2.56 of them MFMA on a SIMD shared by two waves (stamps).  Still one barrier per pass: pass k
-    // writes red[k & 1] while pass k - 1 is read from red[(k - 1) & 1], and pass k + 1 overwrites that copy only behind barrier k.
-    f32x4 a0[6], a1[6], n0[6], n1[6];
-    int f0 = 0, f1 = 0;
-    load_a(0, n0, f0); fix_a(a0, n0, f0);
-    if (ntile > 1) { load_a(1, n1, f1); fix_a(a1, n1, f1); }
-    auto reduce_store = [&](const int tile) {                                  // finish the pass that started at row tile `tile`
-      const float* rb = red[(tile >> 1) & 1];
-      float v0 = bias, v1 = bias;
+        for (int c = 0; c < 3; ++c) {
+          const int g0 = 24 * h + 8 * c;
+          const bool zero2 = (g0 >= 32) && fl_cur;                                            // the centre tap of a presum row belongs to the chain
+          const unsigned onext = (c < 2) ? off_cur + chunk_off(h, c + 1) : off_nxt + chunk_off(hn, 0);
+          const float* wg = wl + g0 * 256;
+          const float* wgn = (c < 2) ? wg + 8 * 256 : wl + (24 * hn) * 256;                  // the k-group behind this chunk's last one: the next chunk's / the next unit's first
 #pragma unroll
-      for (int w = 0; w < 8; ++w) { v0 += rb[((w * 2 + etile) * 4 + ej) * 64 + lane]; v1 += rb[4096 + ((w * 2 + etile) * 4 + ej) * 64 + lane]; }
-      const int me = tile * 16 + aq * 4 + ej;                                 // the rows this thread finishes
-      if (me < M && s_xoff[me] >= 0) pout[(long)(s_prow[me] & 0x3fffffff) * 512 + pcol] = v0;
-      if (tile + 1 < ntile && me + 16 < M && s_xoff[me + 16] >= 0) pout[(long)(s_prow[me + 16] & 0x3fffffff) * 512 + pcol] = v1;
-    };
-    for (int tile = 0; tile < ntile; tile += 2) {
-      const bool two = tile + 1 < ntile;                                      // uniform
-      if (tile + 2 < ntile) load_a(tile + 2, n0, f0);                         // the next pass's rows are in flight during this pass's MFMAs
-      if (tile + 3 < ntile) load_a(tile + 3, n1, f1);
-      f32x4 acc0 = z4, acc1 = z4, acc2 = z4, acc3 = z4;
+          for (int i = 0; i < 8; ++i) {
+            const float* wn = (i < 7) ? wg + (i + 1) * 256 : wgn;
+            const f32x4 nb0 = *reinterpret_cast<const f32x4*>(wn), nb1 = *reinterpret_cast<const f32x4*>(wn + 48 * 256);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 a = ring[i];
+            if (zero2) a = z4;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq0[i][e], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i][e], bq1[i][e], acc1, 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b0[e], acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b1[e], acc1, 0, 0, 0);
+            }
+            ring[i] = ldb(xin, onext + 64u * i);                                              // the slot is refilled behind the MFMAs that read it: eight k-groups ahead
+            __builtin_amdgcn_sched_barrier(0);
+            b0 = nb0; b1 = nb1;
+          }
         }
+        if (!(split && u >= 2 * ta)) {                                                        // a tile this wave finishes on its own
+          if (h == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0[j] = bias0 + acc0[j]; s1[j] = bias1 + acc1[j]; }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int me = tile * 16 + aq * 4 + j;                                            // D layout of the 16 x 16 tile: lane (column ecol, row group aq), register j = row 4 aq + j
+              const int mi = me < 256 ? me : 255;
+              if (me < M && s_xoff[mi] >= 0) {
+                float* o = pout + (long)(s_prow[mi] & 0x3fffffff) * 512 + grp * 16 + ecol;
+                o[0] = s0[j] + acc0[j]; o[256] = s1[j] + acc1[j];
+              }
+            }
+          }
+        }
+        off_cur = off_nxt; fl_cur = fl_nxt;
+        if (p.ts && li == 0 && blockIdx.x == 0 && lane == 0 && u < 4) p.ts[61 + wave * 5 + u] = wall_clock64();      // (DCTTS_TRACE: every wave's unit ends in the first GEMM layer)
       }
-      if (tile > 0) reduce_store(tile - 2);                                   // (between the two tiles' MFMAs: nothing here depends on them)
-      if (two) {
+    }
+    if (split) {                                                                               // the tiles a pair of waves shares: (bias + first half) + second half, as everywhere
+      const int tb_i = wave >> 1, tile = 8 * ta + tb_i;
+      if (nu_tail > 0 && (wave & 1)) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int j = 0; j < 4; ++j) { part[((tb_i * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; part[((tb_i * 2 + 1) * 4 + j) * 64 + lane] = acc1[j]; }
+      }
+      lds_barrier();
+      if (nu_tail > 0 && !(wave & 1)) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bq0[i][e], acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i][e], bq1[i][e], acc3, 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          const int me = tile * 16 + aq * 4 + j;
+          const int mi = me < 256 ? me : 255;
+          if (me < M && s_xoff[mi] >= 0) {
+            float* o = pout + (long)(s_prow[mi] & 0x3fffffff) * 512 + grp * 16 + ecol;
+            o[0] = (bias0 + acc0[j]) + part[((tb_i * 2 + 0) * 4 + j) * 64 + lane];
+            o[256] = (bias1 + acc1[j]) + part[((tb_i * 2 + 1) * 4 + j) * 64 + lane];
           }
         }
       }
-      float* rb = red[(tile >> 1) & 1];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        rb[((wave * 2 + 0) * 4 + j) * 64 + lane] = acc0[j]; rb[((wave * 2 + 1) * 4 + j) * 64 + lane] = acc1[j];
-        rb[4096 + ((wave * 2 + 0) * 4 + j) * 64 + lane] = acc2[j]; rb[4096 + ((wave * 2 + 1) * 4 + j) * 64 + lane] = acc3[j];
-      }
-      lds_barrier();                                                           // LDS only: the next pass's loads keep flying
-      fix_a(a0, n0, f0); fix_a(a1, n1, f1);
     }
-    reduce_store((ntile - 1) & ~1);                                            // the last pass
     // ---- the team's pre-norm rows of this layer are complete
     stamp();                                                                   // contraction done
     arrived += 16u;
@@ -309,26 +366,40 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     stamp();                                                                   // barrier passed
     const bool lastl = li + 1 == p.L;
     if (lastl && !p.tail_rows) break;                                          // the last layer only leaves its presum rows (unless its cone rows are somebody's input)
-    if (!lastl) load_w(li + 1, bq0, bq1);                                      // the next layer's slice lands while this layer's rows are normalised
-    // ---- layer-norm / gate / highway mix of the cone rows (offsets < 0): one wave per row, the team's 128 waves in turn
+    // ---- layer-norm / gate / highway mix of the cone rows (offsets < 0): one wave per row, the team's 128 waves in turn.  The next layer's weight slice is requested
+    //      BEHIND the wave's first row's operands (a wave's requests return in order: in front of them the row would wait for 12 KB of weights): every wave is past
+    //      the barrier behind this layer's last LDS read, and the barrier behind the row pass drains the request.
     const int Rb = R - 1;
-    if (Rb > 0) {
+    {
       float* xout = p.lay[li].xout;
       const long obs = p.lay[li].xout_bstride, or0 = p.lay[li].xout_row0; const int os = p.lay[li].xout_stride;
       const int c = lane * 4;
       // the layer's layer-norm parameters once, with the first row's requests (inside norm_hc_regs they were a second round trip per row)
       const float4 g1 = ld4(p.lay[li].g1 + c), be1 = ld4(p.lay[li].b1 + c), g2 = ld4(p.lay[li].g2 + c), be2 = ld4(p.lay[li].b2 + c);
-      for (int q = grp * 8 + wave; q < nb * Rb; q += 128) {
-        const int bl = q / Rb, r = q - bl * Rb;
-        const int m = bl * R + r;
-        const int xo = s_xoff[m];
-        if (xo < 0) continue;                                                  // wave-uniform: the row does not exist yet (t < 0)
-        const long prow = (long)(s_prow[m] & 0x3fffffff);
-        const float4 h1 = ld4(pout + prow * 512 + c), h2 = ld4(pout + prow * 512 + 256 + c);
-        const float4 xr = ld4(xin + xo + c);                                   // the layer's own input row (modules.py:171,193)
-        const float4 o = norm_hc_vals(h1, h2, xr, g1, be1, g2, be2);
-        const int t = (int)((long)xo / xs - ((long)(b0 + bl) * xbs + xr0));
-        *reinterpret_cast<float4*>(xout + ((long)(b0 + bl) * obs + or0 + t) * os + c) = o;
+      const int nrows = nb * Rb;
+      auto row_of = [&](int q, int& bl, int& xo, long& prow) {       // row q of the pass: its utterance, input offset (-1: does not exist), pre-norm row
+        const int qq = q < nrows ? q : 0;
+        bl = Rb > 0 ? qq / Rb : 0;
+        const int m = bl * R + (qq - bl * Rb);
+        xo = (q < nrows) ? s_xoff[m] : -1;
+        prow = (long)(s_prow[m] & 0x3fffffff);
+      };
+      int q = grp * 8 + wave, bl, xo; long prow;
+      row_of(q, bl, xo, prow);
+      float4 h1 = ld4(pout + prow * 512 + c), h2 = ld4(pout + prow * 512 + 256 + c);      // (a row that does not exist: a readable row, never stored)
+      float4 xr = ld4(xin + (xo >= 0 ? xo : xsafe) + c);                                    // the layer's own input row (modules.py:171,193)
+      if (!lastl) load_slice(li + 1, wave);
+      for (;;) {
+        if (xo >= 0) {                                                                       // wave-uniform
+          const float4 o = norm_hc_vals(h1, h2, xr, g1, be1, g2, be2);
+          const int t = (int)((long)xo / xs - ((long)(b0 + bl) * xbs + xr0));
+          *reinterpret_cast<float4*>(xout + ((long)(b0 + bl) * obs + or0 + t) * os + c) = o;
+        }
+        q += 128;
+        if (q >= nrows) break;
+        row_of(q, bl, xo, prow);
+        h1 = ld4(pout + prow * 512 + c); h2 = ld4(pout + prow * 512 + 256 + c);
+        xr = ld4(xin + (xo >= 0 ? xo : xsafe) + c);
       }
     }
     stamp();                                                                   // row pass done

@@ -60,7 +60,7 @@ struct XTailParams {
   //      earlier (K = 256: the centre tap; the older taps arrive as the side stream's presum), so that their row stays in LDS (and a chain piece was two launches; round 5: one)
   int np; int pad2;
   const float* pP0; const float* pstats0; const float* pg1; const float* pb1;      // C_1's pre-norm rows [b][256], partial statistics [b][16][4], layer-norm parameters
-  XTailP pl[3];
+  XTailP pl[4];                          // (round 6, NP = 4: HC_2 .. HC_5)
   float* xchp; float* schp; int xchp_set, schp_set;       // their exchange: [2][B_pad][512] pre-norm rows, [2][B_pad][16][4] statistics (xgroup_kernel's layout)
   unsigned* sig; unsigned sig_val;                        // first launch of a chain piece: *sig = sig_val ("every earlier piece of this stream is complete")
   const unsigned* wait2; unsigned wait_val;               // ... and the presums + cone rows come from the side stream: poll *wait2 >= wait_val first
@@ -102,8 +102,13 @@ constexpr int XT_LDR = 260;              // LDS row stride (floats) of the activ
 constexpr int XT_MAXM = 20;              // rows a team's layer can have (5 per utterance)
 
 // The kernel's body as a function (returns false for a workgroup that has nothing to do behind it: a passenger, a team without utterances)
-template <bool TS = false>
+// NP (merged form): how many newest-row layers run in front of the cone layers -- 3 (rounds 4-5: HC_2 .. HC_4, then HC_5 .. HC_7 over 5 / 3 / 1 rows) or 4 (round 6:
+// HC_2 .. HC_5, then HC_6 / HC_7 over 3 / 1 rows: HC_5's four older cone rows and its presum moved to the side stream's xcone_kernel, which has the time since
+// its GEMM layers run from LDS-resident weight slices; the chain's HC_5 drops from a K = 768 contraction over 20 rows with 60 staged input rows to a newest-row layer).
+template <bool TS = false, int NP = 3>
 __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
+  static_assert(NP == 3 || NP == 4, "three or four newest-row layers");
+  constexpr int NH = 6 - NP;             // cone layers behind them
   __shared__ __attribute__((aligned(16))) float lds_rows[(60 + XT_MAXM) * XT_LDR];
   float* const bufA = lds_rows;                          // the first layer's input rows (4 x 15), later the second layer's output (4 x 3)
   float* const bufB = lds_rows + 60 * XT_LDR;            // the first layer's output (4 x 5), later the third layer's (4 x 1)
@@ -278,7 +283,7 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
       stamp();                                             // first row built (the wait for the side stream is in here)
       auto player = [&](auto GC) {
         constexpr int g = decltype(GC)::value;
-        constexpr bool lastp = (g == 2);
+        constexpr bool lastp = (g == NP - 1);
         f32x4 acc0 = z4, acc1 = z4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -380,9 +385,14 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
       player(std::integral_constant<int, 1>{});
       load_w3(std::integral_constant<int, 2>{}, p.hc[0].wp, wA0, wA1);
       stage_put(0);
-      stage_req(4);
-      player(std::integral_constant<int, 2>{});
-      stage_put(4);
+      if constexpr (NP == 3) {
+        stage_req(4);
+        player(std::integral_constant<int, 2>{});
+        stage_put(4);
+      } else {                                             // (the first cone layer's 4 x 5 input rows fit the first half's four sweeps)
+        player(std::integral_constant<int, 2>{});
+        player(std::integral_constant<int, 3>{});
+      }
       __syncthreads();
     } else {
       // the newest input row of every utterance: producer's pre-norm row + partial statistics + residual (an earlier launch: plain loads)
@@ -587,10 +597,18 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
       stamp();                                             // output rows rebuilt
     };
     // (the host checks the shape this is unrolled for: 5 / 3 / 1 rows per utterance)
-    hlayer(std::integral_constant<int, 3>{}, 0, bufA, bufB, wA0, wA1, [&]() { load_w(p.hc[1].wp, wB0, wB1); });
-    hlayer(std::integral_constant<int, 2>{}, 1, bufB, bufA, wB0, wB1, [&]() { load_w4(p.hc[2].wp, wA0, wA1); });
-    hlayer(std::integral_constant<int, 1>{}, 2, bufA, bufB, wA0, wA1, [&]() { load_c0(); });
-    const float* const bin = bufB;
+    const float* bin_;
+    if constexpr (NH == 3) {
+      hlayer(std::integral_constant<int, 3>{}, 0, bufA, bufB, wA0, wA1, [&]() { load_w(p.hc[1].wp, wB0, wB1); });
+      hlayer(std::integral_constant<int, 2>{}, 1, bufB, bufA, wB0, wB1, [&]() { load_w4(p.hc[2].wp, wA0, wA1); });
+      hlayer(std::integral_constant<int, 1>{}, 2, bufA, bufB, wA0, wA1, [&]() { load_c0(); });
+      bin_ = bufB;
+    } else {                                               // (host-checked shape: 3 / 1 rows per utterance out of 5 / 3 input rows)
+      hlayer(std::integral_constant<int, 2>{}, 0, bufA, bufB, wA0, wA1, [&]() { load_w4(p.hc[1].wp, wB0, wB1); });
+      hlayer(std::integral_constant<int, 1>{}, 1, bufB, bufA, wB0, wB1, [&]() { load_c0(); });
+      bin_ = bufA;
+    }
+    const float* const bin = bin_;
     // `bin` now holds one row per utterance (row u): the input of the first k = 1 layer
 
     // ---- the k = 1 layers (xmlp_kernel.h's loop)
@@ -717,8 +735,8 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
 }
 
 // grid: 128 blocks of 512 threads, whatever the batch (+ the passengers)
-template <bool TS = false>
-__global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restrict__ pp) { (void)xtail_body<TS>(pp); }
+template <bool TS = false, int NP = 3>
+__global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restrict__ pp) { (void)xtail_body<TS, NP>(pp); }
 
 // Round 5: a chain piece as ONE launch -- xtail_kernel's layers (AudioDec behind C_1, the k = 1 layers around the mel frame), the team's barrier, then xgroup_kernel's
 // AudioEnc run of the next frame + attention row + AudioDec C_1.  What the launch boundary between them cost: ~1.7 us of gap + ~3 us until xgroup_kernel's first row was
@@ -729,9 +747,9 @@ __global__ void __launch_bounds__(512) xtail_kernel(const XTailParams* __restric
 // the AudioEnc run reads was written one launch earlier (decode_host.h: v3_xtail_table).
 // Measured (B = 32, one box, A/B): 80.4 -> 78.8 us per frame.  Tried on top and worth nothing: the attention tail's operands requested in front of the AudioEnc
 // run's first layer; this frame's XGroupParams entry and the next frame's XTailParams entry touched at the launch's start (first-touch scalar loads).
-template <bool TS = false>
+template <bool TS = false, int NP = 3>
 __global__ void __launch_bounds__(512) xchain_kernel(const XTailParams* __restrict__ pt, const XGroupParams* __restrict__ pg) {
-  if (!xtail_body<TS>(pt)) return;
+  if (!xtail_body<TS, NP>(pt)) return;
   typedef const __attribute__((address_space(4))) XTailParams CP;
   CP& p = *(CP*)pt;
   const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;

@@ -36,7 +36,7 @@ def find(rows, prefix):
     return hits
 
 
-@pytest.mark.parametrize("kernel", ["xchain_kernel<false>", "xtail_kernel<false>", "xgroup_kernel<false>", "dctts::xcone_kernel"])
+@pytest.mark.parametrize("kernel", ["xchain_kernel<false, 4>", "xchain_kernel<false, 3>", "xtail_kernel<false, 4>", "xtail_kernel<false, 3>", "xgroup_kernel<false>", "dctts::xcone_kernel"])
 def test_team_kernels_do_not_spill(table, kernel):
     for name, r in find(table, kernel).items():
         assert r["scratch"] == 0, f"{name}: {r['scratch']} bytes of scratch per lane"

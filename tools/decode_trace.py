@@ -11,7 +11,8 @@ from dc_tts_amd.hyperparams import hp
 from dc_tts_amd.weights import synthetic_weights, synthetic_text
 eng = Engine(synthetic_weights(hp), hp, decode_graph=int(os.environ.get("GM", "0")))
 eng.set_decode_mode(int(os.environ.get("DM", "3")))
-L = torch.from_numpy(synthetic_text(hp, B=32)).cuda()
+L = torch.from_numpy(synthetic_text(hp, B=int(os.environ.get("TB", "32")))).cuda()
+if os.environ.get("HP"): torch.cuda.set_stream(torch.cuda.Stream(priority=-1))      # a high-priority caller's stream: the decode's chain runs on it directly
 eng.text2mel(L); torch.cuda.synchronize()
 eng.text2mel(L); torch.cuda.synchronize()
 print(open(out).read())
