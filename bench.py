@@ -202,6 +202,36 @@ def vocoder_section(hp, Z, ms_synth, with_cpu):
     return out
 
 
+def xcone_phase_stamps(eng, L, T):
+    """In-kernel wall-clock stamps (100 MHz) of ONE side-stream launch of a steady-state frame (dctts_debug_set_trace): the two row phases and, per GEMM
+    layer, contraction / barrier / row pass / barrier.  Returns microseconds: {"row_phases", "gemm" (sum of the layers' contraction phases incl. their row tables),
+    "row_passes_and_barriers", "launch"} or None."""
+    import tempfile
+    frame = min(150, T - 2)
+    if frame < 100:
+        return None
+    path = os.path.join(tempfile.gettempdir(), f"dctts_bench_trace_{os.getpid()}.txt")
+    try:
+        eng.debug_set_trace(frame, path)
+        eng.text2mel(L); torch.cuda.synchronize()
+        eng.debug_set_trace(-1)
+        eng.text2mel(L); torch.cuda.synchronize()             # (back on the production instantiations, tables rebuilt)
+        lines = open(path).read().splitlines()
+        os.remove(path)
+    except Exception as e:                                   # a measurement aid: never fatal
+        print(f"[bench] in-kernel stamps unavailable: {e}", file=sys.stderr)
+        return None
+    for i, ln in enumerate(lines):
+        if ln.startswith("# xcone_kernel") and i + 1 < len(lines):
+            v = [float(x) for x in lines[i + 1].split("(")[0].split()]
+            if len(v) < 8 or (len(v) - 4) % 4:
+                return None
+            gemm = sum(v[4 + 4 * k] - v[3 + 4 * k] for k in range((len(v) - 4) // 4))
+            return {"row_phases": round(v[3], 2), "gemm": round(gemm, 2), "row_passes_and_barriers": round(v[-1] - v[3] - gemm, 2), "launch": round(v[-1], 2),
+                    "gemm_layers": (len(v) - 4) // 4, "frame": frame}
+    return None
+
+
 def timed(fn, reps=3):
     fn(); torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -366,6 +396,20 @@ def main():
     if rank == 0 and world > 1:
         assert gathered is not None and tuple(gathered.shape) == (world * B, Z.shape[1], Z.shape[2])
 
+    # ---- placement: where a 128-block launch lands (the team kernels' speed rests on blocks b, b + 8, ... sharing an XCD and on 256 co-resident workgroups;
+    #      their correctness does not), and whether THIS rank's timed decodes ran on the team kernels -- from every rank, not only rank 0
+    xcc, n_cu = eng.debug_xcd_census()
+    k0 = int(xcc[0])
+    nx = int(xcc.max()) + 1
+    mine = {"rank": rank, "decode_team_kernels": fallback is None, "status_report": fallback, "compute_units": n_cu, "xcds_seen": int(len(set(xcc.tolist()))),
+            "blocks_b_and_b_plus_8_share_an_xcd": bool(all(int(xcc[b]) == int(xcc[b % 8]) for b in range(128))),
+            "round_robin_from_block_0": bool(nx > 1 and all(int(xcc[b]) == (k0 + b) % nx for b in range(128))),
+            "team_kernels_state_bits": eng.debug_team_kernels_state()}
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine, group=host_group)
+    else:
+        ranks = [mine]
     if rank == 0:
         frames = world * B * T * args.steps
         value = frames / elapsed
@@ -373,37 +417,51 @@ def main():
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         d = hp.d
         # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r05_kernel_stats.md): xcone_kernel, AudioDec HC_3 and HC_4
-        #      over the rows of a frame's dependency cone (45 and 15 rows per utterance incl. the presum row) + their layer-norm / gate passes (round 4:
-        #      HC_5 .. HC_7 moved to the chain's xtail_kernel), one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one
+        #      (round 6: and HC_5) over the rows of a frame's dependency cone (45 / 15 / 5 rows per utterance incl. the presum row) + their layer-norm / gate passes
+        #      (HC_6, HC_7 run on the chain), one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one
         #      layer: a (3 x 256) x 512 fp32 contraction = 2 * 768 * 512 FLOP; algorithmic bytes of a launch = the rows in and out (256 channels each) +
-        #      the two layers' weights once.
+        #      the layers' weights once.
         row_flop = 2.0 * 3 * d * 2 * d
         roof = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None,
-                "kernel": "xcone_kernel: AudioDec HC_3 and HC_4 (256 ch, k = 3, dilations 3 / 9) over the rows of a frame's dependency cone "
-                          "(45 / 15 rows per utterance) + their layer-norm / gate row passes, ONE launch per frame on the decode's side stream (round 5: the launch also carries AudioDec C_1 / HC_2 over their cone rows as its "
-                          "first two team phases -- row operations that were two launches of their own; the FLOP count here is the GEMM layers' alone): 16x16x4 fp32 "
-                          "MFMA, a 16-workgroup team per four utterances inside one XCD, each workgroup keeps its 96 KB weight slice in registers "
-                          "(the cone's last three layers, 5 / 3 / 1 rows per utterance, run on the chain since round 4: kernels[] has xchain_kernel)",
+                "kernel": "xcone_kernel: AudioDec HC_3, HC_4 and (round 6) HC_5 (256 ch, k = 3, dilations 3 / 9 / 27) over the rows of a frame's dependency cone "
+                          "(45 / 15 / 5 rows per utterance incl. the chain's presum row) + their layer-norm / gate row passes, ONE launch per frame on the decode's side stream; the launch "
+                          "also carries AudioDec C_1 / HC_2 over their cone rows as its first two team phases (row operations; the FLOP count here is the GEMM layers' alone).  "
+                          "16x16x4 fp32 MFMA, a 16-workgroup team per four utterances inside one XCD; round 6: a layer's 96 KB weight slice lives in LDS (global_load_lds) and a wave "
+                          "contracts whole row tiles against it -- no split-K exchange inside a layer (rounds 3-5: slice in registers, K split over the waves, an LDS reduction per pass).  "
+                          "The cone's last two layers (3 / 1 rows per utterance) run on the chain: kernels[] has xchain_kernel",
                 "launches": n_chain, "sampled": "every 16th frame from frame 100 on (full-size cones) of the timed region, HIP events on the side stream",
                 "avg_launch_ms": None, "rows_per_launch": None, "flop_per_row": row_flop,
                 "note": "runs concurrently with the chain's kernels on the other half of the CUs (128 of 256: at most 0.5 of the roof); its launch ends with "
                         "the team leaders polling the chain's counter, so the event-timed duration includes that wait whenever the chain is the longer stream "
-                        "(the two are within 2 us of each other: DESIGN.md section 2); the GEMM layers' work itself is ~48 us, the two row phases ~15 (in-kernel stamps, "
-                        "profiles/r05_decode_trace.txt)"}
+                        "(DESIGN.md section 2).  `frac` prices the WHOLE event-timed launch against the GEMM layers' FLOPs; `frac_gemm_phase` prices the GEMM layers' own phases "
+                        "(in-kernel stamps of one launch, `phases_us`) -- the figure that says how well the contraction itself runs"}
         if n_chain > 0 and chain_layers > 0:
             avg = chain_ms / n_chain
             rpl = chain_layers / n_chain
-            alg_bytes = 4.0 * (rpl * (d + d) + 2 * 3 * d * 2 * d)
+            n_gemm_layers = 3 if rpl / B > 62 else 2                               # 45 + 15 (+ 5) rows per utterance
+            alg_bytes = 4.0 * (rpl * (d + d) + n_gemm_layers * 3 * d * 2 * d)
             tf = row_flop * rpl / (avg * 1e-3) / 1e12
             roof.update(avg_launch_ms=round(avg, 5), rows_per_launch=round(rpl, 1), flop_per_launch=row_flop * rpl, algorithmic_bytes_per_launch=alg_bytes,
                         achieved=round(tf, 3), frac=round(tf / PEAK_F32_MFMA_TFLOPS, 4),
                         frac_hbm=round(alg_bytes / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 5))
-        tj = os.path.join(ROOT, "profiles", "r05_pmc_decode.json")
-        if os.path.exists(tj):
-            pj = json.load(open(tj))
-            if "xcone_kernel" in pj:
-                roof["traffic"] = pj["xcone_kernel"]["hbm_bytes_per_launch"]
-                roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes on this tree: profiles/r05_pmc_decode.json; includes Infinity-Cache hits)"
+        # (a) the launch also carries the two row phases (no MFMA work) and its barriers / row passes: the GEMM layers' own phases from in-kernel stamps of one
+        #     steady-state launch (an untimed extra decode), so that `frac` (whole launch, event-timed) and `frac_gemm_phase` can be told apart
+        if chain_prof and not args.no_extras and roof.get("flop_per_launch"):
+            st = xcone_phase_stamps(eng, L, T)
+            if st:
+                tfg = roof["flop_per_launch"] / (st["gemm"] * 1e-6) / 1e12
+                roof.update(phases_us=st, achieved_gemm_phase=round(tfg, 3), frac_gemm_phase=round(tfg / PEAK_F32_MFMA_TFLOPS, 4),
+                            frac_gemm_phase_of_the_128_cus_the_kernel_owns=round(2 * tfg / PEAK_F32_MFMA_TFLOPS, 4))
+        for tag in ("r06", "r05"):
+            tj = os.path.join(ROOT, "profiles", f"{tag}_pmc_decode.json")
+            if os.path.exists(tj):
+                pj = json.load(open(tj))
+                if "xcone_kernel" in pj:
+                    roof["traffic"] = pj["xcone_kernel"]["hbm_bytes_per_launch"]
+                    roof["traffic_unit"] = (f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes: profiles/{tag}_pmc_decode.json; includes Infinity-Cache hits).  "
+                                            "Form: counter collection serialises queues, so under it the two decode streams meet through events (DCTTS_SYNC_VALUES=0) and a chain piece runs as "
+                                            "the split launches; xcone_kernel itself is the shipping kernel" + ("" if tag == "r06" else " of ROUND 5 (register-resident weight slices, HC_3 / HC_4 only)"))
+                break
         flop_frame = 2 * 3.0789e9 / T + 8.167e6 + 142.254e6 + 0.26e6 + 187.310e6      # SURVEY 8d, per mel frame and utterance
         out = {
             "metric": "mel frames/sec (Text2Mel->SSRN, LJ hyper-parameters)", "value": round(value, 1), "unit": "mel frames/s",
@@ -413,13 +471,13 @@ def main():
             "config": {"workload": f"full Text2Mel autoregressive decode + SSRN, batch={B}/GPU, max_N={hp.max_N}, "
                                    f"max_T={T} mel frames -> ({B},{4 * T},{hp.n_linear}) per GPU; exact-parity incremental decode",
                        "batch_per_gpu": B, "max_N": hp.max_N, "max_T": T, "decode_mode": args.decode_mode, "decode_graph_mode": gm,
-                       "decode_team_kernels": fallback is None,
+                       "decode_team_kernels": all(r["decode_team_kernels"] for r in ranks),
                        "caller_stream": "a high-priority HIP stream (the decode's chain launches run on the caller's stream when it has the highest priority; from a "
                                         "default-priority stream the library moves them to its own high-priority stream between two events: +0.1 ms per decode)",
                        "sharding": f"{world} x {B} utterances, no collective"},
             "pipeline_tflops": round(value * flop_frame / 1e12, 2),
             "pipeline_frac_of_f32_mfma_peak": round(value * flop_frame / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
-            "roofline": roof, "device_bytes": eng.device_bytes(),
+            "roofline": roof, "device_bytes": eng.device_bytes(), "placement": ranks,
             "gather": {"what": "every rank's Z (B,4T,1025) -> its pinned host buffer (D2H) -> rank 0's host over gloo (SURVEY 8e); one rank: the D2H copy",
                        "bytes_per_rank": Z.numel() * 4, "seconds": round(gather_s, 5),
                        "value_incl_gather": round(world * B * T / (elapsed / args.steps + gather_s), 1),
@@ -500,6 +558,20 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
         "ssrn": both_roofs(B * T * 187.310e6, B * (67200 + 3444000) + 113641532.0, ms_ssrn),
     }
     res["roofline_frac_decode_phase_mfma"] = res["phase_rooflines"]["decode"]["frac_mfma"]
+    # ---- (c) what the step costs when the team kernels are OFF (one launch per layer, what a decode falls back to when a team is not on one XCD or the bounded waits
+    #      give up -- e.g. a partition mode with fewer CUs than 128 + 128 workgroups): one untimed extra pass, so that a fallback on another node is interpretable
+    if args.decode_mode == 3:
+        eng.set_team_kernels(False)
+        try:
+            ms_fb = timed(lambda: eng.synthesize(L), reps=2)
+            eng.decode_status()
+            Yf, Zf, mf = eng.synthesize(L); torch.cuda.synchronize()
+            res["fallback"] = {"what": "dctts_set_team_kernels(0): every decode layer a launch of its own (chain3_kernel / hbulk_kernel / row kernels), the two streams as before",
+                               "ms_per_step": round(ms_fb, 3), "mel_frames_per_s": round(B * T / (ms_fb * 1e-3), 1), "vs_team_kernels": round(ms_step / ms_fb, 3),
+                               "max_abs_dY_vs_team_kernels": float((Yf - Y).abs().max())}
+        finally:
+            eng.set_team_kernels(True)
+        eng.synthesize(L); torch.cuda.synchronize(); eng.decode_status()
     # ---- kernels: event-timed extra passes
     kern = []
     eng.prof_enable(PROF_SSRN_HC)

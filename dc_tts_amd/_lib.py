@@ -54,6 +54,8 @@ SYMBOLS = {
     "dctts_debug_layer": (c_int, [c_void_p, ctypes.c_char_p, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dctts_debug_seed_prev_max": (c_int, [c_void_p, c_void_p, c_int]),
     "dctts_debug_copy": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "dctts_debug_set_trace": (c_int, [c_void_p, c_int, ctypes.c_char_p]),
+    "dctts_debug_xcd_census": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "dctts_prof_enable": (c_int, [c_void_p, c_int]),
     "dctts_prof_collect": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_double)]),
     "dctts_prof_rows": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_longlong)]),

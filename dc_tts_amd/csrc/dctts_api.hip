@@ -258,7 +258,7 @@ struct dctts_ctx {
   // HC_2 .. HC_4 as an xgroup_kernel launch in front; 1 = xmlp_kernel: the seven k = 1 layers in team form (HC_5 .. HC_7 stay split between the chain's run
   // and the side stream); 0 = mlp_rows_kernel (round 2: split by rows); 3 / 4: A/B forms (tools/README.md)
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
-  int tail_np = 4, np_eff = 3;         // round 6 (DCTTS_TAIL_NP): newest-row layers in front of the chain launch's cone layers: 4 = HC_2 .. HC_5 (HC_5's older cone rows on the side stream: xcone_kernel runs HC_3 .. HC_5),
+  int tail_np = 4, np_eff = 3;         // round 6 (DCTTS_CHAIN_TAIL=7 selects 3): newest-row layers in front of the chain launch's cone layers: 4 = HC_2 .. HC_5 (HC_5's older cone rows on the side stream: xcone_kernel runs HC_3 .. HC_5),
                                        //   3 = rounds 4-5 (HC_2 .. HC_4; the side stream stops behind HC_4); np_eff: what this decode uses (the merged forms only)
   bool chain_one = false;              // round 5 (chain_tail == 2): a chain piece is ONE launch -- xtail_kernel's layers, a team barrier, the AudioEnc run + attention + C_1 (xchain_kernel); 6: two launches (round 4)
   bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (chain_tail 2 and 6)
@@ -365,7 +365,10 @@ static int get_w(dctts_ctx* c, const std::string& name, const std::vector<int64_
 // every decode launch touches a different layer's weights and buffers, and with one allocation per tensor each launch
 // started with address-translation misses (large contiguous arenas map with big pages and stay within TLB reach).
 static const size_t ARENA_CHUNK = (size_t)512 << 20;      // weights: one context-lifetime pool
-static const size_t WS_CHUNK = (size_t)64 << 20;          // workspaces: one pool per (prefix, geometry) -- a small geometry (B = 1) must not cost 3 x 512 MiB; bigger buffers get an arena of their own size
+#ifndef WS_CHUNK_MB
+#define WS_CHUNK_MB 64
+#endif
+static const size_t WS_CHUNK = (size_t)WS_CHUNK_MB << 20;          // workspaces: one pool per (prefix, geometry) -- a small geometry (B = 1) must not cost 3 x 512 MiB; bigger buffers get an arena of their own size
 // `zero_on`: a workspace arena is zero-filled on the stream of the call that creates it (ordered in front of that call's kernels; calls from other streams are ordered
 // behind it by the use groups); nullptr (weights, at dctts_weights_finalize): a synchronous fill.
 static int arena_alloc(dctts_ctx* c, std::vector<Arena>& pool, size_t bytes, void** out, const hipStream_t* zero_on = nullptr) {
@@ -374,7 +377,15 @@ static int arena_alloc(dctts_ctx* c, std::vector<Arena>& pool, size_t bytes, voi
   const size_t chunk = zero_on ? WS_CHUNK : ARENA_CHUNK;
   Arena a; a.size = bytes > chunk ? bytes : chunk; a.used = bytes;
   HIPALLOC(hipMalloc(&a.base, a.size));
-  if (zero_on) HIPCHK(hipMemsetAsync(a.base, 0, a.size, *zero_on)); else HIPCHK(hipMemset(a.base, 0, a.size));
+  if (zero_on) {
+    HIPCHK(hipMemsetAsync(a.base, 0, a.size, *zero_on));
+#ifndef WS_ZERO_NOSYNC
+    // ... and the fill has COMPLETED when the first call at a new geometry goes on (round 6): with 64 MiB arenas a decode variant's first run at a new batch size
+    // came out wrong (tools/flaky_probe.py: not with 512 MiB arenas, not on any later run) -- the fill and the decode's two own streams, although ordered through
+    // events, see dev_zero_now.  One stream synchronisation per NEW arena, i.e. on the first call of a shape; nothing on the calls that find their buffers.
+    HIPCHK(hipStreamSynchronize(*zero_on));
+#endif
+  } else HIPCHK(hipMemset(a.base, 0, a.size));
   pool.push_back(a);
   *out = a.base;
   return 0;
@@ -568,7 +579,8 @@ static std::vector<std::vector<int>> audiodec_cone(const std::vector<DevLayer>& 
 static void read_env(dctts_ctx* c) {
   auto geti = [](const char* n, int* v) { if (const char* e = getenv(n)) *v = atoi(e); };
   geti("DCTTS_SYNC_VALUES", &c->sync_values); geti("DCTTS_CHAIN_WAIT", &c->chain_wait_inkernel); geti("DCTTS_XGROUP", &c->xgroup); geti("DCTTS_XCONE", &c->xcone); geti("DCTTS_CHAIN_TAIL", &c->chain_tail);
-  geti("DCTTS_TAIL_NP", &c->tail_np); geti("DCTTS_TRACE", &c->trace_frame); geti("DCTTS_PIECETIME", &c->piecetime);
+  geti("DCTTS_TRACE", &c->trace_frame);
+  if (c->chain_tail == 7) { c->chain_tail = 2; c->tail_np = 3; }      // 7 = the default form with round 5's split of the cone (A/B) geti("DCTTS_PIECETIME", &c->piecetime);
   if (const char* e = getenv("DCTTS_TRACE_FILE")) c->trace_file = e;
   // rocprofv3 --pmc serialises dispatches ACROSS queues: a launch that polls the other stream's counter would never see it move
   // (it only times out, with wrong results).  Under counter collection the two decode streams meet through events instead.
@@ -1272,6 +1284,33 @@ extern "C" int dctts_debug_seed_prev_max(dctts_ctx* c, const int32_t* prev_max, 
   for (int b = 0; b < B; ++b) if (prev_max[b] < 0 || prev_max[b] >= c->cfg.max_N) return fail(DCTTS_ERR_ARG, "seed_prev_max: values must lie in [0, max_N)");
   std::lock_guard<std::recursive_mutex> lk_(c->mu);
   c->init_pm.assign(prev_max, prev_max + B);
+  return 0;
+}
+
+extern "C" int dctts_debug_set_trace(dctts_ctx* c, int frame, const char* file) {
+  if (!c) return fail(DCTTS_ERR_ARG, "null ctx");
+  std::lock_guard<std::recursive_mutex> lk_(c->mu);
+  c->trace_frame = frame < 0 ? -1 : frame;                  // (the decode's tables are keyed by it: the next decode builds the ones that carry the stamp buffer)
+  c->trace_file = (frame >= 0 && file) ? file : "";
+  return 0;
+}
+
+__global__ void xcd_census_kernel(int* __restrict__ out) {
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)xg_xcc_id();
+}
+extern "C" int dctts_debug_xcd_census(dctts_ctx* c, int32_t* xcc128, int32_t* n_cu, void* stream) {
+  if (!c || !xcc128) return fail(DCTTS_ERR_ARG, "xcd_census: null argument");
+  DevGuard dev_guard(c);
+  if (!dev_guard.ok) return fail(DCTTS_ERR_HIP, "hipSetDevice");
+  int* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, 128 * sizeof(int)));
+  hipLaunchKernelGGL(xcd_census_kernel, dim3(128), dim3(512), 0, (hipStream_t)stream, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(xcc128, d, 128 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(d);
+  HIPCHK(e);
+  if (n_cu) *n_cu = c->n_cu;
   return 0;
 }
 

@@ -655,7 +655,7 @@ static int v3_xgroup_launch(dctts_ctx* c, int B, int piece, int net, hipStream_t
 static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool insig) {
   const bool fold = c->side_fold && c->cone_len[0] - 1 <= 96 && c->cone_len[1] <= 96 && c->audiodec.size() > 1 && c->audiodec[1].wpp && c->audiodec[1].tap_off[1] == -1;
   c->side_fold = fold;
-  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string(c->np_eff) +
+  const std::string g = geom("xc", B, T) + ":" + std::to_string((size_t)w.pb3[2]) + ":" + std::to_string((size_t)w.ad[1].p) + ":" + std::to_string((size_t)c->xg_mem) + ":" + std::to_string((int)insig) + ":" + std::to_string((size_t)c->wait_ctr) + ":" + std::to_string((int)c->tail_on) + ":" + std::to_string(c->np_eff) + ":" + std::to_string(c->trace_frame) +
                         ":" + std::to_string((int)fold) + ":" + std::to_string((int)c->ae_pass) + ":" + std::to_string((size_t)w.kv.p) + ":" + std::to_string((size_t)w.vw) + ":" + std::to_string((size_t)w.pm_all) + ":" + std::to_string((size_t)w.scal.p);
   if (c->xc_tab && c->xc_geom == g) return 0;
   { dctts_ctx::TabSlot ts; if (tab_lookup(c, "xc", g, &ts)) { c->xc_tab = ts.tab; c->xc_geom = g; return 0; } }

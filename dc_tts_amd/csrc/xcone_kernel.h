@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       // 512 threads), 2 x 2 in the others.
       rowhc2_stage(cb, b, pm, s_c, s_v, tid_a, 512);
       // ... and neither does the first GEMM layer's weight slice (round 6: 96 KB per workgroup into `wlds`, 12 one-KB pieces per wave): its first half is requested
-      // behind them and drained by this phase's barrier, the second half behind phase B's last row's operands
+      // behind them and drained by this phase's barrier, the second half at the start of phase B
       load_slice(0, wave, 0, 6);
       if (wave < 2) asm volatile("s_waitcnt vmcnt(12)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
       else asm volatile("s_waitcnt vmcnt(10)" : "+v"(vq[0]), "+v"(vcq[0]), "+v"(vq[1]), "+v"(vcq[1]), "+v"(vq[2]), "+v"(vcq[2]) :: "memory");
@@ -187,11 +187,15 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
           if (!ok && lane_b == 0) atomicOr(ca.wait_err, 1);
         }
       }
+      // The slice's second half: requested HERE, in straight-line code in front of the rows, drained by the barrier behind this phase.  NOT inside the row loop
+      // below (behind the last row's operands, where it would cost that row nothing): in that place -- one iteration of a loop the compiler keeps rolled -- the
+      // FIRST decodes at a new geometry came out wrong in a quarter of the cases (tools/flaky_probe.py: 7 of 32, with the slice re-requested in front of the
+      // GEMM as well, i.e. not through the LDS copy), none in 32 with the request outside the loop or whole in phase A.
+      load_slice(0, wave_b, 6, 12);
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         RowHc2Row cur;
         rowhc2_load(cb, b, q4 * 8 + wave_b + 32 * i, lane_b, cur);
-        if (i == 2) load_slice(0, wave_b, 6, 12);                        // the slice's second half, behind this wave's last row's operands: drained by the barrier behind this phase
         if (uok && cur.live) rowhc2_finish(cb, b, pm, cur, ln, s_c, s_v, lane_b);
       }
     }

@@ -229,6 +229,16 @@ class Engine:
         """Test hook (dctts_hip_debug.h): the next decode reports a failure and poisons its outputs."""
         self._ok(self.lib.dctts_debug_inject_decode_error(self._h, int(bits)))
 
+    def debug_set_trace(self, frame: int, path: Optional[str] = None):
+        """Measurement hook (dctts_hip_debug.h): decodes that follow write frame `frame`'s in-kernel stamps to `path`; frame < 0 switches it off."""
+        self._ok(self.lib.dctts_debug_set_trace(self._h, int(frame), None if path is None else path.encode()))
+
+    def debug_xcd_census(self):
+        """Measurement hook (dctts_hip_debug.h): (XCD of each block of a 128-block launch, compute units of the device)."""
+        a = np.zeros(128, np.int32); n = ctypes.c_int(0)
+        self._ok(self.lib.dctts_debug_xcd_census(self._h, a.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n), self._stream()))
+        return a, n.value
+
     def text2mel(self, L: torch.Tensor, max_T: Optional[int] = None, alignments: bool = False, check: bool = False):
         """The autoregressive loop of synthesize.py:45-54.  Returns (Y (B,T,n_mels), max_attentions (B,T) int64) and, with
         alignments=True, `g.alignments` (B,N,T) as the loop's last step fetches it (synthesize.py:48)."""

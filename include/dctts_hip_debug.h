@@ -31,6 +31,16 @@ int dctts_debug_inject_decode_error(dctts_ctx* ctx, int bits);
  * dctts_decode_status).  A checked decode's safe retry (dctts_decode_safe_once) must leave this word exactly as it found it. */
 int dctts_debug_team_kernels_state(dctts_ctx* ctx);
 
+/* Measurement hook (bench.py: roofline.frac_gemm_phase): what DCTTS_TRACE / DCTTS_TRACE_FILE do, at run time -- decodes that follow write the in-kernel
+ * wall-clock stamps of frame `frame`'s launches (xchain_kernel's two parts, xcone_kernel: phase boundaries, and every wave's unit ends in its first GEMM layer)
+ * to `file`; frame < 0 switches it off.  The traced frame's launches are the stamped instantiations; every other frame runs the production kernels. */
+int dctts_debug_set_trace(dctts_ctx* ctx, int frame, const char* file);
+
+/* Measurement hook (bench.py: `placement`): where the device puts the workgroups of a 128-block launch -- xcc[b] = the XCD (HW_REG_XCC_ID) block b ran on -- and the
+ * compute units the device reports.  The decode's team kernels are fast when blocks b, b + 8, b + 16, ... share an XCD and 128 + 128 workgroups of 512 threads are
+ * co-resident (one per CU); they are CORRECT either way (a split team is detected and that decode repeated one launch per layer). */
+int dctts_debug_xcd_census(dctts_ctx* ctx, int32_t* xcc128, int32_t* n_cu, void* stream);
+
 /* Calibration aid for the HBM PMC counters: float4 copy of nfloats floats (nfloats % 4 == 0) on `stream`. */
 int dctts_debug_copy(const float* src, float* dst, size_t nfloats, void* stream);
 

@@ -386,6 +386,35 @@ def test_decode_stream_meeting_variants(weights, knob):
     eng.close()
 
 
+def test_first_decodes_at_new_geometries_with_fresh_inputs(weights):
+    """What the other decode tests cannot see: they decode the SAME text several times at one geometry, so a kernel that reads a buffer before its producer has
+    written it finds the previous decode's identical values there, and only the very first decode at a new geometry (new, zero-filled workspaces; new device
+    tables; cold TLB) shows the race.  Round 6 had one (a weight-slice request inside a rolled loop of xcone_kernel's second row phase: a quarter of the first
+    decodes wrong, every later one right; tools/flaky_probe.py).  Here every (B, T) is a new geometry, every decode a new text, each compared with the numpy
+    statement of the incremental algorithm; a second engine is kept busy on the device in between."""
+    from dc_tts_amd.engine import Engine
+    from oracle.incremental_ref import incremental_decode_v3
+    busy = engine_for(weights)
+    Lb = dev(synthetic_text(hp, B=32, seed=5))
+    bad = []
+    for T in (60, 66, 72):
+        h = hp.replace(max_T=T)
+        eng = Engine(weights, h)
+        for B in (5, 8, 32):
+            for rep in range(2):                                       # the first decode at the geometry, then a DIFFERENT text at the same one
+                Lh = synthetic_text(h, B=B, seed=1000 * T + 10 * B + rep)
+                Yr, trajr = incremental_decode_v3(Lh, weights, h, np.float32)
+                if rep: busy.ssrn(torch.rand(8, hp.max_T, hp.n_mels, device="cuda"))
+                Y, mx = eng.text2mel(dev(Lh))
+                eng.synchronize()
+                e = maxabs(Y.cpu().numpy(), Yr)
+                if e >= TOL or not np.array_equal(mx.cpu().numpy(), trajr):
+                    bad.append((T, B, rep, e))
+        eng.close()
+    busy.text_enc(Lb); torch.cuda.synchronize()
+    assert not bad, bad
+
+
 def short_text(h, B, seed):
     rng = np.random.default_rng(seed)
     L = rng.integers(2, len(h.vocab), (B, h.max_N)).astype(np.int32)
@@ -592,6 +621,16 @@ def test_long_form_shape(weights):
     Yo, _, trajo = O.synthesize(Lh[:1], weights, hp.replace(max_T=Tp), np.float32, run_ssrn=False)
     np.testing.assert_array_equal(mx[:1, :Tp].cpu().numpy(), trajo)
     assert maxabs(Y[:1, :Tp].cpu().numpy(), Yo) < TOL
+    # SSRN at the long-form shape (networks.py:214-292 at configs[4]: (8, 1000, 80) -> (8, 4000, 1025)): the whole batch through the HIP path, one utterance's
+    # (4000, 1025) against the oracle -- the synthesize() call of this shape, Z included, not only the decode
+    Y3, Z3, m3 = eng.synthesize(L)
+    eng.synchronize()
+    assert torch.equal(Y3, Y) and torch.equal(m3, mx) and tuple(Z3.shape) == (8, 4 * T, hp.n_linear)
+    u = 5
+    _, Zr = O.SSRN(Y3[u:u + 1].cpu().numpy(), weights, hp.replace(max_T=T), np.float32)
+    ez = maxabs(Z3[u:u + 1].cpu().numpy(), Zr)
+    print(f"T=1000: max|Z - oracle| of utterance {u} over (4000, 1025): {ez:.2e}")
+    assert ez < TOL and bool(torch.isfinite(Z3).all())
 
 
 # ---------------------------------------------------------------- multi-rank plumbing on one GPU (the driver runs the 8-GPU scaling)

@@ -2,7 +2,28 @@
 dc_tts_amd/tf_checkpoint.py (own varints, own protobuf fields, own table blocks with prefix-compressed keys and restart arrays, own bit-serial
 CRC-32C pinned to the RFC 3720 vectors, LevelDB-style SHORTENED separator keys in the index block, any number of shards).  A tiny bundle it
 produced is committed under tests/golden/tf_bundle/ and must be reproduced byte for byte.  TensorFlow itself cannot be installed here, so no
-TF-written file exists: see dc_tts_amd/tf_checkpoint.py for the format references."""
+TF-written file exists: see dc_tts_amd/tf_checkpoint.py for the format references.
+
+STATUS: UNPINNED.  Everything below was written from the published TensorFlow sources as remembered, not from a file TensorFlow wrote; it stays that way until a
+TF-written bundle exists.  Where each byte of the encoder comes from (TensorFlow source tree, r1.x):
+
+| bytes written by `write_bundle` / `_block` | TensorFlow source it restates |
+|---|---|
+| file names `<prefix>.index`, `<prefix>.data-%05d-of-%05d` | `core/util/tensor_bundle/naming.cc` (`MetaFilename`, `DataFilename`) |
+| key `""` -> header, every other key = variable name, keys in sorted order | `core/util/tensor_bundle/tensor_bundle.cc` (`kHeaderEntryKey`, `BundleWriter::Finish`: a `std::map` of entries fed to `table::TableBuilder`) |
+| `BundleHeaderProto {num_shards = 1, endianness = 2 (LITTLE = 0 omitted), version = 3 {producer = 1}}` | `core/protobuf/tensor_bundle.proto`, `core/framework/versions.proto`, `tensor_bundle.cc: kTensorBundleVersion` |
+| `BundleEntryProto {dtype = 1, shape = 2, shard_id = 3, offset = 4, size = 5, crc32c = 6 (fixed32), slices = 7}` | `core/protobuf/tensor_bundle.proto` |
+| `TensorShapeProto {dim = 2 {size = 1}}`, `DT_FLOAT = 1, DT_INT32 = 3, DT_INT64 = 9` | `core/framework/tensor_shape.proto`, `core/framework/types.proto` |
+| tensor bytes raw, little-endian, C order at `[offset, offset + size)` of the shard; `crc32c` = MASKED CRC-32C of exactly those bytes | `tensor_bundle.cc: WriteTensor / BundleWriter::Add` (`crc32c::Mask(crc32c::Value(...))`) |
+| mask = rotate right by 15, add `0xa282ead8` | `core/lib/hash/crc32c.h` (`Mask`, `kMaskDelta`) |
+| block = entries `(varint32 shared, varint32 non_shared, varint32 value_len, key suffix, value)`, then `fixed32` restart offsets, then `fixed32` restart count | `core/lib/io/block_builder.cc` (`BlockBuilder::Add / Finish`); a restart every `block_restart_interval` (default 16) entries: `core/lib/io/table_options.h` |
+| block trailer = 1 byte compression type (`kNoCompression = 0`, `kSnappyCompression = 1`) + `fixed32` masked CRC-32C of block + type byte | `core/lib/io/table_builder.cc` (`WriteRawBlock`), `core/lib/io/format.h` (`kBlockTrailerSize = 5`) |
+| index block: one entry per data block, key = a separator `>=` the block's last key and `<` the next block's first (shortened), value = `BlockHandle` | `table_builder.cc` (`TableBuilder::Add`: `FindShortestSeparator`; `Finish`: `FindShortSuccessor`), restart interval 1 for the index block |
+| `BlockHandle` = `varint64 offset, varint64 size` (size excludes the trailer) | `core/lib/io/format.cc` (`BlockHandle::EncodeTo`) |
+| footer = metaindex handle, index handle, zero padding to 40 bytes, `fixed64` magic `0xdb4775248b80fb57` (48 bytes) | `format.cc` (`Footer::EncodeTo`), `format.h` (`kTableMagicNumber`, `Footer::kEncodedLength`) |
+
+What TensorFlow is free to choose -- data-block size (`table::Options::block_size`, hence keys per block), the restart interval, the number of shards, how far a
+separator key is shortened -- is fuzzed below (`test_reader_under_parameters_a_writer_may_choose`)."""
 import os
 import struct
 
@@ -313,3 +334,41 @@ def test_index_keys_bound_their_blocks_for_a_seeking_reader(tmp_path):
     # tf.train.AdamOptimizer creates beta1_power = beta1 and multiplies it once per update: after t updates it holds beta1 ** (t + 1)
     assert abs(float(t["beta1_power"]) - 0.9 ** 2001) < 1e-12 and abs(float(t["beta2_power"]) - 0.999 ** 2001) < 1e-6
     assert int(t["gs/global_step"]) == 2000
+
+
+def test_reader_under_parameters_a_writer_may_choose(tmp_path):
+    """Hypothesis fuzz over what a conforming writer is free to choose (block size -> keys per block, restart interval, shard count, variable names with long
+    shared prefixes -> separator shortening, scalar / empty-dimension / int tensors): the reader returns every tensor bit for bit, whole and by name."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    name_part = st.sampled_from(["Text2Mel", "SSRN", "TextEnc", "AudioDec", "HC_1", "HC_10", "HC_11", "C_2", "conv1d", "kernel", "bias", "gamma", "beta", "Adam", "Adam_1", "a", "b", "z" * 9])
+    names = st.lists(st.lists(name_part, min_size=1, max_size=4).map("/".join), min_size=1, max_size=14, unique=True)
+    shape = st.lists(st.integers(0, 5), min_size=0, max_size=3)
+    case = {"n": 0}
+
+    @settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(names=names, shapes=st.lists(shape, min_size=14, max_size=14), kinds=st.lists(st.integers(0, 2), min_size=14, max_size=14),
+           kpb=st.integers(1, 9), ri=st.integers(1, 17), shards=st.integers(1, 4), seed=st.integers(0, 2 ** 31 - 1))
+    def run(names, shapes, kinds, kpb, ri, shards, seed):
+        rng = np.random.default_rng(seed)
+        tensors = {}
+        for i, n in enumerate(names):
+            dt = (np.float32, np.int32, np.int64)[kinds[i]]
+            a = rng.normal(size=shapes[i]).astype(np.float32) if dt is np.float32 else rng.integers(-9, 9, size=shapes[i]).astype(dt)
+            tensors[n] = a
+        case["n"] += 1
+        prefix = str(tmp_path / f"fz{case['n']}")
+        write_bundle(prefix, tensors, keys_per_block=kpb, restart_interval=ri, num_shards=shards)
+        got = C.read_checkpoint(prefix)
+        assert sorted(got) == sorted(tensors)
+        for n, a in tensors.items():
+            assert got[n].dtype == a.dtype and got[n].shape == a.shape and got[n].tobytes() == a.tobytes(), n
+        pick = sorted(tensors)[:: max(1, len(tensors) // 3)]
+        sub = C.read_checkpoint(prefix, names=pick)
+        assert sorted(sub) == pick and all(sub[n].tobytes() == tensors[n].tobytes() for n in pick)
+        for f in os.listdir(tmp_path):
+            if f.startswith(f"fz{case['n']}."):
+                os.remove(tmp_path / f)
+
+    run()
