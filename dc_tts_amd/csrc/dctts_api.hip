@@ -260,6 +260,7 @@ struct dctts_ctx {
   int chain_tail = 2; bool tail_on = false, xmlp_on = false;
   int tail_np = 4, np_eff = 3;         // round 6 (DCTTS_CHAIN_TAIL=7 selects 3): newest-row layers in front of the chain launch's cone layers: 4 = HC_2 .. HC_5 (HC_5's older cone rows on the side stream: xcone_kernel runs HC_3 .. HC_5),
                                        //   3 = rounds 4-5 (HC_2 .. HC_4; the side stream stops behind HC_4); np_eff: what this decode uses (the merged forms only)
+  int team_u = 4;                      // utterances per team and round of THIS decode (decode_host.h: team_u_for); DCTTS_XGROUP=2 = the team kernels with four whatever the batch (A/B, tests)
   bool chain_one = false;              // round 5 (chain_tail == 2): a chain piece is ONE launch -- xtail_kernel's layers, a team barrier, the AudioEnc run + attention + C_1 (xchain_kernel); 6: two launches (round 4)
   bool dec_merge = false;              // chain_tail == 2: AudioDec's newest-row layers HC_2 .. HC_4 run in FRONT of xtail_kernel's cone layers in the same launch (chain_tail 2 and 6)
   bool ae_pass_split = false;          // round 4: AudioEnc's presums ride in the PREVIOUS piece's AudioEnc launch (a row ahead), only the C1Q . W2 row stays in the AudioDec launch

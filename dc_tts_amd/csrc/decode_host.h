@@ -514,15 +514,26 @@ static int run_chain3(dctts_ctx* c, const DevLayer& L, int B, int j, const DevLa
 
 
 
+// Utterances per team and round (round 6).  Rounds 3-5: always four -- a batch of 8 then ran on two of the eight teams (XCDs) while six idled, and the frame cost what
+// it costs at B = 32.  Now a batch of at most 8 / 16 is dealt one / two utterances to a team, so that all eight teams work (the side stream's cone GEMMs and row phases
+// shrink with the rows a team owns; the chain's latency-bound layers do not).  The arithmetic of an utterance does not depend on the slot it sits in: results are bitwise
+// those of the four-utterance form (DCTTS_XGROUP=2 forces it: tests).  Only the forms whose three team kernels all know about it (the merged chain forms).
+static inline int team_u_for(const dctts_ctx* c, int B) {
+  if (!c->dec_merge || c->xgroup == 2) return 4;
+  return B > 16 ? 4 : (B > 8 ? 2 : 1);
+}
+static inline int team_rounds(int B, int U) { return ((B + U - 1) / U + 7) / 8; }
+
 // ---- xgroup_kernel plumbing: one XGroupParams per (chain piece, network) in device memory; exchange buffers + team barriers + error word
 struct XgMem { float* xch[2]; float* sch[2]; float* xch_m; float* sch_m; float* xch_h; float* sch_h; unsigned* bar; unsigned* bar_cone; unsigned* bar_mlp; int* err; int bpad; size_t bar_words; };
-static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * (bpad / 4) * XT_MAXM * (512 + 64) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
+static inline int xg_hgroups(int B) { const int bpad = (B + 3) / 4 * 4; return B <= 16 ? bpad : bpad / 4; }      // utterance groups of xtail_kernel's highway exchange: one per utterance when a small batch is dealt singly (team_u_for)
+static size_t xg_mem_floats(int B) { const int bpad = (B + 3) / 4 * 4; return (size_t)2 * (2 * bpad * 512 + 2 * bpad * 64) + (size_t)(2 * bpad * 512 + 2 * bpad * 64) + (size_t)2 * xg_hgroups(B) * XT_MAXM * (512 + 64) + (size_t)3 * ((bpad / 4 + 7) / 8 * 8) * 32 + 64; }
 static XgMem xg_mem(dctts_ctx* c, int B) {
   XgMem m; m.bpad = (B + 3) / 4 * 4;
   float* q = c->xg_mem;
   for (int n = 0; n < 2; ++n) { m.xch[n] = q; q += (size_t)2 * m.bpad * 512; m.sch[n] = q; q += (size_t)2 * m.bpad * 64; }
   m.xch_m = q; q += (size_t)2 * m.bpad * 512; m.sch_m = q; q += (size_t)2 * m.bpad * 64;      // the k = 1 layers' exchange: xmlp_kernel [2][bpad][256] rows + [2][bpad][16][2] statistics; xtail_kernel the same with a tag beside every value: [2][bpad][256][2], [2][bpad][16][4]
-  m.xch_h = q; q += (size_t)2 * (m.bpad / 4) * XT_MAXM * 512; m.sch_h = q; q += (size_t)2 * (m.bpad / 4) * XT_MAXM * 64;   // xtail_kernel's highway layers: [2][groups][20][512], [2][groups][20][16][4]
+  m.xch_h = q; q += (size_t)2 * xg_hgroups(B) * XT_MAXM * 512; m.sch_h = q; q += (size_t)2 * xg_hgroups(B) * XT_MAXM * 64;   // xtail_kernel's highway layers: [2][groups][20][512], [2][groups][20][16][4]
   m.bar_words = (size_t)((m.bpad / 4 + 7) / 8 * 8) * 32;
   m.bar = (unsigned*)q; q += m.bar_words;                     // the chain's teams (xgroup_kernel)
   m.bar_cone = (unsigned*)q; q += m.bar_words;                // the side stream's teams (xcone_kernel): the two run concurrently
@@ -561,7 +572,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
       if (net == 0 && c->tail_on) i1 = i0 + 3;                 // AudioDec HC_2 .. HC_4 only: HC_5 .. HC_7 run in xtail_kernel, the launch behind this one
       const int L = (int)(i1 - i0);
       if (i0 == 0 || L < 2 || L > 10 || Lr[i0 - 1].cout != 256 || Lr[i0 - 1].act != ACT_NONE) return fail(DCTTS_ERR_STATE, "xgroup: a run of 2..10 highway layers after a linear 256-channel layer");
-      p.B = B; p.L = L;
+      p.B = B; p.L = L; p.U = c->team_u;
       const std::vector<float*>& P = net ? w.pe : w.pd; const std::vector<float*>& S = net ? w.se : w.sd;
       const std::vector<View>& H = net ? w.ae : w.ad;
       p.P0 = P[i0 - 1]; p.p0_bs = 256; p.stats0 = S[i0 - 1]; p.pg1 = Lr[i0 - 1].g1; p.pb1 = Lr[i0 - 1].b1;
@@ -594,7 +605,7 @@ static int v3_xgroup_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool i
         p.c1_pout = w.pd[0]; p.c1_stats = w.sd[0];
       }
       if (!(net == 0 && c->dec_merge))                          // (merged form: the AudioDec run is part of xtail_kernel's launch, which has barrier words of its own)
-        arrivals += (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(L - 1 + p.attn) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
+        arrivals += (unsigned)team_rounds(B, c->team_u) * (unsigned)(L - 1 + p.attn) * 16u;      // (a team with more than one utterance group runs them in turn: xgroup_kernel.h)
       if (net == 0) {                                           // the first launch of chain piece j: publishes the chain's counter and waits for bulk piece j
         if (insig) { p.sig = c->sig_ptr; p.sig_val = (unsigned)(j + 1); }
         if (cwait) { p.wait2 = c->wait_ctr + 32; p.wait_val = (unsigned)(j + 1); }
@@ -671,7 +682,7 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   for (int f = 0; f < T; ++f) {
     const long par = f & 1;
     XConeParams p; memset(&p, 0, sizeof(p));
-    p.B = B; p.L = L; p.frame = f; p.tail_rows = tail;
+    p.B = B; p.L = L; p.frame = f; p.tail_rows = tail; p.U = c->team_u;
     for (int k = 0; k < L; ++k) {
       const size_t i = i0 + k; const DevLayer& Ly = AD[i];
       if (Ly.cout != 256 || Ly.cin != 256 || Ly.cin_p != 256 || Ly.ntaps != 3 || Ly.tap_off[2] != 0 || !Ly.wp16 || c->cone_len[i] > 64) return fail(DCTTS_ERR_STATE, "xcone: causal k=3 highway layers over 256 channels, <= 64 cone rows");
@@ -684,10 +695,10 @@ static int v3_xcone_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
       q.offs = c->cone3_dev[i]; q.R = c->cone_len[i];
       for (int t3 = 0; t3 < 3; ++t3) q.tap_off[t3] = Ly.tap_off[t3];
     }
-    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)(((B + 3) / 4 + 7) / 8) * (unsigned)(2 * L - 1 + tail + (fold ? 2 : 0)) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
+    p.bar = m.bar_cone; p.bar_base = (unsigned)f * (unsigned)team_rounds(B, c->team_u) * (unsigned)(2 * L - 1 + tail + (fold ? 2 : 0)) * 16u; p.err = m.err;      // (utterance groups of a team in turn)
     if (fold) { p.fold = 1; p.rc1 = fill_rowc1(c, w, B, c->cfg.max_N, f); p.rhc2 = fill_rowhc2(c, w, B, c->cfg.max_N, f); }
     if (insig) {                                                // the launch's last team publishes "side-stream piece f complete" itself
-      p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)(((B + 3) / 4 < 8) ? (B + 3) / 4 : 8);      // one count per team (at most 8)
+      p.done = (unsigned*)m.err + 1; p.done_target = (unsigned)(f + 1) * (unsigned)(((B + c->team_u - 1) / c->team_u < 8) ? (B + c->team_u - 1) / c->team_u : 8);      // one count per team (at most 8)
       p.sig = c->wait_ctr + 32; p.sig_val = (unsigned)(f + 1);
       if (f + 1 < T) { p.wait = c->wait_ctr; p.wait_val = (unsigned)(f + 1); p.wait_err = (int*)(c->wait_ctr + 64); }      // what side-stream piece f + 1 starts from
     }
@@ -755,7 +766,7 @@ static int fill_xmlp(dctts_ctx* c, const DecodeWs& w, int B, int T, int j, size_
     x->wp = L.wp16; x->bias = L.bias; x->g = L.g1; x->be = L.b1; x->nkg = L.cin_p / 16; x->cout = L.cout; x->act = mel ? ACT_SIGMOID : L.act; x->pad_ = 0;
     return 0;
   };
-  const int rounds = ((B + 3) / 4 + 7) / 8;
+  const int rounds = team_rounds(B, c->team_u);
   XMlpParams p; memset(&p, 0, sizeof(p));
   const long par = j & 1;
   p.B = B;
@@ -816,7 +827,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
   if (NPv == 4 && (nout[0] != 3 || nout[1] != 1 || c->cone_len[h0 - 1] != nout[0] + 2)) return fail(DCTTS_ERR_STATE, "xtail: cone 5 / 3 / 1");
   const int nin0 = c->cone_len[h0 - 1];                                  // input rows per utterance of the first cone layer (its producer's cone)
   const XgMem m = xg_mem(c, B);
-  const int groups = m.bpad / 4;
+  const int groups = xg_hgroups(B);
   const View& xv = w.ad[h0 - 1];                                         // HC_4's output rows: the side stream's xcone_kernel writes its cone rows (parity copy of the frame)
   std::vector<XTailParams> tab((size_t)T);
   for (int j = 0; j < T; ++j) {
@@ -850,7 +861,7 @@ static int v3_xtail_table(dctts_ctx* c, const DecodeWs& w, int B, int T, bool in
         p.pdone = (unsigned*)m.err + 2; p.pdone_target = (unsigned)(j + 1) * (unsigned)(3 * ipl); p.psig = c->wait_ctr + 16; p.psig_val = (unsigned)(j + 1);
       }
     }
-    p.nh = NHv; p.nin0 = nin0; p.frame = j;
+    p.nh = NHv; p.nin0 = nin0; p.frame = j; p.U = c->team_u;
     for (int k = 0; k < NHv; ++k) {
       const DevLayer& Ly = AD[h0 + k];
       XTailHc& q = p.hc[k];
@@ -1102,6 +1113,7 @@ static int decode_v3(dctts_ctx* c, const DecodeWs& w, int B, int N, int T, hipSt
   c->xmlp_on = c->xg_on && c->chain_tail >= 1 && !c->tail_on;
   c->dec_merge = c->tail_on && (c->chain_tail == 2 || c->chain_tail == 6);          // (5: xtail_kernel behind an AudioDec run of xgroup_kernel, the first round-4 form -- A/B)
   c->np_eff = (c->dec_merge && c->tail_np == 4) ? 4 : 3;
+  c->team_u = team_u_for(c, B);
   c->attn_fold = c->xg_on && c->chain_tail >= 1 && c->chain_tail != 3 && c->cfg.d == 256 && c->ad_c1q.wp16 != nullptr;      // (3: xtail_kernel without the fold -- A/B)
   c->chain_one = c->dec_merge && c->chain_tail == 2 && c->attn_fold;      // (6: the chain piece as two launches, round 4's form -- A/B)
   // with in-kernel waits both stream meetings of a frame leave the command processor: the side stream's first launch polls the chain's

@@ -46,7 +46,7 @@ struct XConeParams {
   // one (rowc1_kernel, rowhc2_kernel: 10.4 + 10.3 us per frame for ~3 us of work each) -- are the first two phases of this launch.  A team needs only ITS four
   // utterances' rows, so it meets at its own barrier instead of at two launch boundaries: workgroup grp serves utterance grp / 4 of the team with rows
   // (grp % 4) * 8 + wave + 32 i (eight waves, three rows each), the utterance's shared operands staged in LDS once per workgroup.
-  int fold; int pad_;
+  int fold; int U;                       // U: utterances per team and round (xgroup_kernel.h: XGroupParams::U; 0 = 4)
   RowC1Params rc1; RowHc2Params rhc2;
 };
 
@@ -95,7 +95,8 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
   const int bx = blockIdx.x & 7, bq = blockIdx.x >> 3;
   // the grid is always 128 workgroups (8 teams): a team takes the utterance groups team, team + 8, ... in turn (xgroup_kernel.h says why)
   const int grp = bq & 15, team = bx;
-  if (team * 4 >= p.B) return;
+  const int U = p.U ? p.U : 4;
+  if (team * U >= p.B) return;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
@@ -118,8 +119,8 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       if (k >= k0 && k < k1)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (w12 + k) * 256), (__attribute__((address_space(3))) void*)&wlds[(w12 + k) * 256], 16, 0, 0);
   };
-  for (int b0 = team * 4; b0 < p.B; b0 += 32) {
-  const int nb = (p.B - b0 < 4) ? p.B - b0 : 4;
+  for (int b0 = team * U; b0 < p.B; b0 += 8 * U) {
+  const int nb = (p.B - b0 < U) ? p.B - b0 : U;
   if (p.fold) {
     int tid_a = tid;                                                     // (opaque per phase, like tid_o below: what is derived from the thread index stays inside its phase)
     asm volatile("; xcone: thread index, opaque (phase A)" : "+v"(tid_a));
@@ -129,7 +130,9 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
     f32x4* const s_c = reinterpret_cast<f32x4*>(&aux[0]);              // phase B's shared operands: 18 KB + 18 KB (nothing else uses `aux` before the first GEMM layer)
     f32x4* const s_v = s_c + 9 * 128;
     f32x4* const s_sh = s_v + 9 * 128;                                  // phase A's: 9 KB behind them
-    const int ub = grp >> 2, q4 = grp & 3;
+    // (U utterances share the team's 16 workgroups: 16 / U of them per utterance, each wave a row every 128 / U rows -- U = 4: rows (grp % 4) * 8 + wave + 32 i,
+    //  three per wave; U = 1: one row per wave of all sixteen workgroups)
+    const int wpu = 16 / U, ub = grp / wpu, q4 = grp - ub * wpu, rstep = 8 * wpu;
     const bool uok = ub < nb;
     const int b = uok ? b0 + ub : b0;
     const int pm = pm_row[b];
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
       f32x4 vq[3], vcq[3]; int tt[3]; bool lv[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
-        const int r0 = q4 * 8 + wave + 32 * i;
+        const int r0 = q4 * 8 + wave + rstep * i;
         const int r = r0 < ca.R ? r0 : ca.R - 1;
         const int t_ = ca.contig ? ca.frame - 1 - r : ca.frame + ca.offs[r];
         lv[i] = uok && r0 < ca.R && t_ >= 0;
@@ -178,7 +181,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
         const int rfirst = q4 * 8 + wave_b;
         // row 0 (t = frame - 1) / the presum row R - 1 (t = frame: its taps read frame - 1 and frame - 2), whichever of this wave's three slots it sits in
         // (R - 1 < 96: the host folds the row phases only then, v3_xcone_table)
-        if (rfirst == 0 || (rfirst <= cb.R - 1 && ((cb.R - 1 - rfirst) & 31) == 0)) {
+        if (rfirst == 0 || (rfirst <= cb.R - 1 && (cb.R - 1 - rfirst) % rstep == 0 && (cb.R - 1 - rfirst) / rstep < 3)) {
           bool ok = false;
           for (int i = 0; i < (1 << 20) && !ok; ++i) {
             ok = __hip_atomic_load(ca.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ca.wait_val;
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(512) xcone_kernel(const XConeParams* __restric
 #pragma unroll 1
       for (int i = 0; i < 3; ++i) {
         RowHc2Row cur;
-        rowhc2_load(cb, b, q4 * 8 + wave_b + 32 * i, lane_b, cur);
+        rowhc2_load(cb, b, q4 * 8 + wave_b + rstep * i, lane_b, cur);
         if (uok && cur.live) rowhc2_finish(cb, b, pm, cur, ln, s_c, s_v, lane_b);
       }
     }

@@ -45,6 +45,7 @@ struct XGroupLayer {
 };
 struct XGroupParams {
   int B, L;
+  int U, padu_;                          // utterances per team and round (round 6: 4, or 2 / 1 for batches of at most 16 / 8, so that a small batch spreads over all eight teams); 0 = 4
   const float* P0; int p0_bs; const float* stats0;     // the pre-group producer's pre-norm rows (256 channels, a C layer without activation) + statistics
   const float* pg1; const float* pb1;                   // its layer-norm parameters
   XGroupLayer lay[10];
@@ -135,14 +136,15 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
                :: "s"(p.B), "s"(p.L), "s"(p.P0), "s"(p.p0_bs), "s"(p.stats0), "s"(p.pg1), "s"(p.pb1),
                   "s"(p.lay[0].wp), "s"(p.lay[0].tap2), "s"(p.lay[0].xt), "s"(p.lay[0].xt_bs), "s"(p.lay[0].presum), "s"(p.lay[0].presum_bs),
                   "s"(p.xch), "s"(p.sch), "s"(p.xch_set), "s"(p.sch_set), "s"(p.bar), "s"(p.bar_base), "s"(p.err),
-                  "s"(p.sig), "s"(p.sig_val), "s"(p.wait2), "s"(p.wait_val), "s"(p.pout), "s"(p.stats_out));
+                  "s"(p.sig), "s"(p.sig_val), "s"(p.wait2), "s"(p.wait_val), "s"(p.pout), "s"(p.stats_out), "s"(p.U));
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bx = tbid & 7, bq = tbid >> 3;
   // The grid is ALWAYS 128 team workgroups (8 teams, one per XCD), whatever the batch: a team takes the utterance groups team, team + 8, ... in turn.
   // More team workgroups than that can starve the other stream of CUs while they poll for it (both team kernels are one workgroup per CU by registers):
   // at B = 96 a third round of polling xgroup workgroups held the CUs xcone_kernel needed to finish -- a resource deadlock until the bounded waits gave up.
   const int grp = bq & 15, team = bx;
-  if (team * 4 >= p.B) return;                                             // a team without utterances: uniform per workgroup
+  const int U = p.U ? p.U : 4;                                             // utterances this team serves per round (the four-row machinery below runs whatever U is: slots past U repeat the group's first utterance and store nothing)
+  if (team * U >= p.B) return;                                             // a team without utterances: uniform per workgroup
   const int arow = lane & 15, aq = lane >> 4, c4 = aq * 4;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.bar + team * 32;
@@ -152,17 +154,18 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
   int nts = 0;
   auto stamp = [&]() { if constexpr (TS) { if (p.ts && tbid == 0 && tid == 0 && nts < 120) p.ts[nts++] = wall_clock64(); } };
   stamp();
-  for (int round = 0, m0 = team * 4; m0 < p.B; ++round, m0 += 32) {
+  for (int round = 0, m0 = team * U; m0 < p.B; ++round, m0 += 8 * U) {
+  const int mend = (m0 + U < p.B) ? m0 + U : p.B;                          // this round's utterances: m0 .. mend - 1
   if (round > 0) __syncthreads();                                          // the previous round's last reads of the LDS buffers
   const unsigned rbase = p.bar_base + (unsigned)round * (unsigned)(p.L - 1 + (p.attn ? 1 : 0)) * 16u;      // the team's barrier sequence numbers of this round (the attention tail adds one hand-off)
   const int b = m0 + arow;
   // Only 4 of the 16 rows of an MFMA tile are utterances.  The other lanes run the same instructions on row 0's addresses: what they compute lands in
   // output rows nobody reads (MFMA rows are independent), so nothing is masked or zeroed for them -- per layer that was ~100 v_mov / select / exec-mask
   // instructions per wave, on a path that is bound by instruction issue as much as by latency.
-  const bool valid = arow < 4 && b < p.B;
+  const bool valid = arow < 4 && b < mend;
   const unsigned bb = valid ? (unsigned)b : 0u;
   const int eb = m0 + erow;
-  const bool wr = erow < 4 && eb < p.B;
+  const bool wr = erow < 4 && eb < mend;
 
   // ---- round 5: the contraction runs on v_mfma_f32_4x4x1_16b_f32 -- 16 independent 4 x 4 blocks per instruction, block = lanes 4 i .. 4 i + 3, D[row][lane j]
   //      += A[row of lane] . B[column of lane j].  A team's layer has FOUR rows: on 16 x 16 x 4 tiles 12 of the 16 rows were padding, and the 16 (K = 512: 32)
@@ -174,12 +177,12 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
   const unsigned kgw = (unsigned)(wave + 8 * kh);
   const unsigned wlane = (unsigned)(((cb & 3) * 4 + j4) * 4);             // float offset of this lane's column inside a (tile, k-group) block; + 64 per k / 4
   const unsigned wtile = (unsigned)(grp * 2 + (cb >> 2));
-  const unsigned bj = (m0 + j4 < p.B) ? (unsigned)(m0 + j4) : (unsigned)m0;      // the utterance of this lane's A row
+  const unsigned bj = (m0 + j4 < mend) ? (unsigned)(m0 + j4) : (unsigned)m0;      // the utterance of this lane's A row
   f32x4 wq[4], wtq[4], atq[4] = {z4, z4, z4, z4};
   float p0c[2], g1c[2], b1c[2];
   f32x4 st0;
   const int cr = lane >> 4, cc = lane & 15;
-  const unsigned crow = (m0 + cr < p.B) ? (unsigned)(m0 + cr) : (unsigned)m0;
+  const unsigned crow = (m0 + cr < mend) ? (unsigned)(m0 + cr) : (unsigned)m0;
   {
     const bool t2 = p.lay[0].tap2 != 0;
     const unsigned nkg = t2 ? 32u : 16u, kc = t2 ? 16u : 0u;
@@ -293,7 +296,7 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
       if (wr) naddv = ldg1(Ln.presum, (unsigned)(eb * Ln.presum_bs) + (unsigned)pcol);      // behind the wait for the side stream; never read before in this launch
     }
     // this layer's input row is kept for later launches (history / residual): column group 0 stores it
-    if (grp == 0 && m0 + cr < p.B && s_lay[g].xm) {
+    if (grp == 0 && m0 + cr < mend && s_lay[g].xm) {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
         *reinterpret_cast<__attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(s_lay[g].xm + (long)(m0 + cr) * s_lay[g].xm_bs + (8 * e + wave) * 16 + cc)) = xc[e];
@@ -412,7 +415,7 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
     x[0] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + c4]);
     x[1] = *reinterpret_cast<const float4*>(&xs[(arow & 3) * 32 + 16 + c4]);
     // ---- xs / xc hold Q[j] of the team's four utterances.  Keep the row (column group 0), attend, and run C_1 on it.
-    if (grp == 0 && m0 + cr < p.B) {
+    if (grp == 0 && m0 + cr < mend) {
 #pragma unroll
       for (int e = 0; e < 2; ++e)
         *reinterpret_cast<__attribute__((address_space(1))) float*>(reinterpret_cast<uintptr_t>(p.qhist + (long)(m0 + cr) * p.q_bs + (8 * e + wave) * 16 + cc)) = xc[e];
@@ -467,7 +470,7 @@ __device__ __forceinline__ void xgroup_body(const XGroupParams* __restrict__ pp,
       const float mg = row16_sum(vt) * (1.0f / 16.0f);
       const float dv = vt - mg;
       const float m2g = row16_sum(dv * dv);
-      const bool ok = aq == 0 && m0 + rw < p.B;                         // (lanes 16 .. 63 hold the tile's padding rows)
+      const bool ok = aq == 0 && m0 + rw < mend;                         // (lanes 16 .. 63 hold the tile's padding rows)
       if (ok) {
         const long b_ = m0 + rw; const int col = grp * 16 + ecol;
         p.c1_raw[b_ * p.raw_bs + col] = v_;

@@ -50,7 +50,7 @@ struct XTailP {                          // a newest-row layer of the merged for
 struct XTailParams {
   XMlpParams m;                          // the k = 1 layers; m.P0 / stats0 / g1 .. b2 / res describe the producer of the FIRST highway layer's newest input row (HC_4)
   XTailHc hc[3]; int nh; int nin0;       // highway layers; input rows per utterance of the first one
-  int frame; int pad1;                   // the frame t of the newest row: output row r of a layer is time t - r, and rows in front of t = 0 do not exist -- they are the ZERO padding
+  int frame; int U;                      // utterances per team and round (xgroup_kernel.h: XGroupParams::U; 0 = 4); the frame t of the newest row: output row r of a layer is time t - r, and rows in front of t = 0 do not exist -- they are the ZERO padding
                                          // of the next layer's input (modules.py:173-177 pads every layer's input), not a layer evaluated on padding
   const float* xin; long xin_bs; int xin_stride; int pad0;   // the first layer's other input rows come from the side stream's buffer: row of time t of utterance b at xin + b * xin_bs
   int in_off[16];                        // ... + in_off[q] * xin_stride for input row q (in_off[0] == 0: the newest row, rebuilt here)
@@ -152,7 +152,8 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
   if (blockIdx.x == 0 && tid == 0 && p.np && p.sig) __hip_atomic_store(p.sig, p.sig_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
   const int B = p.m.B;
-  if (team * 4 >= B) return false;
+  const int U = p.U ? p.U : 4;
+  if (team * U >= B) return false;
   const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
   unsigned* const bar = p.m.bar + team * 32;
   const unsigned xcc = xg_xcc_id();
@@ -165,7 +166,8 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
   auto stamp = [&]() { if constexpr (TS) { if (blockIdx.x == 0 && tid == 0 && nts < 60) s_ts[nts++] = wall_clock64(); } };
   stamp();
 
-  for (int round = 0, m0 = team * 4; m0 < B; ++round, m0 += 32) {
+  for (int round = 0, m0 = team * U; m0 < B; ++round, m0 += 8 * U) {
+    const int mend = (m0 + U < B) ? m0 + U : B;            // this round's utterances: m0 .. mend - 1 (the four-utterance machinery runs whatever U is)
     // Everything derived from the thread index is derived INSIDE the round, from a value the compiler cannot see through: hoisted out of this loop (which runs
     // once up to B = 32), ~100 loop-invariant LDS / global offsets of all the phases below lived in registers for the whole kernel, and the kernel spilled.
     int tid_r = threadIdx.x;
@@ -180,8 +182,8 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
     __syncthreads();                                     // (round 0: s_lay / s_go; later rounds: the previous round's last LDS reads)
     bool team_ok = s_go != 0;                            // (merged form, round 0: set behind the wait for the side stream)
     const unsigned rbase = p.m.bar_base + (unsigned)round * (unsigned)(np + nh + nl) * 16u;
-    const int gi = m0 >> 2;                              // utterance group: its rows of the exchange buffers
-    auto bof = [&](int u) { return (m0 + u < B) ? m0 + u : m0; };      // an utterance slot past the batch repeats the group's first utterance (never stored)
+    const int gi = m0 / U;                               // utterance group: its rows of the exchange buffers
+    auto bof = [&](int u) { return (m0 + u < mend) ? m0 + u : m0; };      // an utterance slot past the batch repeats the group's first utterance (never stored)
 
     // ---- request order matters: a wave's loads return in order.  First what is consumed first -- the producer's pre-norm rows / statistics / residual of the
     //      newest input row, then the 59 staged input rows (60 KB per workgroup) -- and only then the weights: the first layer's slice (96 KB per workgroup:
@@ -222,10 +224,10 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
     if (np) {
       // ==== merged form: the three newest-row layers first (xgroup_kernel's layer loop, M = 4 rows: A operand in registers, compact rebuild through s_xs)
       const int b_ = m0 + arow;
-      const unsigned bb = (arow < 4 && b_ < B) ? (unsigned)b_ : (unsigned)m0;        // lanes of MFMA rows nobody reads run on the team's first row
+      const unsigned bb = (arow < 4 && b_ < mend) ? (unsigned)b_ : (unsigned)m0;        // lanes of MFMA rows nobody reads run on the team's first row
       const int erow = aq * 4 + (wave & 3), eb = m0 + erow;
-      const bool wr = erow < 4 && eb < B;
-      const unsigned crow_p = (m0 + cr < B) ? (unsigned)(m0 + cr) : (unsigned)m0;
+      const bool wr = erow < 4 && eb < mend;
+      const unsigned crow_p = (m0 + cr < mend) ? (unsigned)(m0 + cr) : (unsigned)m0;
       // ---- request order: what the first layer needs (C_1's rows, its statistics and layer-norm parameters, the layer's 16-column tiles), then the FIRST CONE LAYER's
       //      slice (96 KB per workgroup, 12 MB per launch out of the Infinity Cache: ~3 us): it lands under the newest-row layers instead of in front of the cone layer
       // (round 5: the contraction on 4 x 4 x 1 MFMA blocks, as in xgroup_kernel.h -- a team's layer has four rows; lane (cb, kh, j): columns 4 cb .. 4 cb + 3 of the
@@ -612,11 +614,11 @@ __device__ __forceinline__ bool xtail_body(const XTailParams* __restrict__ pp) {
     // `bin` now holds one row per utterance (row u): the input of the first k = 1 layer
 
     // ---- the k = 1 layers (xmlp_kernel.h's loop)
-    const unsigned crow = (m0 + cr < B) ? (unsigned)(m0 + cr) : (unsigned)m0;      // (a row slot past the batch repeats the TEAM'S first row: its tags are this team's)
-    const bool crow_ok = m0 + cr < B;
+    const unsigned crow = (m0 + cr < mend) ? (unsigned)(m0 + cr) : (unsigned)m0;      // (a row slot past the batch repeats the TEAM'S first row: its tags are this team's)
+    const bool crow_ok = m0 + cr < mend;
     const int erow = aq * 4 + wave;
     const int eb = m0 + erow;
-    const bool wr = wave < 4 && erow < 4 && eb < B;
+    const bool wr = wave < 4 && erow < 4 && eb < mend;
     float4 x[2];
     x[0] = *reinterpret_cast<const float4*>(&bin[(arow & 3) * XT_LDR + wave * 16 + c4]);
     x[1] = *reinterpret_cast<const float4*>(&bin[(arow & 3) * XT_LDR + (8 + wave) * 16 + c4]);
@@ -753,7 +755,8 @@ __global__ void __launch_bounds__(512) xchain_kernel(const XTailParams* __restri
   typedef const __attribute__((address_space(4))) XTailParams CP;
   CP& p = *(CP*)pt;
   const int team = (int)blockIdx.x & 7, grp = ((int)blockIdx.x >> 3) & 15;
-  const int rounds = ((p.m.B + 3) / 4 + 7) / 8;
+  const int Uc = p.U ? p.U : 4;
+  const int rounds = ((p.m.B + Uc - 1) / Uc + 7) / 8;
   const unsigned target = p.m.bar_base + (unsigned)rounds * (unsigned)(p.np + p.nh + p.m.nl) * 16u + 16u;      // one more meeting than xtail_body's layers (the host counts it)
   const bool go = __hip_atomic_load(p.m.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the k = 1 layers' last stores are in the L2 ...

@@ -386,6 +386,34 @@ def test_decode_stream_meeting_variants(weights, knob):
     eng.close()
 
 
+@pytest.mark.parametrize("B", [8, 7, 12, 16])
+def test_small_batches_spread_over_all_teams_bitwise(weights, B):
+    """Round 6: a batch of at most 8 / 16 utterances is dealt ONE / TWO to a team (XCD) and round instead of four, so that all eight teams work (BASELINE
+    configs[4]'s share of a GPU is 8 utterances: rounds 3-5 ran it on two teams).  An utterance's arithmetic does not depend on the slot it sits in: mel
+    frames and trajectory are bitwise those of the four-utterance form (DCTTS_XGROUP=2) and of the same utterances decoded inside a batch of 32."""
+    from dc_tts_amd.engine import Engine
+    T = 90
+    h = hp.replace(max_T=T)
+    Lh = synthetic_text(h, B=32, seed=77)
+    os.environ["DCTTS_XGROUP"] = "2"
+    try:
+        e4 = Engine(weights, h)
+    finally:
+        del os.environ["DCTTS_XGROUP"]
+    eu = Engine(weights, h)
+    L = dev(Lh[:B])
+    Y4, m4 = e4.text2mel(L); e4.synchronize()
+    Yu, mu = eu.text2mel(L); eu.synchronize()
+    assert torch.equal(Yu, Y4) and torch.equal(mu, m4)
+    Y32, m32 = eu.text2mel(dev(Lh)); eu.synchronize()
+    assert torch.equal(Y32[:B], Yu) and torch.equal(m32[:B], mu)
+    from oracle.incremental_ref import incremental_decode_v3
+    Yr, trajr = incremental_decode_v3(Lh[:B], weights, h, np.float32)
+    np.testing.assert_array_equal(mu.cpu().numpy(), trajr)
+    assert maxabs(Yu.cpu().numpy(), Yr) < TOL
+    e4.close(); eu.close()
+
+
 def test_first_decodes_at_new_geometries_with_fresh_inputs(weights):
     """What the other decode tests cannot see: they decode the SAME text several times at one geometry, so a kernel that reads a buffer before its producer has
     written it finds the previous decode's identical values there, and only the very first decode at a new geometry (new, zero-filled workspaces; new device
