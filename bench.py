@@ -371,7 +371,9 @@ def main():
         any_fail = int(tf.item())
     else:
         any_fail = local_fail
-    if any_fail:                                                     # every rank repeats the region (the library of the failing rank now runs one launch per layer)
+    if any_fail:                                                     # every rank repeats the region; a rank whose decode failed runs one launch per layer from here on (the line says so: `placement`)
+        if local_fail:
+            eng.set_team_kernels(False)
         barrier()
         (Y, Z, mx), elapsed, n_chain, chain_ms, chain_layers = timed_region()
         eng.decode_status()

@@ -47,12 +47,17 @@ hipError_t launch_hconv(const ConvShape& s, const ConvParams& p, hipStream_t str
   if (p.wx) {                                // a k = 1 layer of 32 x 32 + 1 columns: 8 waves x 4 tiles + the last column on the vector ALU (hconv_kernel.h: XC)
     if (s.epi != EPI_C || p.cout != 1025 || p.ntaps != 1 || p.cin_p > 1120) return hipErrorInvalidValue;
     // ring depth 1 and registers capped at 128 (two workgroups per CU): 10.45 ms per SSRN pass at B = 32 against 10.50 (depth 2, one workgroup per CU) and 10.71 (11 waves x 3 tiles)
-    hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), grid, dim3(512), 0, stream, p);
+    // (round 6: + the k-group's requests spread behind single MFMAs, SG = 1: 459 -> 447 us for 768 items, tools/micro/hconv_lab)
+    // (with the registers capped at 128 -- XC = 2, round 5's form -- the spread costs 60 bytes of scratch; uncapped at ring depth 2 it is 451 us without any)
+    hipLaunchKernelGGL((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 0, 1>), grid, dim3(512), 0, stream, p);
     return hipGetLastError();
   }
   HCONV_CASE(EPI_HC, 2, 8, 2, 0)
   HCONV_CASE(EPI_HC, 4, 8, 2, 0)
-  HCONV_CASE(EPI_HC, 8, 8, 1, 1)
+  if (s.epi == EPI_HC && s.nt == 8 && s.nw == 8) {      // SSRN HC_11 / HC_12: SG = 1 (round 6): 2398 -> 2249 us for 768 items = 0.820 -> 0.874 of the fp32 MFMA peak (hconv_lab, same run)
+    hipLaunchKernelGGL((hconv_kernel<EPI_HC, 8, 8, 1, 1, 0, 0, 0, 1>), grid, dim3(512), 0, stream, p);
+    return hipGetLastError();
+  }
   HCONV_CASE(EPI_C, 1, 4, 1, 0)
   HCONV_CASE(EPI_C, 1, 8, 1, 0)
   HCONV_CASE(EPI_C, 2, 8, 2, 0)
@@ -291,6 +296,8 @@ struct dctts_ctx {
   int xcone = 1;
   void* xc_tab = nullptr; std::string xc_geom;   // per frame: XConeParams
   hipStream_t s_bulk = nullptr; hipEvent_t ev_fork = nullptr;
+  unsigned* conc_flags = nullptr; int stream_retries = 0;       // decode_streams_init: the two decode streams are TESTED for running concurrently (decode_host.h); side streams rejected on the way
+  hipStream_t own_tested = nullptr; bool own_ok = false;        // the last caller's high-priority stream tested against the side stream, and the result
   hipStream_t s_chain = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;      // decode mode 3: the chain's launches run on a high-priority stream of the context between two events on the caller's stream (decode_host.h)
   hipEvent_t ev_chain[4] = {nullptr, nullptr, nullptr, nullptr}, ev_bulk[4] = {nullptr, nullptr, nullptr, nullptr};
   int sync_values = 1;                 // the two streams meet through stream memory operations (hipStreamWriteValue32 / WaitValue32 on two counters) instead of events
@@ -634,6 +641,7 @@ extern "C" int dctts_destroy(dctts_ctx* c) {
   if (c->ctr_chain) (void)hipFree(c->ctr_chain);
   if (c->ctr_bulk) (void)hipFree(c->ctr_bulk);
   if (c->wait_ctr) (void)hipFree(c->wait_ctr);
+  if (c->conc_flags) (void)hipFree(c->conc_flags);
   if (c->dstat) (void)hipFree(c->dstat);
   if (c->dstat_host) (void)hipHostFree(c->dstat_host);
   if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1004,6 +1012,9 @@ static void drop_decode_tables(dctts_ctx* c);
 // synchronisation (the only place left where a call waits for the GPU because of a shape change; dctts_set_workspace_limit).
 static int ws_trim(dctts_ctx* c, bool force = false) {
   if (!force && ws_cached_bytes(c) <= c->ws_limit) return 0;
+#ifdef DCTTS_DEBUG_LOG
+  fprintf(stderr, "[dctts] ws_trim: cached %.1f MB, limit %.1f MB, force %d\n", ws_cached_bytes(c) / 1e6, c->ws_limit / 1e6, (int)force);
+#endif
   HIPCHK(hipDeviceSynchronize());
   drop_decode_tables(c);
   free_ws(c);
@@ -1020,6 +1031,9 @@ template <typename F>
 static int oom_retry(dctts_ctx* c, F&& body) {
   g_oom = false;
   int rc = body();
+#ifdef DCTTS_DEBUG_LOG
+  if (rc != 0) fprintf(stderr, "[dctts] entry point failed rc=%d oom=%d: %s\n", rc, (int)g_oom, g_err.c_str());
+#endif
   if (rc != 0 && g_oom) {
     g_oom = false;
     const std::string first = g_err;

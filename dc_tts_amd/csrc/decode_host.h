@@ -194,6 +194,36 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
   return 0;
 }
 
+// ---- Do two streams really run at the same time?  The decode's two streams wait for EACH OTHER inside kernels (and, in the fallback forms, through stream memory
+// operations), so they must sit on different hardware queues.  HIP maps the streams of one priority onto a small pool of queues (four by default) and lets a new
+// stream SHARE the queue of an existing one once the pool is full; two streams that share a queue run their commands one after the other.  Round 6 met exactly that:
+// a caller that had created a high-priority stream of its own (torch.cuda.Stream(priority=-1)) beside one engine's pair left the NEXT engine's pair on one queue --
+// every decode of that engine then ran into its bounded waits (error word 36; with stream-operation meetings it would have hung).  So the pair is TESTED when it is
+// created: a kernel on one stream waits (bounded, ~60 ms) for a flag a kernel on the other stream sets; if it times out the second stream is replaced by a new one
+// (the rejected ones are held until the end, so that the pool's next pick is a different queue).
+__global__ void conc_wait_kernel(const unsigned* __restrict__ flag, unsigned* __restrict__ out) {
+  unsigned ok = 0;
+  for (int i = 0; i < (1 << 15) && !ok; ++i) {
+    ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+    if (!ok) __builtin_amdgcn_s_sleep(32);
+  }
+  __hip_atomic_store(out, ok ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void conc_set_kernel(unsigned* __restrict__ flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+static int streams_run_concurrently(dctts_ctx* c, hipStream_t a, hipStream_t b, bool* ok) {
+  if (!c->conc_flags) { HIPCHK(hipMalloc((void**)&c->conc_flags, 64 * sizeof(unsigned))); }
+  HIPCHK(dev_zero_now(c->conc_flags, 64 * sizeof(unsigned)));
+  hipLaunchKernelGGL(conc_wait_kernel, dim3(1), dim3(1), 0, a, (const unsigned*)c->conc_flags, c->conc_flags + 32);
+  HIPCHK(hipGetLastError());
+  hipLaunchKernelGGL(conc_set_kernel, dim3(1), dim3(1), 0, b, c->conc_flags);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(a)); HIPCHK(hipStreamSynchronize(b));
+  unsigned r = 0;
+  HIPCHK(hipMemcpy(&r, c->conc_flags + 32, sizeof(unsigned), hipMemcpyDeviceToHost));
+  *ok = (r == 1u);
+  return 0;
+}
+
 static int decode_streams_init(dctts_ctx* c) {
   if (c->s_bulk) return 0;
   {
@@ -210,6 +240,24 @@ static int decode_streams_init(dctts_ctx* c) {
     HIPCHK(hipStreamCreateWithPriority(&c->s_chain, hipStreamNonBlocking, hi));
     HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    // the pair must run concurrently (above): replace the side stream until it does
+    std::vector<hipStream_t> rejected;
+    bool ok = false;
+    int rc = 0;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+      rc = streams_run_concurrently(c, c->s_chain, c->s_bulk, &ok);
+      if (rc != 0 || ok) break;
+      rejected.push_back(c->s_bulk); c->s_bulk = nullptr;
+      if (hipStreamCreateWithPriority(&c->s_bulk, hipStreamNonBlocking, hi) != hipSuccess) { rc = fail(DCTTS_ERR_HIP, "hipStreamCreateWithPriority (decode side stream)"); break; }
+    }
+    c->stream_retries = (int)rejected.size();
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    if (rc != 0) return rc;
+    if (!ok) {
+      if (c->s_bulk) { (void)hipStreamDestroy(c->s_bulk); c->s_bulk = nullptr; }
+      return fail(DCTTS_ERR_STATE, "decode: could not obtain two high-priority streams that run concurrently (the process holds too many high-priority streams: HIP lets "
+                                   "new streams share a hardware queue); the decode's two streams wait for each other and must not share one");
+    }
   }
   // the two streams hand data to each other through device memory only: device-scope release on the event markers (no system-scope flush)
   const unsigned evf = (unsigned)hipEventReleaseToDevice | hipEventDisableTiming;
@@ -1330,8 +1378,14 @@ static int decode_impl(dctts_ctx* c, const int32_t* L, int B, int N, int T, floa
     // everything it does later behind it (the two hand-overs cost ~0.1 ms per decode: INTEGRATION.md recommends a high-priority stream to callers who care).
     int lo = 0, hi = 0, pr = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const bool own = st && hipStreamGetPriority(st, &pr) == hipSuccess && pr == hi && hi != lo;
+    bool own = st && hipStreamGetPriority(st, &pr) == hipSuccess && pr == hi && hi != lo;
     if (!own) (void)hipGetLastError();
+    if (own && st != c->own_tested) {        // ... and only if it does not share a hardware queue with the side stream (decode_streams_init; tested once per stream handle)
+      bool ok = false;
+      CHK(streams_run_concurrently(c, st, c->s_bulk, &ok));
+      c->own_tested = st; c->own_ok = ok;
+    }
+    if (own && !c->own_ok) own = false;
     if (own) {
       CHK(decode_v3(c, w, B, N, T, st));
     } else {

@@ -131,7 +131,12 @@ __device__ __forceinline__ float half_sum32(float v) {
 //     v_mfma_f32_32x32x16_bf16 wants its B operand; the A operand is the same 8 consecutive channels of row l & 31 out of the fp32 LDS tile.  The
 //     accumulators come out in the fp32 instruction's layout, so prologue, statistics and epilogue are shared.  NT <= 4 (a 16-k group of weights is
 //     8 NT registers per ring slot); the 64-tile layers run as two column halves (RAW = 2) + the finishing pass.
-template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0, int XC = 0, int BF = 0>
+//   * SG (round 6): where the NT + 1 requests of a k-group (NT weight fragments, the next A fragment) sit among its 4 NT MFMAs.  0: wherever the compiler's scheduler
+//     puts them (rounds 1-5; a PIN in front of the MFMAs was 27 % slower in round 3).  1 / 2: spread with sched_group_barrier -- one MFMA, the LDS read, then one
+//     weight request behind every three (1) / four (2) MFMAs.  tools/micro/mfma_feed_lab.hip: a wave issues in order, so requests clustered in front of a k-group's
+//     MFMAs cost matrix-pipe time even with a second wave on the SIMD (38 against 34.7 cycles per MFMA in the decode's 16 x 16 x 4 loop).  Here (hconv_lab, 768 items,
+//     same run): HC_11 2449 -> 2260 us with SB = 0 (0.803 -> 0.870 of the fp32 MFMA peak), the 1025-column layers 457 -> 445, HC_8 669 -> 655; C_10 gets slower (262 -> 274).
+template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0, int XC = 0, int BF = 0, int SG = 0>
 __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const ConvParams p) {      // (XC = 2: the same with registers capped for two workgroups per CU)
   static_assert(XC == 0 || (EPI == EPI_C && RAW == 0 && NW == 8), "the extra column rides in the fused k = 1 form: 8 waves x 4 rows");
   static_assert(BF == 0 || (RAW != 1 && NT <= 4 && (BD == 1 || BD == 2)), "split-bf16: whole-K items, at most four tiles per wave, ring rotated by the two groups of a chunk");
@@ -342,6 +347,22 @@ __global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const
         bq[BD - 1][i] = bnext[i];
       }
       a = an;
+      if constexpr (SG == 1) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, NT - 1, 0);
+      } else if constexpr (SG == 2) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i + 1 < NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      } else if constexpr (SG == 3) {        // the requests in the FIRST half of the k-group's MFMAs (two MFMAs apart), nothing behind them
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT - 1, 0);
+      }
     }
     }
     cb = cb1;

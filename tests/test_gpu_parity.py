@@ -900,6 +900,41 @@ def test_decode_from_a_high_priority_stream_and_beside_ssrn_on_another_stream(we
         for z in Zs: assert torch.equal(z, Z)
 
 
+def test_new_engines_get_two_streams_that_really_run_concurrently(weights):
+    """Round 6: the decode's two streams wait for each other, so they must sit on different hardware queues -- and HIP lets a NEW high-priority stream share the queue
+    of an existing one once its pool of queues is full.  With one engine's pair and a caller's own high-priority stream alive, the next engines' pairs landed on ONE
+    queue: every decode of theirs ran into its bounded waits (error word 36; rounds 1-5 had the same hole, tools/ctx_probe.py).  The pair is now tested when it is
+    created (a kernel on one stream waits for a flag set by a kernel on the other) and the side stream replaced until it passes; a caller's high-priority stream is
+    tested against the side stream the same way before the chain is put on it.  Here: exactly that history, then several new engines, each decoding at once -- in
+    the default form, with stream-operation meetings (which would HANG on a shared queue) and in the per-layer fallback form."""
+    from dc_tts_amd.engine import Engine
+    T = 40
+    h = hp.replace(max_T=T)
+    e1 = engine_for(weights, max_T=T)
+    L = dev(synthetic_text(h, B=32, seed=31))
+    Yg, mg = e1.text2mel(L); e1.synchronize()
+    his = [torch.cuda.Stream(priority=-1) for _ in range(3)]        # (kept alive: they hold hardware queues of the high-priority pool)
+    for s in his:
+        with torch.cuda.stream(s):
+            Yh, mh = e1.text2mel(L)
+        torch.cuda.synchronize(); e1.decode_status()
+        assert torch.equal(Yh, Yg) and torch.equal(mh, mg)
+    for k, knob in enumerate(["", "", "DCTTS_CHAIN_WAIT=0", "DCTTS_XGROUP=0,DCTTS_XCONE=0", "", ""]):
+        pairs = [kv.split("=") for kv in knob.split(",")] if knob else []
+        for name, val in pairs: os.environ[name] = val
+        try:
+            e2 = Engine(weights, h)
+        finally:
+            for name, _ in pairs: del os.environ[name]
+        Y2, m2 = e2.text2mel(L); e2.synchronize()
+        assert torch.equal(m2, mg) and maxabs(Y2.cpu().numpy(), Yg.cpu().numpy()) < 1e-5, (k, knob)
+        with torch.cuda.stream(his[k % 3]):                          # ... and from a caller's high-priority stream
+            Y3, m3 = e2.text2mel(L)
+        torch.cuda.synchronize(); e2.decode_status()
+        assert torch.equal(m3, mg) and maxabs(Y3.cpu().numpy(), Yg.cpu().numpy()) < 1e-5, (k, knob)
+        e2.close()
+
+
 def test_checked_retry_leaves_the_team_kernel_settings_alone(weights):
     """the safe retry of a checked decode is a ONE-SHOT form of that decode (dctts_decode_safe_once); it must not switch the team kernels back on for a
     caller who switched them off, nor re-enable them after dctts_decode_status switched them off for good."""

@@ -83,21 +83,36 @@ int main(int argc, char** argv) {
         RUN((hconv_kernel<EPI_HC, 8, 8, 1, 1>), 512, 1, "production hconv_kernel<HC,8,8,BD=1,SB=1>", false, q.out = ref)
         RUN((hconv_kernel<EPI_HC, 8, 8, 2, 1>), 512, 1, "BD=2", true, )
         RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0>), 512, 1, "SB=0", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 1, 0, 0, 0, 1>), 512, 1, "SB=1 SG=1 (requests spread: one behind every three MFMAs)", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0, 0, 0, 0, 1>), 512, 1, "SB=0 SG=1", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0, 0, 0, 0, 2>), 512, 1, "SB=0 SG=2 (every four)", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0, 0, 0, 0, 3>), 512, 1, "SB=0 SG=3 (every two, first half)", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 8, 2, 0, 0, 0, 0, 1>), 512, 1, "BD=2 SB=0 SG=1", true, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1, 2, 0, 1>), 512, 2, "split-bf16: two column halves (pre-norm values to HBM; + the finishing pass, not timed)", false, q.raw_out = raw; q.raw_ld = 2 * q.cout)
       } else if (si == 1) {
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 0>), 512, 1, "production hconv_kernel<HC,4,8,BD=2,SB=0>", false, q.out = ref)
         RUN((hconv_kernel<EPI_HC, 4, 8, 1, 1>), 512, 1, "BD=1 SB=1", true, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1>), 512, 1, "BD=2 SB=1", true, )
+        RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1, 0, 0, 0, 1>), 512, 1, "BD=2 SB=1 SG=1", true, )
+        RUN((hconv_kernel<EPI_HC, 4, 8, 2, 0, 0, 0, 0, 1>), 512, 1, "BD=2 SB=0 SG=1", true, )
+        RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1, 0, 0, 0, 2>), 512, 1, "BD=2 SB=1 SG=2", true, )
+        RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1, 0, 0, 0, 3>), 512, 1, "BD=2 SB=1 SG=3", true, )
+        RUN((hconv_kernel<EPI_HC, 4, 8, 4, 1, 0, 0, 0, 1>), 512, 1, "BD=4 SB=1 SG=1", true, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1, 0, 0, 1>), 512, 1, "split-bf16 BD=2", false, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 1, 1, 0, 0, 1>), 512, 1, "split-bf16 BD=1", false, )
       } else if (si == 2) {
         RUN((hconv_kernel<EPI_C, 3, 11, 2, 1>), 704, 1, "rounds 1-4: hconv_kernel<C,3,11,BD=2,SB=1> (33 tiles on 11 waves)", false, q.out = ref)
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), 512, 1, "production: 8 waves x 4 tiles + column 1024 on the vector ALU, 128 registers (XC=2)", false, q.wx = wx)
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1>), 512, 1, "the same at ring depth 2, registers uncapped (one workgroup per CU)", false, q.wx = wx)
+        RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2, 0, 1>), 512, 1, "XC=2 SG=1", false, q.wx = wx)
+        RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2, 0, 2>), 512, 1, "XC=2 SG=2", false, q.wx = wx)
+        RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 0, 1>), 512, 1, "XC=1 BD=2 SG=1", false, q.wx = wx)
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 1>), 512, 1, "split-bf16 XC BD=2", false, q.wx = wx)
       } else {
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1>), 512, 1, "production hconv_kernel<C,4,8,BD=1,SB=1>", false, q.out = ref)
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1>), 512, 1, "BD=2", true, )
+        RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 0, 0, 1>), 512, 1, "BD=2 SG=1", true, )
+        RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 0, 0, 2>), 512, 1, "BD=1 SG=2", true, )
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 0, 1>), 512, 1, "split-bf16 BD=2", false, )
       }
       for (auto& v : vars) {
