@@ -116,7 +116,13 @@ hipError_t launch_hconv_tail(const ConvShape& s, const ConvParams& p, hipStream_
     if (p.ntaps != 3) return hipErrorInvalidValue;
     HCONV_TAIL_CASE(2, 8, 2, 0)
     HCONV_TAIL_CASE(4, 8, 2, 0)
-    HCONV_TAIL_CASE(8, 8, 1, 1)
+    if (s.nt == 8 && s.nw == 8) {          // HC_11 / HC_12's row tail: the same spread of the k-group's requests as their main launch (SG = 1)
+      hipLaunchKernelGGL((hconv_kernel<EPI_HC, 8, 8, 1, 1, 1, 0, 0, 1>), grid, dim3(512), 0, stream, p);
+      hipError_t e_ = hipGetLastError();
+      if (e_ != hipSuccess) return e_;
+      hipLaunchKernelGGL(hc_tail_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, p, (const float*)p.raw_out, 3);
+      return hipGetLastError();
+    }
   } else {
     if (p.ntaps != 1 || p.cout > 1280) return hipErrorInvalidValue;
     HCONV_CTAIL_CASE(4, 8, 1, 1)
@@ -131,7 +137,7 @@ hipError_t launch_hconv_cols(const ConvShape& s, const ConvParams& p, hipStream_
   if (rows <= 0) return hipSuccess;
   if (!p.raw_out || s.epi != EPI_HC || s.nt != 4 || s.nw != 8 || p.cout != 512) return hipErrorInvalidValue;
   const dim3 grid((rows + 31) / 32, 4);
-  hipLaunchKernelGGL((hconv_kernel<EPI_HC, 2, 4, 4, 1, 2>), grid, dim3(256), 0, stream, p);      // (weight requests four k-groups ahead, wave-uniform tile bases: 2.04 -> 2.01 ms for TextEnc)
+  hipLaunchKernelGGL((hconv_kernel<EPI_HC, 2, 4, 4, 1, 2>), grid, dim3(256), 0, stream, p);      // (weight requests four k-groups ahead, wave-uniform tile bases: 2.04 -> 2.01 ms for TextEnc; round 6: with the requests spread behind single MFMAs, SG = 1, 1.96 -> 2.01 ms: not here)
   hipError_t e_ = hipGetLastError();
   if (e_ != hipSuccess) return e_;
   hipLaunchKernelGGL(hc_tail_finish_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, p, (const float*)p.raw_out, 1);
