@@ -9,12 +9,15 @@ Multi-GPU: utterances shard embarrassingly, 32 per GPU, no collective on the dat
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 What the JSON line holds besides the contract's fields (everything is measured in this run unless it says otherwise):
-  roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r05_kernel_stats.md): xcone_kernel, the re-evaluation of
+  roofline            the kernel that dominates the step by TIME (rocprofv3 --stats: profiles/r06_kernel_stats.md): xcone_kernel, the re-evaluation of
                       AudioDec's dependency cone on the decode's side stream; HIP-event timed on ITS stream inside the timed region (every 16th
-                      frame from frame 100 on), fp32-MFMA bound; `traffic` = PMC bytes per launch (profiles/r05_pmc_decode.json, separate passes)
+                      frame from frame 100 on), fp32-MFMA bound; `frac` = the whole launch, `frac_gemm_phase` = its GEMM layers' own phases (in-kernel stamps);
+                      `traffic` = PMC bytes per launch (profiles/r06_pmc_decode.json, separate passes)
   kernels             the same figures for xchain_kernel (the chain's launch; DCTTS_CHAIN_TAIL=6: xtail_kernel and xgroup_kernel), the FLOP-dominant kernel (SSRN HC_11/12 + its tail
                       launch) and SSRN's 1025-column layers (event-timed in untimed extra passes)
   phases / phase_rooflines   TextEnc / decode / SSRN times and their fractions of both roofs (SURVEY 8d algorithmic work)
+  placement           per rank: where a 128-block launch lands (XCD census), compute units, whether the rank's timed decodes ran on the team kernels
+  fallback            the step with the team kernels off (one launch per layer): what a rank falls back to when a team is not on one XCD / the waits give up
   other_configs       BASELINE configs[1] (decode only), [2] (SSRN only, B=128), [4] (max_T=1000, B=8 = one GPU's share); decode-only at B = 64 / 128;
                       pipelined_depth2[_with_vocoder]: two batches in flight on two streams of one engine (a SECOND line: the headline stays the serial batch)
   cpu_baseline        the reference's loop restated on torch-CPU fp32 (oracle/torch_ref.py) on the host cores, bounded sample; + the numpy
@@ -418,7 +421,7 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         rtf = elapsed / (world * B * args.steps * T * hp.seconds_per_mel_frame)
         d = hp.d
-        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r05_kernel_stats.md): xcone_kernel, AudioDec HC_3 and HC_4
+        # ---- roofline: the kernel that dominates the step by TIME (rocprofv3 --stats, profiles/r06_kernel_stats.md): xcone_kernel, AudioDec HC_3 and HC_4
         #      (round 6: and HC_5) over the rows of a frame's dependency cone (45 / 15 / 5 rows per utterance incl. the presum row) + their layer-norm / gate passes
         #      (HC_6, HC_7 run on the chain), one launch per frame on the decode's side stream.  Unit of work = one cone ROW of one
         #      layer: a (3 x 256) x 512 fp32 contraction = 2 * 768 * 512 FLOP; algorithmic bytes of a launch = the rows in and out (256 channels each) +
@@ -608,20 +611,22 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
         nt, mst = eng.prof_collect()
         one_launch = bool(nt) and not n          # round 5 default: a chain piece is ONE launch (xchain_kernel); DCTTS_CHAIN_TAIL=6: round 4's two launches
         if one_launch:
-            fl = 2.0 * (3 * d * 2 * d + 9 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)          # xtail_kernel's part (below)
-            by = 4.0 * (3 * d * 2 * d + 3 * 3 * d * 2 * d + 5 * d * d + 2 * d * hp.n_mels) + 4.0 * B * (3 * 2 * d + 14 * d + d + hp.n_mels)
+            # xtail_kernel's part per utterance and frame (round 6): the newest row of HC_2 .. HC_5 (K = 256 -> 512 columns each), HC_6 / HC_7 over 3 / 1 rows (K = 768),
+            # C_8 .. C_10, C_11 (256 -> 80), AudioEnc C_1 (80 -> 256), C_2, C_3
+            fl = 2.0 * (4 * d * 2 * d + 4 * 3 * d * 2 * d + 3 * d * d + d * hp.n_mels + hp.n_mels * d + 2 * d * d)
+            by = 4.0 * (4 * d * 2 * d + 2 * 3 * d * 2 * d + 5 * d * d + 2 * d * hp.n_mels) + 4.0 * B * (4 * 2 * d + 4 * d + d + hp.n_mels)      # the 13 layers' weights once + per utterance four presum rows, the 4 staged rows, the mel frame, the output row
             lay_bytes = 4.0 * (d * 2 * d + 3 * B * 2 * d + 2 * B * 64 + B * d + 4 * d)      # one AudioEnc layer: weights 256 x 512, presum / rows out / rows in, statistics, kept row, LN parameters
             lay_flop = 2.0 * B * d * 2 * d
             fl_tail = 2.0 * B * (3 * d + d * d)                                               # attention logits over the 3-key window + C_1's Q half (256 x 256)
             by_tail = 4.0 * (d * d + B * (3 * 2 * d + 3 * d + 2 * d))
-            e = dict(kernel="xchain_kernel (decode chain, round 5: a chain piece as ONE launch in team form -- xtail_kernel's part: AudioDec's newest-row layers HC_2 .. HC_4, "
-                            "HC_5 .. HC_7 over the 5 / 3 / 1 cone rows they need, the seven k = 1 layers around the mel frame; a team barrier; xgroup_kernel's part: the AudioEnc "
-                            "run HC_4 .. HC_13 of the next frame, its attention row and AudioDec C_1.  It also carries the presum GEMMs as passenger workgroups, and its "
-                            "event-timed duration includes the wait for the side stream whenever that is the longer one; the two parts timed separately: "
-                            "profiles/r05_chain_tail_split.txt, DCTTS_CHAIN_TAIL=6)",
+            e = dict(kernel="xchain_kernel (decode chain: a chain piece as ONE launch in team form -- xtail_kernel's part: AudioDec's newest-row layers HC_2 .. HC_5 (round 6: HC_5's "
+                            "older cone rows moved to the side stream), HC_6 / HC_7 over the 3 / 1 cone rows they need, the seven k = 1 layers around the mel frame; a team barrier; "
+                            "xgroup_kernel's part: the AudioEnc run HC_4 .. HC_13 of the next frame, its attention row and AudioDec C_1.  It also carries the presum GEMMs as passenger "
+                            "workgroups, and its event-timed duration includes the wait for the side stream whenever that is the longer one; the two parts timed separately: "
+                            "profiles/r06_chain_tail_split.txt, DCTTS_CHAIN_TAIL=6)",
                      bound="latency (25 dependent all-to-all layers)", launches=nt, avg_launch_ms=round(mst / nt, 5), layers_per_launch=25,
                      **both_roofs(fl * B + 10 * lay_flop + fl_tail, by + 10 * lay_bytes + by_tail, mst / nt))
-            tj = os.path.join(ROOT, "profiles", "r05_pmc_decode.json")
+            tj = os.path.join(ROOT, "profiles", "r06_pmc_decode.json")
             if os.path.exists(tj):
                 pj = json.load(open(tj))
                 if "xgroup_kernel" in pj and "xtail_kernel" in pj:
@@ -649,7 +654,7 @@ def extras(eng, args, hp, W, L, Y, Z, B, T, gm, ms_step):
                             "4-utterance team, rows and statistics exchanged through the L2 of the team's XCD)",
                      bound="latency (16 dependent all-to-all layers per frame)", launches=n, avg_launch_ms=round(ms / n, 5), layers_per_launch=lpl,
                      algorithmic_bytes_per_layer=lay_bytes, flop_per_layer=lay_flop, **both_roofs(lay_flop * lpl, lay_bytes * lpl, ms / n))
-            tj = os.path.join(ROOT, "profiles", "r05_pmc_decode.json")
+            tj = os.path.join(ROOT, "profiles", "r06_pmc_decode.json")
             if os.path.exists(tj):
                 pj = json.load(open(tj))
                 if "xgroup_kernel" in pj:
