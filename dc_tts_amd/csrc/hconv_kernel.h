@@ -137,7 +137,7 @@ __device__ __forceinline__ float half_sum32(float v) {
 //     MFMAs cost matrix-pipe time even with a second wave on the SIMD (38 against 34.7 cycles per MFMA in the decode's 16 x 16 x 4 loop).  Here (hconv_lab, 768 items,
 //     same run): HC_11 2449 -> 2260 us with SB = 0 (0.803 -> 0.870 of the fp32 MFMA peak), the 1025-column layers 457 -> 445, HC_8 669 -> 655; C_10 gets slower (262 -> 274).
 template <int EPI, int NT, int NW, int BD = 1, int SB = 0, int RAW = 0, int XC = 0, int BF = 0, int SG = 0>
-__global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : 1) hconv_kernel(const ConvParams p) {      // (XC = 2: the same with registers capped for two workgroups per CU)
+__global__ void __launch_bounds__(NW * 64, (XC == 2) ? 4 : ((NW == 4 && NT == 8 && RAW == 0) ? 2 : 1)) hconv_kernel(const ConvParams p) {      // (XC = 2: the same with registers capped for two workgroups per CU)
   static_assert(XC == 0 || (EPI == EPI_C && RAW == 0 && NW == 8), "the extra column rides in the fused k = 1 form: 8 waves x 4 rows");
   static_assert(BF == 0 || (RAW != 1 && NT <= 4 && (BD == 1 || BD == 2)), "split-bf16: whole-K items, at most four tiles per wave, ring rotated by the two groups of a chunk");
   constexpr bool KPART = (RAW == 1);        // this workgroup contracts a PART of K (grid y = part)

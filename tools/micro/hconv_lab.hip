@@ -92,6 +92,9 @@ int main(int argc, char** argv) {
       } else if (si == 1) {
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 0>), 512, 1, "production hconv_kernel<HC,4,8,BD=2,SB=0>", false, q.out = ref)
         RUN((hconv_kernel<EPI_HC, 4, 8, 1, 1>), 512, 1, "BD=1 SB=1", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 4, 1, 1, 0, 0, 0, 1>), 256, 1, "4 waves x 8 tiles, two workgroups per CU, SG=1", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 4, 1, 1, 0, 0, 0, 0>), 256, 1, "4 waves x 8 tiles, two workgroups per CU, SG=0", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 4, 1, 0, 0, 0, 0, 1>), 256, 1, "4 waves x 8 tiles, two workgroups per CU, SB=0 SG=1", true, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1>), 512, 1, "BD=2 SB=1", true, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 1, 0, 0, 0, 1>), 512, 1, "BD=2 SB=1 SG=1", true, )
         RUN((hconv_kernel<EPI_HC, 4, 8, 2, 0, 0, 0, 0, 1>), 512, 1, "BD=2 SB=0 SG=1", true, )
@@ -111,6 +114,8 @@ int main(int argc, char** argv) {
       } else {
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1>), 512, 1, "production hconv_kernel<C,4,8,BD=1,SB=1>", false, q.out = ref)
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1>), 512, 1, "BD=2", true, )
+        RUN((hconv_kernel<EPI_C, 8, 4, 1, 1, 0, 0, 0, 1>), 256, 1, "4 waves x 8 tiles, two workgroups per CU, SG=1", true, )
+        RUN((hconv_kernel<EPI_C, 8, 4, 1, 1>), 256, 1, "4 waves x 8 tiles, two workgroups per CU, SG=0", true, )
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 0, 0, 1>), 512, 1, "BD=2 SG=1", true, )
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 0, 0, 2>), 512, 1, "BD=1 SG=2", true, )
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 0, 1>), 512, 1, "split-bf16 BD=2", false, )
