@@ -138,6 +138,8 @@ class Engine:
         _check(L, "L", torch.int32, 2, self.device)
         B, N = L.shape
         K = self._new(B, N, self.hp.d); V = self._new(B, N, self.hp.d)
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return K, V
         self._ok(self.lib.dctts_textenc_fwd(self._h, _ptr(L), B, N, _ptr(K), _ptr(V), self._stream()))
         return K, V
 
@@ -147,6 +149,8 @@ class Engine:
         if C != self.hp.n_mels:
             raise ValueError(f"S: last dim {C} != n_mels {self.hp.n_mels}")
         Q = self._new(B, T, self.hp.d)
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return Q
         self._ok(self.lib.dctts_audioenc_fwd(self._h, _ptr(S), B, T, _ptr(Q), self._stream()))
         return Q
 
@@ -166,6 +170,8 @@ class Engine:
                 raise ValueError(f"Attention: monotonic mode needs N == hp.max_N ({self.hp.max_N}) and T == hp.max_T "
                                  f"({self.hp.max_T}); got N={N}, T={T}")
         R = self._new(B, T, 2 * d); al = self._new(B, N, T); mx = self._new(B, T, dtype=torch.int64)
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return R, al, mx
         self._ok(self.lib.dctts_attention_fwd(self._h, _ptr(Q), _ptr(K), _ptr(V), B, T, N, int(bool(mononotic_attention)),
                                               _ptr(prev_max_attentions), _ptr(R), _ptr(al), _ptr(mx), self._stream()))
         return R, al, mx
@@ -176,6 +182,8 @@ class Engine:
         if C != 2 * self.hp.d:
             raise ValueError(f"R: last dim {C} != 2*d")
         logits = self._new(B, T, self.hp.n_mels); Y = self._new(B, T, self.hp.n_mels)
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return logits, Y
         self._ok(self.lib.dctts_audiodec_fwd(self._h, _ptr(R), B, T, _ptr(logits), _ptr(Y), self._stream()))
         return logits, Y
 
@@ -187,6 +195,8 @@ class Engine:
         F = self.hp.n_linear
         Z = self._new(B, self.hp.r * T, F)
         logits = self._new(B, self.hp.r * T, F) if want_logits else None
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return logits, Z
         self._ok(self.lib.dctts_ssrn_fwd(self._h, _ptr(Y), B, T, _ptr(logits), _ptr(Z), self._stream()))
         return logits, Z
 
@@ -249,6 +259,8 @@ class Engine:
             raise ValueError(f"L must be padded to hp.max_N={self.hp.max_N} (data_load.py:83); got {N}")
         Y = self._new(B, T, self.hp.n_mels); mx = self._new(B, T, dtype=torch.int64)
         al = self._new(B, N, T) if alignments else None
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return (Y, mx, al) if alignments else (Y, mx)
         self._decode(lambda: self._ok(self.lib.dctts_text2mel_decode(self._h, _ptr(L), B, N, T, _ptr(Y), _ptr(mx), _ptr(al), self._stream())), check)
         return (Y, mx, al) if alignments else (Y, mx)
 
@@ -262,5 +274,7 @@ class Engine:
         Y = self._new(B, T, self.hp.n_mels); Z = self._new(B, self.hp.r * T, self.hp.n_linear)
         mx = self._new(B, T, dtype=torch.int64)
         al = self._new(B, N, T) if alignments else None
+        if B == 0:                                                           # an empty batch: what sess.run returns for an empty feed (arrays with a zero leading dimension); nothing to launch
+            return (Y, Z, mx, al) if alignments else (Y, Z, mx)
         self._decode(lambda: self._ok(self.lib.dctts_synthesize(self._h, _ptr(L), B, N, T, _ptr(Y), _ptr(Z), _ptr(mx), _ptr(al), self._stream())), check)
         return (Y, Z, mx, al) if alignments else (Y, Z, mx)

@@ -600,6 +600,32 @@ def test_ragged_batch_sizes(weights):
     assert bool(torch.isfinite(Y33).all())
 
 
+def test_empty_batch_returns_empty_results(weights):
+    """An empty feed (B = 0; e.g. a rank of a sharded run that owns no utterance, or a serving loop with nothing queued): the reference's sess.run returns arrays with
+    a zero leading dimension and the right trailing shape; so does every function of the drop-in, without a launch.  The C ABI itself keeps rejecting B <= 0."""
+    eng = engine_for(weights)
+    L0 = torch.zeros((0, hp.max_N), dtype=torch.int32, device="cuda")
+    Y, Z, mx = eng.synthesize(L0, check=True)
+    assert tuple(Y.shape) == (0, hp.max_T, hp.n_mels) and tuple(Z.shape) == (0, hp.r * hp.max_T, hp.n_linear) and tuple(mx.shape) == (0, hp.max_T) and mx.dtype == torch.int64
+    Y2, mx2, al = eng.text2mel(L0, alignments=True)
+    assert tuple(Y2.shape) == (0, hp.max_T, hp.n_mels) and tuple(al.shape) == (0, hp.max_N, hp.max_T)
+    K, V = eng.text_enc(L0)
+    assert tuple(K.shape) == (0, hp.max_N, hp.d) == tuple(V.shape)
+    Q = eng.audio_enc(torch.zeros((0, 7, hp.n_mels), device="cuda"))
+    R, A, m = eng.attention(Q, torch.zeros((0, 9, hp.d), device="cuda"), torch.zeros((0, 9, hp.d), device="cuda"))
+    assert tuple(Q.shape) == (0, 7, hp.d) and tuple(R.shape) == (0, 7, 2 * hp.d) and tuple(A.shape) == (0, 9, 7)
+    lg, Yd = eng.audio_dec(R)
+    lz, Zs = eng.ssrn(Yd)
+    assert tuple(Yd.shape) == (0, 7, hp.n_mels) and tuple(Zs.shape) == (0, 28, hp.n_linear) and tuple(lz.shape) == (0, 28, hp.n_linear)
+    eng.synchronize()
+    # ... and the context is as usable as before
+    L = dev(synthetic_text(hp, B=2, seed=5))
+    Ya, _ = eng.text2mel(L); eng.synchronize()
+    assert bool(torch.isfinite(Ya).all())
+    import ctypes
+    assert eng.lib.dctts_text2mel_decode(eng._h, ctypes.c_void_p(L.data_ptr()), 0, hp.max_N, hp.max_T, ctypes.c_void_p(Ya.data_ptr()), None, None, None) < 0
+
+
 def test_large_batch_team_rounds(weights):
     """B = 134: 34 teams of the decode's team kernels = 640 team workgroups, more than two rounds of the 256 CUs, the last team with two utterances.
     Every utterance's mel rows and trajectory are bitwise those of the same utterance decoded inside a batch of 32 (teams that all fit at once)."""
