@@ -199,11 +199,12 @@ static int run_split(dctts_ctx* c, int MF, const DevLayer& L, int B, int R, cons
 // stream SHARE the queue of an existing one once the pool is full; two streams that share a queue run their commands one after the other.  Round 6 met exactly that:
 // a caller that had created a high-priority stream of its own (torch.cuda.Stream(priority=-1)) beside one engine's pair left the NEXT engine's pair on one queue --
 // every decode of that engine then ran into its bounded waits (error word 36; with stream-operation meetings it would have hung).  So the pair is TESTED when it is
-// created: a kernel on one stream waits (bounded, ~60 ms) for a flag a kernel on the other stream sets; if it times out the second stream is replaced by a new one
-// (the rejected ones are held until the end, so that the pool's next pick is a different queue).
+// created: a kernel on one stream waits (bounded, ~0.5 s: a device that is busy with other work -- another context's SSRN, another process -- must not look like a shared
+// queue) for a flag a kernel on the other stream sets; if it times out the second stream is replaced by a new one (the rejected ones are held until the end, so that
+// the pool's next pick is a different queue).
 __global__ void conc_wait_kernel(const unsigned* __restrict__ flag, unsigned* __restrict__ out) {
   unsigned ok = 0;
-  for (int i = 0; i < (1 << 15) && !ok; ++i) {
+  for (int i = 0; i < (1 << 19) && !ok; ++i) {
     ok = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
     if (!ok) __builtin_amdgcn_s_sleep(32);
   }
@@ -237,9 +238,9 @@ static int decode_streams_init(dctts_ctx* c) {
     // ... and so do the chain's launches: they run on a high-priority stream of the context, between two events on the caller's stream (decode_impl).  On the caller's
     // own (default-priority) stream the chain's team kernels met the same fate as xcone_kernel once that one had priority: 9 of 1500 decodes beside SSRN + vocoder
     // reported a team hand-off time-out of the chain.
-    HIPCHK(hipStreamCreateWithPriority(&c->s_chain, hipStreamNonBlocking, hi));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    if (!c->s_chain) HIPCHK(hipStreamCreateWithPriority(&c->s_chain, hipStreamNonBlocking, hi));      // (a call that failed further down may come again)
+    if (!c->ev_in) HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    if (!c->ev_out) HIPCHK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     // the pair must run concurrently (above): replace the side stream until it does
     std::vector<hipStream_t> rejected;
     bool ok = false;
