@@ -6,6 +6,7 @@
             (unrelated kernels competing for CUs, L2 and the fabric)
   phase D   N4 rounds of 2 x SSRN, 2 x TextEnc and 2 x synthesize of DIFFERENT inputs enqueued on two streams of the one engine (round 5: same-kind calls are
             ordered by the context's use groups): every output compared bitwise with the solo run of its input
+  phase E   (round 6) N5 decodes each at B = 8, 16, 5: teams of one / two utterances per round
 
 Every decode's outputs are compared ON THE DEVICE with the first decode of its phase (bitwise: the decode is deterministic); the status word is
 read every `--every` decodes.  A failed decode shows up three ways -- the status report, NaN outputs, a mismatch count -- and all three are printed.
@@ -117,6 +118,7 @@ def main():
     ap.add_argument("--n2", type=int, default=500)
     ap.add_argument("--n3", type=int, default=1500)
     ap.add_argument("--n4", type=int, default=1000)
+    ap.add_argument("--n5", type=int, default=1000)
     ap.add_argument("--every", type=int, default=250)
     a = ap.parse_args()
     torch.cuda.set_device(0)
@@ -141,6 +143,10 @@ def main():
         state["i"] += 1
     bad += phase(eng, "C (SSRN + vocoder on a second stream)", 32, a.n3, a.every, hp.max_T, side)
     bad += phase_d(eng, a.n4, a.every)
+    # phase E (round 6): the batch-sized teams -- one / two utterances per team and round (B <= 8 / 16)
+    if a.n5 > 0:
+        for B, T in ((8, hp.max_T), (16, 120), (5, 90)):
+            bad += phase(eng, f"E (teams sized by the batch, B = {B})", B, a.n5, a.every, T)
     print("TOTAL failures:", bad)
     return 0
 
