@@ -80,10 +80,10 @@ int main(int argc, char** argv) {
       std::vector<Variant> vars;
 #define RUN(KERN, THREADS, GY, LABEL, CHECK, PATCH) { ConvParams q = p; PATCH; const dim3 grid_(items, GY); vars.push_back({LABEL, [=] { hipLaunchKernelGGL(KERN, grid_, dim3(THREADS), 0, 0, q); }, CHECK, {}}); }
       if (si == 0) {
-        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 1>), 512, 1, "production hconv_kernel<HC,8,8,BD=1,SB=1>", false, q.out = ref)
+        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 1>), 512, 1, "round 5: hconv_kernel<HC,8,8,BD=1,SB=1>", false, q.out = ref)
         RUN((hconv_kernel<EPI_HC, 8, 8, 2, 1>), 512, 1, "BD=2", true, )
         RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0>), 512, 1, "SB=0", true, )
-        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 1, 0, 0, 0, 1>), 512, 1, "SB=1 SG=1 (requests spread: one behind every three MFMAs)", true, )
+        RUN((hconv_kernel<EPI_HC, 8, 8, 1, 1, 0, 0, 0, 1>), 512, 1, "production (round 6): SB=1 SG=1 (requests spread: one behind every three MFMAs)", true, )
         RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0, 0, 0, 0, 1>), 512, 1, "SB=0 SG=1", true, )
         RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0, 0, 0, 0, 2>), 512, 1, "SB=0 SG=2 (every four)", true, )
         RUN((hconv_kernel<EPI_HC, 8, 8, 1, 0, 0, 0, 0, 3>), 512, 1, "SB=0 SG=3 (every two, first half)", true, )
@@ -105,11 +105,11 @@ int main(int argc, char** argv) {
         RUN((hconv_kernel<EPI_HC, 4, 8, 1, 1, 0, 0, 1>), 512, 1, "split-bf16 BD=1", false, )
       } else if (si == 2) {
         RUN((hconv_kernel<EPI_C, 3, 11, 2, 1>), 704, 1, "rounds 1-4: hconv_kernel<C,3,11,BD=2,SB=1> (33 tiles on 11 waves)", false, q.out = ref)
-        RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), 512, 1, "production: 8 waves x 4 tiles + column 1024 on the vector ALU, 128 registers (XC=2)", false, q.wx = wx)
+        RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2>), 512, 1, "round 5: 8 waves x 4 tiles + column 1024 on the vector ALU, 128 registers (XC=2)", false, q.wx = wx)
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1>), 512, 1, "the same at ring depth 2, registers uncapped (one workgroup per CU)", false, q.wx = wx)
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2, 0, 1>), 512, 1, "XC=2 SG=1", false, q.wx = wx)
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1, 0, 2, 0, 2>), 512, 1, "XC=2 SG=2", false, q.wx = wx)
-        RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 0, 1>), 512, 1, "XC=1 BD=2 SG=1", false, q.wx = wx)
+        RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 0, 1>), 512, 1, "production (round 6): XC=1 BD=2 SG=1", false, q.wx = wx)
         RUN((hconv_kernel<EPI_C, 4, 8, 2, 1, 0, 1, 1>), 512, 1, "split-bf16 XC BD=2", false, q.wx = wx)
       } else {
         RUN((hconv_kernel<EPI_C, 4, 8, 1, 1>), 512, 1, "production hconv_kernel<C,4,8,BD=1,SB=1>", false, q.out = ref)
